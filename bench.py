@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- depth-frames/s integrated (640x480 -> 512^3 TSDF @ 2 cm) on MI355X, with the HBM roofline
+fraction of the dominant kernel and the CPU restatement timed beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic depth frame (BASELINE.json configs[1]): the frames
+and poses are generated up front and are resident in HBM before the timed region starts.  For N > 1 the
+driver launches one process per GPU (torch.distributed.run); each rank integrates its own stream into its
+own submap (the path shards by submap, SURVEY.md section 8e: no data-path collective), so scaling is weak.
+Rank 0 prints exactly one JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C2 = dict(map_scale=[10.24, 10.24], voxel_scale=0.02, num_voxel_per_blk_axis=16, max_ray_length=5.0,
+          min_ray_length=0.3, internal_voxels=10, recast_step=2, texture_enabled=False)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy
+
+
+def cpu_baseline(frames, budget_s=20.0):
+    """Time the CPU restatement of the reference (oracle, FAITHFUL = sequential f16 replay) on the host cores
+    of this box for a bounded sample of the same stream.  The oracle is only the measured baseline here."""
+    from oracle import FAITHFUL, OracleTSDF
+    from taichislam_amd.utils import synthetic as syn
+    o = OracleTSDF(**C2)
+    o.set_intrinsics(syn.K_DEPTH)
+    n, t0 = 0, time.perf_counter()
+    for R, T, d in frames:
+        o.integrate_depth(R, T, d, mode=FAITHFUL)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} frames of the same 640x480 stream into the same 512^3/2cm map, {dt:.1f} s, 1 thread, "
+                      f"oracle FAITHFUL mode (sequential f16 replay of dense_tsdf.py:188-270; Taichi itself unavailable)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--split", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    dev = local_rank if distributed else 0
+    torch.cuda.set_device(dev)
+
+    from taichislam_amd import _lib
+    from taichislam_amd.mapping import DenseTSDF
+    from taichislam_amd.utils import synthetic as syn
+
+    # ---- synthetic stream: each rank starts 45 degrees further round the room ----
+    nframes = args.warmup + args.steps
+    start_deg = 45.0 * rank
+    host = list(syn.sphere_room_stream(nframes, start_deg=start_deg))
+    depth_dev = torch.from_numpy(np.stack([d for _, _, d in host]).view(np.int16)).cuda(dev)   # resident in HBM
+    poses = [(np.ascontiguousarray(R), np.ascontiguousarray(T)) for R, T, _ in host]
+
+    m = DenseTSDF(**C2, device=dev)
+    m.set_dep_camera_intrinsic(syn.K_DEPTH)
+    m.set_base_pose_submap(0, np.eye(3), np.zeros(3))
+    if args.variant is not None:
+        m.set_option("variant", args.variant)
+    if args.split is not None:
+        m.set_option("split", args.split)
+
+    def step(f):
+        R, T = poses[f]
+        m.recast_depth_to_map(R, T, depth_dev[f], None)
+
+    for f in range(args.warmup):
+        step(f)
+    m.sync()
+    stats = m.last_frame_stats()
+    m.enable_profiling(True)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        m.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, nframes):
+        step(f)
+    m.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern = {}
+    for kid, name in _lib.KERNEL_NAMES.items():
+        ms, n = m.kernel_time(kid)
+        if n:
+            kern[name] = {"avg_us": 1000.0 * ms / n, "launches": n}
+    m.enable_profiling(False)
+    stats = m.last_frame_stats()
+
+    if rank == 0:
+        fps = world * args.steps / dt
+        # algorithmic bytes (SURVEY.md section 8d / DESIGN.md): phase A = 2*P_used + 24*P_valid, phase B = 9*U + V_pcl
+        bytes_a = 2 * stats["p_used"] + 24 * stats["p_valid"]
+        bytes_b = 9 * stats["unique"] + stats["v_pcl"]
+        dom = max(kern, key=lambda k: kern[k]["avg_us"]) if kern else None
+        roof = None
+        if dom:
+            alg = bytes_b if dom in ("integrate", "finalize") else bytes_a
+            ach = alg / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[dom]["avg_us"],
+                    "frame_bytes": bytes_a + bytes_b, "frame_gbs": (bytes_a + bytes_b) * fps / world / 1e9,
+                    "frame_frac": (bytes_a + bytes_b) * fps / world / 1e9 / HBM_PEAK_GBS}
+        out = {
+            "metric": "depth-frames/s integrated (640x480->512^3 TSDF)", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 + int64 fixed-point arithmetic",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single 640x480 u16 depth stream (sphere room r=3 m, 1 deg/frame) -> "
+                                   "DenseTSDF 512^3 / 2 cm, recast_step 2, max_ray 5 m; one stream+submap per GPU",
+                       "frame_stats": stats, "kernels_us": kern,
+                       "updates_per_s": stats["steps"] * fps},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host[: max(8, min(len(host), 200))])
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

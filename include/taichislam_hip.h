@@ -1,0 +1,192 @@
+/*
+ * taichislam_hip.h -- C-ABI of the MI355X-native dense-mapping backend (libtaichislam_hip.so).
+ *
+ * The reference (xuhao1/TaichiSLAM) has no FFI seam: its callers use the Python classes of
+ * taichi_slam/mapping directly.  This ABI is what taichislam_amd/mapping/ *.py (ctypes shims that
+ * keep those class surfaces) binds, and what any C/C++ host would bind.  Each entry point cites the
+ * reference method it replaces (paths relative to the reference root).
+ *
+ * Conventions: opaque handles; plain pointers and sizes; int status return (0 = TSL_OK, <0 = error,
+ * text via tsl_last_error()); no exceptions cross the boundary.  One handle = one device + one HIP
+ * stream; a handle is NOT thread-safe, distinct handles are independent.  Pointers named *_dev are
+ * device pointers (e.g. torch tensor .data_ptr()); all others are caller-owned host buffers.
+ * Integration calls are asynchronous on the handle's stream; every call that returns data to the
+ * host synchronises.  R/T are row-major float64 camera-to-world poses (scripts/taichislam_node.py:381).
+ */
+#ifndef TAICHISLAM_HIP_H
+#define TAICHISLAM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSL_OK              0
+#define TSL_ERR_ARG        -1
+#define TSL_ERR_HIP        -2
+#define TSL_ERR_CAPACITY   -3   /* brick pool / frame scratch / output buffer exhausted */
+#define TSL_ERR_NO_DEVICE  -4
+
+typedef struct tsl_tsdf tsl_tsdf;   /* DenseTSDF                 taichi_slam/mapping/dense_tsdf.py:12      */
+typedef struct tsl_octo tsl_octo;   /* Octomap                   taichi_slam/mapping/taichi_octomap.py:12  */
+
+/* DenseTSDF.__init__ kwargs (dense_tsdf.py:13-16) + backend sizing knobs (0 = default). */
+typedef struct {
+    double  map_size_xy, map_size_z;
+    double  voxel_scale;
+    int32_t num_voxel_per_blk_axis;
+    double  max_ray_length, min_ray_length;
+    int32_t internal_voxels;
+    int32_t max_submap_num;
+    int32_t is_global_map;
+    int32_t texture_enabled;
+    double  disp_ceiling, disp_floor;
+    int32_t recast_step;
+    int32_t color_same_proj;
+    int64_t max_disp_particles;
+    /* backend sizing */
+    int32_t max_bricks;          /* 16^3 brick pool capacity (24 KiB each)                */
+    int32_t max_frame_bricks;    /* bricks one frame may touch (64 KiB scratch each)      */
+    int32_t max_points;          /* pixels/points per integrate call                       */
+} tsl_tsdf_cfg;
+
+typedef struct {
+    int64_t p_used;      /* pixels / points visited                                   */
+    int64_t p_valid;     /* passed the range gate and inside the sensor-centred grid  */
+    int64_t p_oob;       /* passed the gate but outside the sensor-centred grid       */
+    int64_t v_pcl;       /* sensor-grid voxels with count>0 (= rays)                  */
+    int64_t v_skipped;   /* degenerate rays skipped                                   */
+    int64_t steps;       /* ray-steps applied (S)                                     */
+    int64_t steps_oob;   /* ray-steps outside the map volume (skipped)                */
+    int64_t unique;      /* distinct voxels touched this frame (U)                    */
+    int64_t bricks;      /* distinct 16^3 bricks touched this frame                   */
+} tsl_frame_stats;
+
+/* kernel ids for tsl_tsdf_prof_query */
+enum { TSL_K_VOXELIZE = 0, TSL_K_SORT = 1, TSL_K_RAYS = 2, TSL_K_INTEGRATE = 3, TSL_K_FINALIZE = 4,
+       TSL_K_MESH = 5, TSL_K_COUNT };
+
+const char* tsl_version(void);
+const char* tsl_last_error(void);
+int  tsl_device_count(int* n);
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int  tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out);        /* dense_tsdf.py:13-50,52-118 */
+void tsl_tsdf_destroy(tsl_tsdf* m);
+int  tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* block_num_xy, int32_t* block_num_z);
+int  tsl_tsdf_sync(tsl_tsdf* m);
+int  tsl_tsdf_reset(tsl_tsdf* m);                                                    /* dense_tsdf.py:309-310 */
+int  tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* bytes);
+int  tsl_tsdf_bricks_in_use(tsl_tsdf* m, int32_t* n);
+
+/* ---- poses / camera ------------------------------------------------------------------------ */
+int  tsl_tsdf_set_intrinsics(tsl_tsdf* m, const double Kdep[9], const double Kcol[9]);   /* mapping_common.py:25-29 */
+int  tsl_tsdf_set_base_pose(tsl_tsdf* m, const double R[9], const double T[3]);           /* mapping_common.py:141-147 */
+int  tsl_tsdf_set_base_pose_submap(tsl_tsdf* m, int sid, const double R[9], const double T[3]);   /* mapping_common.py:121-131 */
+int  tsl_tsdf_get_active_submap(const tsl_tsdf* m, int32_t* sid);                         /* mapping_common.py:113-114 */
+int  tsl_tsdf_set_active_submap(tsl_tsdf* m, int32_t sid);                                /* mapping_common.py:116-119 */
+int  tsl_tsdf_set_colormap(tsl_tsdf* m, const float rgb[1024 * 3]);                       /* mapping_common.py:158-163 */
+
+/* ---- integration (the hot path) --------------------------------------------------------------
+ * recast_depth_to_map(R, T, depthmap, texture)  dense_tsdf.py:162-165,188-270
+ * depth: uint16 millimetres [h][w] C-contiguous; tex: uint8 [th][tw][3] or NULL. */
+int  tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3],
+                              const uint16_t* depth, int h, int w, const uint8_t* tex, int th, int tw);
+int  tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[3],
+                                  const void* depth_dev, int h, int w, const void* tex_dev, int th, int tw);
+/* recast_pcl_to_map(R, T, xyz_array, rgb_array)  dense_tsdf.py:157-160,167-186; xyz f32 [n][3] */
+int  tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
+                               const float* xyz, const uint8_t* rgb, int64_t n);
+int  tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3],
+                                   const void* xyz_dev, const void* rgb_dev, int64_t n);
+/* counters of the most recent integrate call (synchronises) */
+int  tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out);
+
+/* ---- sparse export / import  (dense_tsdf.py:412-498) -------------------------------------------- */
+int  tsl_tsdf_count_active(tsl_tsdf* m, int64_t* n);                                       /* :412-423 */
+int  tsl_tsdf_export_sparse(tsl_tsdf* m, int16_t* idx, uint16_t* tsdf_h, uint16_t* w_h, int8_t* occ,
+                            uint16_t* color_h, int64_t cap, int64_t* n);                   /* to_numpy :425-440 */
+int  tsl_tsdf_import_sparse(tsl_tsdf* m, int sid, const int16_t* idx, const uint16_t* tsdf_h,
+                            const uint16_t* w_h, const int8_t* occ, const uint16_t* color_h, int64_t n);   /* load_numpy :442-454 */
+int  tsl_tsdf_export_occupied(tsl_tsdf* m, int16_t* idx, int8_t* occ, int64_t cap, int64_t* n);
+
+/* ---- visualisation exports (device-resident result buffers, max_disp_particles rows) ---------- */
+/* cvt_TSDF_surface_to_voxels[_to]  dense_tsdf.py:323-365.  add_to_cur: keep the current count and
+ * append (the `_to` form); the true count is returned even when it exceeds the capacity. */
+int  tsl_tsdf_surface_voxels(tsl_tsdf* m, tsl_tsdf* dst /* NULL = m itself */, int add_to_cur, int32_t* n);
+/* cvt_TSDF_to_voxels_slice(z, dz, clear_last)  dense_tsdf.py:367-389 */
+int  tsl_tsdf_slice_voxels(tsl_tsdf* m, float z, float dz, int clear_last, int32_t* n);
+/* read back export_TSDF_xyz / export_color / export_TSDF (any may be NULL), rows [0, n) */
+int  tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64_t n);
+int  tsl_tsdf_num_particles(tsl_tsdf* m, int32_t* n);
+int  tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n);
+
+/* ---- submap fusion  (dense_tsdf.py:272-318) ------------------------------------------------------ */
+int  tsl_tsdf_fuse_submaps(tsl_tsdf* global, tsl_tsdf* submaps);
+/* multi-GPU form: splat this rank's submaps into exact int64 accumulators over the global grid,
+ * all-reduce(sum) them with RCCL (caller side: torch.distributed / ncclAllReduce on the *_dev
+ * buffers), then finalise.  Buffers: int64 [N*N*Nz] each (num, den) and int32 [N*N*Nz] (cnt_occ:
+ * contribution count in the high 16 bits, occupancy sum in the low 16). */
+int  tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* global, tsl_tsdf* submaps, void* num_dev, void* den_dev, void* cnt_occ_dev);
+int  tsl_tsdf_fuse_finalize_dev(tsl_tsdf* global, const void* num_dev, const void* den_dev, const void* cnt_occ_dev);
+
+/* ---- marching cubes  (marching_cube_mesher.py:127-193) ------------------------------------------- */
+/* generate_mesh(step): result stays on the device in the map's mesh buffers (3*max_tri rows each);
+ * n_tri is the true triangle count.  read with tsl_mesh_read. */
+int  tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tri, int32_t* n_tri);
+int  tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int64_t n_vertices);
+
+/* ---- ESDF  (dense_esdf.py:228-333, see DESIGN.md for the definition used) ------------------------ */
+int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters);
+int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);
+
+/* backend knobs for A/B-ing kernel variants: name in {"variant" (0|1), "split" (lanes per ray, divides 64)} */
+int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);
+
+/* ---- profiling: HIP-event timing of the per-frame kernels on the handle's stream ----------------- */
+int  tsl_tsdf_prof_enable(tsl_tsdf* m, int on);
+int  tsl_tsdf_prof_query(tsl_tsdf* m, int kernel_id, double* total_ms, int64_t* launches);   /* synchronises, resets */
+
+/* ======== Octomap hit counter (taichi_octomap.py) =================================================== */
+typedef struct {
+    double  map_size_xy, map_size_z, voxel_scale;
+    double  min_occupy_thres;
+    int32_t texture_enabled;
+    double  min_ray_length, max_ray_length;
+    int32_t K;
+    int32_t max_submap_num;
+    double  disp_ceiling, disp_floor;
+    int32_t is_global_map;
+    int32_t recast_step;
+    int32_t color_same_proj;
+    int64_t max_disp_particles;
+    int32_t max_bricks;
+    int32_t max_points;
+} tsl_octo_cfg;
+
+int  tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out);        /* taichi_octomap.py:14-84 */
+void tsl_octo_destroy(tsl_octo* m);
+int  tsl_octo_get_dims(const tsl_octo* m, int32_t* N, int32_t* Nz, int32_t* Rxy, int32_t* Rz, double* voxel_scale);
+int  tsl_octo_sync(tsl_octo* m);
+int  tsl_octo_reset(tsl_octo* m);                                                    /* :210-211 */
+int  tsl_octo_set_intrinsics(tsl_octo* m, const double Kdep[9], const double Kcol[9]);
+int  tsl_octo_set_base_pose_submap(tsl_octo* m, int sid, const double R[9], const double T[3]);
+int  tsl_octo_get_active_submap(const tsl_octo* m, int32_t* sid);
+int  tsl_octo_set_active_submap(tsl_octo* m, int32_t sid);
+int  tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
+                              const uint8_t* tex, int th, int tw);                   /* :130-132,147-169 */
+int  tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
+                                  const void* tex_dev, int th, int tw);
+int  tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n);   /* :126-128,134-145 */
+int  tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out);
+int  tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, int64_t cap, int64_t* n);
+/* cvt_occupy_to_voxels(level) / cvt_occupy_voxels_to(...)  :90-114 */
+int  tsl_octo_occupied_voxels(tsl_octo* m, tsl_octo* dst /* NULL = m */, int level, int add_to_cur, int32_t* n);
+int  tsl_octo_read_exports(tsl_octo* m, float* xyz, float* rgb, int64_t n);
+int  tsl_octo_num_particles(tsl_octo* m, int32_t* n);
+int  tsl_octo_fuse_submaps(tsl_octo* global, tsl_octo* submaps);                     /* :171-199 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,894 @@
+/*
+ * tsl_oracle.c -- CPU ORACLE (test infrastructure only; see tsl_oracle.h header comment).
+ *
+ * Plain-C restatement of xuhao1/TaichiSLAM taichi_slam/mapping (reference paths below are
+ * relative to the reference root).  PARITY UNPINNED by any reference test (none exist).
+ *
+ * Numeric model (DESIGN.md "Assumed Taichi semantics" A1-A10):
+ *   h(x)   round-to-nearest-even to IEEE binary16; every f16 (op) f16 is h(f32(a) op f32(b));
+ *          f16 (op) f32 is plain f32.
+ *   rnd(x) round-half-away-from-zero, then convert to i32 (ti.round(x, ti.i32)).
+ *   int()/range(float) truncate toward zero; ti.floor floors.
+ *   reading a never-written voxel yields 0.
+ * Build with -ffp-contract=off (no FMA contraction) -- the HIP side does the same.
+ */
+#include "tsl_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* f16 <-> f32 (software, RNE, subnormals kept)                                                */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+uint16_t ora_f32_to_f16(float f)
+{
+    uint32_t x = f32_bits(f);
+    uint32_t s = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(s | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x >= 0x477ff000u) return (uint16_t)(s | 0x7c00u);          /* >= 65520 rounds to inf */
+    if (x >= 0x38800000u) {                                        /* normal f16            */
+        uint32_t m = x - 0x38000000u;
+        uint32_t r = m + 0xfffu + ((m >> 13) & 1u);
+        return (uint16_t)(s | (r >> 13));
+    }
+    if (x < 0x33000000u) return (uint16_t)s;                        /* < 2^-25 -> 0          */
+    {
+        uint32_t e = x >> 23;
+        uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        uint32_t shift = 126u - e;                                  /* 14..24                */
+        uint32_t r = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t)(s | r);
+    }
+}
+
+float ora_f16_to_f32(uint16_t hv)
+{
+    uint32_t s = ((uint32_t)hv & 0x8000u) << 16;
+    uint32_t e = (hv >> 10) & 0x1fu;
+    uint32_t m = hv & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return bits_f32(s);
+        /* subnormal: m * 2^-24 */
+        float v = (float)m * 5.9604644775390625e-08f;
+        return s ? -v : v;
+    }
+    if (e == 31) return bits_f32(s | 0x7f800000u | (m << 13));
+    return bits_f32(s | ((e + 112u) << 23) | (m << 13));
+}
+
+typedef uint16_t f16;
+#define H(x)   ora_f32_to_f16(x)
+#define F(x)   ora_f16_to_f32(x)
+static inline f16 hadd(f16 a, f16 b) { return H(F(a) + F(b)); }
+static inline f16 hsub(f16 a, f16 b) { return H(F(a) - F(b)); }
+static inline f16 hmul(f16 a, f16 b) { return H(F(a) * F(b)); }
+static inline f16 hdiv(f16 a, f16 b) { return H(F(a) / F(b)); }
+static inline f16 hsqrt(f16 a) { return H(sqrtf(F(a))); }
+
+/* ti.round(x, ti.i32): round half away from zero (A1) */
+static inline float rnd_f(float x)
+{
+    float r = truncf(x);
+    float d = fabsf(x - r);
+    if (d >= 0.5f) r += copysignf(1.0f, x);
+    return r;
+}
+static inline int rnd_i(float x) { return (int)rnd_f(x); }
+static inline int sgn_f(float v) { return (0.0f < v) - (v < 0.0f); }   /* mapping_common.py:5-7 */
+
+/* per-frame accumulators are 2^-24 fixed point (BATCHED mode) */
+#define FIX_SCALE 16777216.0f
+#define FIX_INV   (1.0 / 16777216.0)
+#define W_CLAMP   65536.0f
+#define WMAX      1000.0f                                               /* dense_tsdf.py:8 */
+static inline int64_t to_fix(float v) { return (int64_t)llrintf(v * FIX_SCALE); }
+static inline float from_fix(int64_t q) { return (float)((double)q * FIX_INV); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Map storage: per submap a table of lazily allocated 16^3 bricks                             */
+/* ------------------------------------------------------------------------------------------ */
+#define BRK 16
+#define BRK3 4096
+typedef struct {
+    f16     tsdf[BRK3], w[BRK3];
+    int8_t  obs[BRK3], occ[BRK3];
+    f16     col[BRK3][3];
+    int64_t num[BRK3], den[BRK3];      /* per-frame accumulators (zero between frames) */
+    uint32_t win[BRK3];                /* per-frame colour winner (ray order + 1)      */
+    int     touched;                   /* in the frame touched list                    */
+} brick_t;
+
+typedef struct { brick_t** tab; } submap_t;
+
+struct ora_tsdf {
+    ora_tsdf_cfg cfg;
+    int N, Nz, nbx, nbz;
+    int pcl_lo, pcl_hi, pcl_blk;       /* sensor grid index range [lo, hi) and its block size */
+    float vs;
+    float fx, fy, cx, cy, fxc, fyc, cxc, cyc;
+    float thr_max, thr_min;            /* max_ray*1000, min_ray*1000 as f32 */
+    float max_ray_f, max_steps_f, internal_f;
+    float surf_thres;
+    float disp_floor, disp_ceiling;
+    int   nsub;
+    submap_t* sub;
+    double* baseR; double* baseT;      /* per submap, double (the *_np arrays)  mapping_common.py:106-107 */
+    float*  baseRf; float* baseTf;     /* f32 device-field copies                mapping_common.py:104-105 */
+    double  gbaseR[9], gbaseT[3];      /* base_R_np/base_T_np (unused when submap_enabled) */
+    int     active;
+    float   inR[9], inT[3];            /* input_R / input_T                      mapping_common.py:12-13 */
+    float   colormap[1024][3];
+    /* frame scratch */
+    brick_t** touched; int ntouched, captouched;
+};
+
+static int ceil_div_blk(double scale, double voxel, int blk)
+{
+    return (int)ceil(scale / voxel / (double)blk);   /* dense_tsdf.py:24-28 (Python double arithmetic) */
+}
+
+static void jet_colormap(float cm[1024][3]);
+
+ora_tsdf* ora_tsdf_create(const ora_tsdf_cfg* cfg)
+{
+    ora_tsdf* m = (ora_tsdf*)calloc(1, sizeof(ora_tsdf));
+    m->cfg = *cfg;
+    int blk = cfg->num_voxel_per_blk_axis;
+    m->N = ceil_div_blk(cfg->map_size_xy, cfg->voxel_scale, blk) * blk;          /* dense_tsdf.py:24 */
+    m->Nz = ceil_div_blk(cfg->map_size_z, cfg->voxel_scale, blk) * blk;         /* dense_tsdf.py:25 */
+    m->nbx = (m->N + BRK - 1) / BRK;
+    m->nbz = (m->Nz + BRK - 1) / BRK;
+    /* sensor-centred grid  dense_tsdf.py:67-70 */
+    int grp = (int)(3.2 * cfg->max_ray_length / (double)blk / cfg->voxel_scale);
+    if (grp < 1) grp = 1;
+    {
+        int ext = blk * grp;
+        int off = -ext / 2; if ((-ext) % 2 != 0) off -= 1;    /* Python floor division of a negative */
+        m->pcl_lo = off; m->pcl_hi = off + ext; m->pcl_blk = blk;
+    }
+    m->vs = (float)cfg->voxel_scale;
+    m->thr_max = (float)(cfg->max_ray_length * 1000.0);                            /* dense_tsdf.py:198 */
+    m->thr_min = (float)(cfg->min_ray_length * 1000.0);
+    m->max_ray_f = (float)cfg->max_ray_length;                                    /* dense_tsdf.py:177 */
+    m->max_steps_f = (float)(cfg->max_ray_length / cfg->voxel_scale);             /* dense_tsdf.py:249 */
+    m->internal_f = (float)cfg->internal_voxels;
+    m->surf_thres = (float)(cfg->voxel_scale * 1.8);                              /* dense_tsdf.py:39 */
+    m->disp_floor = (float)cfg->disp_floor; m->disp_ceiling = (float)cfg->disp_ceiling;
+    m->nsub = cfg->is_global_map ? 1 : cfg->max_submap_num;                        /* dense_tsdf.py:86-88 */
+    if (m->nsub < 1) m->nsub = 1;
+    m->sub = (submap_t*)calloc((size_t)m->nsub, sizeof(submap_t));
+    int np = cfg->max_submap_num > m->nsub ? cfg->max_submap_num : m->nsub;
+    m->baseR = (double*)calloc((size_t)np * 9, sizeof(double));
+    m->baseT = (double*)calloc((size_t)np * 3, sizeof(double));
+    m->baseRf = (float*)calloc((size_t)np * 9, sizeof(float));
+    m->baseTf = (float*)calloc((size_t)np * 3, sizeof(float));
+    /* DEVIATION: the reference zero-initialises submaps_base_R_np
+     * (mapping_common.py:106) which makes an un-posed map collapse every point to the origin;
+     * we start from identity. */
+    for (int s = 0; s < np; ++s) for (int i = 0; i < 3; ++i) { m->baseR[s * 9 + i * 4] = 1.0; m->baseRf[s * 9 + i * 4] = 1.0f; }
+    for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
+    for (int i = 0; i < 3; ++i) m->inR[i * 4] = 1.0f;
+    jet_colormap(m->colormap);
+    return m;
+}
+
+static void free_submap(ora_tsdf* m, submap_t* s)
+{
+    if (!s->tab) return;
+    size_t nb = (size_t)m->nbx * m->nbx * m->nbz;
+    for (size_t b = 0; b < nb; ++b) free(s->tab[b]);
+    free(s->tab); s->tab = NULL;
+}
+
+void ora_tsdf_destroy(ora_tsdf* m)
+{
+    if (!m) return;
+    for (int s = 0; s < m->nsub; ++s) free_submap(m, &m->sub[s]);
+    free(m->sub); free(m->baseR); free(m->baseT); free(m->baseRf); free(m->baseTf); free(m->touched);
+    free(m);
+}
+
+void ora_tsdf_reset(ora_tsdf* m)      /* dense_tsdf.py:309-310 */
+{
+    for (int s = 0; s < m->nsub; ++s) free_submap(m, &m->sub[s]);
+}
+
+void ora_tsdf_get_dims(const ora_tsdf* m, int* N, int* Nz, int* lo, int* hi)
+{ if (N) *N = m->N; if (Nz) *Nz = m->Nz; if (lo) *lo = m->pcl_lo; if (hi) *hi = m->pcl_hi; }
+
+void ora_tsdf_set_intrinsics(ora_tsdf* m, const double Kd[9], const double Kc[9])   /* mapping_common.py:25-41 */
+{
+    if (Kd) { m->fx = (float)Kd[0]; m->fy = (float)Kd[4]; m->cx = (float)Kd[2]; m->cy = (float)Kd[5]; }
+    if (Kc) { m->fxc = (float)Kc[0]; m->fyc = (float)Kc[4]; m->cxc = (float)Kc[2]; m->cyc = (float)Kc[5]; }
+}
+
+void ora_tsdf_set_base_pose(ora_tsdf* m, const double R[9], const double T[3])      /* mapping_common.py:141-147 */
+{ memcpy(m->gbaseR, R, sizeof(double) * 9); memcpy(m->gbaseT, T, sizeof(double) * 3); }
+
+void ora_tsdf_set_base_pose_submap(ora_tsdf* m, int sid, const double R[9], const double T[3])   /* mapping_common.py:121-131 */
+{
+    memcpy(m->baseR + sid * 9, R, sizeof(double) * 9); memcpy(m->baseT + sid * 3, T, sizeof(double) * 3);
+    for (int i = 0; i < 9; ++i) m->baseRf[sid * 9 + i] = (float)R[i];
+    for (int i = 0; i < 3; ++i) m->baseTf[sid * 3 + i] = (float)T[i];
+}
+int  ora_tsdf_get_active_submap(const ora_tsdf* m) { return m->active; }
+void ora_tsdf_set_active_submap(ora_tsdf* m, int sid) { m->active = sid; }
+
+/* map-side submap slot: a global map has one tree (dense_tsdf.py:112-114) */
+static inline int map_slot(const ora_tsdf* m, int s) { return m->cfg.is_global_map ? 0 : s; }
+
+static inline int in_volume(const ora_tsdf* m, int i, int j, int k)
+{
+    int h = m->N / 2, hz = m->Nz / 2;
+    return i >= -h && i < m->N - h && j >= -h && j < m->N - h && k >= -hz && k < m->Nz - hz;
+}
+
+static brick_t* get_brick(const ora_tsdf* m, int s, int i, int j, int k, int create, int* local)
+{
+    int ui = i + m->N / 2, uj = j + m->N / 2, uk = k + m->Nz / 2;
+    submap_t* sm = &m->sub[s];
+    size_t b = ((size_t)(ui >> 4) * m->nbx + (size_t)(uj >> 4)) * m->nbz + (size_t)(uk >> 4);
+    *local = ((ui & 15) * 16 + (uj & 15)) * 16 + (uk & 15);
+    if (!sm->tab) {
+        if (!create) return NULL;
+        sm->tab = (brick_t**)calloc((size_t)m->nbx * m->nbx * m->nbz, sizeof(brick_t*));
+    }
+    if (!sm->tab[b] && create) sm->tab[b] = (brick_t*)calloc(1, sizeof(brick_t));
+    return sm->tab[b];
+}
+
+static void touch_brick(ora_tsdf* m, brick_t* b)
+{
+    if (b->touched) return;
+    b->touched = 1;
+    if (m->ntouched == m->captouched) {
+        m->captouched = m->captouched ? m->captouched * 2 : 1024;
+        m->touched = (brick_t**)realloc(m->touched, sizeof(brick_t*) * (size_t)m->captouched);
+    }
+    m->touched[m->ntouched++] = b;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* set_pose: mapping_common.py:149-156 + convert_by_base :91-100 (float64, then cast f32)      */
+/* ------------------------------------------------------------------------------------------ */
+static void set_pose(ora_tsdf* m, const double R[9], const double T[3])
+{
+    const double* Rb = m->baseR + m->active * 9;     /* submap_enabled is always True for DenseTSDF */
+    const double* Tb = m->baseT + m->active * 3;
+    double d[3] = { T[0] - Tb[0], T[1] - Tb[1], T[2] - Tb[2] };
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += Rb[k * 3 + i] * R[k * 3 + j];      /* Rb^T @ R */
+            m->inR[i * 3 + j] = (float)acc;
+        }
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) acc += Rb[k * 3 + i] * d[k];
+        m->inT[i] = (float)acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Sensor-centred scratch grid (dense_tsdf.py:64-70): open-addressing hash in insertion order  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int c[3];
+    int cnt;
+    f16 sum[3], z, csum[3];
+} pcl_cell;
+typedef struct {
+    pcl_cell* cells; int n, cap;
+    int* slots; int nslots;            /* power of two */
+} pcl_grid;
+
+static void pcl_init(pcl_grid* g, int64_t expect)
+{
+    int ns = 1024; while (ns < expect * 2 + 16) ns <<= 1;
+    g->nslots = ns; g->slots = (int*)malloc(sizeof(int) * (size_t)ns);
+    for (int i = 0; i < ns; ++i) g->slots[i] = -1;
+    g->cap = (int)(expect > 16 ? expect : 16); g->n = 0;
+    g->cells = (pcl_cell*)calloc((size_t)g->cap, sizeof(pcl_cell));
+}
+static void pcl_free(pcl_grid* g) { free(g->cells); free(g->slots); }
+static pcl_cell* pcl_get(pcl_grid* g, int cx, int cy, int cz)
+{
+    uint64_t hsh = ((uint64_t)(uint32_t)cx * 0x9E3779B1u) ^ ((uint64_t)(uint32_t)cy * 0x85EBCA77u) ^ ((uint64_t)(uint32_t)cz * 0xC2B2AE3Du);
+    hsh ^= hsh >> 29;
+    int mask = g->nslots - 1;
+    int s = (int)(hsh & (uint64_t)mask);
+    for (;;) {
+        int id = g->slots[s];
+        if (id < 0) {
+            if (g->n == g->cap) { g->cap *= 2; g->cells = (pcl_cell*)realloc(g->cells, sizeof(pcl_cell) * (size_t)g->cap); }
+            pcl_cell* c = &g->cells[g->n]; memset(c, 0, sizeof(*c));
+            c->c[0] = cx; c->c[1] = cy; c->c[2] = cz;
+            g->slots[s] = g->n++;
+            return c;
+        }
+        pcl_cell* c = &g->cells[id];
+        if (c->c[0] == cx && c->c[1] == cy && c->c[2] == cz) return c;
+        s = (s + 1) & mask;
+    }
+}
+
+/* process_point  dense_tsdf.py:227-234 : f16 accumulators, value cast to f16 before the add (A5) */
+static int process_point(ora_tsdf* m, pcl_grid* g, const float pt[3], float z, const uint8_t* rgb)
+{
+    int c[3];
+    for (int a = 0; a < 3; ++a) c[a] = rnd_i(pt[a] / m->vs);                       /* mapping_common.py:241-243,264-266 */
+    for (int a = 0; a < 3; ++a) if (c[a] < m->pcl_lo || c[a] >= m->pcl_hi) return 0;   /* outside the 800^3 scratch grid: undefined in the reference, skipped (Q20) */
+    pcl_cell* cell = pcl_get(g, c[0], c[1], c[2]);
+    cell->cnt += 1;
+    for (int a = 0; a < 3; ++a) cell->sum[a] = hadd(cell->sum[a], H(pt[a]));
+    cell->z = hadd(cell->z, H(z));
+    if (rgb) for (int a = 0; a < 3; ++a) cell->csum[a] = hadd(cell->csum[a], H((float)rgb[a]));
+    return 1;
+}
+
+/* Taichi struct-for order over the sensor grid: pointer block lexicographic, then dense cell (k fastest) (A6) */
+static int g_cmp_lo, g_cmp_blk, g_cmp_nblk;
+static int cmp_pcl_order(const void* a, const void* b)
+{
+    const pcl_cell* x = (const pcl_cell*)a; const pcl_cell* y = (const pcl_cell*)b;
+    int64_t kx = 0, ky = 0, lx = 0, ly = 0;
+    for (int d = 0; d < 3; ++d) {
+        int ux = x->c[d] - g_cmp_lo, uy = y->c[d] - g_cmp_lo;
+        kx = kx * g_cmp_nblk + ux / g_cmp_blk; ky = ky * g_cmp_nblk + uy / g_cmp_blk;
+        lx = lx * g_cmp_blk + ux % g_cmp_blk;  ly = ly * g_cmp_blk + uy % g_cmp_blk;
+    }
+    if (kx != ky) return kx < ky ? -1 : 1;
+    if (lx != ly) return lx < ly ? -1 : 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* process_new_pcl  dense_tsdf.py:236-270                                                      */
+/* ------------------------------------------------------------------------------------------ */
+static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats* st)
+{
+    const int tex = m->cfg.texture_enabled;
+    const int s = map_slot(m, m->active);                                           /* :238 */
+    g_cmp_lo = m->pcl_lo; g_cmp_blk = m->pcl_blk; g_cmp_nblk = (m->pcl_hi - m->pcl_lo) / m->pcl_blk;
+    qsort(g->cells, (size_t)g->n, sizeof(pcl_cell), cmp_pcl_order);
+    const float vs = m->vs;
+    m->ntouched = 0;
+    for (int r = 0; r < g->n; ++r) {
+        pcl_cell* cell = &g->cells[r];
+        st->v_pcl++;
+        f16 c = H((float)cell->cnt);                                                 /* :242 */
+        f16 p[3]; for (int a = 0; a < 3; ++a) p[a] = hdiv(cell->sum[a], c);           /* :243 */
+        f16 len = hsqrt(hadd(hadd(hmul(p[0], p[0]), hmul(p[1], p[1])), hmul(p[2], p[2])));   /* :244 */
+        f16 zbar = hdiv(cell->z, c);                                                 /* :247 */
+        f16 zz = hmul(zbar, zbar);
+        float lenf = F(len), zzf = F(zz);
+        if (!(lenf > 0.0f) || !isfinite(lenf) || !(zzf > 0.0f) || !isfinite(zzf)) { st->v_skipped++; continue; }   /* degenerate ray: NaN/inf in the reference; skipped */
+        f16 dir[3]; for (int a = 0; a < 3; ++a) dir[a] = hdiv(p[a], len);            /* :245 */
+        float pf[3], dirf[3], P[3];
+        for (int a = 0; a < 3; ++a) { pf[a] = F(p[a]); dirf[a] = F(dir[a]); P[a] = pf[a] + m->inT[a]; }   /* :246 */
+        {   /* :248  occupy[sxyz_to_ijk(submap_id, pos_p)] = 1 */
+            int oi = rnd_i(P[0] / vs), oj = rnd_i(P[1] / vs), ok = rnd_i(P[2] / vs);
+            if (in_volume(m, oi, oj, ok)) { int l; brick_t* b = get_brick(m, s, oi, oj, ok, 1, &l); b->occ[l] = 1; }
+        }
+        float nf = lenf / vs + m->internal_f;                                        /* :249 */
+        if (m->max_steps_f < nf) nf = m->max_steps_f;
+        int n = (int)nf;
+        float w = 1.0f / zzf;                                                        /* w_x_p :216-225 with d>=0 (Q3) */
+        if (w > W_CLAMP) w = W_CLAMP;
+        int64_t qden = to_fix(w);
+        f16 col[3] = {0, 0, 0};
+        if (tex) for (int a = 0; a < 3; ++a) col[a] = H(F(hdiv(cell->csum[a], c)) / 255.0f);   /* :269 */
+        float jf = 0.0f;
+        for (int jj = 0; jj < n; ++jj) {                                              /* :251-269 */
+            jf += 1.0f;
+            float x[3]; int xi[3];
+            for (int a = 0; a < 3; ++a) { x[a] = (dirf[a] * jf) * vs + m->inT[a]; xi[a] = rnd_i(x[a] / vs); }   /* :253-254 */
+            if (!in_volume(m, xi[0], xi[1], xi[2])) { st->steps_oob++; continue; }
+            float v[3] = { P[0] - x[0], P[1] - x[1], P[2] - x[2] };                    /* :258 */
+            float dist = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);            /* :259 */
+            float dot = (v[0] * pf[0] + v[1] * pf[1]) + v[2] * pf[2];
+            float sd = dist * (float)sgn_f(dot);                                       /* :260 */
+            int l; brick_t* b = get_brick(m, s, xi[0], xi[1], xi[2], 1, &l);
+            touch_brick(m, b);
+            st->steps++;
+            b->num[l] += to_fix(w * sd);
+            b->den[l] += qden;
+            if (tex) { b->win[l] = (uint32_t)r + 1u; }
+            if (mode == ORA_FAITHFUL) {
+                f16 T0 = b->tsdf[l], W0 = b->w[l];
+                b->tsdf[l] = H((F(hmul(T0, W0)) + w * sd) / (F(W0) + w));             /* :264 */
+                b->obs[l] = 1;                                                         /* :265 */
+                float wn = F(W0) + w; if (WMAX < wn) wn = WMAX;
+                b->w[l] = H(wn);                                                       /* :267 */
+                if (tex) for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];             /* :268-269 */
+            } else if (tex) {
+                /* BATCHED colour: the last ray in struct-for order wins (deterministic stand-in for the race) */
+                for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];
+            }
+        }
+    }
+    /* finalize: apply the per-frame sums once per touched voxel (BATCHED) and clear scratch */
+    st->bricks += m->ntouched;
+    for (int t = 0; t < m->ntouched; ++t) {
+        brick_t* b = m->touched[t];
+        for (int l = 0; l < BRK3; ++l) {
+            if (b->den[l] == 0) continue;
+            st->unique++;
+            if (mode == ORA_BATCHED) {
+                float num = from_fix(b->num[l]), den = from_fix(b->den[l]);
+                f16 T0 = b->tsdf[l], W0 = b->w[l];
+                b->tsdf[l] = H((F(hmul(T0, W0)) + num) / (F(W0) + den));
+                float wn = F(W0) + den; if (WMAX < wn) wn = WMAX;
+                b->w[l] = H(wn);
+                b->obs[l] = 1;
+            }
+            b->num[l] = 0; b->den[l] = 0; b->win[l] = 0;
+        }
+        b->touched = 0;
+    }
+    m->ntouched = 0;
+}
+
+/* recast_depth_to_map  dense_tsdf.py:162-165,188-214 */
+int ora_tsdf_integrate_depth(ora_tsdf* m, int mode, const double R[9], const double T[3],
+                             const uint16_t* depth, int h, int w,
+                             const uint8_t* tex, int th, int tw, ora_frame_stats* st_out)
+{
+    ora_frame_stats st; memset(&st, 0, sizeof(st));
+    set_pose(m, R, T);
+    const int step = m->cfg.recast_step;
+    const int hh = (int)((float)h / (float)step), ww = (int)((float)w / (float)step);   /* :192,:194 (A3) */
+    pcl_grid g; pcl_init(&g, (int64_t)hh * ww);
+    const int use_tex = m->cfg.texture_enabled && tex;
+    for (int jj = 0; jj < hh; ++jj) {
+        int j = jj * step;
+        for (int ii = 0; ii < ww; ++ii) {
+            int i = ii * step;
+            st.p_used++;
+            uint16_t d = depth[(size_t)j * w + i];
+            if (d == 0) continue;                                                      /* :196 */
+            if ((float)d > m->thr_max || (float)d < m->thr_min) continue;              /* :198 */
+            float dep = (float)d / 1000.0f;                                            /* :201 */
+            float pt[3] = { ((float)i - m->cx) * dep / m->fx, ((float)j - m->cy) * dep / m->fy, dep };   /* mapping_common.py:37-40 */
+            float pm[3];
+            for (int a = 0; a < 3; ++a) pm[a] = (m->inR[a * 3] * pt[0] + m->inR[a * 3 + 1] * pt[1]) + m->inR[a * 3 + 2] * pt[2];   /* :203 */
+            const uint8_t* rgb = NULL;
+            if (use_tex) {
+                if (m->cfg.color_same_proj) rgb = tex + ((size_t)j * tw + i) * 3;      /* :206 */
+                else {                                                                /* mapping_common.py:43-58 */
+                    int ci = (int)((((float)i - m->cx) / m->fx) * m->fxc + m->cxc);
+                    int cj = (int)((((float)j - m->cy) / m->fy) * m->fyc + m->cyc);
+                    /* the reference passes (w=texture.shape[1], h=texture.shape[0]) but tests color_i against h and color_j against w (:56) */
+                    if (ci < 0 || ci >= th || cj < 0 || cj >= tw) { ci = 0; cj = 0; }
+                    if (cj >= th || ci >= tw) { ci = 0; cj = 0; }                       /* keep the read inside the buffer */
+                    rgb = tex + ((size_t)cj * tw + ci) * 3;
+                }
+            }
+            if (process_point(m, &g, pm, dep, rgb)) st.p_valid++; else st.p_oob++;
+        }
+    }
+    process_new_pcl(m, &g, mode, &st);
+    pcl_free(&g);
+    if (st_out) *st_out = st;
+    return 0;
+}
+
+/* recast_pcl_to_map  dense_tsdf.py:157-160,167-186 */
+int ora_tsdf_integrate_points(ora_tsdf* m, int mode, const double R[9], const double T[3],
+                              const float* xyz, const uint8_t* rgb, int64_t n, ora_frame_stats* st_out)
+{
+    ora_frame_stats st; memset(&st, 0, sizeof(st));
+    set_pose(m, R, T);
+    pcl_grid g; pcl_init(&g, n);
+    const int use_tex = m->cfg.texture_enabled && rgb;
+    for (int64_t idx = 0; idx < n; ++idx) {
+        st.p_used++;
+        const float* pt = xyz + idx * 3;
+        float pm[3];
+        for (int a = 0; a < 3; ++a) pm[a] = (m->inR[a * 3] * pt[0] + m->inR[a * 3 + 1] * pt[1]) + m->inR[a * 3 + 2] * pt[2];   /* :175 */
+        float len = sqrtf((pm[0] * pm[0] + pm[1] * pm[1]) + pm[2] * pm[2]);            /* :176 */
+        if (!(len < m->max_ray_f)) continue;                                           /* :177 */
+        if (process_point(m, &g, pm, len, use_tex ? rgb + idx * 3 : NULL)) st.p_valid++; else st.p_oob++;   /* :183-185 (z := range, Q5) */
+    }
+    process_new_pcl(m, &g, mode, &st);
+    pcl_free(&g);
+    if (st_out) *st_out = st;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* iteration helpers                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+typedef void (*voxel_fn)(void* ctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l);
+static void for_each_voxel(const ora_tsdf* m, int s, voxel_fn fn, void* ctx)
+{
+    const submap_t* sm = &m->sub[s];
+    if (!sm->tab) return;
+    for (int bi = 0; bi < m->nbx; ++bi) for (int li = 0; li < 16; ++li)
+    for (int bj = 0; bj < m->nbx; ++bj) for (int lj = 0; lj < 16; ++lj)
+    for (int bk = 0; bk < m->nbz; ++bk) {
+        const brick_t* b = sm->tab[((size_t)bi * m->nbx + bj) * m->nbz + bk];
+        if (!b) continue;
+        for (int lk = 0; lk < 16; ++lk) {
+            int l = (li * 16 + lj) * 16 + lk;
+            fn(ctx, m, s, bi * 16 + li - m->N / 2, bj * 16 + lj - m->N / 2, bk * 16 + lk - m->Nz / 2, b, l);
+        }
+    }
+}
+
+/* count_active  dense_tsdf.py:412-423 */
+static void cnt_fn(void* ctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
+{ (void)m; (void)s; (void)i; (void)j; (void)k; if (b->obs[l] > 0) ++*(int64_t*)ctx; }
+int64_t ora_tsdf_count_active(const ora_tsdf* m)
+{ int64_t n = 0; for_each_voxel(m, map_slot(m, m->active), cnt_fn, &n); return n; }
+
+/* to_numpy  dense_tsdf.py:425-440 (we emit in sorted (i,j,k) order) */
+typedef struct { int16_t* idx; uint16_t* t; uint16_t* w; int8_t* occ; uint16_t* col; int64_t cap, n; int occ_only; } exp_ctx;
+static void exp_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
+{
+    (void)m; (void)s;
+    exp_ctx* c = (exp_ctx*)vctx;
+    if (c->occ_only ? (b->occ[l] == 0) : (b->obs[l] <= 0)) return;
+    if (c->n < c->cap) {
+        int64_t n = c->n;
+        c->idx[n * 3] = (int16_t)i; c->idx[n * 3 + 1] = (int16_t)j; c->idx[n * 3 + 2] = (int16_t)k;
+        if (c->t) c->t[n] = b->tsdf[l];
+        if (c->w) c->w[n] = b->w[l];
+        if (c->occ) c->occ[n] = b->occ[l];
+        if (c->col) for (int a = 0; a < 3; ++a) c->col[n * 3 + a] = b->col[l][a];
+    }
+    c->n++;
+}
+int64_t ora_tsdf_export_sparse(const ora_tsdf* m, int16_t* idx, uint16_t* t, uint16_t* w, int8_t* occ, uint16_t* col, int64_t cap)
+{ exp_ctx c = { idx, t, w, occ, col, cap, 0, 0 }; for_each_voxel(m, map_slot(m, m->active), exp_fn, &c); return c.n; }
+int64_t ora_tsdf_export_occupied(const ora_tsdf* m, int16_t* idx, int8_t* occ, int64_t cap)
+{ exp_ctx c = { idx, NULL, NULL, occ, NULL, cap, 0, 1 }; for_each_voxel(m, map_slot(m, m->active), exp_fn, &c); return c.n; }
+
+/* load_numpy  dense_tsdf.py:442-454 */
+int ora_tsdf_import_sparse(ora_tsdf* m, int sid, const int16_t* idx, const uint16_t* t, const uint16_t* w,
+                           const int8_t* occ, const uint16_t* col, int64_t n)
+{
+    int s = map_slot(m, sid);
+    for (int64_t q = 0; q < n; ++q) {
+        int i = idx[q * 3], j = idx[q * 3 + 1], k = idx[q * 3 + 2];
+        if (!in_volume(m, i, j, k)) continue;
+        int l; brick_t* b = get_brick(m, s, i, j, k, 1, &l);
+        b->tsdf[l] = t[q]; b->w[l] = w[q]; b->occ[l] = occ ? occ[q] : 0;
+        if (col && m->cfg.texture_enabled) for (int a = 0; a < 3; ++a) b->col[l][a] = col[q * 3 + a];
+        b->obs[l] = 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* colormap: matplotlib cm.jet(i/1024.0)  (mapping_common.py:158-163)                          */
+/* ------------------------------------------------------------------------------------------ */
+static double interp_seg(const double (*seg)[2], int n, double x)
+{
+    if (x <= seg[0][0]) return seg[0][1];
+    for (int i = 1; i < n; ++i) if (x <= seg[i][0]) {
+        double t = (x - seg[i - 1][0]) / (seg[i][0] - seg[i - 1][0]);
+        return seg[i - 1][1] + t * (seg[i][1] - seg[i - 1][1]);
+    }
+    return seg[n - 1][1];
+}
+static void jet_colormap(float cm[1024][3])
+{
+    static const double r[][2] = { {0, 0}, {0.35, 0}, {0.66, 1}, {0.89, 1}, {1, 0.5} };
+    static const double g[][2] = { {0, 0}, {0.125, 0}, {0.375, 1}, {0.64, 1}, {0.91, 0}, {1, 0} };
+    static const double b[][2] = { {0, 0.5}, {0.11, 1}, {0.34, 1}, {0.65, 0}, {1, 0} };
+    for (int i = 0; i < 1024; ++i) {
+        /* LinearSegmentedColormap with N=256: cm.jet(x) -> lut[int(x*256)], lut[k] sampled at k/255 */
+        int k = (int)((double)i / 1024.0 * 256.0); if (k > 255) k = 255;
+        double x = (double)k / 255.0;
+        cm[i][0] = (float)interp_seg(r, 5, x); cm[i][1] = (float)interp_seg(g, 6, x); cm[i][2] = (float)interp_seg(b, 5, x);
+    }
+}
+/* color_from_colomap  mapping_common.py:216-219 */
+static const float* colormap_at(const ora_tsdf* m, float z, float lo, float hi)
+{
+    float t = ((z - lo) / (hi - lo)) * 1023.0f;
+    if (t > 1023.0f) t = 1023.0f;
+    if (!(t > 0.0f)) t = 0.0f;
+    return m->colormap[(int)t];
+}
+
+static void voxel_xyz(const ora_tsdf* m, int s, int i, int j, int k, float out[3])
+{
+    float p[3] = { (float)i * m->vs, (float)j * m->vs, (float)k * m->vs };           /* mapping_common.py:221-227 */
+    if (m->cfg.is_global_map) { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; return; }
+    const float* R = m->baseRf + s * 9; const float* T = m->baseTf + s * 3;           /* :229-232 */
+    for (int a = 0; a < 3; ++a) out[a] = ((R[a * 3] * p[0] + R[a * 3 + 1] * p[1]) + R[a * 3 + 2] * p[2]) + T[a];
+}
+
+/* cvt_TSDF_surface_to_voxels_kernel  dense_tsdf.py:339-365 */
+typedef struct { float* xyz; float* rgb; float* val; int64_t cap, n; float z; float dz; int idx; } surf_ctx;
+static void surf_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
+{
+    surf_ctx* c = (surf_ctx*)vctx;
+    if (b->obs[l] != 1) return;
+    if (!(fabsf(F(b->tsdf[l])) < m->surf_thres)) return;
+    float xyz[3]; voxel_xyz(m, m->active, i, j, k, xyz); (void)s;
+    if (xyz[2] > m->disp_ceiling || xyz[2] < m->disp_floor) return;
+    if (c->n < c->cap) {
+        for (int a = 0; a < 3; ++a) c->xyz[c->n * 3 + a] = xyz[a];
+        if (c->rgb) {
+            if (m->cfg.texture_enabled) for (int a = 0; a < 3; ++a) c->rgb[c->n * 3 + a] = F(b->col[l][a]);
+            else { const float* cc = colormap_at(m, xyz[2], m->disp_floor, m->disp_ceiling); for (int a = 0; a < 3; ++a) c->rgb[c->n * 3 + a] = cc[a]; }
+        }
+    }
+    c->n++;
+}
+int64_t ora_tsdf_surface_voxels(const ora_tsdf* m, float* xyz, float* rgb, int64_t cap)
+{ surf_ctx c = { xyz, rgb, NULL, cap, 0, 0, 0, 0 }; for_each_voxel(m, map_slot(m, m->active), surf_fn, &c); return c.n; }
+
+/* cvt_TSDF_to_voxels_slice_kernel  dense_tsdf.py:367-385 */
+static void slice_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
+{
+    surf_ctx* c = (surf_ctx*)vctx; (void)s;
+    if (b->obs[l] <= 0) return;
+    if (!((float)c->idx - c->dz < (float)k && (float)k < (float)c->idx + c->dz)) return;   /* :377 */
+    if (c->n < c->cap) {
+        float xyz[3]; voxel_xyz(m, m->active, i, j, k, xyz);
+        for (int a = 0; a < 3; ++a) c->xyz[c->n * 3 + a] = xyz[a];
+        float t = F(b->tsdf[l]);
+        if (c->val) c->val[c->n] = t;
+        if (c->rgb) { const float* cc = colormap_at(m, t, -0.5f, 0.5f); for (int a = 0; a < 3; ++a) c->rgb[c->n * 3 + a] = cc[a]; }
+    }
+    c->n++;
+}
+int64_t ora_tsdf_slice_voxels(const ora_tsdf* m, float z, float dz, float* xyz, float* val, float* rgb, int64_t cap)
+{
+    /* slice_z is an f16 field (dense_tsdf.py:72); _index = int(z/voxel_scale) (:370) */
+    float zq = F(H(z));
+    surf_ctx c = { xyz, rgb, val, cap, 0, zq, dz, (int)(zq / m->vs) };
+    for_each_voxel(m, map_slot(m, m->active), slice_fn, &c); return c.n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fuse_submaps  dense_tsdf.py:272-318                                                         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { ora_tsdf* g; const ora_tsdf* sub; int mode; } fuse_ctx;
+static void fuse_fn(void* vctx, const ora_tsdf* sm, int s, int i, int j, int k, const brick_t* sb, int sl)
+{
+    fuse_ctx* c = (fuse_ctx*)vctx; ora_tsdf* g = c->g; (void)sm;
+    if (sb->obs[sl] <= 0) return;                                                     /* :292 */
+    const float vs = g->vs;
+    float p[3] = { (float)i * vs, (float)j * vs, (float)k * vs };
+    const float* R = g->baseRf + s * 9; const float* T = g->baseTf + s * 3;           /* :293 uses the GLOBAL map's pose table */
+    float xyz[3], f[3]; int lo[3];
+    for (int a = 0; a < 3; ++a) xyz[a] = ((R[a * 3] * p[0] + R[a * 3 + 1] * p[1]) + R[a * 3 + 2] * p[2]) + T[a];
+    for (int a = 0; a < 3; ++a) { f[a] = xyz[a] / vs; lo[a] = (int)floorf(f[a]); }    /* :294-296 */
+    float tsdf = F(sb->tsdf[sl]), wsrc = F(sb->w[sl]);
+    for (int di = 0; di < 2; ++di) for (int dj = 0; dj < 2; ++dj) for (int dk = 0; dk < 2; ++dk) {
+        if (di + dj + dk == 0) continue;                                              /* :300 (Q8) */
+        int ci = lo[0] + di, cj = lo[1] + dj, ck = lo[2] + dk;
+        float wt = ((1.0f - fabsf((float)ci - f[0])) * (1.0f - fabsf((float)cj - f[1]))) * (1.0f - fabsf((float)ck - f[2]));   /* :303 */
+        float w_tsdf = wsrc * wt;                                                     /* :307 */
+        if (!in_volume(g, ci, cj, ck)) continue;
+        int l; brick_t* b = get_brick(g, 0, ci, cj, ck, 1, &l);
+        if (c->mode == ORA_FAITHFUL) {                                                /* fuse_with_interploation :272-280 */
+            float w_new = w_tsdf + F(b->w[l]);
+            b->tsdf[l] = H((F(hmul(b->w[l], b->tsdf[l])) + w_tsdf * tsdf) / w_new);
+            b->w[l] = H(w_new);
+            b->obs[l] = 1;
+            b->occ[l] = (int8_t)(b->occ[l] + sb->occ[sl]);
+        } else {
+            touch_brick(g, b);
+            b->num[l] += to_fix(w_tsdf * tsdf);
+            b->den[l] += to_fix(w_tsdf);
+            b->win[l] += 1;                       /* contribution count: observed even if the weights quantise to 0 */
+            b->occ[l] = (int8_t)(b->occ[l] + sb->occ[sl]);
+        }
+    }
+}
+int ora_tsdf_fuse_submaps(ora_tsdf* g, const ora_tsdf* sub, int mode)
+{
+    ora_tsdf_reset(g);                                                                 /* :313 */
+    int nsub = sub->active;                                                            /* :315 num_submaps = submaps.active_submap_id */
+    for (int s = 0; s < nsub && s < g->cfg.max_submap_num; ++s) {                      /* :286-290 refresh f32 pose fields from the *_np tables */
+        for (int a = 0; a < 9; ++a) g->baseRf[s * 9 + a] = (float)g->baseR[s * 9 + a];
+        for (int a = 0; a < 3; ++a) g->baseTf[s * 3 + a] = (float)g->baseT[s * 3 + a];
+    }
+    fuse_ctx c = { g, sub, mode };
+    g->ntouched = 0;
+    for (int s = 0; s < sub->nsub; ++s) for_each_voxel(sub, s, fuse_fn, &c);           /* :291 every cell of every submap */
+    if (mode == ORA_BATCHED) {
+        for (int t = 0; t < g->ntouched; ++t) {
+            brick_t* b = g->touched[t];
+            for (int l = 0; l < BRK3; ++l) {
+                if (b->win[l] == 0) continue;
+                float num = from_fix(b->num[l]), den = from_fix(b->den[l]);
+                b->tsdf[l] = H(num / den);                /* global map starts empty: T0 = W0 = 0 */
+                b->w[l] = H(den);
+                b->obs[l] = 1;
+                b->num[l] = 0; b->den[l] = 0; b->win[l] = 0;
+            }
+            b->touched = 0;
+        }
+        g->ntouched = 0;
+    }
+    return 0;
+}
+
+#include "mc_tables.h"
+
+/* ------------------------------------------------------------------------------------------ */
+/* marching cubes  marching_cube_mesher.py:44-187                                              */
+/* ------------------------------------------------------------------------------------------ */
+static inline float rd_tsdf(const ora_tsdf* m, int s, int i, int j, int k, int* obs)
+{
+    if (!in_volume(m, i, j, k)) { if (obs) *obs = 0; return 0.0f; }
+    int l; brick_t* b = get_brick(m, s, i, j, k, 0, &l);
+    if (!b) { if (obs) *obs = 0; return 0.0f; }
+    if (obs) *obs = b->obs[l];
+    return F(b->tsdf[l]);
+}
+static inline f16 rd_tsdf_h(const ora_tsdf* m, int s, int i, int j, int k)
+{
+    if (!in_volume(m, i, j, k)) return 0;
+    int l; brick_t* b = get_brick(m, s, i, j, k, 0, &l);
+    return b ? b->tsdf[l] : (f16)0;
+}
+static inline const f16* rd_col(const ora_tsdf* m, int s, int i, int j, int k)
+{
+    static const f16 zero[3] = {0, 0, 0};
+    if (!in_volume(m, i, j, k)) return zero;
+    int l; brick_t* b = get_brick(m, s, i, j, k, 0, &l);
+    return b ? b->col[l] : zero;
+}
+
+/* generate_normal :84-93 -- f16 differences, f16 normalisation (invlen = 1/norm; invlen*v) */
+static void gen_normal(const ora_tsdf* m, int s, const float p[3], float out[3])
+{
+    int q[3]; for (int a = 0; a < 3; ++a) q[a] = (int)rnd_f(p[a]);
+    f16 n[3];
+    n[0] = hsub(rd_tsdf_h(m, s, q[0] + 1, q[1], q[2]), rd_tsdf_h(m, s, q[0] - 1, q[1], q[2]));
+    n[1] = hsub(rd_tsdf_h(m, s, q[0], q[1] + 1, q[2]), rd_tsdf_h(m, s, q[0], q[1] - 1, q[2]));
+    n[2] = hsub(rd_tsdf_h(m, s, q[0], q[1], q[2] + 1), rd_tsdf_h(m, s, q[0], q[1], q[2] - 1));
+    f16 nrm = hsqrt(hadd(hadd(hmul(n[0], n[0]), hmul(n[1], n[1])), hmul(n[2], n[2])));
+    f16 inv = H(1.0f / F(nrm));
+    for (int a = 0; a < 3; ++a) out[a] = F(hmul(inv, n[a]));
+}
+
+#define MC_EPS 1e-6f
+static const int MC_GRID[8][3] = { {0,0,0},{1,0,0},{1,1,0},{0,1,0},{0,0,1},{1,0,1},{1,1,1},{0,1,1} };   /* :196-206 */
+static const int MC_EDGE[12][2] = { {0,1},{1,2},{2,3},{3,0},{4,5},{5,6},{6,7},{7,4},{0,4},{1,5},{2,6},{3,7} };   /* :208-221 */
+
+typedef struct { const ora_tsdf* m; int step; float thres; int64_t max_tri, n; float* v; float* nrm; float* col; int s; } mc_ctx;
+static void mc_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
+{
+    mc_ctx* c = (mc_ctx*)vctx;
+    if (!(b->obs[l] > 0 && F(b->tsdf[l]) < c->thres)) return;                           /* :184 */
+    const int step = c->step;
+    float val[8]; int bad = 0;
+    for (int q = 0; q < 8; ++q) {                                                        /* :133-138 */
+        int o; val[q] = rd_tsdf(m, s, i + MC_GRID[q][0] * step, j + MC_GRID[q][1] * step, k + MC_GRID[q][2] * step, &o);
+        if (o == 0) bad = 1;
+    }
+    if (bad) return;
+    int cube = 0; for (int q = 0; q < 8; ++q) if (val[q] < 0.0f) cube |= 1 << q;         /* :141-144 */
+    int flags = mc_edge_table(cube);                                                      /* :146 */
+    if (!flags) return;
+    float vert[12][3]; float vcol[12][3]; memset(vert, 0, sizeof(vert)); memset(vcol, 0, sizeof(vcol));
+    for (int e = 0; e < 12; ++e) if (flags & (1 << e)) {                                  /* :151-172 */
+        const int* g0 = MC_GRID[MC_EDGE[e][0]]; const int* g1 = MC_GRID[MC_EDGE[e][1]];
+        int a0[3] = { i + g0[0] * step, j + g0[1] * step, k + g0[2] * step };
+        int a1[3] = { i + g1[0] * step, j + g1[1] * step, k + g1[2] * step };
+        float v0 = val[MC_EDGE[e][0]], v1 = val[MC_EDGE[e][1]];
+        float p0[3] = { (float)a0[0], (float)a0[1], (float)a0[2] }, p1[3] = { (float)a1[0], (float)a1[1], (float)a1[2] };
+        float mu = 0.0f;
+        if (fabsf(0.0f - v0) < MC_EPS) { for (int a = 0; a < 3; ++a) vert[e][a] = p0[a]; }           /* vertexInterp :44-60 */
+        else if (fabsf(0.0f - v1) < MC_EPS) { for (int a = 0; a < 3; ++a) vert[e][a] = p1[a]; }
+        else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) vert[e][a] = p0[a] + mu * (p1[a] - p0[a]); }
+        if (c->col) {                                                                    /* vertexInterp_color :62-82 (Q13) */
+            const f16* c0 = rd_col(m, s, a0[0], a0[1], a0[2]); const f16* c1 = rd_col(m, s, a1[0], a1[1], a1[2]);
+            float c0f[3] = { F(c0[0]), F(c0[1]), F(c0[2]) }, c1f[3] = { F(c1[0]), F(c1[1]), F(c1[2]) };
+            for (int a = 0; a < 3; ++a) vcol[e][a] = c0f[a];
+            if (c0f[0] == 0.0f) { for (int a = 0; a < 3; ++a) vcol[e][a] = c1f[a]; }
+            else if (!(c1f[0] == 0.0f)) { for (int a = 0; a < 3; ++a) vcol[e][a] = c0f[a] + mu * (c1f[a] - c0f[a]); }
+        }
+    }
+    for (int t = 0; t < 5; ++t) {                                                         /* :173-177 */
+        int e0 = mc_tri_table(cube, t * 3);
+        if (e0 < 0) continue;
+        int64_t idx = c->n++;                                                            /* :114 */
+        if (idx < c->max_tri) {                                                          /* Q10: clamp by returned index */
+            for (int q = 0; q < 3; ++q) {
+                int e = mc_tri_table(cube, t * 3 + q);
+                for (int a = 0; a < 3; ++a) c->v[(idx * 3 + q) * 3 + a] = vert[e][a] * m->vs;     /* :41-42,:97-99 */
+                gen_normal(m, s, vert[e], c->nrm + (idx * 3 + q) * 3);                   /* :100-102 */
+                if (c->col) for (int a = 0; a < 3; ++a) c->col[(idx * 3 + q) * 3 + a] = vcol[e][a];
+            }
+        }
+    }
+}
+int64_t ora_mesh_generate(const ora_tsdf* m, int step, float surface_thres, int64_t max_tri, float* verts, float* normals, float* colors)
+{
+    /* generate_mesh_kernel iterates every (s,i,j,k) of the field (:183): all submaps of a collection */
+    mc_ctx c = { m, step, surface_thres, max_tri, 0, verts, normals, m->cfg.texture_enabled ? colors : NULL, 0 };
+    for (int s = 0; s < m->nsub; ++s) for_each_voxel(m, s, mc_fn, &c);
+    return c.n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ESDF: definition from dense_esdf.py:228-333 evaluated non-incrementally         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { float d; int32_t v; } heap_item;
+typedef struct { heap_item* a; int n, cap; } heap_t;
+static void heap_push(heap_t* h, float d, int32_t v)
+{
+    if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 4096; h->a = (heap_item*)realloc(h->a, sizeof(heap_item) * (size_t)h->cap); }
+    int i = h->n++;
+    while (i > 0) { int p = (i - 1) / 2; if (h->a[p].d <= d) break; h->a[i] = h->a[p]; i = p; }
+    h->a[i].d = d; h->a[i].v = v;
+}
+static heap_item heap_pop(heap_t* h)
+{
+    heap_item top = h->a[0]; heap_item last = h->a[--h->n];
+    int i = 0;
+    for (;;) { int c = 2 * i + 1; if (c >= h->n) break; if (c + 1 < h->n && h->a[c + 1].d < h->a[c].d) c++; if (last.d <= h->a[c].d) break; h->a[i] = h->a[c]; i = c; }
+    h->a[i] = last; return top;
+}
+typedef struct { int16_t* idx; float* t; int8_t* obs; int64_t n, cap; } esdf_collect;
+static void esdf_collect_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
+{
+    (void)m; (void)s; esdf_collect* c = (esdf_collect*)vctx;
+    if (b->obs[l] <= 0) return;
+    if (c->n < c->cap) { c->idx[c->n * 3] = (int16_t)i; c->idx[c->n * 3 + 1] = (int16_t)j; c->idx[c->n * 3 + 2] = (int16_t)k; c->t[c->n] = F(b->tsdf[l]); }
+    c->n++;
+}
+int64_t ora_esdf_compute(const ora_tsdf* m, float gamma, float max_dist, int16_t* idx, float* esdf, int64_t cap)
+{
+    /* observed voxels are the graph nodes; sources are the fixed band |TSDF| < gamma with ESDF := TSDF
+     * (dense_esdf.py:228-230,313-317); every other observed voxel starts at sign(TSDF)*max_dist (:325,:329)
+     * and is lowered in magnitude through its 26-neighbourhood with edge cost |dir|*voxel (:282-297). */
+    esdf_collect c = { idx, esdf, NULL, 0, cap };
+    float* tbuf = (float*)malloc(sizeof(float) * (size_t)(cap > 0 ? cap : 1)); c.t = tbuf;
+    for_each_voxel(m, map_slot(m, m->active), esdf_collect_fn, &c);
+    int64_t n = c.n < cap ? c.n : cap;
+    /* dense lookup from voxel -> node id */
+    size_t vol = (size_t)m->N * m->N * m->Nz;
+    int32_t* id = (int32_t*)malloc(sizeof(int32_t) * vol); memset(id, 0xff, sizeof(int32_t) * vol);
+    #define VID(i,j,k) ((((size_t)((i) + m->N / 2)) * m->N + (size_t)((j) + m->N / 2)) * m->Nz + (size_t)((k) + m->Nz / 2))
+    for (int64_t q = 0; q < n; ++q) id[VID(idx[q * 3], idx[q * 3 + 1], idx[q * 3 + 2])] = (int32_t)q;
+    float* mag = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    heap_t hp = { NULL, 0, 0 };
+    for (int64_t q = 0; q < n; ++q) {
+        if (fabsf(tbuf[q]) < gamma) { mag[q] = fabsf(tbuf[q]); heap_push(&hp, mag[q], (int32_t)q); }
+        else mag[q] = max_dist;
+    }
+    const float vs = m->vs;
+    while (hp.n) {
+        heap_item it = heap_pop(&hp);
+        if (it.d > mag[it.v]) continue;
+        int i = idx[it.v * 3], j = idx[it.v * 3 + 1], k = idx[it.v * 3 + 2];
+        int sg = sgn_f(tbuf[it.v]); if (sg == 0) sg = 1;
+        for (int di = -1; di <= 1; ++di) for (int dj = -1; dj <= 1; ++dj) for (int dk = -1; dk <= 1; ++dk) {
+            if (!di && !dj && !dk) continue;
+            int ni = i + di, nj = j + dj, nk = k + dk;
+            if (!in_volume(m, ni, nj, nk)) continue;
+            int32_t nid = id[VID(ni, nj, nk)];
+            if (nid < 0) continue;
+            int nsg = sgn_f(tbuf[nid]); if (nsg == 0) nsg = 1;
+            if (nsg != sg) continue;             /* distances only propagate within one side of the surface (:289,:295) */
+            float step = sqrtf((float)(di * di + dj * dj + dk * dk)) * vs;               /* :286 */
+            float nd = it.d + step;
+            if (nd < mag[nid]) { mag[nid] = nd; heap_push(&hp, nd, nid); }
+        }
+    }
+    for (int64_t q = 0; q < n; ++q) {
+        if (fabsf(tbuf[q]) < gamma) esdf[q] = tbuf[q];
+        else { int sg = sgn_f(tbuf[q]); esdf[q] = (float)sg * mag[q]; }
+    }
+    free(id); free(mag); free(hp.a); free(tbuf);
+    return c.n;
+    #undef VID
+}

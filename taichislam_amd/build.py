@@ -1,0 +1,60 @@
+"""Builds libtaichislam_hip.so (the HIP/CDNA4 kernels + C-ABI) in-tree with hipcc for gfx950."""
+import glob
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIBDIR, "libtaichislam_hip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               # bit-exact parity with the CPU oracle: no FMA contraction, IEEE divide/sqrt, keep denormals
+               "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _deps():
+    return sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in _deps())
+
+
+def build_library(force=False, verbose=False):
+    """Compile every csrc/*.hip into lib/libtaichislam_hip.so.  Returns the library path."""
+    if not force and not is_stale():
+        return LIB
+    cc = _hipcc()
+    if cc is None:
+        if os.path.exists(LIB):
+            return LIB          # GPU box without a toolchain: use the prebuilt library that travelled with the repo
+        raise RuntimeError("hipcc not found and no prebuilt libtaichislam_hip.so present")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [cc] + HIPCC_FLAGS + sources() + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

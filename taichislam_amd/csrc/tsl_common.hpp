@@ -1,0 +1,154 @@
+// tsl_common.hpp -- shared host/device helpers of the MI355X dense-mapping backend (gfx950 only).
+//
+// Numeric contract (DESIGN.md "Defined semantics"): all f32 arithmetic is IEEE, no FMA contraction
+// (-ffp-contract=off), correctly rounded divide/sqrt; f16 values are stored as raw bits and every
+// f16 (op) f16 is computed in f32 and rounded RNE (v_cvt_f16_f32).  Per-frame voxel contributions are
+// summed in exact 2^-24 fixed point (int64 atomics), so results do not depend on thread order.
+#pragma once
+#include <cstring>
+#include <string.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/taichislam_hip.h"
+
+#define TSL_BRK   16
+#define TSL_BRK3  4096
+#define TSL_EMPTY  (-1)
+#define TSL_LOCKED (-2)
+#define TSL_FULL   (-3)
+
+namespace tsl {
+
+void set_error(const std::string& s);
+#define TSL_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    tsl::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return TSL_ERR_HIP; } } while (0)
+#define TSL_REQUIRE(cond, msg) do { if (!(cond)) { tsl::set_error(msg); return TSL_ERR_ARG; } } while (0)
+
+// ---- f16 as raw bits -----------------------------------------------------------------------------
+typedef uint16_t h16;
+__device__ __forceinline__ h16 f2h(float x) { _Float16 v = (_Float16)x; return __builtin_bit_cast(h16, v); }
+__device__ __forceinline__ float h2f(h16 b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ h16 hadd(h16 a, h16 b) { return f2h(h2f(a) + h2f(b)); }
+__device__ __forceinline__ h16 hsub(h16 a, h16 b) { return f2h(h2f(a) - h2f(b)); }
+__device__ __forceinline__ h16 hmul(h16 a, h16 b) { return f2h(h2f(a) * h2f(b)); }
+__device__ __forceinline__ h16 hdiv(h16 a, h16 b) { return f2h(h2f(a) / h2f(b)); }
+__device__ __forceinline__ h16 hsqrt(h16 a) { return f2h(__fsqrt_rn(h2f(a))); }
+
+// ti.round(x, ti.i32): round half away from zero (mapping_common.py:263-266, assumption A1)
+__device__ __forceinline__ float rnd_f(float x)
+{
+    float r = truncf(x);
+    float d = fabsf(x - r);
+    if (d >= 0.5f) r += copysignf(1.0f, x);
+    return r;
+}
+__device__ __forceinline__ int rnd_i(float x) { return (int)rnd_f(x); }
+__device__ __forceinline__ int sgn_f(float v) { return (0.0f < v) - (v < 0.0f); }     // mapping_common.py:5-7
+
+// ---- 2^-24 fixed point ------------------------------------------------------------------------------
+#define TSL_FIX_SCALE 16777216.0f
+#define TSL_FIX_INV   (1.0 / 16777216.0)
+#define TSL_W_CLAMP   65536.0f
+#define TSL_WMAX      1000.0f                                                             // dense_tsdf.py:8
+__device__ __forceinline__ long long to_fix(float v) { return __float2ll_rn(v * TSL_FIX_SCALE); }
+__device__ __forceinline__ float from_fix(long long q) { return (float)((double)q * TSL_FIX_INV); }
+
+// ---- wave64 helpers -----------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+// number of set bits of m strictly below this lane
+__device__ __forceinline__ int rank_below(unsigned long long m)
+{ return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
+
+// one atomic per wave: adds `v` of every lane with pred, returns nothing
+__device__ __forceinline__ void atomic_add_i64(int64_t* ctr, long long v)
+{ __hip_atomic_fetch_add(reinterpret_cast<long long*>(ctr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wave_count_add(int64_t* ctr, bool pred)
+{
+    unsigned long long m = __ballot(pred);
+    if (m && lane_id() == (int)__builtin_ctzll(m)) atomic_add_i64(ctr, (long long)popc64(m));
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+// wave-aggregated slot reservation: lanes with pred get consecutive indices from *ctr
+__device__ __forceinline__ int wave_reserve(int* ctr, bool pred)
+{
+    unsigned long long m = __ballot(pred);
+    if (!m) return -1;
+    int leader = (int)__builtin_ctzll(m);
+    int base = 0;
+    if (lane_id() == leader) base = __hip_atomic_fetch_add(ctr, popc64(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = __shfl(base, leader);
+    return pred ? base + rank_below(m) : -1;
+}
+
+// Claim-or-read an index stored in *entry (EMPTY -> allocate from *counter).  Safe inside divergent
+// SIMT code: a lane never waits on a lane of its own wave (winners publish in the same iteration).
+__device__ __forceinline__ int claim_index(int* entry, int* counter, int cap)
+{
+    int v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v == TSL_EMPTY || v == TSL_LOCKED) {
+        if (v == TSL_EMPTY) {
+            int old = atomicCAS(entry, TSL_EMPTY, TSL_LOCKED);
+            if (old == TSL_EMPTY) {
+                int idx = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (idx >= cap) idx = TSL_FULL;
+                __hip_atomic_store(entry, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return idx;
+            }
+            v = old;
+        } else {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return v;
+}
+
+// ---- device-side views (PODs passed by value to kernels) -------------------------------------------------
+struct MapDev {
+    int N, Nz, nbx, nbz, nb3, nsub;
+    int hN, hNz;               // N/2, Nz/2
+    int max_bricks;
+    int* table;                // [nsub][nb3] -> pool brick index, TSL_EMPTY when absent
+    uint32_t* tw;              // [max_bricks][4096]  lo16 = TSDF f16 bits, hi16 = W_TSDF f16 bits
+    int8_t* obs;               // [max_bricks][4096]
+    int8_t* occ;               // [max_bricks][4096]
+    uint16_t* col;             // [max_bricks][4096][4] f16 rgb (+pad) or nullptr
+    int* owner;                // [max_bricks] -> s*nb3 + b
+    int* pool_top;             // bricks handed out so far
+    int* err;                  // sticky device error flags (bit0: brick pool full, bit1: frame scratch full)
+};
+
+__device__ __forceinline__ bool in_volume(const MapDev& M, int i, int j, int k)
+{
+    return i >= -M.hN && i < M.N - M.hN && j >= -M.hN && j < M.N - M.hN && k >= -M.hNz && k < M.Nz - M.hNz;
+}
+// brick id inside a submap + voxel id inside the brick (k fastest)
+__device__ __forceinline__ int brick_of(const MapDev& M, int i, int j, int k, int* local)
+{
+    int ui = i + M.hN, uj = j + M.hN, uk = k + M.hNz;
+    *local = ((ui & 15) << 8) | ((uj & 15) << 4) | (uk & 15);
+    return ((ui >> 4) * M.nbx + (uj >> 4)) * M.nbz + (uk >> 4);
+}
+__device__ __forceinline__ int pool_lookup(const MapDev& M, int s, int b)
+{ return __hip_atomic_load(M.table + (size_t)s * M.nb3 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// read-only lookup through the normal (cached) path: for kernels that run after all allocation is done
+__device__ __forceinline__ int pool_lookup_ro(const MapDev& M, int s, int b) { return M.table[(size_t)s * M.nb3 + b]; }
+__device__ __forceinline__ int pool_claim(const MapDev& M, int s, int b)
+{
+    int* e = M.table + (size_t)s * M.nb3 + b;
+    int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= 0) return v;
+    v = claim_index(e, M.pool_top, M.max_bricks);
+    if (v >= 0) M.owner[v] = s * M.nb3 + b;      // idempotent: every claimer of a fresh brick writes the same value
+    else atomicOr(M.err, 1);
+    return v;
+}
+
+}  // namespace tsl

@@ -1,0 +1,990 @@
+// tsl_tsdf.hip -- DenseTSDF on MI355X (gfx950): depth/point-cloud integration, sparse export/import,
+// surface/slice compaction.  Replaces taichi_slam/mapping/dense_tsdf.py:157-270,309-454 (reference root).
+//
+// Per-frame pipeline (all on the handle's stream, no host round trip between kernels):
+//   K1 k_voxelize_depth / k_voxelize_points : pixel -> sensor-centred voxel (Morton key), f16 payload
+//   K2 rocprim radix sort (stable)           : groups pixels per sensor voxel, raster order kept
+//   K3 k_build_rays                           : per sensor voxel: raster-order f16 sums -> one ray record
+//   K4 k_integrate<variant>                   : ray march, exact int64 fixed-point atomics into per-frame
+//                                               brick scratch; bricks are allocated on first touch
+//   K5 k_finalize                             : one weighted running-average update per touched voxel
+#include "tsl_tsdf.hpp"
+#include <rocprim/rocprim.hpp>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace tsl {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+// ------------------------------------------------------------------------------------------------------
+// Morton keys (3 x <=10 bits in 32, 3 x <=21 bits in 64): consecutive keys are spatially compact, so the 64
+// rays of a wave stay close to each other along the whole march (coherent atomics, cheap de-duplication)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t part1by2_32(uint32_t x)
+{
+    x &= 0x3ffu;
+    x = (x ^ (x << 16)) & 0xff0000ffu;
+    x = (x ^ (x << 8)) & 0x0300f00fu;
+    x = (x ^ (x << 4)) & 0x030c30c3u;
+    x = (x ^ (x << 2)) & 0x09249249u;
+    return x;
+}
+__device__ __forceinline__ uint64_t part1by2_64(uint64_t x)
+{
+    x &= 0x1fffffull;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+template <typename K> struct KeyOps;
+template <> struct KeyOps<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(int x, int y, int z) { return (part1by2_32(x) << 2) | (part1by2_32(y) << 1) | part1by2_32(z); }
+    static __device__ __host__ __forceinline__ uint32_t invalid(int bits) { return 1u << (3 * bits); }
+};
+template <> struct KeyOps<uint64_t> {
+    static __device__ __forceinline__ uint64_t make(int x, int y, int z) { return (part1by2_64(x) << 2) | (part1by2_64(y) << 1) | part1by2_64(z); }
+    static __device__ __host__ __forceinline__ uint64_t invalid(int bits) { return 1ull << (3 * bits); }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// K1: depth image -> sensor-centred voxel key + f16 payload       dense_tsdf.py:188-213, process_point :227-229
+// ------------------------------------------------------------------------------------------------------
+template <typename K>
+__global__ void __launch_bounds__(256) k_voxelize_depth(FrameParams P, FrameDev F, const uint16_t* __restrict__ depth, K* __restrict__ keys)
+{
+    const int total = P.hh * P.ww;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool gate = false, inside = false;
+    if (p < total) {
+        const int jj = p / P.ww, ii = p - jj * P.ww;
+        const int j = jj * P.step, i = ii * P.step;
+        const uint16_t d = depth[(size_t)j * P.W + i];
+        K key = KeyOps<K>::invalid(P.pcl_bits);
+        uint2 payload = make_uint2(0u, 0u);
+        const float df = (float)d;
+        if (d != 0 && !(df > P.thr_max) && !(df < P.thr_min)) {                     // :196-199
+            gate = true;
+            const float dep = df / 1000.0f;                                           // :201
+            const float px = ((float)i - P.cx) * dep / P.fx;                          // mapping_common.py:37-40
+            const float py = ((float)j - P.cy) * dep / P.fy;
+            const float pz = dep;
+            const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;               // :203 (rotation only)
+            const float my = (P.R[3] * px + P.R[4] * py) + P.R[5] * pz;
+            const float mz = (P.R[6] * px + P.R[7] * py) + P.R[8] * pz;
+            const int cx = rnd_i(mx / P.vs) - P.pcl_lo, cy = rnd_i(my / P.vs) - P.pcl_lo, cz = rnd_i(mz / P.vs) - P.pcl_lo;   // :229
+            if (cx >= 0 && cx < P.pcl_ext && cy >= 0 && cy < P.pcl_ext && cz >= 0 && cz < P.pcl_ext) {
+                inside = true;
+                key = KeyOps<K>::make(cx, cy, cz);
+                payload.x = (uint32_t)f2h(mx) | ((uint32_t)f2h(my) << 16);
+                payload.y = (uint32_t)f2h(mz) | ((uint32_t)f2h(dep) << 16);
+            }
+        }
+        keys[p] = key;
+        F.vals[p] = (uint32_t)p;
+        F.pix[p] = payload;
+    }
+    wave_count_add(&F.stats->p_valid, inside);
+    wave_count_add(&F.stats->p_oob, gate && !inside);
+}
+
+// recast_pcl_to_map_kernel  dense_tsdf.py:167-186 (z := range, gate on the range)
+template <typename K>
+__global__ void __launch_bounds__(256) k_voxelize_points(FrameParams P, FrameDev F, const float* __restrict__ xyz, int n, K* __restrict__ keys)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool gate = false, inside = false;
+    if (p < n) {
+        const float px = xyz[(size_t)p * 3], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
+        const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;                   // :175
+        const float my = (P.R[3] * px + P.R[4] * py) + P.R[5] * pz;
+        const float mz = (P.R[6] * px + P.R[7] * py) + P.R[8] * pz;
+        const float len = __fsqrt_rn((mx * mx + my * my) + mz * mz);                  // :176
+        K key = KeyOps<K>::invalid(P.pcl_bits);
+        uint2 payload = make_uint2(0u, 0u);
+        if (len < P.max_ray_f) {                                                      // :177
+            gate = true;
+            const int cx = rnd_i(mx / P.vs) - P.pcl_lo, cy = rnd_i(my / P.vs) - P.pcl_lo, cz = rnd_i(mz / P.vs) - P.pcl_lo;
+            if (cx >= 0 && cx < P.pcl_ext && cy >= 0 && cy < P.pcl_ext && cz >= 0 && cz < P.pcl_ext) {
+                inside = true;
+                key = KeyOps<K>::make(cx, cy, cz);
+                payload.x = (uint32_t)f2h(mx) | ((uint32_t)f2h(my) << 16);
+                payload.y = (uint32_t)f2h(mz) | ((uint32_t)f2h(len) << 16);
+            }
+        }
+        keys[p] = key;
+        F.vals[p] = (uint32_t)p;
+        F.pix[p] = payload;
+    }
+    wave_count_add(&F.stats->p_valid, inside);
+    wave_count_add(&F.stats->p_oob, gate && !inside);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: one thread per sorted entry; segment heads replay their pixels in raster order with per-add f16
+// rounding (process_point :230-232) and emit the ray record (process_new_pcl :242-249)
+// ------------------------------------------------------------------------------------------------------
+template <typename K>
+__global__ void __launch_bounds__(256) k_build_rays(FrameParams P, FrameDev F, const K* __restrict__ keys_s, int total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const K bad = KeyOps<K>::invalid(P.pcl_bits);
+    bool head = false, ok = false;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    int nsteps = 0;
+    if (i < total) {
+        const K k = keys_s[i];
+        head = (k != bad) && (i == 0 || keys_s[i - 1] != k);
+        if (head) {
+            int cnt = 0;
+            h16 sx = 0, sy = 0, sz = 0, zs = 0;
+            for (int q = i; q < total && keys_s[q] == k; ++q) {
+                const uint2 pl = F.pix[F.vals_s[q]];
+                sx = hadd(sx, (h16)(pl.x & 0xffffu)); sy = hadd(sy, (h16)(pl.x >> 16));      // :231
+                sz = hadd(sz, (h16)(pl.y & 0xffffu)); zs = hadd(zs, (h16)(pl.y >> 16));      // :232
+                ++cnt;                                                                       // :230
+            }
+            const h16 c = f2h((float)cnt);                                                   // :242
+            const h16 px = hdiv(sx, c), py = hdiv(sy, c), pz = hdiv(sz, c);                  // :243
+            const h16 len = hsqrt(hadd(hadd(hmul(px, px), hmul(py, py)), hmul(pz, pz)));     // :244
+            const h16 zbar = hdiv(zs, c);                                                    // :247
+            const float lenf = h2f(len), zzf = h2f(hmul(zbar, zbar));
+            ok = (lenf > 0.0f) && isfinite(lenf) && (zzf > 0.0f) && isfinite(zzf);
+            if (ok) {
+                const h16 dx = hdiv(px, len), dy = hdiv(py, len), dz = hdiv(pz, len);        // :245
+                float nf = lenf / P.vs + P.internal_f;                                       // :249
+                if (P.max_steps_f < nf) nf = P.max_steps_f;
+                nsteps = (int)nf;
+                float w = 1.0f / zzf;                                                        // w_x_p :216-225 (d >= 0 always, Q3)
+                if (w > TSL_W_CLAMP) w = TSL_W_CLAMP;
+                rec.x = (uint32_t)px | ((uint32_t)py << 16);
+                rec.y = (uint32_t)pz | ((uint32_t)dx << 16);
+                rec.z = (uint32_t)dy | ((uint32_t)dz << 16);
+                rec.w = __float_as_uint(w);
+            }
+        }
+    }
+    const int r = wave_reserve(&F.counters[0], ok);
+    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; }
+    wave_count_add(&F.stats->v_pcl, head);
+    wave_count_add(&F.stats->v_skipped, head && !ok);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4: ray march  process_new_pcl :246-269.  SPLIT lanes share one ray (strided steps).
+// ------------------------------------------------------------------------------------------------------
+struct BrickCursor { int b; unsigned long long* acc; };
+
+__device__ __forceinline__ unsigned long long* frame_slot(const MapDev& M, const FrameDev& F, int s, int b)
+{
+    const int p = pool_claim(M, s, b);
+    if (p < 0) return nullptr;
+    int* e = F.slot_of_pool + p;
+    int sl = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sl < 0) {
+        sl = claim_index(e, &F.counters[1], F.max_frame_bricks);
+        if (sl >= 0) F.touched[sl] = p; else atomicOr(M.err, 2);
+    }
+    if (sl < 0) return nullptr;
+    return F.acc + (size_t)sl * (TSL_BRK3 * 2);
+}
+
+// VARIANT 0: one no-return int64 atomic pair per ray-step
+// VARIANT 1: wave-uniform fast path -- when all live lanes hit the same voxel, reduce in-wave, one atomic pair
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, FrameParams P)
+{
+    const int split = P.split;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int r = gid / split, sub = gid - r * split;
+    const int nrays = F.counters[0];
+    const bool live = r < nrays;
+    long long n_ok = 0, n_oob = 0;
+    int n = 0;
+    float pf0 = 0, pf1 = 0, pf2 = 0, d0 = 0, d1 = 0, d2 = 0, P0 = 0, P1 = 0, P2 = 0, w = 0;
+    long long qden = 0;
+    if (live) {
+        const uint4 rec = F.rayA[r];
+        n = F.rayN[r];
+        pf0 = h2f((h16)(rec.x & 0xffffu)); pf1 = h2f((h16)(rec.x >> 16)); pf2 = h2f((h16)(rec.y & 0xffffu));
+        d0 = h2f((h16)(rec.y >> 16)); d1 = h2f((h16)(rec.z & 0xffffu)); d2 = h2f((h16)(rec.z >> 16));
+        w = __uint_as_float(rec.w);
+        qden = to_fix(w);
+        P0 = pf0 + P.T[0]; P1 = pf1 + P.T[1]; P2 = pf2 + P.T[2];                              // :246
+        if (sub == 0) {                                                                        // :248 occupy[pos_p] = 1
+            const int oi = rnd_i(P0 / P.vs), oj = rnd_i(P1 / P.vs), ok = rnd_i(P2 / P.vs);
+            if (in_volume(M, oi, oj, ok)) {
+                int l; const int b = brick_of(M, oi, oj, ok, &l);
+                const int p = pool_claim(M, P.slot, b);
+                if (p >= 0) M.occ[(size_t)p * TSL_BRK3 + l] = 1;
+            }
+        }
+    }
+    BrickCursor cur = { -1, nullptr };
+    int nmax = n;
+    if (VARIANT == 1) { for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; } }
+    const int iters = (nmax + split - 1) / split;          // wave-uniform trip count when VARIANT == 1 (cross-lane ops inside)
+    for (int it = 0; it < iters; ++it) {                                                       // :251-253
+        const int j = 1 + sub + it * split;
+        const bool act = live && j <= n;
+        unsigned long long* dst = nullptr;
+        long long qn = 0;
+        if (act) {
+            const float jf = (float)j;
+            const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];   // :253
+            const int xi = rnd_i(x0 / P.vs), xj = rnd_i(x1 / P.vs), xk = rnd_i(x2 / P.vs);                                // :254
+            if (in_volume(M, xi, xj, xk)) {
+                const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2 - x2;                            // :258
+                const float dist = __fsqrt_rn((v0 * v0 + v1 * v1) + v2 * v2);                    // :259
+                const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
+                const float sd = dist * (float)sgn_f(dot);                                       // :260
+                qn = to_fix(w * sd);                                                             // :264 numerator term
+                int l; const int b = brick_of(M, xi, xj, xk, &l);
+                if (b != cur.b) { cur.b = b; cur.acc = frame_slot(M, F, P.slot, b); }
+                if (cur.acc) { dst = cur.acc + (size_t)l * 2; ++n_ok; }
+            } else ++n_oob;
+        }
+        if (VARIANT == 1) {
+            const unsigned long long m = __ballot(dst != nullptr);
+            if (m) {
+                const int leader = (int)__builtin_ctzll(m);
+                const unsigned long long lead = __shfl((unsigned long long)dst, leader);
+                const bool same = (dst == nullptr) || ((unsigned long long)dst == lead);
+                if (__all(same)) {
+                    const long long sn = wave_sum_ll(dst ? qn : 0), sdn = wave_sum_ll(dst ? qden : 0);
+                    if (lane_id() == leader) {
+                        __hip_atomic_fetch_add(dst, (unsigned long long)sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(dst + 1, (unsigned long long)sdn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    continue;
+                }
+            }
+        }
+        if (dst) {
+            __hip_atomic_fetch_add(dst, (unsigned long long)qn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dst + 1, (unsigned long long)qden, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    n_ok = wave_sum_ll(n_ok); n_oob = wave_sum_ll(n_oob);
+    if (lane_id() == 0) {
+        if (n_ok) atomic_add_i64(&F.stats->steps, n_ok);
+        if (n_oob) atomic_add_i64(&F.stats->steps_oob, n_oob);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K5: apply the per-frame sums once per touched voxel (:264-267 with the frame's total weight), clear scratch
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F)
+{
+    const int ntouched = min(F.counters[1], F.max_frame_bricks);
+    long long uniq = 0;
+    for (int sl = blockIdx.x; sl < ntouched; sl += gridDim.x) {
+        const int p = F.touched[sl];
+        ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)sl * (TSL_BRK3 * 2));
+        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+        int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const ulonglong2 a = acc[l];
+            if (a.y != 0ull) {
+                const float num = from_fix((long long)a.x), den = from_fix((long long)a.y);
+                const uint32_t old = tw[l];
+                const h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
+                const h16 Tn = f2h((h2f(hmul(T0, W0)) + num) / (h2f(W0) + den));                 // :264
+                float wn = h2f(W0) + den; if (TSL_WMAX < wn) wn = TSL_WMAX;                      // :267
+                tw[l] = (uint32_t)Tn | ((uint32_t)f2h(wn) << 16);
+                obs[l] = 1;                                                                      // :265
+                acc[l] = make_ulonglong2(0ull, 0ull);
+                ++uniq;
+            }
+        }
+        if (threadIdx.x == 0) F.slot_of_pool[p] = TSL_EMPTY;
+    }
+    uniq = wave_sum_ll(uniq);
+    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
+    if (blockIdx.x == 0 && threadIdx.x == 0) F.stats->bricks = ntouched;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// sparse export / import / compaction kernels (struct-for over active cells in the reference)
+// ------------------------------------------------------------------------------------------------------
+// count_active  dense_tsdf.py:412-423
+__global__ void __launch_bounds__(256) k_count_active(MapDev M, int s, long long* out)
+{
+    long long c = 0;
+    for (int b = blockIdx.x; b < M.nb3; b += gridDim.x) {
+        const int p = pool_lookup_ro(M, s, b);
+        if (p < 0) continue;
+        const int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) c += obs[l] > 0;
+    }
+    c = wave_sum_ll(c);
+    if (lane_id() == 0 && c) __hip_atomic_fetch_add(out, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void voxel_ijk(const MapDev& M, int b, int l, int* i, int* j, int* k)
+{
+    const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
+    *i = bi * 16 + (l >> 8) - M.hN; *j = bj * 16 + ((l >> 4) & 15) - M.hN; *k = bk * 16 + (l & 15) - M.hNz;
+}
+
+// to_numpy  dense_tsdf.py:425-440 (mode 0: observed voxels; mode 1: occupy != 0)
+__global__ void __launch_bounds__(256) k_export_sparse(MapDev M, int s, int mode, int16_t* idx, uint16_t* t, uint16_t* w, int8_t* occ, uint16_t* col,
+                                                       long long cap, int* counter)
+{
+    for (int b = blockIdx.x; b < M.nb3; b += gridDim.x) {
+        const int p = pool_lookup_ro(M, s, b);
+        if (p < 0) continue;
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
+            const int l = l0 + threadIdx.x;
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            const bool pred = mode == 0 ? (M.obs[v] > 0) : (M.occ[v] != 0);
+            const int o = wave_reserve(counter, pred);
+            if (pred && o < cap) {
+                int i, j, k; voxel_ijk(M, b, l, &i, &j, &k);
+                idx[(size_t)o * 3] = (int16_t)i; idx[(size_t)o * 3 + 1] = (int16_t)j; idx[(size_t)o * 3 + 2] = (int16_t)k;
+                const uint32_t tv = M.tw[v];
+                if (t) t[o] = (uint16_t)(tv & 0xffffu);
+                if (w) w[o] = (uint16_t)(tv >> 16);
+                if (occ) occ[o] = M.occ[v];
+                if (col && M.col) for (int a = 0; a < 3; ++a) col[(size_t)o * 3 + a] = M.col[v * 4 + a];
+            }
+        }
+    }
+}
+
+// load_numpy  dense_tsdf.py:442-454
+__global__ void __launch_bounds__(256) k_import_sparse(MapDev M, int s, const int16_t* idx, const uint16_t* t, const uint16_t* w, const int8_t* occ,
+                                                       const uint16_t* col, long long n)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const int i = idx[q * 3], j = idx[q * 3 + 1], k = idx[q * 3 + 2];
+    if (!in_volume(M, i, j, k)) return;
+    int l; const int b = brick_of(M, i, j, k, &l);
+    const int p = pool_claim(M, s, b);
+    if (p < 0) return;
+    const size_t v = (size_t)p * TSL_BRK3 + l;
+    M.tw[v] = (uint32_t)t[q] | ((uint32_t)w[q] << 16);
+    M.occ[v] = occ ? occ[q] : (int8_t)0;
+    if (col && M.col) for (int a = 0; a < 3; ++a) M.col[v * 4 + a] = col[q * 3 + a];
+    M.obs[v] = 1;
+}
+
+struct PoseF { float R[9], T[3]; };
+// color_from_colomap  mapping_common.py:216-219
+__device__ __forceinline__ int colormap_index(float z, float lo, float hi)
+{
+    float t = ((z - lo) / (hi - lo)) * 1023.0f;
+    if (t > 1023.0f) t = 1023.0f;
+    if (!(t > 0.0f)) t = 0.0f;
+    return (int)t;
+}
+__device__ __forceinline__ void voxel_xyz(const PoseF& B, int is_global, float vs, int i, int j, int k, float* o)
+{
+    const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;                    // mapping_common.py:221-227
+    if (is_global) { o[0] = p0; o[1] = p1; o[2] = p2; return; }
+    for (int a = 0; a < 3; ++a) o[a] = ((B.R[a * 3] * p0 + B.R[a * 3 + 1] * p1) + B.R[a * 3 + 2] * p2) + B.T[a];   // :229-232
+}
+
+// cvt_TSDF_surface_to_voxels_kernel :339-365 (mode 0) and cvt_TSDF_to_voxels_slice_kernel :367-385 (mode 1)
+__global__ void __launch_bounds__(256) k_export_particles(MapDev M, int s, int mode, PoseF B, int is_global, float vs, float thres, float zfloor, float zceil,
+                                                          int slice_index, float slice_dz, const float* __restrict__ cmap,
+                                                          float* xyz, float* rgb, float* val, long long cap, int* counter)
+{
+    for (int b = blockIdx.x; b < M.nb3; b += gridDim.x) {
+        const int p = pool_lookup_ro(M, s, b);
+        if (p < 0) continue;
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
+            const int l = l0 + threadIdx.x;
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            const int8_t ob = M.obs[v];
+            const float tv = h2f((h16)(M.tw[v] & 0xffffu));
+            int i, j, k; voxel_ijk(M, b, l, &i, &j, &k);
+            float o[3] = {0, 0, 0};
+            bool pred;
+            if (mode == 0) {
+                pred = (ob == 1) && (fabsf(tv) < thres);                                      // :349-350
+                if (pred) { voxel_xyz(B, is_global, vs, i, j, k, o); pred = !(o[2] > zceil || o[2] < zfloor); }   // :356
+            } else {
+                pred = (ob > 0) && ((float)slice_index - slice_dz < (float)k) && ((float)k < (float)slice_index + slice_dz);   // :376-377
+                if (pred) voxel_xyz(B, is_global, vs, i, j, k, o);
+            }
+            const int idx = wave_reserve(counter, pred);                                      // :358 (Q10: clamp by the returned index)
+            if (pred && idx < cap) {
+                for (int a = 0; a < 3; ++a) xyz[(size_t)idx * 3 + a] = o[a];
+                if (mode == 1 && val) val[idx] = tv;                                          // :380
+                if (rgb) {
+                    if (mode == 0 && M.col) { for (int a = 0; a < 3; ++a) rgb[(size_t)idx * 3 + a] = h2f(M.col[v * 4 + a]); }    // :361
+                    else {
+                        const int ci = mode == 0 ? colormap_index(o[2], zfloor, zceil) : colormap_index(tv, -0.5f, 0.5f);      // :364,:385
+                        for (int a = 0; a < 3; ++a) rgb[(size_t)idx * 3 + a] = cmap[ci * 3 + a];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// reset(): hand every brick back (dense_tsdf.py:309-310 deactivates the whole tree)
+__global__ void __launch_bounds__(256) k_reset_bricks(MapDev M, int nused)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+        uint32_t* ob = reinterpret_cast<uint32_t*>(M.obs + (size_t)p * TSL_BRK3);
+        uint32_t* oc = reinterpret_cast<uint32_t*>(M.occ + (size_t)p * TSL_BRK3);
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) tw[l] = 0u;
+        for (int l = threadIdx.x; l < TSL_BRK3 / 4; l += 256) { ob[l] = 0u; oc[l] = 0u; }
+        if (M.col) { uint2* c = reinterpret_cast<uint2*>(M.col + (size_t)p * TSL_BRK3 * 4); for (int l = threadIdx.x; l < TSL_BRK3; l += 256) c[l] = make_uint2(0u, 0u); }
+        if (threadIdx.x == 0) M.table[M.owner[p]] = TSL_EMPTY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+int grow(void** p, size_t* have, size_t need)
+{
+    if (*have >= need) return TSL_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    size_t want = need + need / 4 + 4096;
+    TSL_HIP(hipMalloc(p, want));
+    *have = want;
+    return TSL_OK;
+}
+
+int dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill)
+{
+    TSL_HIP(hipMalloc(p, bytes));
+    TSL_HIP(hipMemsetAsync(*p, fill, bytes, m->stream));
+    m->bytes += (int64_t)bytes;
+    return TSL_OK;
+}
+
+void prof_begin(tsl_tsdf* m, int kid)
+{
+    if (!m->prof_on) return;
+    ProfSlot s; s.kid = kid;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    (void)hipEventRecord(s.a, m->stream);
+    m->prof.push_back(s);
+}
+void prof_end(tsl_tsdf* m)
+{
+    if (!m->prof_on || m->prof.empty()) return;
+    (void)hipEventRecord(m->prof.back().b, m->stream);
+}
+
+// set_pose + convert_by_base  mapping_common.py:91-100,149-156 (float64, fixed summation order, then f32)
+void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT)
+{
+    const double d[3] = { T[0] - Tb[0], T[1] - Tb[1], T[2] - Tb[2] };
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += Rb[k * 3 + i] * R[k * 3 + j];
+            outR[i * 3 + j] = (float)acc;
+        }
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) acc += Rb[k * 3 + i] * d[k];
+        outT[i] = (float)acc;
+    }
+}
+
+static int map_slot(const tsl_tsdf* m, int s) { return m->cfg.is_global_map ? 0 : s; }
+
+static PoseF pose_of(const tsl_tsdf* m, int s)
+{
+    PoseF B;
+    for (int a = 0; a < 9; ++a) B.R[a] = m->baseRf[(size_t)s * 9 + a];
+    for (int a = 0; a < 3; ++a) B.T[a] = m->baseTf[(size_t)s * 3 + a];
+    return B;
+}
+
+template <typename K>
+static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
+{
+    FrameParams& P = m->P;
+    FrameDev& F = m->F;
+    const int total = xyz_dev ? (int)npts : P.hh * P.ww;
+    TSL_REQUIRE(total <= F.max_points, "integrate: more pixels/points than max_points");
+    TSL_HIP(hipMemsetAsync(F.stats, 0, sizeof(tsl_frame_stats), m->stream));
+    TSL_HIP(hipMemsetAsync(F.counters, 0, sizeof(int) * 4, m->stream));
+    if (total == 0) return TSL_OK;
+    K* keys = reinterpret_cast<K*>(F.keys);
+    K* keys_s = reinterpret_cast<K*>(F.keys_s);
+    const int blocks = (total + 255) / 256;
+    prof_begin(m, TSL_K_VOXELIZE);
+    if (xyz_dev) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const float*)xyz_dev, total, keys);
+    else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const uint16_t*)depth_dev, keys);
+    prof_end(m);
+    prof_begin(m, TSL_K_SORT);
+    size_t tb = m->sort_temp_bytes;
+    TSL_HIP(rocprim::radix_sort_pairs(m->sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * P.pcl_bits + 1), m->stream));
+    prof_end(m);
+    prof_begin(m, TSL_K_RAYS);
+    hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const K*)keys_s, total);
+    prof_end(m);
+    prof_begin(m, TSL_K_INTEGRATE);
+    const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
+    if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
+    else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
+    prof_end(m);
+    prof_begin(m, TSL_K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream, m->M, F);
+    prof_end(m);
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+
+static int sort_temp_size(tsl_tsdf* m, size_t* bytes)
+{
+    size_t a = 0, b = 0;
+    TSL_HIP(rocprim::radix_sort_pairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                      (size_t)m->F.max_points, 0u, 32u, m->stream));
+    TSL_HIP(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                      (size_t)m->F.max_points, 0u, 64u, m->stream));
+    *bytes = a > b ? a : b;
+    return TSL_OK;
+}
+
+static void fill_frame_params(tsl_tsdf* m, const double R[9], const double T[3])
+{
+    const int s = m->active;
+    convert_pose(&m->baseR[(size_t)s * 9], &m->baseT[(size_t)s * 3], R, T, m->P.R, m->P.T);   // submap_enabled is always True for DenseTSDF
+    m->P.slot = map_slot(m, s);
+    m->P.variant = m->variant; m->P.split = m->split;
+}
+
+}  // namespace tsl
+
+using namespace tsl;
+
+// ======================================================================================================
+// C-ABI
+// ======================================================================================================
+extern "C" {
+
+const char* tsl_version(void) { return "taichislam_hip 0.1 (gfx950)"; }
+const char* tsl_last_error(void) { return g_err.c_str(); }
+int tsl_device_count(int* n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { c = 0; }
+    if (n) *n = c;
+    return TSL_OK;
+}
+
+int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
+{
+    TSL_REQUIRE(cfg && out, "tsl_tsdf_create: null argument");
+    TSL_REQUIRE(cfg->voxel_scale > 0 && cfg->num_voxel_per_blk_axis >= 1 && cfg->recast_step >= 1, "tsl_tsdf_create: bad config");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available"); return TSL_ERR_NO_DEVICE; }
+    TSL_REQUIRE(device >= 0 && device < ndev, "tsl_tsdf_create: bad device index");
+    TSL_HIP(hipSetDevice(device));
+    tsl_tsdf* m = new tsl_tsdf();
+    m->cfg = *cfg; m->device = device; m->bytes = 0;
+    TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    const int blk = cfg->num_voxel_per_blk_axis;
+    m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
+    m->Nz = (int)std::ceil(cfg->map_size_z / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:25
+    TSL_REQUIRE(m->N > 0 && m->Nz > 0 && m->N <= 32768 && m->Nz <= 32768, "tsl_tsdf_create: map extent must fit int16 voxel indices");
+    m->nbx = (m->N + 15) / 16; m->nbz = (m->Nz + 15) / 16; m->nb3 = m->nbx * m->nbx * m->nbz;
+    m->nsub = cfg->is_global_map ? 1 : (cfg->max_submap_num > 0 ? cfg->max_submap_num : 1); // dense_tsdf.py:86-88
+    m->npose = cfg->max_submap_num > m->nsub ? cfg->max_submap_num : m->nsub;
+    {   // sensor-centred scratch grid  dense_tsdf.py:67-70
+        int grp = (int)(3.2 * cfg->max_ray_length / (double)blk / cfg->voxel_scale);
+        if (grp < 1) grp = 1;
+        const int ext = blk * grp;
+        int off = -ext / 2; if ((-ext) % 2 != 0) off -= 1;                                   // Python floor division
+        m->pcl_lo = off; m->pcl_ext = ext;
+        int bits = 1; while ((1 << bits) < ext) ++bits;
+        m->pcl_bits = bits;
+        TSL_REQUIRE(bits <= 20, "tsl_tsdf_create: sensor grid too large");
+    }
+    FrameParams& P = m->P; std::memset(&P, 0, sizeof(P));
+    for (int i = 0; i < 3; ++i) P.R[i * 4] = 1.0f;
+    P.vs = (float)cfg->voxel_scale;
+    P.thr_max = (float)(cfg->max_ray_length * 1000.0); P.thr_min = (float)(cfg->min_ray_length * 1000.0);
+    P.max_ray_f = (float)cfg->max_ray_length;
+    P.max_steps_f = (float)(cfg->max_ray_length / cfg->voxel_scale);
+    P.internal_f = (float)cfg->internal_voxels;
+    P.pcl_lo = m->pcl_lo; P.pcl_ext = m->pcl_ext; P.pcl_bits = m->pcl_bits;
+    P.step = cfg->recast_step; P.same_proj = cfg->color_same_proj;
+    m->surf_thres = (float)(cfg->voxel_scale * 1.8);                                        // dense_tsdf.py:39
+    m->disp_floor = (float)cfg->disp_floor; m->disp_ceiling = (float)cfg->disp_ceiling;
+    m->baseR.assign((size_t)m->npose * 9, 0.0); m->baseT.assign((size_t)m->npose * 3, 0.0);
+    m->baseRf.assign((size_t)m->npose * 9, 0.0f); m->baseTf.assign((size_t)m->npose * 3, 0.0f);
+    // identity default instead of the reference's zero matrices (mapping_common.py:106)
+    for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
+    std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
+    for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
+    m->active = 0; m->variant = 1; m->split = 4;
+    m->prof_on = false; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
+    m->sort_temp = nullptr; m->sort_temp_bytes = 0; m->stage_in = nullptr; m->stage_in_bytes = 0; m->stage_tex = nullptr; m->stage_tex_bytes = 0;
+    m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
+    m->esdf = nullptr; m->esdf_flag = nullptr; m->esdf_bricks = 0; m->pose_dev = nullptr;
+
+    // ---- map storage ----
+    MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
+    M.N = m->N; M.Nz = m->Nz; M.nbx = m->nbx; M.nbz = m->nbz; M.nb3 = m->nb3; M.nsub = m->nsub; M.hN = m->N / 2; M.hNz = m->Nz / 2;
+    int64_t want = cfg->max_bricks > 0 ? cfg->max_bricks : 32768;
+    const int64_t all = (int64_t)m->nsub * m->nb3;
+    if (want > all) want = all;
+    M.max_bricks = (int)want;
+    int rc;
+    if ((rc = dev_alloc(m, (void**)&M.table, sizeof(int) * (size_t)all, 0xff))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.tw, sizeof(uint32_t) * (size_t)want * TSL_BRK3, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.obs, (size_t)want * TSL_BRK3, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.occ, (size_t)want * TSL_BRK3, 0))) return rc;
+    if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&M.col, sizeof(uint16_t) * 4 * (size_t)want * TSL_BRK3, 0))) return rc; }
+    if ((rc = dev_alloc(m, (void**)&M.owner, sizeof(int) * (size_t)want, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
+    M.err = M.pool_top + 1;
+
+    // ---- frame scratch ----
+    FrameDev& F = m->F; std::memset(&F, 0, sizeof(F));
+    F.max_points = cfg->max_points > 0 ? cfg->max_points : 640 * 480;
+    F.max_frame_bricks = cfg->max_frame_bricks > 0 ? cfg->max_frame_bricks : 4096;
+    if (F.max_frame_bricks > M.max_bricks) F.max_frame_bricks = M.max_bricks;
+    const size_t np = (size_t)F.max_points;
+    if ((rc = dev_alloc(m, (void**)&F.keys, 8 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.keys_s, 8 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.vals, 4 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.vals_s, 4 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.pix, 8 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.rayA, 16 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.rayN, 4 * np, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.slot_of_pool, sizeof(int) * (size_t)want, 0xff))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.touched, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.counters, sizeof(int) * 4, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.stats, sizeof(tsl_frame_stats), 0))) return rc;
+    if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
+    if ((rc = dev_alloc(m, &m->sort_temp, m->sort_temp_bytes + 256, 0))) return rc;
+    TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
+    TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
+    std::memset(m->h_stats, 0, sizeof(tsl_frame_stats));
+
+    // ---- export buffers  dense_tsdf.py:53-60,129-134 ----
+    m->max_disp = cfg->max_disp_particles > 0 ? cfg->max_disp_particles : 1024 * 1024;
+    if ((rc = dev_alloc(m, (void**)&m->exp_xyz, sizeof(float) * 3 * (size_t)m->max_disp, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&m->exp_rgb, sizeof(float) * 3 * (size_t)m->max_disp, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&m->exp_val, sizeof(float) * (size_t)m->max_disp, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&m->num_particles, sizeof(int) * 4, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&m->colormap, sizeof(float) * 3 * 1024, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&m->pose_dev, sizeof(float) * 12 * (size_t)m->npose, 0))) return rc;
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    *out = m;
+    return TSL_OK;
+}
+
+void tsl_tsdf_destroy(tsl_tsdf* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.keys, m->F.keys_s, m->F.vals, m->F.vals_s,
+                     m->F.pix, m->F.rayA, m->F.rayN, m->F.slot_of_pool, m->F.touched, m->F.acc, m->F.counters, m->F.stats, m->sort_temp,
+                     m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (m->h_stats) (void)hipHostFree(m->h_stats);
+    if (m->h_ints) (void)hipHostFree(m->h_ints);
+    for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* bxy, int32_t* bz)
+{
+    TSL_REQUIRE(m, "null handle");
+    const int blk = m->cfg.num_voxel_per_blk_axis;
+    if (N) *N = m->N; if (Nz) *Nz = m->Nz;
+    if (bxy) *bxy = m->N / blk; if (bz) *bz = m->Nz / blk;                                   // dense_tsdf.py:27-28
+    return TSL_OK;
+}
+int tsl_tsdf_sync(tsl_tsdf* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
+int tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* b) { TSL_REQUIRE(m && b, "null"); *b = m->bytes; return TSL_OK; }
+
+static int read_int(tsl_tsdf* m, const int* dev, int* out)
+{
+    TSL_HIP(hipMemcpyAsync(m->h_ints, dev, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    *out = m->h_ints[0];
+    return TSL_OK;
+}
+static int check_dev_err(tsl_tsdf* m)
+{
+    int e = 0; int rc = read_int(m, m->M.err, &e); if (rc) return rc;
+    if (e) {
+        set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : ""));
+        (void)hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream);
+        return TSL_ERR_CAPACITY;
+    }
+    return TSL_OK;
+}
+int tsl_tsdf_bricks_in_use(tsl_tsdf* m, int32_t* n)
+{
+    TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device));
+    int v = 0; int rc = read_int(m, m->M.pool_top, &v); if (rc) return rc;
+    *n = v > m->M.max_bricks ? m->M.max_bricks : v;
+    return TSL_OK;
+}
+
+int tsl_tsdf_reset(tsl_tsdf* m)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
+    int used = 0; int rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
+    if (used > 0) hipLaunchKernelGGL(k_reset_bricks, dim3(used < 4096 ? used : 4096), dim3(256), 0, m->stream, m->M, used);
+    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, m->stream));
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+
+int tsl_tsdf_set_intrinsics(tsl_tsdf* m, const double Kd[9], const double Kc[9])
+{
+    TSL_REQUIRE(m, "null handle");
+    if (Kd) { m->P.fx = (float)Kd[0]; m->P.fy = (float)Kd[4]; m->P.cx = (float)Kd[2]; m->P.cy = (float)Kd[5]; }
+    if (Kc) { m->P.fxc = (float)Kc[0]; m->P.fyc = (float)Kc[4]; m->P.cxc = (float)Kc[2]; m->P.cyc = (float)Kc[5]; }
+    return TSL_OK;
+}
+int tsl_tsdf_set_base_pose(tsl_tsdf* m, const double R[9], const double T[3])
+{ TSL_REQUIRE(m && R && T, "null"); std::memcpy(m->gbaseR, R, 72); std::memcpy(m->gbaseT, T, 24); return TSL_OK; }
+int tsl_tsdf_set_base_pose_submap(tsl_tsdf* m, int sid, const double R[9], const double T[3])
+{
+    TSL_REQUIRE(m && R && T, "null"); TSL_REQUIRE(sid >= 0 && sid < m->npose, "set_base_pose_submap: submap id out of range");
+    std::memcpy(&m->baseR[(size_t)sid * 9], R, 72); std::memcpy(&m->baseT[(size_t)sid * 3], T, 24);
+    for (int a = 0; a < 9; ++a) m->baseRf[(size_t)sid * 9 + a] = (float)R[a];
+    for (int a = 0; a < 3; ++a) m->baseTf[(size_t)sid * 3 + a] = (float)T[a];
+    return TSL_OK;
+}
+int tsl_tsdf_get_active_submap(const tsl_tsdf* m, int32_t* sid) { TSL_REQUIRE(m && sid, "null"); *sid = m->active; return TSL_OK; }
+int tsl_tsdf_set_active_submap(tsl_tsdf* m, int32_t sid)
+{ TSL_REQUIRE(m, "null"); TSL_REQUIRE(sid >= 0 && sid < m->npose, "set_active_submap: id out of range"); m->active = sid; return TSL_OK; }
+int tsl_tsdf_set_colormap(tsl_tsdf* m, const float* rgb)
+{
+    TSL_REQUIRE(m && rgb, "null"); TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipMemcpyAsync(m->colormap, rgb, sizeof(float) * 3 * 1024, hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    return TSL_OK;
+}
+
+int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
+                                 const void* tex_dev, int th, int tw)
+{
+    TSL_REQUIRE(m && R && T && depth_dev, "integrate_depth: null argument");
+    TSL_REQUIRE(h > 0 && w > 0, "integrate_depth: bad image size");
+    TSL_REQUIRE(!(m->cfg.texture_enabled && tex_dev) || true, "");
+    TSL_REQUIRE(m->active < m->nsub || m->cfg.is_global_map, "integrate: active submap beyond max_submap_num");
+    TSL_HIP(hipSetDevice(m->device));
+    fill_frame_params(m, R, T);
+    FrameParams& P = m->P;
+    P.H = h; P.W = w;
+    P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);           // dense_tsdf.py:192,194
+    P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0;
+    m->h_stats->p_used = (int64_t)P.hh * P.ww;
+    return m->pcl_bits <= 10 ? run_frame<uint32_t>(m, depth_dev, nullptr, 0) : run_frame<uint64_t>(m, depth_dev, nullptr, 0);
+}
+
+int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
+                             const uint8_t* tex, int th, int tw)
+{
+    TSL_REQUIRE(m && depth, "integrate_depth: null argument"); TSL_REQUIRE(h > 0 && w > 0, "integrate_depth: bad image size");
+    TSL_HIP(hipSetDevice(m->device));
+    const size_t nb = (size_t)h * w * sizeof(uint16_t);
+    int rc = grow(&m->stage_in, &m->stage_in_bytes, nb); if (rc) return rc;
+    TSL_HIP(hipMemcpyAsync(m->stage_in, depth, nb, hipMemcpyHostToDevice, m->stream));
+    void* tdev = nullptr;
+    if (tex && m->cfg.texture_enabled && th > 0 && tw > 0) {
+        const size_t tb = (size_t)th * tw * 3;
+        rc = grow(&m->stage_tex, &m->stage_tex_bytes, tb); if (rc) return rc;
+        TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, tb, hipMemcpyHostToDevice, m->stream));
+        tdev = m->stage_tex;
+    }
+    TSL_HIP(hipStreamSynchronize(m->stream));      // the caller may reuse its host buffers after return
+    return tsl_tsdf_integrate_depth_dev(m, R, T, m->stage_in, h, w, tdev, th, tw);
+}
+
+int tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3], const void* xyz_dev, const void* rgb_dev, int64_t n)
+{
+    TSL_REQUIRE(m && R && T, "integrate_points: null argument"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz_dev), "integrate_points: bad input");
+    TSL_HIP(hipSetDevice(m->device));
+    fill_frame_params(m, R, T);
+    m->P.tex = (m->cfg.texture_enabled && rgb_dev) ? 1 : 0;
+    m->h_stats->p_used = n;
+    return m->pcl_bits <= 10 ? run_frame<uint32_t>(m, nullptr, xyz_dev, n) : run_frame<uint64_t>(m, nullptr, xyz_dev, n);
+}
+
+int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz), "integrate_points: bad input");
+    TSL_HIP(hipSetDevice(m->device));
+    const size_t nb = (size_t)n * 3 * sizeof(float);
+    int rc = grow(&m->stage_in, &m->stage_in_bytes, nb + 16); if (rc) return rc;
+    if (n) TSL_HIP(hipMemcpyAsync(m->stage_in, xyz, nb, hipMemcpyHostToDevice, m->stream));
+    void* cdev = nullptr;
+    if (rgb && m->cfg.texture_enabled && n) {
+        rc = grow(&m->stage_tex, &m->stage_tex_bytes, (size_t)n * 3); if (rc) return rc;
+        TSL_HIP(hipMemcpyAsync(m->stage_tex, rgb, (size_t)n * 3, hipMemcpyHostToDevice, m->stream));
+        cdev = m->stage_tex;
+    }
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    return tsl_tsdf_integrate_points_dev(m, R, T, m->stage_in, cdev, n);
+}
+
+int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
+{
+    TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
+    const int64_t used = m->h_stats->p_used;
+    tsl_frame_stats tmp;
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->F.stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    std::memcpy(&tmp, m->h_ints, sizeof(tmp));
+    tmp.p_used = used;
+    *out = tmp;
+    return check_dev_err(m);
+}
+
+int tsl_tsdf_count_active(tsl_tsdf* m, int64_t* n)
+{
+    TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device));
+    long long* tmp = reinterpret_cast<long long*>(m->num_particles + 2);      // 8-byte scratch word
+    TSL_HIP(hipMemsetAsync(tmp, 0, sizeof(long long), m->stream));
+    hipLaunchKernelGGL(k_count_active, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, m->stream, m->M, map_slot(m, m->active), tmp);
+    long long v = 0;
+    TSL_HIP(hipMemcpyAsync(&v, tmp, sizeof(long long), hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    *n = v;
+    return TSL_OK;
+}
+
+static int export_common(tsl_tsdf* m, int mode, int16_t* idx, uint16_t* t, uint16_t* w, int8_t* occ, uint16_t* col, int64_t cap, int64_t* n)
+{
+    TSL_REQUIRE(m && n, "null"); TSL_REQUIRE(cap >= 0, "bad capacity"); TSL_HIP(hipSetDevice(m->device));
+    const size_t c = (size_t)cap;
+    const size_t o_idx = 0, o_t = o_idx + c * 6, o_w = o_t + c * 2, o_occ = o_w + c * 2, o_col = ((o_occ + c + 15) / 16) * 16, total = o_col + c * 6 + 64;
+    int rc = grow(&m->xbuf, &m->xbuf_bytes, total); if (rc) return rc;
+    char* base = (char*)m->xbuf;
+    int* counter = m->num_particles + 2;
+    TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));
+    hipLaunchKernelGGL(k_export_sparse, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, m->stream, m->M, map_slot(m, m->active), mode,
+                       (int16_t*)(base + o_idx), (uint16_t*)(base + o_t), (uint16_t*)(base + o_w), (int8_t*)(base + o_occ),
+                       (col && m->M.col) ? (uint16_t*)(base + o_col) : (uint16_t*)nullptr, (long long)cap, counter);
+    int cnt = 0; rc = read_int(m, counter, &cnt); if (rc) return rc;
+    *n = cnt;
+    const size_t k = (size_t)(cnt < cap ? cnt : cap);
+    if (k) {
+        if (idx) TSL_HIP(hipMemcpy(idx, base + o_idx, k * 6, hipMemcpyDeviceToHost));
+        if (t) TSL_HIP(hipMemcpy(t, base + o_t, k * 2, hipMemcpyDeviceToHost));
+        if (w) TSL_HIP(hipMemcpy(w, base + o_w, k * 2, hipMemcpyDeviceToHost));
+        if (occ) TSL_HIP(hipMemcpy(occ, base + o_occ, k, hipMemcpyDeviceToHost));
+        if (col && m->M.col) TSL_HIP(hipMemcpy(col, base + o_col, k * 6, hipMemcpyDeviceToHost));
+    }
+    return TSL_OK;
+}
+int tsl_tsdf_export_sparse(tsl_tsdf* m, int16_t* idx, uint16_t* t, uint16_t* w, int8_t* occ, uint16_t* col, int64_t cap, int64_t* n)
+{ return export_common(m, 0, idx, t, w, occ, col, cap, n); }
+int tsl_tsdf_export_occupied(tsl_tsdf* m, int16_t* idx, int8_t* occ, int64_t cap, int64_t* n)
+{ return export_common(m, 1, idx, nullptr, nullptr, occ, nullptr, cap, n); }
+
+int tsl_tsdf_import_sparse(tsl_tsdf* m, int sid, const int16_t* idx, const uint16_t* t, const uint16_t* w, const int8_t* occ, const uint16_t* col, int64_t n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0, "bad count"); if (n == 0) return TSL_OK;
+    TSL_REQUIRE(idx && t && w, "import_sparse: null arrays");
+    TSL_REQUIRE(sid >= 0 && (m->cfg.is_global_map || sid < m->nsub), "import_sparse: submap id out of range");
+    TSL_HIP(hipSetDevice(m->device));
+    const size_t c = (size_t)n;
+    const size_t o_idx = 0, o_t = o_idx + c * 6, o_w = o_t + c * 2, o_occ = o_w + c * 2, o_col = ((o_occ + c + 15) / 16) * 16, total = o_col + c * 6 + 64;
+    int rc = grow(&m->xbuf, &m->xbuf_bytes, total); if (rc) return rc;
+    char* base = (char*)m->xbuf;
+    TSL_HIP(hipMemcpy(base + o_idx, idx, c * 6, hipMemcpyHostToDevice));
+    TSL_HIP(hipMemcpy(base + o_t, t, c * 2, hipMemcpyHostToDevice));
+    TSL_HIP(hipMemcpy(base + o_w, w, c * 2, hipMemcpyHostToDevice));
+    if (occ) TSL_HIP(hipMemcpy(base + o_occ, occ, c, hipMemcpyHostToDevice));
+    const bool hc = col && m->M.col;
+    if (hc) TSL_HIP(hipMemcpy(base + o_col, col, c * 6, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_import_sparse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, map_slot(m, sid),
+                       (const int16_t*)(base + o_idx), (const uint16_t*)(base + o_t), (const uint16_t*)(base + o_w),
+                       occ ? (const int8_t*)(base + o_occ) : (const int8_t*)nullptr, hc ? (const uint16_t*)(base + o_col) : (const uint16_t*)nullptr, (long long)n);
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    return check_dev_err(m);
+}
+
+static int export_particles(tsl_tsdf* m, tsl_tsdf* dst, int mode, int keep, int slice_index, float dz, int32_t* n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
+    if (!dst) dst = m;
+    TSL_REQUIRE(dst->device == m->device, "export: destination map lives on another device");
+    if (!keep) TSL_HIP(hipMemsetAsync(dst->num_particles, 0, sizeof(int), m->stream));          // :342-343 / :372-373
+    const PoseF B = pose_of(m, m->active);
+    hipLaunchKernelGGL(k_export_particles, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, m->stream, m->M, map_slot(m, m->active), mode, B,
+                       m->cfg.is_global_map, m->P.vs, m->surf_thres, m->disp_floor, m->disp_ceiling, slice_index, dz, m->colormap,
+                       dst->exp_xyz, dst->exp_rgb, dst->exp_val, (long long)dst->max_disp, dst->num_particles);
+    int cnt = 0; int rc = read_int(m, dst->num_particles, &cnt); if (rc) return rc;
+    if (n) *n = cnt;
+    return TSL_OK;
+}
+int tsl_tsdf_surface_voxels(tsl_tsdf* m, tsl_tsdf* dst, int add_to_cur, int32_t* n) { return export_particles(m, dst, 0, add_to_cur, 0, 0.0f, n); }
+int tsl_tsdf_slice_voxels(tsl_tsdf* m, float z, float dz, int clear_last, int32_t* n)
+{
+    TSL_REQUIRE(m, "null handle");
+    // slice_z is an f16 field (dense_tsdf.py:72,388); _index = int(z/voxel_scale) (:370)
+    _Float16 zh = (_Float16)z; const float zq = (float)zh;
+    return export_particles(m, nullptr, 1, !clear_last, (int)(zq / m->P.vs), dz, n);
+}
+int tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64_t n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "read_exports: n out of range"); TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    if (n == 0) return TSL_OK;
+    if (xyz) TSL_HIP(hipMemcpy(xyz, m->exp_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    if (rgb) TSL_HIP(hipMemcpy(rgb, m->exp_rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    if (val) TSL_HIP(hipMemcpy(val, m->exp_val, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    return TSL_OK;
+}
+int tsl_tsdf_num_particles(tsl_tsdf* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device)); int v = 0; int rc = read_int(m, m->num_particles, &v); *n = v; return rc; }
+int tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n)
+{
+    TSL_REQUIRE(m, "null"); TSL_HIP(hipSetDevice(m->device));
+    m->h_ints[8] = n;
+    TSL_HIP(hipMemcpyAsync(m->num_particles, &m->h_ints[8], sizeof(int), hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    return TSL_OK;
+}
+
+int tsl_tsdf_prof_enable(tsl_tsdf* m, int on) { TSL_REQUIRE(m, "null"); m->prof_on = on != 0; return TSL_OK; }
+int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launches)
+{
+    TSL_REQUIRE(m, "null"); TSL_REQUIRE(kid >= 0 && kid < TSL_K_COUNT, "bad kernel id"); TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    for (auto& s : m->prof) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { m->prof_ms[s.kid] += ms; m->prof_n[s.kid] += 1; }
+        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+    }
+    m->prof.clear();
+    if (total_ms) *total_ms = m->prof_ms[kid];
+    if (launches) *launches = m->prof_n[kid];
+    m->prof_ms[kid] = 0.0; m->prof_n[kid] = 0;
+    return TSL_OK;
+}
+
+/* backend knobs used by bench.py / tests to A/B kernel variants: name in {"variant","split"} */
+int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
+{
+    TSL_REQUIRE(m && name, "null");
+    if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value == 0 || value == 1, "variant must be 0 or 1"); m->variant = value; return TSL_OK; }
+    if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
+    set_error("unknown option"); return TSL_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// tsl_tsdf.hpp -- host-side state of one DenseTSDF handle (internal; the public surface is include/taichislam_hip.h)
+#pragma once
+#include "tsl_common.hpp"
+
+namespace tsl {
+
+// per-call constants handed to the per-frame kernels (dense_tsdf.py:188-270 uses them as ti.static constants)
+struct FrameParams {
+    float R[9], T[3];                  // input_R / input_T  (mapping_common.py:12-13,149-156)
+    float fx, fy, cx, cy;              // depth intrinsics   (mapping_common.py:31-41)
+    float fxc, fyc, cxc, cyc;          // colour intrinsics  (mapping_common.py:43-58)
+    float vs;                          // voxel_scale as f32
+    float thr_max, thr_min;            // max/min_ray_length*1000  (dense_tsdf.py:198)
+    float max_ray_f;                   // dense_tsdf.py:177
+    float max_steps_f;                 // max_ray_length/voxel_scale (dense_tsdf.py:249)
+    float internal_f;                  // internal_voxels
+    int   pcl_lo, pcl_ext, pcl_bits;   // sensor-centred grid: index range [lo, lo+ext), bits per axis
+    int   step, hh, ww, H, W;          // recast_step, visited rows/cols, image size
+    int   th, tw, tex, same_proj;
+    int   slot;                        // map-side submap slot written by this frame
+    int   variant, split;              // integrate kernel variant / lanes per ray
+};
+
+struct FrameDev {
+    uint32_t *keys, *keys_s, *vals, *vals_s;     // sensor-grid Morton key + pixel id, unsorted / sorted
+    uint2* pix;                                  // per pixel: f16 bits {x,y | z,depth}
+    uint4* rayA;                                 // per ray: {p01, p2|d0, d12, w bits}
+    int*   rayN;                                 // per ray: step count
+    int*   slot_of_pool;                         // [max_bricks] -> frame scratch slot
+    int*   touched;                              // [max_frame_bricks] -> pool brick
+    unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
+    int*   counters;                             // [0] rays  [1] touched bricks
+    tsl_frame_stats* stats;
+    int    max_frame_bricks;
+    int    max_points;
+};
+
+struct ProfSlot { hipEvent_t a, b; int kid; };
+
+}  // namespace tsl
+
+struct tsl_tsdf {
+    tsl_tsdf_cfg cfg;
+    int device;
+    hipStream_t stream;
+    int N, Nz, nbx, nbz, nb3, nsub, npose;
+    int pcl_lo, pcl_ext, pcl_bits;
+    tsl::MapDev M;
+    tsl::FrameDev F;
+    tsl::FrameParams P;                  // constants filled at create / set_intrinsics
+    std::vector<double> baseR, baseT;    // submaps_base_R_np / T_np  (mapping_common.py:106-107)
+    std::vector<float> baseRf, baseTf;   // f32 field copies          (mapping_common.py:104-105)
+    double gbaseR[9], gbaseT[3];
+    int active;
+    float surf_thres, disp_floor, disp_ceiling;
+    void* sort_temp; size_t sort_temp_bytes;
+    tsl_frame_stats* h_stats;            // pinned
+    int* h_ints;                         // pinned scratch (16 ints)
+    // staging for host-pointer integrate calls
+    void* stage_in; size_t stage_in_bytes;
+    void* stage_tex; size_t stage_tex_bytes;
+    // export buffers (export_TSDF_xyz / export_color / export_TSDF, num_TSDF_particles)  dense_tsdf.py:53-60
+    float *exp_xyz, *exp_rgb, *exp_val; int* num_particles; int64_t max_disp;
+    float* colormap;                     // [1024][3]
+    float* pose_dev;                     // [npose][12] f32 (R row-major, T) for fusion
+    // sparse export staging
+    void* xbuf; size_t xbuf_bytes;
+    // mesh buffers (mesh_vertices / mesh_normals / mesh_colors, num_facelets)  marching_cube_mesher.py:16-22
+    float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap;
+    // esdf
+    float* esdf; int* esdf_flag; int64_t esdf_bricks;
+    // profiling
+    bool prof_on; std::vector<tsl::ProfSlot> prof;
+    double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
+    int variant, split;
+    int64_t bytes;
+};
+
+namespace tsl {
+int  grow(void** p, size_t* have, size_t need);
+void prof_begin(tsl_tsdf* m, int kid);
+void prof_end(tsl_tsdf* m);
+void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
+int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
+}

@@ -1,0 +1,3 @@
+"""taichislam_amd.mapping -- drop-in for taichi_slam.mapping (reference taichi_slam/mapping/__init__.py:1-6)."""
+from .mapping_common import BaseMap  # noqa: F401
+from .dense_tsdf import DenseTSDF  # noqa: F401

@@ -1,0 +1,309 @@
+"""DenseTSDF: drop-in for taichi_slam.mapping.DenseTSDF (reference taichi_slam/mapping/dense_tsdf.py:12-516)
+running on hand-written HIP kernels for MI355X through include/taichislam_hip.h.
+
+Same constructor keywords, methods and attribute names as the reference; numpy in / numpy out.  Depth images
+and point clouds may also be torch CUDA tensors (their device pointer is handed to the *_dev entry points)."""
+import ctypes as C
+import math
+import time
+
+import numpy as np
+
+from .. import _lib
+from .fields import DeviceArrayField, MapFieldRef, ScalarField
+from .mapping_common import BaseMap, _dptr, jet_colormap
+
+Wmax = 1000
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and x.is_cuda
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DenseTSDF(BaseMap):
+    _prefix = "tsl_tsdf"
+
+    def __init__(self, map_scale=[10, 10], voxel_scale=0.05, texture_enabled=False,
+                 max_disp_particles=1024 * 1024, num_voxel_per_blk_axis=16, max_ray_length=10, min_ray_length=0.3,
+                 internal_voxels=10, max_submap_num=1024, is_global_map=False,
+                 disp_ceiling=1.8, disp_floor=-0.3, recast_step=2, color_same_proj=True,
+                 # legacy keywords still passed by tests/marching_cube_test.py:12-16 and TaichiSLAM_demo.py:147-152
+                 min_occupy_thres=None, enable_esdf=None,
+                 # backend knobs (not in the reference)
+                 device=0, max_bricks=0, max_frame_bricks=0, max_points=0):
+        super(DenseTSDF, self).__init__(voxel_scale)
+        self.num_voxel_per_blk_axis = num_voxel_per_blk_axis
+        self.voxel_scale = voxel_scale
+        self.N = math.ceil(map_scale[0] / voxel_scale / num_voxel_per_blk_axis) * num_voxel_per_blk_axis
+        self.Nz = math.ceil(map_scale[1] / voxel_scale / num_voxel_per_blk_axis) * num_voxel_per_blk_axis
+        self.block_num_xy = math.ceil(map_scale[0] / voxel_scale / num_voxel_per_blk_axis)
+        self.block_num_z = math.ceil(map_scale[1] / voxel_scale / num_voxel_per_blk_axis)
+        self.map_size_xy = voxel_scale * self.N
+        self.map_size_z = voxel_scale * self.Nz
+        self.max_disp_particles = max_disp_particles
+        self.enable_texture = texture_enabled
+        self.max_ray_length = max_ray_length
+        self.min_ray_length = min_ray_length
+        self.tsdf_surface_thres = self.voxel_scale * 1.8
+        self.internal_voxels = internal_voxels
+        self.max_submap_num = max_submap_num
+        self.is_global_map = is_global_map
+        self.disp_ceiling = disp_ceiling
+        self.disp_floor = disp_floor
+        self.recast_step = recast_step
+        self.color_same_proj = color_same_proj
+        self.clear_last_TSDF_exporting = False
+        self.device = device
+        self.mem_per_voxel = 2 + 2 + 1 + 1 + (6 if texture_enabled else 0)
+
+        cfg = _lib.TsdfCfg(float(map_scale[0]), float(map_scale[1]), float(voxel_scale), int(num_voxel_per_blk_axis),
+                           float(max_ray_length), float(min_ray_length), int(internal_voxels), int(max_submap_num),
+                           int(bool(is_global_map)), int(bool(texture_enabled)), float(disp_ceiling), float(disp_floor),
+                           int(recast_step), int(bool(color_same_proj)), int(max_disp_particles),
+                           int(max_bricks), int(max_frame_bricks), int(max_points))
+        h = C.c_void_p()
+        _lib.check(self.L.tsl_tsdf_create(C.byref(cfg), int(device), C.byref(h)))
+        self.h = h
+        n, nz = C.c_int32(), C.c_int32()
+        self._call("get_dims", C.byref(n), C.byref(nz), None, None)
+        assert (n.value, nz.value) == (self.N, self.Nz), "host/device extent mismatch"
+        self.initialize_fields()
+        print(f"TSDF map initialized blocks {self.block_num_xy}x{self.block_num_xy}x{self.block_num_z}")
+
+    # ---- fields (dense_tsdf.py:52-106) -------------------------------------------------------------------
+    def initialize_fields(self):
+        self.num_TSDF_particles = ScalarField(self._get_num_particles, self._set_num_particles, "num_TSDF_particles")
+        self.num_export_particles = ScalarField(lambda: 0, None, "num_export_particles")
+        self.num_export_ESDF_particles = ScalarField(lambda: 0, None, "num_export_ESDF_particles")
+        md = self.max_disp_particles
+        self.export_TSDF_xyz = DeviceArrayField(self, lambda n: self._read_exports(n)[0], md, 3, "export_TSDF_xyz")
+        self.export_color = DeviceArrayField(self, lambda n: self._read_exports(n)[1], md, 3, "export_color")
+        self.export_TSDF = DeviceArrayField(self, lambda n: self._read_exports(n)[2], md, 1, "export_TSDF")
+        self.export_x = self.export_TSDF_xyz
+        self.TSDF = MapFieldRef(self, "TSDF")
+        self.W_TSDF = MapFieldRef(self, "W_TSDF")
+        self.TSDF_observed = MapFieldRef(self, "TSDF_observed")
+        self.occupy = MapFieldRef(self, "occupy")
+        self.color = MapFieldRef(self, "color") if self.enable_texture else None
+        self.colormap = jet_colormap()
+        self._call("set_colormap", _vp(self.colormap))
+        self.initialize_submap_fields(self.max_submap_num)
+
+    def _get_num_particles(self):
+        v = C.c_int32()
+        self._call("num_particles", C.byref(v))
+        return v.value
+
+    def _set_num_particles(self, n):
+        self._call("set_num_particles", int(n))
+
+    def _read_exports(self, n):
+        n = int(max(0, min(n, self.max_disp_particles)))
+        xyz = np.empty((n, 3), np.float32)
+        rgb = np.empty((n, 3), np.float32)
+        val = np.empty(n, np.float32)
+        self._call("read_exports", _vp(xyz), _vp(rgb), _vp(val), n)
+        return xyz, rgb, val
+
+    # ---- backend knobs ---------------------------------------------------------------------------------
+    def set_option(self, name, value):
+        self._call("set_option", name.encode(), int(value))
+
+    def enable_profiling(self, on=True):
+        self._call("prof_enable", int(bool(on)))
+
+    def kernel_time(self, kernel_id):
+        """(total_ms, launches) recorded by HIP events since the last query; synchronises."""
+        ms, n = C.c_double(), C.c_int64()
+        self._call("prof_query", int(kernel_id), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def last_frame_stats(self):
+        st = _lib.FrameStats()
+        self._call("last_frame_stats", C.byref(st))
+        return st.as_dict()
+
+    def memory_bytes(self):
+        v = C.c_int64()
+        self._call("memory_bytes", C.byref(v))
+        return v.value
+
+    def bricks_in_use(self):
+        v = C.c_int32()
+        self._call("bricks_in_use", C.byref(v))
+        return v.value
+
+    # ---- integration (dense_tsdf.py:157-165) -----------------------------------------------------------------
+    def recast_pcl_to_map(self, R, T, xyz_array, rgb_array=None, n=None):
+        """recast_pcl_to_map(R, T, xyz_array, rgb_array); the third positional `n` of the stale demo
+        (TaichiSLAM_demo.py:52) is tolerated and ignored."""
+        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
+        if _is_device_tensor(xyz_array):
+            x = xyz_array.contiguous().float()
+            self._keep = x
+            self._call("integrate_points_dev", r, t, C.c_void_p(x.data_ptr()), None, int(x.shape[0]))
+            return
+        xyz = np.ascontiguousarray(np.asarray(xyz_array, dtype=np.float32).reshape(-1, 3))
+        rgb = None
+        if self.enable_texture and rgb_array is not None and getattr(rgb_array, "size", 0):
+            rgb = np.ascontiguousarray(np.asarray(rgb_array, dtype=np.uint8).reshape(-1, 3))
+        self._call("integrate_points", r, t, _vp(xyz), _vp(rgb), int(xyz.shape[0]))
+
+    def recast_depth_to_map(self, R, T, depthmap, texture=None):
+        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
+        if _is_device_tensor(depthmap):
+            assert depthmap.dim() == 2 and depthmap.element_size() == 2 and depthmap.is_contiguous(), \
+                "device depth must be a contiguous 16-bit [h,w] tensor (uint16 millimetres)"
+            tex_ptr, th, tw = None, 0, 0
+            if self.enable_texture and texture is not None and _is_device_tensor(texture):
+                tex_ptr, th, tw = C.c_void_p(texture.data_ptr()), int(texture.shape[0]), int(texture.shape[1])
+            self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]),
+                       int(depthmap.shape[1]), tex_ptr, th, tw)
+            return
+        depth = np.ascontiguousarray(np.asarray(depthmap, dtype=np.uint16))
+        if depth.ndim != 2:
+            raise ValueError("depthmap must be a 2-d uint16 array")
+        tex, th, tw = None, 0, 0
+        if self.enable_texture and texture is not None and getattr(texture, "size", 0):
+            tex = np.ascontiguousarray(np.asarray(texture, dtype=np.uint8))
+            th, tw = tex.shape[:2]
+        self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], _vp(tex), th, tw)
+
+    # north-star alias (BASELINE.json says "integrate"; the reference method is recast_depth_to_map)
+    integrate = recast_depth_to_map
+
+    # ---- fusion (dense_tsdf.py:309-318) -------------------------------------------------------------------------
+    def reset(self):
+        self._call("reset")
+
+    def fuse_submaps(self, submaps):
+        t = time.time()
+        # the kernel reads the global map's pose table (dense_tsdf.py:286-293): make sure the handle has it
+        _lib.check(self.L.tsl_tsdf_fuse_submaps(self.h, submaps.h))
+        print(f"[DenseTSDF] Fuse submaps {(time.time() - t) * 1000:.1f}ms, active local: "
+              f"{submaps.active_submap_id[None]} remote: {submaps.remote_submap_num[None]}")
+
+    # ---- visualisation exports (dense_tsdf.py:320-404) --------------------------------------------------------------
+    def cvt_occupy_to_voxels(self):
+        self.cvt_TSDF_surface_to_voxels()
+
+    def cvt_TSDF_surface_to_voxels(self):
+        n = C.c_int32()
+        self._call("surface_voxels", None, 0, C.byref(n))
+
+    def cvt_TSDF_surface_to_voxels_to(self, num_TSDF_particles, max_disp_particles, export_TSDF_xyz, export_color):
+        """Append this map's surface voxels to another map's export buffers (submap_mapping.py:212-213)."""
+        dst = export_TSDF_xyz._owner
+        n = C.c_int32()
+        self._call("surface_voxels", dst.h, 1, C.byref(n))
+
+    def cvt_TSDF_to_voxels_slice(self, z, dz=0.5, clear_last=True):
+        n = C.c_int32()
+        self._call("slice_voxels", float(z), float(dz), int(bool(clear_last)), C.byref(n))
+
+    def get_voxels_TSDF_surface(self):
+        self.cvt_TSDF_surface_to_voxels()
+        n = self.num_TSDF_particles[None]
+        xyz, rgb, val = self._read_exports(n)
+        return xyz, val, (rgb if self.enable_texture else None)
+
+    def get_voxels_TSDF_slice(self, z):
+        self.cvt_TSDF_to_voxels_slice(z)
+        xyz, _, val = self._read_exports(self.num_TSDF_particles[None])
+        return xyz, val
+
+    def get_voxels_occupy(self):
+        self.cvt_occupy_to_voxels()
+        xyz, rgb, _ = self._read_exports(self.num_TSDF_particles[None])
+        return xyz, rgb
+
+    # ---- sparse export / import (dense_tsdf.py:412-515) ----------------------------------------------------------------
+    def count_active(self):
+        v = C.c_int64()
+        self._call("count_active", C.byref(v))
+        return v.value
+
+    def to_numpy(self, data_indices, data_tsdf, data_wtsdf, data_occ, data_color):
+        n = C.c_int64()
+        col = data_color if (self.enable_texture and getattr(data_color, "size", 0)) else None
+        self._call("export_sparse", _vp(data_indices), _vp(data_tsdf), _vp(data_wtsdf), _vp(data_occ), _vp(col),
+                   int(data_tsdf.shape[0]), C.byref(n))
+        return n.value
+
+    def load_numpy(self, submap_id, data_indices, data_tsdf, data_wtsdf, data_occ, data_color):
+        idx = np.ascontiguousarray(data_indices, dtype=np.int16)
+        t = np.ascontiguousarray(data_tsdf, dtype=np.float16)
+        w = np.ascontiguousarray(data_wtsdf, dtype=np.float16)
+        occ = np.ascontiguousarray(data_occ, dtype=np.int8)
+        col = None
+        if self.enable_texture and data_color is not None and getattr(data_color, "size", 0):
+            col = np.ascontiguousarray(data_color, dtype=np.float16)
+        self._call("import_sparse", int(submap_id), _vp(idx), _vp(t), _vp(w), _vp(occ), _vp(col), int(t.shape[0]))
+
+    def export_submap(self):
+        s = time.time()
+        num = self.count_active()
+        indices = np.zeros((num, 3), np.int16)
+        tsdf = np.zeros((num), np.float16)
+        w_tsdf = np.zeros((num), np.float16)
+        occupy = np.zeros((num), np.int8)
+        color = np.zeros((num, 3), np.float16) if self.enable_texture else np.array([])
+        self.to_numpy(indices, tsdf, w_tsdf, occupy, color)
+        obj = {
+            'indices': indices, 'TSDF': tsdf, 'W_TSDF': w_tsdf, 'color': color, 'occupy': occupy,
+            "map_scale": [self.map_size_xy, self.map_size_z], "voxel_scale": self.voxel_scale,
+            "texture_enabled": self.enable_texture, "num_voxel_per_blk_axis": self.num_voxel_per_blk_axis,
+        }
+        print(f"Export submap {self.active_submap_id[None]} to numpy, voxels {num / 1024:.1f}k, "
+              f"time: {1000 * (time.time() - s):.1f}ms")
+        return obj
+
+    def export_occupied(self):
+        """(indices int16[n,3], occupy int8[n]) of voxels with occupy != 0 (backend extra, used by parity tests)."""
+        n = C.c_int64()
+        self._call("export_occupied", None, None, 0, C.byref(n))
+        idx = np.zeros((n.value, 3), np.int16)
+        occ = np.zeros(n.value, np.int8)
+        self._call("export_occupied", _vp(idx), _vp(occ), n.value, C.byref(n))
+        return idx, occ
+
+    def saveMap(self, filename):
+        np.save(filename, self.export_submap())
+
+    @staticmethod
+    def loadMap(filename, **backend_opts):
+        obj = np.load(filename, allow_pickle=True).item()
+        mapping = DenseTSDF(map_scale=obj['map_scale'], voxel_scale=obj['voxel_scale'],
+                            texture_enabled=obj['texture_enabled'],
+                            num_voxel_per_blk_axis=obj['num_voxel_per_blk_axis'], is_global_map=True, **backend_opts)
+        mapping.load_numpy(0, obj['indices'], obj['TSDF'], obj['W_TSDF'], obj['occupy'], obj['color'])
+        print(f"[SubmapMapping] Loaded {obj['TSDF'].shape[0]} voxels from {filename}")
+        return mapping
+
+    def input_remote_submap(self, submap):
+        # remote submaps are stored from the top of the submap axis downwards (dense_tsdf.py:500-515)
+        self.remote_submap_num[None] = self.remote_submap_num[None] + 1
+        idx = self.max_submap_num - self.remote_submap_num[None]
+        R, T = submap['pose']
+        color = submap['color'] if self.enable_texture else np.array([])
+        self.load_numpy(idx, submap['indices'], submap['TSDF'], submap['W_TSDF'], submap['occupy'], color)
+        self.set_base_pose_submap(idx, R, T)
+        return idx
+
+    def init_sphere(self, voxels=30, radius=None):
+        """dense_tsdf.py:136-146 as intended by tests/marching_cube_test.py: an analytic sphere SDF of
+        `voxels`^3 cells centred on the map origin, every cell observed (the reference body is broken at HEAD:
+        3-index access on 4-d fields)."""
+        radius = self.voxel_scale * 3 if radius is None else radius
+        r = np.arange(-(voxels // 2), voxels - voxels // 2, dtype=np.int16)
+        ii, jj, kk = np.meshgrid(r, r, r, indexing="ij")
+        idx = np.stack([ii, jj, kk], -1).reshape(-1, 3)
+        p = idx.astype(np.float32) * np.float32(self.voxel_scale)
+        tsdf = (np.sqrt((p * p).sum(1)) - np.float32(radius)).astype(np.float16)
+        n = idx.shape[0]
+        col = np.zeros((n, 3), np.float16) if self.enable_texture else np.array([])
+        self.load_numpy(self.get_active_submap_id(), idx, tsdf, np.ones(n, np.float16), np.zeros(n, np.int8), col)

@@ -1,0 +1,217 @@
+"""GPU parity: HIP DenseTSDF (through the C-ABI) vs the CPU oracle in BATCHED mode -- bit-exact.
+
+Reference behaviour under test: taichi_slam/mapping/dense_tsdf.py:157-270 (integration), :412-454 (sparse
+export/import), :339-389 (particle exports)."""
+import numpy as np
+import pytest
+
+from taichislam_amd.utils import synthetic as syn
+from util import C2, SMALL, assert_export_equal, make_pair, small_stream, sorted_rows
+
+pytestmark = pytest.mark.gpu
+
+STAT_KEYS = ("p_used", "p_valid", "p_oob", "v_pcl", "v_skipped", "steps", "steps_oob", "unique", "bricks")
+
+
+def _run_both(g, o, frames):
+    from oracle import BATCHED
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, np.array([], dtype=int))
+        so = o.integrate_depth(R, T, d, mode=BATCHED)
+        sg = g.last_frame_stats()
+        assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+
+
+def test_small_stream_bit_exact(hip_lib):
+    K, frames = small_stream(4)
+    g, o = make_pair(SMALL, K)
+    _run_both(g, o, frames)
+    assert g.count_active() == o.count_active() > 10000
+    assert_export_equal(g.export_submap(), o.export_sparse(), "small stream")
+    gi, go = g.export_occupied()
+    oi, oo = o.export_occupied()
+    assert np.array_equal(sorted_rows(gi), sorted_rows(oi)) and gi.shape[0] > 100
+
+
+@pytest.mark.parametrize("variant,split", [(0, 1), (0, 4), (1, 1), (1, 4), (1, 16), (1, 64)])
+def test_kernel_variants_agree(hip_lib, variant, split):
+    K, frames = small_stream(2)
+    g, o = make_pair(SMALL, K)
+    g.set_option("variant", variant)
+    g.set_option("split", split)
+    _run_both(g, o, frames)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"variant {variant} split {split}")
+
+
+def test_full_size_c2_bit_exact(hip_lib):
+    """BASELINE.json configs[1]: 640x480 depth into 512^3 @ 2 cm; two frames against the oracle."""
+    g, o = make_pair(C2, syn.K_DEPTH)
+    frames = list(syn.sphere_room_stream(2))
+    _run_both(g, o, frames)
+    st = g.last_frame_stats()
+    assert st["p_valid"] == 76800 and st["steps"] > 3_000_000 and st["steps_oob"] == 0
+    assert_export_equal(g.export_submap(), o.export_sparse(), "C2")
+
+
+def test_full_size_properties(hip_lib):
+    """Size-independent properties at the benchmark size: determinism across runs and variants, export/import
+    round trip, count == export length, W monotone and clamped."""
+    from taichislam_amd.mapping import DenseTSDF
+    frames = list(syn.sphere_room_stream(6))
+    exports = []
+    for variant, split in ((1, 4), (0, 2)):
+        m = DenseTSDF(**C2)
+        m.set_dep_camera_intrinsic(syn.K_DEPTH)
+        m.set_option("variant", variant)
+        m.set_option("split", split)
+        wprev = None
+        for R, T, d in frames:
+            m.recast_depth_to_map(R, T, d, None)
+        e = m.export_submap()
+        assert e["TSDF"].shape[0] == m.count_active()
+        w = e["W_TSDF"].astype(np.float32)
+        assert w.min() > 0 and w.max() <= 1000.0 and np.isfinite(e["TSDF"].astype(np.float32)).all()
+        exports.append(e)
+    assert_export_equal(exports[0], exports[1], "determinism across variants")
+    m2 = DenseTSDF(**C2)
+    e = exports[0]
+    m2.load_numpy(0, e["indices"], e["TSDF"], e["W_TSDF"], e["occupy"], e["color"])
+    assert_export_equal(m2.export_submap(), e, "export -> import -> export")
+
+
+def test_points_input(hip_lib):
+    """recast_pcl_to_map (dense_tsdf.py:167-186): range gate on the norm, z := range."""
+    rng = np.random.default_rng(7)
+    g, o = make_pair(SMALL, syn.K_DEPTH)
+    R, T = syn.camera_pose(3)
+    d = rng.normal(size=(20000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = (d * rng.uniform(0.2, 6.0, size=(20000, 1))).astype(np.float32)      # some beyond max_ray_length
+    pts[:5] = 0.0                                                               # degenerate: at the sensor origin
+    from oracle import BATCHED
+    g.recast_pcl_to_map(R, T, pts, np.array([]))
+    so = o.integrate_points(R, T, pts, None, mode=BATCHED)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    assert so["v_skipped"] >= 1
+    assert_export_equal(g.export_submap(), o.export_sparse(), "points")
+
+
+@pytest.mark.parametrize("h,w,step", [(121, 163, 2), (120, 160, 3), (97, 131, 1)])
+def test_ragged_image_sizes(hip_lib, h, w, step):
+    cfg = dict(SMALL, recast_step=step)
+    K = syn.scaled_intrinsics(h, w)
+    g, o = make_pair(cfg, K)
+    frames = []
+    for f in range(2):
+        R, T = syn.camera_pose(f)
+        frames.append((R, T, syn.sphere_room_depth(R, T, h, w, K=K)))
+    _run_both(g, o, frames)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"ragged {h}x{w}/{step}")
+
+
+def test_empty_and_gated_depth(hip_lib):
+    """All-zero depth, depth beyond max_ray_length and below min_ray_length integrate nothing (dense_tsdf.py:196-199)."""
+    K, frames = small_stream(1)
+    g, o = make_pair(SMALL, K)
+    R, T, d = frames[0]
+    for img in (np.zeros_like(d), np.full_like(d, 60000), np.full_like(d, 100)):
+        g.recast_depth_to_map(R, T, img, None)
+        st = g.last_frame_stats()
+        assert st["p_valid"] == 0 and st["v_pcl"] == 0 and st["steps"] == 0
+    assert g.count_active() == 0
+    half = d.copy()
+    half[:, : d.shape[1] // 2] = 0
+    _run_both(g, o, [(R, T, half)])
+    assert_export_equal(g.export_submap(), o.export_sparse(), "half-empty")
+
+
+def test_rays_leaving_the_volume(hip_lib):
+    """A map smaller than the scene: out-of-volume ray-steps are skipped and counted."""
+    cfg = dict(SMALL, map_scale=[2.56, 2.56])
+    K, frames = small_stream(2)
+    g, o = make_pair(cfg, K)
+    _run_both(g, o, frames)
+    assert g.last_frame_stats()["steps_oob"] > 0
+    assert_export_equal(g.export_submap(), o.export_sparse(), "small volume")
+
+
+def test_submap_base_pose_and_switch(hip_lib):
+    """Integration goes into the active submap in that submap's frame (mapping_common.py:91-100, dense_tsdf.py:238)."""
+    K, frames = small_stream(4)
+    cfg = dict(SMALL, max_submap_num=8)
+    g, o = make_pair(cfg, K)
+    R0, T0, _ = frames[0]
+    g.set_base_pose_submap(0, R0, T0)
+    o.set_base_pose_submap(0, R0, T0)
+    _run_both(g, o, frames[:2])
+    assert_export_equal(g.export_submap(), o.export_sparse(), "submap 0")
+    assert g.switch_to_next_submap() == 1
+    o.set_active_submap(1)
+    R2, T2, _ = frames[2]
+    g.set_base_pose_submap(1, R2, T2)
+    o.set_base_pose_submap(1, R2, T2)
+    _run_both(g, o, frames[2:])
+    assert_export_equal(g.export_submap(), o.export_sparse(), "submap 1")
+
+
+def test_particle_exports(hip_lib):
+    """cvt_TSDF_surface_to_voxels / cvt_TSDF_to_voxels_slice (dense_tsdf.py:339-389) as sorted sets."""
+    K, frames = small_stream(3)
+    cfg = dict(SMALL, disp_ceiling=1.0, disp_floor=-1.0)
+    g, o = make_pair(cfg, K)
+    _run_both(g, o, frames)
+    g.cvt_TSDF_surface_to_voxels()
+    n = g.num_TSDF_particles[None]
+    oxyz, orgb, on = o.surface_voxels()
+    assert n == on > 100
+    gxyz = g.export_TSDF_xyz.to_numpy()[:n]
+    grgb = g.export_color.to_numpy()[:n]
+    a = sorted_rows(np.concatenate([gxyz, grgb], 1))
+    b = sorted_rows(np.concatenate([oxyz, orgb], 1))
+    assert np.array_equal(a[:, :3], b[:, :3])
+    assert np.allclose(a[:, 3:], b[:, 3:], atol=1e-6)
+    g.cvt_TSDF_to_voxels_slice(0.2, dz=1.5)
+    n = g.num_TSDF_particles[None]
+    sxyz, sval, _, sn = o.slice_voxels(0.2, 1.5)
+    assert n == sn > 100
+    a = sorted_rows(np.concatenate([g.export_TSDF_xyz.to_numpy()[:n], g.export_TSDF.to_numpy()[:n, None]], 1))
+    b = sorted_rows(np.concatenate([sxyz, sval[:, None]], 1))
+    assert np.array_equal(a, b)
+
+
+def test_reset_and_reuse(hip_lib):
+    K, frames = small_stream(2)
+    g, o = make_pair(SMALL, K)
+    _run_both(g, o, frames)
+    assert g.bricks_in_use() > 0
+    g.reset()
+    assert g.count_active() == 0 and g.bricks_in_use() == 0
+    o.reset()
+    _run_both(g, o, frames[1:])
+    assert_export_equal(g.export_submap(), o.export_sparse(), "after reset")
+
+
+def test_device_pointer_input(hip_lib):
+    import torch
+    K, frames = small_stream(2)
+    g, o = make_pair(SMALL, K)
+    from oracle import BATCHED
+    for R, T, d in frames:
+        dt = torch.from_numpy(d.view(np.int16)).cuda()
+        g.recast_depth_to_map(R, T, dt, None)
+        g.sync()
+        o.integrate_depth(R, T, d, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), "device pointer")
+
+
+def test_capacity_error_is_loud(hip_lib):
+    from taichislam_amd._lib import TslError
+    from taichislam_amd.mapping import DenseTSDF
+    K, frames = small_stream(1)
+    m = DenseTSDF(**SMALL, max_bricks=8)
+    m.set_dep_camera_intrinsic(K)
+    R, T, d = frames[0]
+    m.recast_depth_to_map(R, T, d, None)
+    with pytest.raises(TslError):
+        m.last_frame_stats()
