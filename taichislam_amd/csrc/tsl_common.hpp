@@ -34,7 +34,10 @@ __device__ __forceinline__ h16 hadd(h16 a, h16 b) { return f2h(h2f(a) + h2f(b));
 __device__ __forceinline__ h16 hsub(h16 a, h16 b) { return f2h(h2f(a) - h2f(b)); }
 __device__ __forceinline__ h16 hmul(h16 a, h16 b) { return f2h(h2f(a) * h2f(b)); }
 __device__ __forceinline__ h16 hdiv(h16 a, h16 b) { return f2h(h2f(a) / h2f(b)); }
-__device__ __forceinline__ h16 hsqrt(h16 a) { return f2h(__fsqrt_rn(h2f(a))); }
+// sqrtf() is the correctly rounded form under -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn lowers to a bare
+// v_sqrt_f32 (1 ulp) on gfx950 and breaks bit parity with the CPU oracle.
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+__device__ __forceinline__ h16 hsqrt(h16 a) { return f2h(sqrt_rn(h2f(a))); }
 
 // ti.round(x, ti.i32): round half away from zero (mapping_common.py:263-266, assumption A1)
 __device__ __forceinline__ float rnd_f(float x)
@@ -69,6 +72,19 @@ __device__ __forceinline__ void wave_count_add(int64_t* ctr, bool pred)
 {
     unsigned long long m = __ballot(pred);
     if (m && lane_id() == (int)__builtin_ctzll(m)) atomic_add_i64(ctr, (long long)popc64(m));
+}
+// block-wide count of `pred` with ONE global atomic per block (same-address global atomics cost ~12 ns each on
+// MI355X and serialise; tools/ubench/atomics.hip).  Must be reached by every thread of the block.
+__device__ __forceinline__ void block_count_add(int64_t* ctr, bool pred)
+{
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned long long m = __ballot(pred);
+    if (m && lane_id() == (int)__builtin_ctzll(m)) atomicAdd(&s_cnt, popc64(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomic_add_i64(ctr, (long long)s_cnt);
+    __syncthreads();
 }
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {

@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(FrameParams P, FrameDev 
         F.vals[p] = (uint32_t)p;
         F.pix[p] = payload;
     }
-    wave_count_add(&F.stats->p_valid, inside);
-    wave_count_add(&F.stats->p_oob, gate && !inside);
+    block_count_add(&F.stats->p_valid, inside);
+    block_count_add(&F.stats->p_oob, gate && !inside);
 }
 
 // recast_pcl_to_map_kernel  dense_tsdf.py:167-186 (z := range, gate on the range)
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_voxelize_points(FrameParams P, FrameDev
         const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;                   // :175
         const float my = (P.R[3] * px + P.R[4] * py) + P.R[5] * pz;
         const float mz = (P.R[6] * px + P.R[7] * py) + P.R[8] * pz;
-        const float len = __fsqrt_rn((mx * mx + my * my) + mz * mz);                  // :176
+        const float len = sqrt_rn((mx * mx + my * my) + mz * mz);                  // :176
         K key = KeyOps<K>::invalid(P.pcl_bits);
         uint2 payload = make_uint2(0u, 0u);
         if (len < P.max_ray_f) {                                                      // :177
@@ -121,8 +121,8 @@ __global__ void __launch_bounds__(256) k_voxelize_points(FrameParams P, FrameDev
         F.vals[p] = (uint32_t)p;
         F.pix[p] = payload;
     }
-    wave_count_add(&F.stats->p_valid, inside);
-    wave_count_add(&F.stats->p_oob, gate && !inside);
+    block_count_add(&F.stats->p_valid, inside);
+    block_count_add(&F.stats->p_oob, gate && !inside);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -171,8 +171,8 @@ __global__ void __launch_bounds__(256) k_build_rays(FrameParams P, FrameDev F, c
     }
     const int r = wave_reserve(&F.counters[0], ok);
     if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; }
-    wave_count_add(&F.stats->v_pcl, head);
-    wave_count_add(&F.stats->v_skipped, head && !ok);
+    block_count_add(&F.stats->v_pcl, head);
+    block_count_add(&F.stats->v_skipped, head && !ok);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, FramePa
             const int xi = rnd_i(x0 / P.vs), xj = rnd_i(x1 / P.vs), xk = rnd_i(x2 / P.vs);                                // :254
             if (in_volume(M, xi, xj, xk)) {
                 const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2 - x2;                            // :258
-                const float dist = __fsqrt_rn((v0 * v0 + v1 * v1) + v2 * v2);                    // :259
+                const float dist = sqrt_rn((v0 * v0 + v1 * v1) + v2 * v2);                    // :259
                 const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
                 const float sd = dist * (float)sgn_f(dot);                                       // :260
                 qn = to_fix(w * sd);                                                             // :264 numerator term
