@@ -64,7 +64,7 @@ typedef struct {
 
 /* kernel ids for tsl_tsdf_prof_query */
 enum { TSL_K_VOXELIZE = 0, TSL_K_SORT = 1, TSL_K_RAYS = 2, TSL_K_INTEGRATE = 3, TSL_K_FINALIZE = 4,
-       TSL_K_MESH = 5, TSL_K_COUNT };
+       TSL_K_MESH = 5, TSL_K_SEGMENTS = 6, TSL_K_BIN = 7, TSL_K_COUNT };
 
 const char* tsl_version(void);
 const char* tsl_last_error(void);
@@ -140,7 +140,7 @@ int  tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int
 int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters);
 int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);
 
-/* backend knobs for A/B-ing kernel variants: name in {"variant" (0|1), "split" (lanes per ray, divides 64)} */
+/* backend knobs for A/B-ing kernel variants: name in {"variant" (0|1|2), "split" (lanes per ray, divides 64)} */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);
 
 /* ---- profiling: HIP-event timing of the per-frame kernels on the handle's stream ----------------- */

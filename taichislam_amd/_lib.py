@@ -6,9 +6,9 @@ import os
 from . import build as _build
 
 TSL_OK = 0
-K_VOXELIZE, K_SORT, K_RAYS, K_INTEGRATE, K_FINALIZE, K_MESH = range(6)
+K_VOXELIZE, K_SORT, K_RAYS, K_INTEGRATE, K_FINALIZE, K_MESH, K_SEGMENTS, K_BIN = range(8)
 KERNEL_NAMES = {K_VOXELIZE: "voxelize", K_SORT: "sort", K_RAYS: "build_rays", K_INTEGRATE: "integrate",
-                K_FINALIZE: "finalize", K_MESH: "marching_cubes"}
+                K_FINALIZE: "finalize", K_MESH: "marching_cubes", K_SEGMENTS: "segments", K_BIN: "bin"}
 
 
 class TsdfCfg(C.Structure):

@@ -103,6 +103,26 @@ __device__ __forceinline__ int wave_reserve(int* ctr, bool pred)
     return pred ? base + rank_below(m) : -1;
 }
 
+// block-aggregated reservation (256-thread blocks): ONE global atomic per block; must be reached by every thread
+__device__ __forceinline__ int block_reserve(int* ctr, bool pred)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_b;
+    const unsigned long long m = __ballot(pred);
+    const int wid = threadIdx.x >> 6;
+    if (lane_id() == 0) s_w[wid] = popc64(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        s_b = tot ? __hip_atomic_fetch_add(ctr, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+    __syncthreads();
+    int off = s_b + rank_below(m);
+    for (int w = 0; w < wid; ++w) off += s_w[w];
+    __syncthreads();
+    return pred ? off : -1;
+}
+
 // Claim-or-read an index stored in *entry (EMPTY -> allocate from *counter).  Safe inside divergent
 // SIMT code: a lane never waits on a lane of its own wave (winners publish in the same iteration).
 __device__ __forceinline__ int claim_index(int* entry, int* counter, int cap)

@@ -1,0 +1,417 @@
+// tsl_integrate.hip -- the dominant kernel family: per-voxel weighted TSDF update of one frame's rays.
+// Replaces process_new_pcl (taichi_slam/mapping/dense_tsdf.py:236-270, reference root).
+//
+// Two interchangeable strategies, bit-identical results (exact int64 fixed-point sums):
+//
+//   variant 0/1  "global atomics": every ray-step adds {w*sd, w} with two no-return int64 atomics into a
+//                per-frame brick scratch in HBM/L2, k_finalize applies the sums.  Priced on MI355X at
+//                ~11.7 G pairs/s scattered and ~12 ns per lane for same-address hits (tools/ubench/atomics.hip):
+//                ~1 ms/frame at BASELINE configs[1].  Kept as the simple cross-check.
+//
+//   variant 2    "brick-binned LDS" (default): all updates of one 16^3 brick happen in LDS.
+//                K4a k_segments   : every ray is cut into runs of consecutive steps inside one brick
+//                                   ("segments", one u64 each), staged in LDS and appended block-wise; a
+//                                   per-brick histogram is kept in LDS and flushed once per block.
+//                K4b k_scan       : exclusive scan of the per-brick segment counts (<= 4096 bricks/frame).
+//                K4c k_scatter    : counting-sort the segments by brick (LDS histogram per 4096-segment tile,
+//                                   one global reservation per (tile, brick)).
+//                K4d k_integrate_bricks : one workgroup per chunk of the sorted list; the brick's 4096
+//                                   {num,den} int64 accumulators live in 64 KiB of LDS (ds_add_u64, >400 G
+//                                   pairs/s chip-wide), then the brick is finalised in place with coalesced
+//                                   row reads/writes.  Bricks whose segment list straddles chunks flush their
+//                                   partial sums to the HBM scratch (wave-coherent int64 atomics) and
+//                K4e k_finalize   : ... are finalised from there.
+#include "tsl_tsdf.hpp"
+
+namespace tsl {
+
+// segment key: [0,6) step count  [6,18) first step  [18,42) ray id  [42,58) frame slot of the brick
+#define SEG_CNT_BITS 6
+#define SEG_J_BITS   12
+#define SEG_RAY_BITS 24
+#define SEG_SLOT_SHIFT (SEG_CNT_BITS + SEG_J_BITS + SEG_RAY_BITS)
+#define SEG_MAX_CNT 63
+#define SEG_LDS_CAP 4096
+#define SLOT_LDS    4096            // per-block LDS histogram size == max_frame_bricks upper bound for variant 2
+#define SCATTER_TILE 4096
+
+struct RayRegs { float pf0, pf1, pf2, d0, d1, d2, P0, P1, P2, w; long long qden; int n; };
+
+__device__ __forceinline__ RayRegs load_ray(const FrameDev& F, const FrameParams& P, int r)
+{
+    RayRegs R;
+    const uint4 rec = F.rayA[r];
+    R.n = F.rayN[r];
+    R.pf0 = h2f((h16)(rec.x & 0xffffu)); R.pf1 = h2f((h16)(rec.x >> 16)); R.pf2 = h2f((h16)(rec.y & 0xffffu));
+    R.d0 = h2f((h16)(rec.y >> 16)); R.d1 = h2f((h16)(rec.z & 0xffffu)); R.d2 = h2f((h16)(rec.z >> 16));
+    R.w = __uint_as_float(rec.w);
+    R.qden = to_fix(R.w);
+    R.P0 = R.pf0 + P.T[0]; R.P1 = R.pf1 + P.T[1]; R.P2 = R.pf2 + P.T[2];                      // dense_tsdf.py:246
+    return R;
+}
+// voxel visited at step j  (dense_tsdf.py:253-254)
+__device__ __forceinline__ void step_voxel(const RayRegs& R, const FrameParams& P, int j, float* x, int* xi)
+{
+    const float jf = (float)j;
+    x[0] = (R.d0 * jf) * P.vs + P.T[0]; x[1] = (R.d1 * jf) * P.vs + P.T[1]; x[2] = (R.d2 * jf) * P.vs + P.T[2];
+    xi[0] = rnd_i(x[0] / P.vs); xi[1] = rnd_i(x[1] / P.vs); xi[2] = rnd_i(x[2] / P.vs);
+}
+// numerator term of the running average  (dense_tsdf.py:258-264)
+__device__ __forceinline__ long long step_term(const RayRegs& R, const float* x)
+{
+    const float v0 = R.P0 - x[0], v1 = R.P1 - x[1], v2 = R.P2 - x[2];
+    const float dist = sqrt_rn((v0 * v0 + v1 * v1) + v2 * v2);
+    const float dot = (v0 * R.pf0 + v1 * R.pf1) + v2 * R.pf2;
+    const float sd = dist * (float)sgn_f(dot);
+    return to_fix(R.w * sd);
+}
+// occupy[pos_p] = 1  (dense_tsdf.py:248)
+__device__ __forceinline__ void mark_occupied(const MapDev& M, const FrameParams& P, const RayRegs& R)
+{
+    const int oi = rnd_i(R.P0 / P.vs), oj = rnd_i(R.P1 / P.vs), ok = rnd_i(R.P2 / P.vs);
+    if (in_volume(M, oi, oj, ok)) {
+        int l; const int b = brick_of(M, oi, oj, ok, &l);
+        const int p = pool_claim(M, P.slot, b);
+        if (p >= 0) M.occ[(size_t)p * TSL_BRK3 + l] = 1;
+    }
+}
+// frame scratch slot of a brick (allocating the brick and the slot on first touch); < 0 when out of capacity
+__device__ __forceinline__ int frame_slot(const MapDev& M, const FrameDev& F, int s, int b)
+{
+    const int p = pool_claim(M, s, b);
+    if (p < 0) return -1;
+    int* e = F.slot_of_pool + p;
+    int sl = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sl < 0) {
+        sl = claim_index(e, &F.counters[1], F.max_frame_bricks);
+        if (sl >= 0) F.touched[sl] = p; else atomicOr(M.err, 2);
+    }
+    return sl;
+}
+
+// apply one frame's sums to a voxel  (dense_tsdf.py:264-267 with the frame's total weight)
+__device__ __forceinline__ uint32_t apply_update(uint32_t old, long long qnum, long long qden)
+{
+    const float num = from_fix(qnum), den = from_fix(qden);
+    const h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
+    const h16 Tn = f2h((h2f(hmul(T0, W0)) + num) / (h2f(W0) + den));
+    float wn = h2f(W0) + den; if (TSL_WMAX < wn) wn = TSL_WMAX;
+    return (uint32_t)Tn | ((uint32_t)f2h(wn) << 16);
+}
+
+// =====================================================================================================
+// variant 0/1: global int64 atomics
+// =====================================================================================================
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, FrameParams P)
+{
+    const int split = P.split;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int r = gid / split, sub = gid - r * split;
+    const int nrays = F.counters[0];
+    const bool live = r < nrays;
+    long long n_ok = 0, n_oob = 0;
+    RayRegs R; R.n = 0; R.qden = 0;
+    if (live) { R = load_ray(F, P, r); if (sub == 0) mark_occupied(M, P, R); }
+    int cur_b = -1; unsigned long long* cur_acc = nullptr;
+    int nmax = R.n;
+    if (VARIANT == 1) { for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; } }
+    const int iters = (nmax + split - 1) / split;          // wave-uniform trip count when VARIANT == 1 (cross-lane ops inside)
+    for (int it = 0; it < iters; ++it) {
+        const int j = 1 + sub + it * split;
+        const bool act = live && j <= R.n;
+        unsigned long long* dst = nullptr;
+        long long qn = 0;
+        if (act) {
+            float x[3]; int xi[3];
+            step_voxel(R, P, j, x, xi);
+            if (in_volume(M, xi[0], xi[1], xi[2])) {
+                qn = step_term(R, x);
+                int l; const int b = brick_of(M, xi[0], xi[1], xi[2], &l);
+                if (b != cur_b) { cur_b = b; const int sl = frame_slot(M, F, P.slot, b); cur_acc = sl >= 0 ? F.acc + (size_t)sl * (TSL_BRK3 * 2) : nullptr; }
+                if (cur_acc) { dst = cur_acc + (size_t)l * 2; ++n_ok; }
+            } else ++n_oob;
+        }
+        if (VARIANT == 1) {     // wave-uniform fast path: all live lanes hit one voxel -> reduce in-wave, one atomic pair
+            const unsigned long long m = __ballot(dst != nullptr);
+            if (m) {
+                const int leader = (int)__builtin_ctzll(m);
+                const unsigned long long lead = __shfl((unsigned long long)dst, leader);
+                const bool same = (dst == nullptr) || ((unsigned long long)dst == lead);
+                if (__all(same)) {
+                    const long long sn = wave_sum_ll(dst ? qn : 0), sdn = wave_sum_ll(dst ? R.qden : 0);
+                    if (lane_id() == leader) {
+                        __hip_atomic_fetch_add(dst, (unsigned long long)sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(dst + 1, (unsigned long long)sdn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    continue;
+                }
+            }
+        }
+        if (dst) {
+            __hip_atomic_fetch_add(dst, (unsigned long long)qn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dst + 1, (unsigned long long)R.qden, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    n_ok = wave_sum_ll(n_ok); n_oob = wave_sum_ll(n_oob);
+    if (lane_id() == 0) {
+        if (n_ok) atomic_add_i64(&F.stats->steps, n_ok);
+        if (n_oob) atomic_add_i64(&F.stats->steps_oob, n_oob);
+    }
+}
+
+// finalise bricks from the HBM scratch.  list == nullptr: every touched slot; else the `*nlist` slots in list.
+// Always releases the frame slots of all touched bricks (slot_of_pool) for the next frame.
+__global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F, const int* list, const int* nlist)
+{
+    const int ntouched = min(F.counters[1], F.max_frame_bricks);
+    const int nwork = list ? min(*nlist, F.max_frame_bricks) : ntouched;
+    long long uniq = 0;
+    for (int q = blockIdx.x; q < nwork; q += gridDim.x) {
+        const int sl = list ? list[q] : q;
+        const int p = F.touched[sl];
+        ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)sl * (TSL_BRK3 * 2));
+        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+        int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const ulonglong2 a = acc[l];
+            if (a.y != 0ull) {
+                tw[l] = apply_update(tw[l], (long long)a.x, (long long)a.y);
+                obs[l] = 1;                                                                      // dense_tsdf.py:265
+                acc[l] = make_ulonglong2(0ull, 0ull);
+                ++uniq;
+            }
+        }
+    }
+    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < ntouched; sl += gridDim.x * 256) F.slot_of_pool[F.touched[sl]] = TSL_EMPTY;
+    uniq = wave_sum_ll(uniq);
+    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
+    if (blockIdx.x == 0 && threadIdx.x == 0) F.stats->bricks = ntouched;
+}
+
+// =====================================================================================================
+// variant 2: brick-binned segments, LDS accumulation
+// =====================================================================================================
+// K4a: cut rays into per-brick segments
+__global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FrameParams P)
+{
+    __shared__ unsigned long long s_seg[SEG_LDS_CAP];
+    __shared__ int s_hist[SLOT_LDS];
+    __shared__ int s_n, s_base;
+    for (int i = threadIdx.x; i < SLOT_LDS; i += 256) s_hist[i] = 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+
+    const int split = P.split;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int r = gid / split, sub = gid - r * split;
+    const int nrays = F.counters[0];
+    long long n_ok = 0, n_oob = 0;
+    if (r < nrays) {
+        const RayRegs R = load_ray(F, P, r);
+        if (sub == 0) mark_occupied(M, P, R);
+        const int len = (R.n + split - 1) / split;
+        const int ja = 1 + sub * len, jb = min(R.n, ja + len - 1);
+        int run_b = -1, run_j0 = 0, run_cnt = 0;
+        auto emit = [&]() {
+            if (run_cnt == 0) return;
+            const int sl = frame_slot(M, F, P.slot, run_b);
+            if (sl >= 0) {
+                n_ok += run_cnt;
+                const unsigned long long key = ((unsigned long long)sl << SEG_SLOT_SHIFT) | ((unsigned long long)r << (SEG_CNT_BITS + SEG_J_BITS)) |
+                                               ((unsigned long long)run_j0 << SEG_CNT_BITS) | (unsigned long long)run_cnt;
+                const int idx = atomicAdd(&s_n, 1);
+                if (idx < SEG_LDS_CAP) { s_seg[idx] = key; atomicAdd(&s_hist[sl], 1); }
+                else {      // rare: block staging full -> append directly
+                    const int pos = __hip_atomic_fetch_add(&F.counters[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pos < F.seg_cap) { F.seg[pos] = key; __hip_atomic_fetch_add(&F.hist[sl], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    else atomicOr(M.err, 4);
+                }
+            }
+            run_cnt = 0;
+        };
+        for (int j = ja; j <= jb; ++j) {
+            float x[3]; int xi[3];
+            step_voxel(R, P, j, x, xi);
+            if (!in_volume(M, xi[0], xi[1], xi[2])) { emit(); run_b = -1; ++n_oob; continue; }
+            int l; const int b = brick_of(M, xi[0], xi[1], xi[2], &l);
+            if (b != run_b || run_cnt == SEG_MAX_CNT) { emit(); run_b = b; run_j0 = j; }
+            ++run_cnt;
+        }
+        emit();
+    }
+    __syncthreads();
+    const int n = min(s_n, SEG_LDS_CAP);
+    if (threadIdx.x == 0) s_base = n ? __hip_atomic_fetch_add(&F.counters[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (base + i < F.seg_cap) F.seg[base + i] = s_seg[i];
+        else { atomicOr(M.err, 4); }
+    }
+    for (int i = threadIdx.x; i < SLOT_LDS; i += 256) {
+        const int c = s_hist[i];
+        if (c) __hip_atomic_fetch_add(&F.hist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    n_ok = wave_sum_ll(n_ok); n_oob = wave_sum_ll(n_oob);
+    if (lane_id() == 0) {
+        if (n_ok) atomic_add_i64(&F.stats->steps, n_ok);
+        if (n_oob) atomic_add_i64(&F.stats->steps_oob, n_oob);
+    }
+}
+
+// K4b: offset[s] = sum_{t<s} hist[t], offset[nt] = total   (single block, <= SLOT_LDS entries)
+__global__ void __launch_bounds__(1024) k_scan(FrameDev F)
+{
+    __shared__ int s_wave[16];
+    const int nt = min(F.counters[1], F.max_frame_bricks);
+    const int t = threadIdx.x;
+    int v[4], s = 0;
+    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; v[q] = i < nt ? F.hist[i] : 0; s += v[q]; }
+    int inc = s;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((t & 63) >= d) inc += o; }
+    if ((t & 63) == 63) s_wave[t >> 6] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (t >> 6); ++w) wbase += s_wave[w];
+    int run = wbase + inc - s;
+    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; if (i <= nt) F.offset[i] = run; run += v[q]; }
+    if (t == 1023) {
+        if (nt == SLOT_LDS) F.offset[SLOT_LDS] = run;
+        F.counters[3] = min(run, F.seg_cap);                     // total segments
+    }
+}
+
+// K4c: counting sort by brick slot
+__global__ void __launch_bounds__(256) k_scatter(FrameDev F)
+{
+    __shared__ int s_hist[SLOT_LDS];
+    __shared__ int s_base[SLOT_LDS];
+    const int total = min(F.counters[2], F.seg_cap);
+    const int ntiles = (total + SCATTER_TILE - 1) / SCATTER_TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < SLOT_LDS; i += 256) s_hist[i] = 0;
+        __syncthreads();
+        const int t0 = tile * SCATTER_TILE;
+        unsigned long long key[SCATTER_TILE / 256]; int rank[SCATTER_TILE / 256];
+#pragma unroll
+        for (int q = 0; q < SCATTER_TILE / 256; ++q) {
+            const int i = t0 + q * 256 + threadIdx.x;
+            rank[q] = -1;
+            if (i < total) { key[q] = F.seg[i]; rank[q] = atomicAdd(&s_hist[(int)(key[q] >> SEG_SLOT_SHIFT)], 1); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < SLOT_LDS; i += 256) {
+            const int c = s_hist[i];
+            if (c) s_base[i] = F.offset[i] + __hip_atomic_fetch_add(&F.cursor[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SCATTER_TILE / 256; ++q)
+            if (rank[q] >= 0) F.seg_sorted[s_base[(int)(key[q] >> SEG_SLOT_SHIFT)] + rank[q]] = key[q];
+        __syncthreads();
+    }
+}
+
+// K4d: LDS accumulation per brick, in-place finalise
+__global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, FrameParams P)
+{
+    __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
+    const int total = F.counters[3];
+    const int nblk = gridDim.x;
+    int chunk = (total + nblk - 1) / nblk;
+    if (chunk < 256) chunk = 256;
+    const int cb = blockIdx.x * chunk, ce = min(total, cb + chunk);
+    long long uniq = 0;
+    int pos = cb;
+    while (pos < ce) {
+        const int sl = (int)(F.seg_sorted[pos] >> SEG_SLOT_SHIFT);
+        const int b0 = F.offset[sl], b1 = F.offset[sl + 1];
+        const int run_end = min(b1, ce);
+        const bool whole = (pos == b0) && (run_end == b1);
+        for (int i = threadIdx.x; i < TSL_BRK3 * 2; i += 256) s_acc[i] = 0ull;
+        __syncthreads();
+        for (int i = pos + threadIdx.x; i < run_end; i += 256) {
+            const unsigned long long key = F.seg_sorted[i];
+            const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
+            const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << SEG_RAY_BITS) - 1));
+            const RayRegs R = load_ray(F, P, r);
+            for (int j = j0; j < j0 + cnt; ++j) {
+                float x[3]; int xi[3];
+                step_voxel(R, P, j, x, xi);
+                int l; (void)brick_of(M, xi[0], xi[1], xi[2], &l);
+                const long long qn = step_term(R, x);
+                atomicAdd(&s_acc[l * 2], (unsigned long long)qn);
+                atomicAdd(&s_acc[l * 2 + 1], (unsigned long long)R.qden);
+            }
+        }
+        __syncthreads();
+        const int p = F.touched[sl];
+        if (whole) {
+            uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+            int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+                const unsigned long long qd = s_acc[l * 2 + 1];
+                if (qd != 0ull) {
+                    tw[l] = apply_update(tw[l], (long long)s_acc[l * 2], (long long)qd);
+                    obs[l] = 1;
+                    ++uniq;
+                }
+            }
+        } else {
+            unsigned long long* acc = F.acc + (size_t)sl * (TSL_BRK3 * 2);
+            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+                const unsigned long long qd = s_acc[l * 2 + 1];
+                if (qd != 0ull) {
+                    __hip_atomic_fetch_add(acc + l * 2, s_acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + l * 2 + 1, qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (threadIdx.x == 0 && atomicExch(&F.shared_flag[sl], 1) == 0) {
+                const int q = __hip_atomic_fetch_add(&F.counters[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                F.shared_list[q] = sl;
+            }
+        }
+        __syncthreads();
+        pos = run_end;
+    }
+    uniq = wave_sum_ll(uniq);
+    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
+}
+
+int launch_integrate(tsl_tsdf* m, int total)
+{
+    FrameParams& P = m->P;
+    FrameDev& F = m->F;
+    const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
+    if (P.variant == 2) {
+        TSL_REQUIRE(F.max_frame_bricks <= SLOT_LDS, "variant 2 needs max_frame_bricks <= 4096");
+        TSL_REQUIRE(P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << SEG_RAY_BITS), "variant 2: ray too long / too many points for the segment key");
+        TSL_HIP(hipMemsetAsync(F.hist, 0, sizeof(int) * (size_t)(3 * SLOT_LDS + 8), m->stream));      // hist | cursor | shared_flag
+        prof_begin(m, TSL_K_SEGMENTS);
+        hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
+        prof_end(m);
+        prof_begin(m, TSL_K_BIN);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, F);
+        hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, m->stream, F);
+        prof_end(m);
+        prof_begin(m, TSL_K_INTEGRATE);
+        hipLaunchKernelGGL(k_integrate_bricks, dim3(512), dim3(256), 0, m->stream, m->M, F, P);
+        prof_end(m);
+        prof_begin(m, TSL_K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, m->stream, m->M, F, (const int*)F.shared_list, (const int*)&F.counters[4]);
+        prof_end(m);
+    } else {
+        prof_begin(m, TSL_K_INTEGRATE);
+        if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
+        else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
+        prof_end(m);
+        prof_begin(m, TSL_K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const int*)nullptr, (const int*)nullptr);
+        prof_end(m);
+    }
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+
+}  // namespace tsl

@@ -169,145 +169,10 @@ __global__ void __launch_bounds__(256) k_build_rays(FrameParams P, FrameDev F, c
             }
         }
     }
-    const int r = wave_reserve(&F.counters[0], ok);
+    const int r = block_reserve(&F.counters[0], ok);
     if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; }
     block_count_add(&F.stats->v_pcl, head);
     block_count_add(&F.stats->v_skipped, head && !ok);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// K4: ray march  process_new_pcl :246-269.  SPLIT lanes share one ray (strided steps).
-// ------------------------------------------------------------------------------------------------------
-struct BrickCursor { int b; unsigned long long* acc; };
-
-__device__ __forceinline__ unsigned long long* frame_slot(const MapDev& M, const FrameDev& F, int s, int b)
-{
-    const int p = pool_claim(M, s, b);
-    if (p < 0) return nullptr;
-    int* e = F.slot_of_pool + p;
-    int sl = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sl < 0) {
-        sl = claim_index(e, &F.counters[1], F.max_frame_bricks);
-        if (sl >= 0) F.touched[sl] = p; else atomicOr(M.err, 2);
-    }
-    if (sl < 0) return nullptr;
-    return F.acc + (size_t)sl * (TSL_BRK3 * 2);
-}
-
-// VARIANT 0: one no-return int64 atomic pair per ray-step
-// VARIANT 1: wave-uniform fast path -- when all live lanes hit the same voxel, reduce in-wave, one atomic pair
-template <int VARIANT>
-__global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, FrameParams P)
-{
-    const int split = P.split;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int r = gid / split, sub = gid - r * split;
-    const int nrays = F.counters[0];
-    const bool live = r < nrays;
-    long long n_ok = 0, n_oob = 0;
-    int n = 0;
-    float pf0 = 0, pf1 = 0, pf2 = 0, d0 = 0, d1 = 0, d2 = 0, P0 = 0, P1 = 0, P2 = 0, w = 0;
-    long long qden = 0;
-    if (live) {
-        const uint4 rec = F.rayA[r];
-        n = F.rayN[r];
-        pf0 = h2f((h16)(rec.x & 0xffffu)); pf1 = h2f((h16)(rec.x >> 16)); pf2 = h2f((h16)(rec.y & 0xffffu));
-        d0 = h2f((h16)(rec.y >> 16)); d1 = h2f((h16)(rec.z & 0xffffu)); d2 = h2f((h16)(rec.z >> 16));
-        w = __uint_as_float(rec.w);
-        qden = to_fix(w);
-        P0 = pf0 + P.T[0]; P1 = pf1 + P.T[1]; P2 = pf2 + P.T[2];                              // :246
-        if (sub == 0) {                                                                        // :248 occupy[pos_p] = 1
-            const int oi = rnd_i(P0 / P.vs), oj = rnd_i(P1 / P.vs), ok = rnd_i(P2 / P.vs);
-            if (in_volume(M, oi, oj, ok)) {
-                int l; const int b = brick_of(M, oi, oj, ok, &l);
-                const int p = pool_claim(M, P.slot, b);
-                if (p >= 0) M.occ[(size_t)p * TSL_BRK3 + l] = 1;
-            }
-        }
-    }
-    BrickCursor cur = { -1, nullptr };
-    int nmax = n;
-    if (VARIANT == 1) { for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; } }
-    const int iters = (nmax + split - 1) / split;          // wave-uniform trip count when VARIANT == 1 (cross-lane ops inside)
-    for (int it = 0; it < iters; ++it) {                                                       // :251-253
-        const int j = 1 + sub + it * split;
-        const bool act = live && j <= n;
-        unsigned long long* dst = nullptr;
-        long long qn = 0;
-        if (act) {
-            const float jf = (float)j;
-            const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];   // :253
-            const int xi = rnd_i(x0 / P.vs), xj = rnd_i(x1 / P.vs), xk = rnd_i(x2 / P.vs);                                // :254
-            if (in_volume(M, xi, xj, xk)) {
-                const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2 - x2;                            // :258
-                const float dist = sqrt_rn((v0 * v0 + v1 * v1) + v2 * v2);                    // :259
-                const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
-                const float sd = dist * (float)sgn_f(dot);                                       // :260
-                qn = to_fix(w * sd);                                                             // :264 numerator term
-                int l; const int b = brick_of(M, xi, xj, xk, &l);
-                if (b != cur.b) { cur.b = b; cur.acc = frame_slot(M, F, P.slot, b); }
-                if (cur.acc) { dst = cur.acc + (size_t)l * 2; ++n_ok; }
-            } else ++n_oob;
-        }
-        if (VARIANT == 1) {
-            const unsigned long long m = __ballot(dst != nullptr);
-            if (m) {
-                const int leader = (int)__builtin_ctzll(m);
-                const unsigned long long lead = __shfl((unsigned long long)dst, leader);
-                const bool same = (dst == nullptr) || ((unsigned long long)dst == lead);
-                if (__all(same)) {
-                    const long long sn = wave_sum_ll(dst ? qn : 0), sdn = wave_sum_ll(dst ? qden : 0);
-                    if (lane_id() == leader) {
-                        __hip_atomic_fetch_add(dst, (unsigned long long)sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(dst + 1, (unsigned long long)sdn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    continue;
-                }
-            }
-        }
-        if (dst) {
-            __hip_atomic_fetch_add(dst, (unsigned long long)qn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(dst + 1, (unsigned long long)qden, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    n_ok = wave_sum_ll(n_ok); n_oob = wave_sum_ll(n_oob);
-    if (lane_id() == 0) {
-        if (n_ok) atomic_add_i64(&F.stats->steps, n_ok);
-        if (n_oob) atomic_add_i64(&F.stats->steps_oob, n_oob);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// K5: apply the per-frame sums once per touched voxel (:264-267 with the frame's total weight), clear scratch
-// ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F)
-{
-    const int ntouched = min(F.counters[1], F.max_frame_bricks);
-    long long uniq = 0;
-    for (int sl = blockIdx.x; sl < ntouched; sl += gridDim.x) {
-        const int p = F.touched[sl];
-        ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)sl * (TSL_BRK3 * 2));
-        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
-        int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-            const ulonglong2 a = acc[l];
-            if (a.y != 0ull) {
-                const float num = from_fix((long long)a.x), den = from_fix((long long)a.y);
-                const uint32_t old = tw[l];
-                const h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
-                const h16 Tn = f2h((h2f(hmul(T0, W0)) + num) / (h2f(W0) + den));                 // :264
-                float wn = h2f(W0) + den; if (TSL_WMAX < wn) wn = TSL_WMAX;                      // :267
-                tw[l] = (uint32_t)Tn | ((uint32_t)f2h(wn) << 16);
-                obs[l] = 1;                                                                      // :265
-                acc[l] = make_ulonglong2(0ull, 0ull);
-                ++uniq;
-            }
-        }
-        if (threadIdx.x == 0) F.slot_of_pool[p] = TSL_EMPTY;
-    }
-    uniq = wave_sum_ll(uniq);
-    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
-    if (blockIdx.x == 0 && threadIdx.x == 0) F.stats->bricks = ntouched;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -515,7 +380,7 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
     TSL_REQUIRE(total <= F.max_points, "integrate: more pixels/points than max_points");
     TSL_HIP(hipMemsetAsync(F.stats, 0, sizeof(tsl_frame_stats), m->stream));
-    TSL_HIP(hipMemsetAsync(F.counters, 0, sizeof(int) * 4, m->stream));
+    TSL_HIP(hipMemsetAsync(F.counters, 0, sizeof(int) * 8, m->stream));
     if (total == 0) return TSL_OK;
     K* keys = reinterpret_cast<K*>(F.keys);
     K* keys_s = reinterpret_cast<K*>(F.keys_s);
@@ -531,14 +396,7 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     prof_begin(m, TSL_K_RAYS);
     hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const K*)keys_s, total);
     prof_end(m);
-    prof_begin(m, TSL_K_INTEGRATE);
-    const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
-    if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
-    else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
-    prof_end(m);
-    prof_begin(m, TSL_K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream, m->M, F);
-    prof_end(m);
+    { int rc = launch_integrate(m, total); if (rc) return rc; }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -627,7 +485,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->active = 0; m->variant = 1; m->split = 4;
+    m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0; m->stage_in = nullptr; m->stage_in_bytes = 0; m->stage_tex = nullptr; m->stage_tex_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
@@ -666,7 +524,17 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&F.slot_of_pool, sizeof(int) * (size_t)want, 0xff))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.touched, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.counters, sizeof(int) * 4, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.counters, sizeof(int) * 8, 0))) return rc;
+    {   // ray segments: ~ (steps/16 + 3 axis crossings) per ray; 32 per point is a generous bound
+        const int64_t cap = (int64_t)F.max_points * 32;
+        F.seg_cap = (int)(cap > (1ll << 30) ? (1ll << 30) : cap);
+        if ((rc = dev_alloc(m, (void**)&F.seg, 8 * (size_t)F.seg_cap, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.seg_sorted, 8 * (size_t)F.seg_cap, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.hist, sizeof(int) * (3 * 4096 + 8), 0))) return rc;
+        F.cursor = F.hist + 4096; F.shared_flag = F.hist + 2 * 4096;
+        if ((rc = dev_alloc(m, (void**)&F.offset, sizeof(int) * (4096 + 8), 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.shared_list, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    }
     if ((rc = dev_alloc(m, (void**)&F.stats, sizeof(tsl_frame_stats), 0))) return rc;
     if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
     if ((rc = dev_alloc(m, &m->sort_temp, m->sort_temp_bytes + 256, 0))) return rc;
@@ -693,7 +561,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.keys, m->F.keys_s, m->F.vals, m->F.vals_s,
-                     m->F.pix, m->F.rayA, m->F.rayN, m->F.slot_of_pool, m->F.touched, m->F.acc, m->F.counters, m->F.stats, m->sort_temp,
+                     m->F.pix, m->F.rayA, m->F.rayN, m->F.slot_of_pool, m->F.touched, m->F.acc, m->F.counters, m->F.stats, m->F.seg, m->F.seg_sorted, m->F.hist, m->F.offset, m->F.shared_list, m->sort_temp,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -982,7 +850,7 @@ int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launche
 int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
 {
     TSL_REQUIRE(m && name, "null");
-    if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value == 0 || value == 1, "variant must be 0 or 1"); m->variant = value; return TSL_OK; }
+    if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
 }

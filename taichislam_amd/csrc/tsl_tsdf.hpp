@@ -29,7 +29,12 @@ struct FrameDev {
     int*   slot_of_pool;                         // [max_bricks] -> frame scratch slot
     int*   touched;                              // [max_frame_bricks] -> pool brick
     unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
-    int*   counters;                             // [0] rays  [1] touched bricks
+    int*   counters;                             // [0] rays [1] touched bricks [2] segments appended [3] segments sorted [4] shared bricks
+    unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick slot
+    int    seg_cap;
+    int   *hist, *cursor, *shared_flag;          // [4096] each, contiguous, cleared per frame
+    int   *offset;                               // [4097] exclusive scan of hist
+    int   *shared_list;                          // slots whose segment list straddles integrate chunks
     tsl_frame_stats* stats;
     int    max_frame_bricks;
     int    max_points;
@@ -82,4 +87,5 @@ void prof_begin(tsl_tsdf* m, int kid);
 void prof_end(tsl_tsdf* m);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
+int  launch_integrate(tsl_tsdf* m, int total);
 }

@@ -33,7 +33,7 @@ def test_small_stream_bit_exact(hip_lib):
     assert np.array_equal(sorted_rows(gi), sorted_rows(oi)) and gi.shape[0] > 100
 
 
-@pytest.mark.parametrize("variant,split", [(0, 1), (0, 4), (1, 1), (1, 4), (1, 16), (1, 64)])
+@pytest.mark.parametrize("variant,split", [(0, 1), (0, 4), (1, 1), (1, 4), (1, 64), (2, 1), (2, 2), (2, 4), (2, 8)])
 def test_kernel_variants_agree(hip_lib, variant, split):
     K, frames = small_stream(2)
     g, o = make_pair(SMALL, K)
@@ -59,7 +59,7 @@ def test_full_size_properties(hip_lib):
     from taichislam_amd.mapping import DenseTSDF
     frames = list(syn.sphere_room_stream(6))
     exports = []
-    for variant, split in ((1, 4), (0, 2)):
+    for variant, split in ((2, 2), (1, 4)):
         m = DenseTSDF(**C2)
         m.set_dep_camera_intrinsic(syn.K_DEPTH)
         m.set_option("variant", variant)
