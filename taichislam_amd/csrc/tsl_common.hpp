@@ -125,7 +125,7 @@ __device__ __forceinline__ int block_reserve(int* ctr, bool pred)
 
 // Claim-or-read an index stored in *entry (EMPTY -> allocate from *counter).  Safe inside divergent
 // SIMT code: a lane never waits on a lane of its own wave (winners publish in the same iteration).
-__device__ __forceinline__ int claim_index(int* entry, int* counter, int cap)
+__device__ __forceinline__ int claim_index_1(int* entry, int* counter, int cap)
 {
     int v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (v == TSL_EMPTY || v == TSL_LOCKED) {
@@ -142,6 +142,26 @@ __device__ __forceinline__ int claim_index(int* entry, int* counter, int cap)
             __builtin_amdgcn_s_sleep(2);
             v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    return v;
+}
+// Wave-cooperative form: the lanes that reach this point together usually want the SAME entry (coherent rays
+// enter a new brick in the same step).  64 same-address CAS cost 64 x ~12 ns on MI355X, so one lane per
+// distinct entry does the claim and the result is broadcast.  Callable from divergent code: only the
+// currently active lanes take part.
+__device__ __forceinline__ int claim_index(int* entry, int* counter, int cap)
+{
+    int v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long todo = __ballot(v == TSL_EMPTY || v == TSL_LOCKED);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const unsigned long long lead = __shfl((unsigned long long)entry, leader);
+        int r = 0;
+        if (lane_id() == leader) r = claim_index_1(entry, counter, cap);
+        r = __shfl(r, leader);
+        const bool mine = ((unsigned long long)entry == lead);
+        if (mine) v = r;
+        todo &= ~__ballot(mine);
     }
     return v;
 }
@@ -176,12 +196,15 @@ __device__ __forceinline__ int pool_lookup(const MapDev& M, int s, int b)
 { return __hip_atomic_load(M.table + (size_t)s * M.nb3 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // read-only lookup through the normal (cached) path: for kernels that run after all allocation is done
 __device__ __forceinline__ int pool_lookup_ro(const MapDev& M, int s, int b) { return M.table[(size_t)s * M.nb3 + b]; }
+// COOP: wave-cooperative claim (callers are coherent rays that usually want the same brick); !COOP: every lane claims
+// on its own (callers hold distinct bricks).
+template <bool COOP = true>
 __device__ __forceinline__ int pool_claim(const MapDev& M, int s, int b)
 {
     int* e = M.table + (size_t)s * M.nb3 + b;
     int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= 0) return v;
-    v = claim_index(e, M.pool_top, M.max_bricks);
+    v = COOP ? claim_index(e, M.pool_top, M.max_bricks) : claim_index_1(e, M.pool_top, M.max_bricks);
     if (v >= 0) M.owner[v] = s * M.nb3 + b;      // idempotent: every claimer of a fresh brick writes the same value
     else atomicOr(M.err, 1);
     return v;

@@ -75,18 +75,24 @@ __device__ __forceinline__ void mark_occupied(const MapDev& M, const FrameParams
         if (p >= 0) M.occ[(size_t)p * TSL_BRK3 + l] = 1;
     }
 }
-// frame scratch slot of a brick (allocating the brick and the slot on first touch); < 0 when out of capacity
+// frame scratch slot of a brick (allocating the brick and the slot on first touch); < 0 when out of capacity.
+// Fast path: one plain, L1-cacheable load of the per-frame table (entries only go EMPTY -> slot inside a frame
+// and are reset by k_finalize, so a non-negative value is never stale); slow path: wave-cooperative claim.
+template <bool COOP = true>
+__device__ __forceinline__ int frame_slot_slow(const MapDev& M, const FrameDev& F, int s, int b)
+{
+    const int sl = COOP ? claim_index(F.slot_tab + b, &F.counters[1], F.max_frame_bricks) : claim_index_1(F.slot_tab + b, &F.counters[1], F.max_frame_bricks);
+    if (sl >= 0) {
+        const int p = pool_claim<COOP>(M, s, b);
+        if (p >= 0) { F.touched[sl] = p; F.touched_b[sl] = b; }      // idempotent: every claimer writes the same values
+        else return -1;
+    } else atomicOr(M.err, 2);
+    return sl;
+}
 __device__ __forceinline__ int frame_slot(const MapDev& M, const FrameDev& F, int s, int b)
 {
-    const int p = pool_claim(M, s, b);
-    if (p < 0) return -1;
-    int* e = F.slot_of_pool + p;
-    int sl = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sl < 0) {
-        sl = claim_index(e, &F.counters[1], F.max_frame_bricks);
-        if (sl >= 0) F.touched[sl] = p; else atomicOr(M.err, 2);
-    }
-    return sl;
+    const int sl = F.slot_tab[b];
+    return sl >= 0 ? sl : frame_slot_slow(M, F, s, b);
 }
 
 // apply one frame's sums to a voxel  (dense_tsdf.py:264-267 with the frame's total weight)
@@ -99,6 +105,24 @@ __device__ __forceinline__ uint32_t apply_update(uint32_t old, long long qnum, l
     return (uint32_t)Tn | ((uint32_t)f2h(wn) << 16);
 }
 
+// Frame prologue on the phase-B stream: clear the per-frame counters / histograms and pre-claim the 5^3 bricks
+// around the sensor.  Every ray starts at the sensor, so without this ~all waves of k_segments hit the same
+// EMPTY table entries in their first steps and pay a same-address CAS storm (~12 ns per wave and brick).
+__global__ void __launch_bounds__(1024) k_frame_begin(MapDev M, FrameDev F, FrameParams P, int nclear, int preclaim)
+{
+    for (int i = threadIdx.x; i < nclear; i += 1024) F.hist[i] = 0;          // hist | cursor | shared_flag
+    if (threadIdx.x >= 1 && threadIdx.x < 8) __hip_atomic_store(&F.counters[threadIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (preclaim && threadIdx.x < 125) {
+        const int t = threadIdx.x;
+        const int ci = rnd_i(P.T[0] / P.vs) + M.hN, cj = rnd_i(P.T[1] / P.vs) + M.hN, ck = rnd_i(P.T[2] / P.vs) + M.hNz;
+        const int bi = (ci >> 4) + (t % 5) - 2, bj = (cj >> 4) + ((t / 5) % 5) - 2, bk = (ck >> 4) + (t / 25) - 2;
+        if (bi >= 0 && bi < M.nbx && bj >= 0 && bj < M.nbx && bk >= 0 && bk < M.nbz)
+            (void)frame_slot_slow<false>(M, F, P.slot, (bi * M.nbx + bj) * M.nbz + bk);
+    }
+}
+
 // =====================================================================================================
 // variant 0/1: global int64 atomics
 // =====================================================================================================
@@ -108,7 +132,7 @@ __global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, FramePa
     const int split = P.split;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int r = gid / split, sub = gid - r * split;
-    const int nrays = F.counters[0];
+    const int nrays = *F.nrays;
     const bool live = r < nrays;
     long long n_ok = 0, n_oob = 0;
     RayRegs R; R.n = 0; R.qden = 0;
@@ -173,20 +197,24 @@ __global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F, const in
         ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)sl * (TSL_BRK3 * 2));
         uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
         int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-            const ulonglong2 a = acc[l];
-            if (a.y != 0ull) {
-                tw[l] = apply_update(tw[l], (long long)a.x, (long long)a.y);
+        ulonglong2 a[TSL_BRK3 / 256]; uint32_t old[TSL_BRK3 / 256];
+#pragma unroll
+        for (int q = 0; q < TSL_BRK3 / 256; ++q) { a[q] = acc[q * 256 + threadIdx.x]; old[q] = tw[q * 256 + threadIdx.x]; }
+#pragma unroll
+        for (int q = 0; q < TSL_BRK3 / 256; ++q) {
+            const int l = q * 256 + threadIdx.x;
+            if (a[q].y != 0ull) {
+                tw[l] = apply_update(old[q], (long long)a[q].x, (long long)a[q].y);
                 obs[l] = 1;                                                                      // dense_tsdf.py:265
                 acc[l] = make_ulonglong2(0ull, 0ull);
                 ++uniq;
             }
         }
     }
-    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < ntouched; sl += gridDim.x * 256) F.slot_of_pool[F.touched[sl]] = TSL_EMPTY;
+    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < ntouched; sl += gridDim.x * 256) F.slot_tab[F.touched_b[sl]] = TSL_EMPTY;
     uniq = wave_sum_ll(uniq);
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
-    if (blockIdx.x == 0 && threadIdx.x == 0) F.stats->bricks = ntouched;
+    if (!list && blockIdx.x == 0 && threadIdx.x == 0) F.stats->bricks = ntouched;
 }
 
 // =====================================================================================================
@@ -205,17 +233,17 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FramePar
     const int split = P.split;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int r = gid / split, sub = gid - r * split;
-    const int nrays = F.counters[0];
+    const int nrays = *F.nrays;
     long long n_ok = 0, n_oob = 0;
     if (r < nrays) {
         const RayRegs R = load_ray(F, P, r);
         if (sub == 0) mark_occupied(M, P, R);
         const int len = (R.n + split - 1) / split;
         const int ja = 1 + sub * len, jb = min(R.n, ja + len - 1);
-        int run_b = -1, run_j0 = 0, run_cnt = 0;
+        int run_b = -1, run_j0 = 0, run_cnt = 0, run_sl = -1;
         auto emit = [&]() {
             if (run_cnt == 0) return;
-            const int sl = frame_slot(M, F, P.slot, run_b);
+            const int sl = run_sl >= 0 ? run_sl : frame_slot_slow(M, F, P.slot, run_b);
             if (sl >= 0) {
                 n_ok += run_cnt;
                 const unsigned long long key = ((unsigned long long)sl << SEG_SLOT_SHIFT) | ((unsigned long long)r << (SEG_CNT_BITS + SEG_J_BITS)) |
@@ -235,7 +263,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FramePar
             step_voxel(R, P, j, x, xi);
             if (!in_volume(M, xi[0], xi[1], xi[2])) { emit(); run_b = -1; ++n_oob; continue; }
             int l; const int b = brick_of(M, xi[0], xi[1], xi[2], &l);
-            if (b != run_b || run_cnt == SEG_MAX_CNT) { emit(); run_b = b; run_j0 = j; }
+            if (b != run_b || run_cnt == SEG_MAX_CNT) { emit(); run_b = b; run_j0 = j; run_sl = F.slot_tab[b]; }
             ++run_cnt;
         }
         emit();
@@ -260,25 +288,41 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FramePar
     }
 }
 
-// K4b: offset[s] = sum_{t<s} hist[t], offset[nt] = total   (single block, <= SLOT_LDS entries)
+// K4b: offset[s] = sum_{t<s} hist[t] (offset[nt] = total) and part_off[s] = sum_{t<s} ceil(hist[t]/PART_SEGS):
+// a brick with more than PART_SEGS segments is integrated by several workgroups.  Single block.
+#define PART_SEGS 1024
+__device__ __forceinline__ int block_excl_scan_1024(int s, int* s_wave, int* total)
+{
+    const int t = threadIdx.x;
+    int inc = s;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((t & 63) >= d) inc += o; }
+    __syncthreads();
+    if ((t & 63) == 63) s_wave[t >> 6] = inc;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { if (w < (t >> 6)) wbase += s_wave[w]; tot += s_wave[w]; }
+    *total = tot;
+    return wbase + inc - s;
+}
 __global__ void __launch_bounds__(1024) k_scan(FrameDev F)
 {
     __shared__ int s_wave[16];
     const int nt = min(F.counters[1], F.max_frame_bricks);
     const int t = threadIdx.x;
-    int v[4], s = 0;
-    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; v[q] = i < nt ? F.hist[i] : 0; s += v[q]; }
-    int inc = s;
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((t & 63) >= d) inc += o; }
-    if ((t & 63) == 63) s_wave[t >> 6] = inc;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (t >> 6); ++w) wbase += s_wave[w];
-    int run = wbase + inc - s;
-    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; if (i <= nt) F.offset[i] = run; run += v[q]; }
+    int v[4], pv[4], s = 0, ps = 0;
+    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; v[q] = i < nt ? F.hist[i] : 0; pv[q] = (v[q] + PART_SEGS - 1) / PART_SEGS; s += v[q]; ps += pv[q]; }
+    int nz = 0;
+    for (int q = 0; q < 4; ++q) nz += v[q] > 0;
+    nz = (int)wave_sum_ll(nz);
+    if ((t & 63) == 0 && nz) atomic_add_i64(&F.stats->bricks, nz);
+    int tot, ptot;
+    int run = block_excl_scan_1024(s, s_wave, &tot);
+    int prun = block_excl_scan_1024(ps, s_wave, &ptot);
+    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; if (i <= nt) { F.offset[i] = run; F.part_off[i] = prun; } run += v[q]; prun += pv[q]; }
     if (t == 1023) {
-        if (nt == SLOT_LDS) F.offset[SLOT_LDS] = run;
-        F.counters[3] = min(run, F.seg_cap);                     // total segments
+        if (nt == SLOT_LDS) { F.offset[SLOT_LDS] = run; F.part_off[SLOT_LDS] = prun; }
+        F.counters[3] = min(tot, F.seg_cap);                     // total segments
+        F.counters[5] = ptot;                                    // total parts
     }
 }
 
@@ -317,18 +361,18 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, FrameParams P)
 {
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
-    const int total = F.counters[3];
-    const int nblk = gridDim.x;
-    int chunk = (total + nblk - 1) / nblk;
-    if (chunk < 256) chunk = 256;
-    const int cb = blockIdx.x * chunk, ce = min(total, cb + chunk);
+    const int nt = min(F.counters[1], F.max_frame_bricks);
+    const int nparts = F.counters[5];
     long long uniq = 0;
-    int pos = cb;
-    while (pos < ce) {
-        const int sl = (int)(F.seg_sorted[pos] >> SEG_SLOT_SHIFT);
+    for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
+        int lo = 0, hi = nt;                                  // largest sl with part_off[sl] <= part
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.part_off[mid] <= part) lo = mid; else hi = mid; }
+        const int sl = lo;
         const int b0 = F.offset[sl], b1 = F.offset[sl + 1];
-        const int run_end = min(b1, ce);
-        const bool whole = (pos == b0) && (run_end == b1);
+        const int np = F.part_off[sl + 1] - F.part_off[sl], k = part - F.part_off[sl];
+        const int per = (b1 - b0 + np - 1) / np;
+        const int pos = b0 + k * per, run_end = min(b1, pos + per);
+        const bool whole = np == 1;
         for (int i = threadIdx.x; i < TSL_BRK3 * 2; i += 256) s_acc[i] = 0ull;
         __syncthreads();
         for (int i = pos + threadIdx.x; i < run_end; i += 256) {
@@ -350,10 +394,15 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
         if (whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
             int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            uint32_t old[TSL_BRK3 / 256];
+#pragma unroll
+            for (int q = 0; q < TSL_BRK3 / 256; ++q) old[q] = tw[q * 256 + threadIdx.x];      // all row loads in flight at once
+#pragma unroll
+            for (int q = 0; q < TSL_BRK3 / 256; ++q) {
+                const int l = q * 256 + threadIdx.x;
                 const unsigned long long qd = s_acc[l * 2 + 1];
                 if (qd != 0ull) {
-                    tw[l] = apply_update(tw[l], (long long)s_acc[l * 2], (long long)qd);
+                    tw[l] = apply_update(old[q], (long long)s_acc[l * 2], (long long)qd);
                     obs[l] = 1;
                     ++uniq;
                 }
@@ -373,7 +422,6 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
             }
         }
         __syncthreads();
-        pos = run_end;
     }
     uniq = wave_sum_ll(uniq);
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
@@ -387,7 +435,8 @@ int launch_integrate(tsl_tsdf* m, int total)
     if (P.variant == 2) {
         TSL_REQUIRE(F.max_frame_bricks <= SLOT_LDS, "variant 2 needs max_frame_bricks <= 4096");
         TSL_REQUIRE(P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << SEG_RAY_BITS), "variant 2: ray too long / too many points for the segment key");
-        TSL_HIP(hipMemsetAsync(F.hist, 0, sizeof(int) * (size_t)(3 * SLOT_LDS + 8), m->stream));      // hist | cursor | shared_flag
+        const int nclear = 3 * SLOT_LDS + 8;                                                              // hist | cursor | shared_flag
+        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, nclear, 1);
         prof_begin(m, TSL_K_SEGMENTS);
         hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
@@ -396,12 +445,13 @@ int launch_integrate(tsl_tsdf* m, int total)
         hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, m->stream, F);
         prof_end(m);
         prof_begin(m, TSL_K_INTEGRATE);
-        hipLaunchKernelGGL(k_integrate_bricks, dim3(512), dim3(256), 0, m->stream, m->M, F, P);
+        hipLaunchKernelGGL(k_integrate_bricks, dim3(1024), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
         prof_begin(m, TSL_K_FINALIZE);
         hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, m->stream, m->M, F, (const int*)F.shared_list, (const int*)&F.counters[4]);
         prof_end(m);
     } else {
+        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, 0, 0);
         prof_begin(m, TSL_K_INTEGRATE);
         if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
         else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_build_rays(FrameParams P, FrameDev F, c
             }
         }
     }
-    const int r = block_reserve(&F.counters[0], ok);
+    const int r = block_reserve(F.nrays, ok);
     if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; }
     block_count_add(&F.stats->v_pcl, head);
     block_count_add(&F.stats->v_skipped, head && !ok);
@@ -332,18 +332,18 @@ int dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill)
     return TSL_OK;
 }
 
-void prof_begin(tsl_tsdf* m, int kid)
+void prof_begin(tsl_tsdf* m, int kid, hipStream_t st)
 {
     if (!m->prof_on) return;
     ProfSlot s; s.kid = kid;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
-    (void)hipEventRecord(s.a, m->stream);
+    (void)hipEventRecord(s.a, st ? st : m->stream);
     m->prof.push_back(s);
 }
-void prof_end(tsl_tsdf* m)
+void prof_end(tsl_tsdf* m, hipStream_t st)
 {
     if (!m->prof_on || m->prof.empty()) return;
-    (void)hipEventRecord(m->prof.back().b, m->stream);
+    (void)hipEventRecord(m->prof.back().b, st ? st : m->stream);
 }
 
 // set_pose + convert_by_base  mapping_common.py:91-100,149-156 (float64, fixed summation order, then f32)
@@ -379,24 +379,39 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     FrameDev& F = m->F;
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
     TSL_REQUIRE(total <= F.max_points, "integrate: more pixels/points than max_points");
-    TSL_HIP(hipMemsetAsync(F.stats, 0, sizeof(tsl_frame_stats), m->stream));
-    TSL_HIP(hipMemsetAsync(F.counters, 0, sizeof(int) * 8, m->stream));
-    if (total == 0) return TSL_OK;
-    K* keys = reinterpret_cast<K*>(F.keys);
-    K* keys_s = reinterpret_cast<K*>(F.keys_s);
-    const int blocks = (total + 255) / 256;
-    prof_begin(m, TSL_K_VOXELIZE);
-    if (xyz_dev) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const float*)xyz_dev, total, keys);
-    else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const uint16_t*)depth_dev, keys);
-    prof_end(m);
-    prof_begin(m, TSL_K_SORT);
-    size_t tb = m->sort_temp_bytes;
-    TSL_HIP(rocprim::radix_sort_pairs(m->sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * P.pcl_bits + 1), m->stream));
-    prof_end(m);
-    prof_begin(m, TSL_K_RAYS);
-    hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, m->stream, P, F, (const K*)keys_s, total);
-    prof_end(m);
-    { int rc = launch_integrate(m, total); if (rc) return rc; }
+    // ---- phase A (depth -> rays) on stream A into working set `si`; it never touches the map ----
+    const int si = (int)(m->frame_no & 1);
+    ASet& A = m->aset[si];
+    hipStream_t sa = m->overlap ? m->streamA : m->stream;
+    F.keys = (uint32_t*)A.keys; F.keys_s = (uint32_t*)A.keys_s; F.vals = A.vals; F.vals_s = A.vals_s; F.pix = A.pix;
+    F.rayA = A.rayA; F.rayN = A.rayN; F.nrays = A.nrays; F.stats = A.stats;
+    if (m->overlap && A.b_pending) TSL_HIP(hipStreamWaitEvent(sa, A.b_done, 0));      // phase B of frame f-2 still reads this set
+    TSL_HIP(hipMemsetAsync(A.stats, 0, sizeof(tsl_frame_stats), sa));
+    TSL_HIP(hipMemsetAsync(A.nrays, 0, sizeof(int), sa));
+    m->last_set = si; m->frame_no++;
+    if (total > 0) {
+        K* keys = reinterpret_cast<K*>(A.keys);
+        K* keys_s = reinterpret_cast<K*>(A.keys_s);
+        const int blocks = (total + 255) / 256;
+        prof_begin(m, TSL_K_VOXELIZE, sa);
+        if (xyz_dev) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const float*)xyz_dev, total, keys);
+        else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const uint16_t*)depth_dev, keys);
+        prof_end(m, sa);
+        prof_begin(m, TSL_K_SORT, sa);
+        size_t tb = m->sort_temp_bytes;
+        TSL_HIP(rocprim::radix_sort_pairs(A.sort_temp, tb, keys, keys_s, A.vals, A.vals_s, (size_t)total, 0u, (unsigned)(3 * P.pcl_bits + 1), sa));
+        prof_end(m, sa);
+        prof_begin(m, TSL_K_RAYS, sa);
+        hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const K*)keys_s, total);
+        prof_end(m, sa);
+    }
+    if (m->overlap) {
+        TSL_HIP(hipEventRecord(A.a_done, sa));
+        TSL_HIP(hipStreamWaitEvent(m->stream, A.a_done, 0));
+    }
+    // ---- phase B (rays -> map) on the main stream ----
+    if (total > 0) { int rc = launch_integrate(m, total); if (rc) return rc; }
+    if (m->overlap) { TSL_HIP(hipEventRecord(A.b_done, m->stream)); A.b_pending = true; }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -451,6 +466,8 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     tsl_tsdf* m = new tsl_tsdf();
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    TSL_HIP(hipStreamCreateWithFlags(&m->streamA, hipStreamNonBlocking));
+    m->frame_no = 0; m->overlap = 1; m->last_set = 0;
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
     m->Nz = (int)std::ceil(cfg->map_size_z / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:25
@@ -514,15 +531,27 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     F.max_frame_bricks = cfg->max_frame_bricks > 0 ? cfg->max_frame_bricks : 4096;
     if (F.max_frame_bricks > M.max_bricks) F.max_frame_bricks = M.max_bricks;
     const size_t np = (size_t)F.max_points;
-    if ((rc = dev_alloc(m, (void**)&F.keys, 8 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.keys_s, 8 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.vals, 4 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.vals_s, 4 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.pix, 8 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.rayA, 16 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.rayN, 4 * np, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.slot_of_pool, sizeof(int) * (size_t)want, 0xff))) return rc;
+    if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
+    for (int si = 0; si < 2; ++si) {
+        ASet& A = m->aset[si];
+        if ((rc = dev_alloc(m, &A.keys, 8 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, &A.keys_s, 8 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.vals, 4 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.vals_s, 4 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.pix, 8 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.rayA, 16 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.rayN, 4 * np, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.nrays, sizeof(int) * 4, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&A.stats, sizeof(tsl_frame_stats), 0))) return rc;
+        if ((rc = dev_alloc(m, &A.sort_temp, m->sort_temp_bytes + 256, 0))) return rc;
+        TSL_HIP(hipEventCreateWithFlags(&A.a_done, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&A.b_done, hipEventDisableTiming));
+        A.b_pending = false;
+    }
+    F.stats = m->aset[0].stats; F.nrays = m->aset[0].nrays;
+    if ((rc = dev_alloc(m, (void**)&F.slot_tab, sizeof(int) * (size_t)m->nb3, 0xff))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.touched, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.counters, sizeof(int) * 8, 0))) return rc;
     {   // ray segments: ~ (steps/16 + 3 axis crossings) per ray; 32 per point is a generous bound
@@ -533,11 +562,9 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = dev_alloc(m, (void**)&F.hist, sizeof(int) * (3 * 4096 + 8), 0))) return rc;
         F.cursor = F.hist + 4096; F.shared_flag = F.hist + 2 * 4096;
         if ((rc = dev_alloc(m, (void**)&F.offset, sizeof(int) * (4096 + 8), 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.part_off, sizeof(int) * (4096 + 8), 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&F.shared_list, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     }
-    if ((rc = dev_alloc(m, (void**)&F.stats, sizeof(tsl_frame_stats), 0))) return rc;
-    if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
-    if ((rc = dev_alloc(m, &m->sort_temp, m->sort_temp_bytes + 256, 0))) return rc;
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
     std::memset(m->h_stats, 0, sizeof(tsl_frame_stats));
@@ -560,15 +587,21 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.keys, m->F.keys_s, m->F.vals, m->F.vals_s,
-                     m->F.pix, m->F.rayA, m->F.rayN, m->F.slot_of_pool, m->F.touched, m->F.acc, m->F.counters, m->F.stats, m->F.seg, m->F.seg_sorted, m->F.hist, m->F.offset, m->F.shared_list, m->sort_temp,
+    (void)hipStreamSynchronize(m->streamA);
+    for (int si = 0; si < 2; ++si) {
+        ASet& A = m->aset[si];
+        void* ap[] = { A.keys, A.keys_s, A.vals, A.vals_s, A.pix, A.rayA, A.rayN, A.nrays, A.stats, A.sort_temp };
+        for (void* p : ap) if (p) (void)hipFree(p);
+        (void)hipEventDestroy(A.a_done); (void)hipEventDestroy(A.b_done);
+    }
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.part_off, m->F.acc, m->F.counters, m->F.seg, m->F.seg_sorted, m->F.hist, m->F.offset, m->F.shared_list,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
     if (m->h_ints) (void)hipHostFree(m->h_ints);
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
-    (void)hipStreamDestroy(m->stream);
+    (void)hipStreamDestroy(m->stream); (void)hipStreamDestroy(m->streamA);
     delete m;
 }
 
@@ -580,7 +613,7 @@ int tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* bxy, 
     if (bxy) *bxy = m->N / blk; if (bz) *bz = m->Nz / blk;                                   // dense_tsdf.py:27-28
     return TSL_OK;
 }
-int tsl_tsdf_sync(tsl_tsdf* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
+int tsl_tsdf_sync(tsl_tsdf* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(m->streamA)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
 int tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* b) { TSL_REQUIRE(m && b, "null"); *b = m->bytes; return TSL_OK; }
 
 static int read_int(tsl_tsdf* m, const int* dev, int* out)
@@ -670,15 +703,16 @@ int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], 
     TSL_HIP(hipSetDevice(m->device));
     const size_t nb = (size_t)h * w * sizeof(uint16_t);
     int rc = grow(&m->stage_in, &m->stage_in_bytes, nb); if (rc) return rc;
-    TSL_HIP(hipMemcpyAsync(m->stage_in, depth, nb, hipMemcpyHostToDevice, m->stream));
+    hipStream_t sa = m->overlap ? m->streamA : m->stream;
+    TSL_HIP(hipMemcpyAsync(m->stage_in, depth, nb, hipMemcpyHostToDevice, sa));
     void* tdev = nullptr;
     if (tex && m->cfg.texture_enabled && th > 0 && tw > 0) {
         const size_t tb = (size_t)th * tw * 3;
         rc = grow(&m->stage_tex, &m->stage_tex_bytes, tb); if (rc) return rc;
-        TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, tb, hipMemcpyHostToDevice, m->stream));
+        TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, tb, hipMemcpyHostToDevice, sa));
         tdev = m->stage_tex;
     }
-    TSL_HIP(hipStreamSynchronize(m->stream));      // the caller may reuse its host buffers after return
+    TSL_HIP(hipStreamSynchronize(sa));             // the caller may reuse its host buffers after return
     return tsl_tsdf_integrate_depth_dev(m, R, T, m->stage_in, h, w, tdev, th, tw);
 }
 
@@ -698,14 +732,15 @@ int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
     TSL_HIP(hipSetDevice(m->device));
     const size_t nb = (size_t)n * 3 * sizeof(float);
     int rc = grow(&m->stage_in, &m->stage_in_bytes, nb + 16); if (rc) return rc;
-    if (n) TSL_HIP(hipMemcpyAsync(m->stage_in, xyz, nb, hipMemcpyHostToDevice, m->stream));
+    hipStream_t sa = m->overlap ? m->streamA : m->stream;
+    if (n) TSL_HIP(hipMemcpyAsync(m->stage_in, xyz, nb, hipMemcpyHostToDevice, sa));
     void* cdev = nullptr;
     if (rgb && m->cfg.texture_enabled && n) {
         rc = grow(&m->stage_tex, &m->stage_tex_bytes, (size_t)n * 3); if (rc) return rc;
-        TSL_HIP(hipMemcpyAsync(m->stage_tex, rgb, (size_t)n * 3, hipMemcpyHostToDevice, m->stream));
+        TSL_HIP(hipMemcpyAsync(m->stage_tex, rgb, (size_t)n * 3, hipMemcpyHostToDevice, sa));
         cdev = m->stage_tex;
     }
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(sa));
     return tsl_tsdf_integrate_points_dev(m, R, T, m->stage_in, cdev, n);
 }
 
@@ -714,7 +749,8 @@ int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
     TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
     const int64_t used = m->h_stats->p_used;
     tsl_frame_stats tmp;
-    TSL_HIP(hipMemcpyAsync(m->h_ints, m->F.stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->streamA));
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->aset[m->last_set].stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
     TSL_HIP(hipStreamSynchronize(m->stream));
     std::memcpy(&tmp, m->h_ints, sizeof(tmp));
     tmp.p_used = used;
@@ -851,6 +887,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
 {
     TSL_REQUIRE(m && name, "null");
     if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
+    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value != 0; for (auto& A : m->aset) A.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
 }

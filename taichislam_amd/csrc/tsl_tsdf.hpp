@@ -26,14 +26,17 @@ struct FrameDev {
     uint2* pix;                                  // per pixel: f16 bits {x,y | z,depth}
     uint4* rayA;                                 // per ray: {p01, p2|d0, d12, w bits}
     int*   rayN;                                 // per ray: step count
-    int*   slot_of_pool;                         // [max_bricks] -> frame scratch slot
+    int*   nrays;                                // ray count of this frame (phase-A set)
+    int*   slot_tab;                             // [nb3] brick id (inside the written submap) -> frame scratch slot, EMPTY between frames
     int*   touched;                              // [max_frame_bricks] -> pool brick
+    int*   touched_b;                            // [max_frame_bricks] -> brick id
     unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
-    int*   counters;                             // [0] rays [1] touched bricks [2] segments appended [3] segments sorted [4] shared bricks
+    int*   counters;                             // [0] rays [1] touched bricks [2] segments appended [3] segments sorted [4] shared bricks [5] parts
     unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick slot
     int    seg_cap;
     int   *hist, *cursor, *shared_flag;          // [4096] each, contiguous, cleared per frame
     int   *offset;                               // [4097] exclusive scan of hist
+    int   *part_off;                             // [4097] exclusive scan of ceil(hist/PART_SEGS)
     int   *shared_list;                          // slots whose segment list straddles integrate chunks
     tsl_frame_stats* stats;
     int    max_frame_bricks;
@@ -42,12 +45,21 @@ struct FrameDev {
 
 struct ProfSlot { hipEvent_t a, b; int kid; };
 
+// phase-A working set (depth -> rays).  Two of them, so phase A of frame f+1 (stream A) overlaps phase B of frame f.
+struct ASet {
+    void *keys, *keys_s; uint32_t *vals, *vals_s; uint2* pix; uint4* rayA; int* rayN; int* nrays;
+    tsl_frame_stats* stats; void* sort_temp;
+    hipEvent_t a_done, b_done; bool b_pending;
+};
+
 }  // namespace tsl
 
 struct tsl_tsdf {
     tsl_tsdf_cfg cfg;
     int device;
-    hipStream_t stream;
+    hipStream_t stream;                  // phase B + everything else
+    hipStream_t streamA;                 // phase A (depth -> rays) of the next frame
+    tsl::ASet aset[2]; int64_t frame_no; int overlap; int last_set;
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;
     tsl::MapDev M;
@@ -83,8 +95,8 @@ struct tsl_tsdf {
 
 namespace tsl {
 int  grow(void** p, size_t* have, size_t need);
-void prof_begin(tsl_tsdf* m, int kid);
-void prof_end(tsl_tsdf* m);
+void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr);
+void prof_end(tsl_tsdf* m, hipStream_t st = nullptr);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  launch_integrate(tsl_tsdf* m, int total);
