@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--split", type=int, default=None)
+    ap.add_argument("--overlap", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,6 +90,8 @@ def main():
         m.set_option("variant", args.variant)
     if args.split is not None:
         m.set_option("split", args.split)
+    if args.overlap is not None:
+        m.set_option("overlap", args.overlap)
 
     def step(f):
         R, T = poses[f]

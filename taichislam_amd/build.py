@@ -48,7 +48,7 @@ def build_library(force=False, verbose=False):
             return LIB          # GPU box without a toolchain: use the prebuilt library that travelled with the repo
         raise RuntimeError("hipcc not found and no prebuilt libtaichislam_hip.so present")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [cc] + HIPCC_FLAGS + sources() + ["-o", LIB + ".tmp"]
+    cmd = [cc] + HIPCC_FLAGS + os.environ.get("TSL_EXTRA_FLAGS", "").split() + sources() + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

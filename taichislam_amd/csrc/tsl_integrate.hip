@@ -25,6 +25,15 @@
 
 namespace tsl {
 
+#ifdef TSL_TIMING
+// developer timing: every wave stores raw timestamps (plain stores, no atomics) at dbg[wave*16 + k]
+#define TSL_T0() const int _wv = (blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6
+#define TSL_TICK(F, k) do { long long _n = wall_clock64(); if (lane_id() == 0 && _wv < 16384) (F).dbg[_wv * 16 + (k)] = _n; } while (0)
+#else
+#define TSL_T0() do {} while (0)
+#define TSL_TICK(F, k) do {} while (0)
+#endif
+
 // segment key: [0,6) step count  [6,18) first step  [18,42) ray id  [42,58) frame slot of the brick
 #define SEG_CNT_BITS 6
 #define SEG_J_BITS   12
@@ -220,67 +229,150 @@ __global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F, const in
 // =====================================================================================================
 // variant 2: brick-binned segments, LDS accumulation
 // =====================================================================================================
-// K4a: cut rays into per-brick segments
+// exact voxel coordinate of step j along one axis  (dense_tsdf.py:253-254, one component)
+__device__ __forceinline__ int axis_coord(float d, float T, float vs, int j) { return rnd_i(((d * (float)j) * vs + T) / vs); }
+// "cell" of a coordinate along one axis: -1 below the volume, nb above it, else the brick coordinate.  Monotone in c.
+__device__ __forceinline__ int axis_cell(int c, int h, int N, int nb) { const int u = c + h; return u < 0 ? -1 : (u >= N ? nb : (u >> 4)); }
+
+// Smallest step e in (j, jb] at which the ray's cell along one axis differs from `cell` (the cell at step j), or jb+1.
+// The coordinate is a monotone function of the step (every operation in axis_coord is monotone), so the event is
+// located from a real-arithmetic estimate and then fixed up with exact evaluations -- typically two.
+__device__ __forceinline__ int next_axis_event(float d, float T, float vs, float t_over_vs, int j, int jb, int cell, int h, int N, int nb)
+{
+    if (j >= jb) return jb + 1;
+    int bound;                       // first coordinate that belongs to the next cell in the direction of travel
+    bool up;
+    if (d > 0.0f) { if (cell >= nb) return jb + 1; up = true; bound = (cell < 0 ? 0 : min((cell + 1) * 16, N)) - h; }
+    else if (d < 0.0f) { if (cell < 0) return jb + 1; up = false; bound = (cell >= nb ? N - 1 : cell * 16 - 1) - h; }
+    else return jb + 1;
+    const float est = ((float)bound + (up ? -0.5f : 0.5f) - t_over_vs) / d;      // real-valued crossing step
+    int e = (int)fminf(fmaxf(ceilf(est), (float)(j + 1)), (float)jb);
+    #define TSL_PRED(q) (up ? (axis_coord(d, T, vs, (q)) >= bound) : (axis_coord(d, T, vs, (q)) <= bound))
+    if (TSL_PRED(e)) { while (e - 1 > j && TSL_PRED(e - 1)) --e; }
+    else { ++e; while (e <= jb && !TSL_PRED(e)) ++e; }
+    #undef TSL_PRED
+    return e;
+}
+
+// ---- small open-addressing hash in LDS: brick id -> counter (a block / tile only touches ~100 distinct bricks) ----
+#define LH_SIZE 1024
+#define LH_EMPTY (-1)
+__device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-insert; returns the table index or -1 when full
+{
+    unsigned h = ((unsigned)b * 2654435761u) >> 22;
+    for (int probe = 0; probe < LH_SIZE; ++probe) {
+        const int k = keys[h];
+        if (k == b) return (int)h;
+        if (k == LH_EMPTY) { const int old = atomicCAS(&keys[h], LH_EMPTY, b); if (old == LH_EMPTY || old == b) return (int)h; }
+        h = (h + 1) & (LH_SIZE - 1);
+    }
+    return -1;
+}
+
+// K4a: cut rays into per-brick segments without visiting every step: per axis the next brick/volume boundary
+// crossing is searched directly (next_axis_event), so a ray costs ~12 crossings x ~2 exact coordinate evaluations
+// instead of ~135 full voxel evaluations.  Segments are keyed by BRICK id (no per-frame slot claims anywhere: the
+// dense renumbering of the frame's bricks falls out of k_scan); per-brick counts are kept in an LDS hash and flushed
+// once per block.
+// segment: [0,6) count [6,18) first step [18,40) ray [40,64) brick id
+#define STG_RAY_BITS 22
+#define STG_B_SHIFT (SEG_CNT_BITS + SEG_J_BITS + STG_RAY_BITS)
 __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FrameParams P)
 {
     __shared__ unsigned long long s_seg[SEG_LDS_CAP];
-    __shared__ int s_hist[SLOT_LDS];
+    __shared__ int s_key[LH_SIZE];
+    __shared__ int s_cnt[LH_SIZE];
     __shared__ int s_n, s_base;
-    for (int i = threadIdx.x; i < SLOT_LDS; i += 256) s_hist[i] = 0;
+    TSL_T0();
+    TSL_TICK(F, 8);
+    for (int i = threadIdx.x; i < LH_SIZE; i += 256) { s_key[i] = LH_EMPTY; s_cnt[i] = 0; }
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    TSL_TICK(F, 0);
 
     const int split = P.split;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int r = gid / split, sub = gid - r * split;
     const int nrays = *F.nrays;
     long long n_ok = 0, n_oob = 0;
+    const bool working = __any(r < nrays);
     if (r < nrays) {
         const RayRegs R = load_ray(F, P, r);
         if (sub == 0) mark_occupied(M, P, R);
+        TSL_TICK(F, 1);
         const int len = (R.n + split - 1) / split;
         const int ja = 1 + sub * len, jb = min(R.n, ja + len - 1);
-        int run_b = -1, run_j0 = 0, run_cnt = 0, run_sl = -1;
-        auto emit = [&]() {
-            if (run_cnt == 0) return;
-            const int sl = run_sl >= 0 ? run_sl : frame_slot_slow(M, F, P.slot, run_b);
-            if (sl >= 0) {
-                n_ok += run_cnt;
-                const unsigned long long key = ((unsigned long long)sl << SEG_SLOT_SHIFT) | ((unsigned long long)r << (SEG_CNT_BITS + SEG_J_BITS)) |
-                                               ((unsigned long long)run_j0 << SEG_CNT_BITS) | (unsigned long long)run_cnt;
-                const int idx = atomicAdd(&s_n, 1);
-                if (idx < SEG_LDS_CAP) { s_seg[idx] = key; atomicAdd(&s_hist[sl], 1); }
-                else {      // rare: block staging full -> append directly
-                    const int pos = __hip_atomic_fetch_add(&F.counters[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (pos < F.seg_cap) { F.seg[pos] = key; __hip_atomic_fetch_add(&F.hist[sl], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    else atomicOr(M.err, 4);
+        const float d[3] = { R.d0, R.d1, R.d2 };
+        const float tv[3] = { P.T[0] / P.vs, P.T[1] / P.vs, P.T[2] / P.vs };
+        const int hh[3] = { M.hN, M.hN, M.hNz }, NN[3] = { M.N, M.N, M.Nz }, nb[3] = { M.nbx, M.nbx, M.nbz };
+        if (ja <= jb) {
+            int cell[3], ev[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                cell[a] = axis_cell(axis_coord(d[a], P.T[a], P.vs, ja), hh[a], NN[a], nb[a]);
+                ev[a] = next_axis_event(d[a], P.T[a], P.vs, tv[a], ja, jb, cell[a], hh[a], NN[a], nb[a]);
+            }
+            int j = ja;
+            while (j <= jb) {
+                const int e = min(min(ev[0], ev[1]), ev[2]);                 // first step of the next run (or jb+1)
+                const bool inside = cell[0] >= 0 && cell[0] < nb[0] && cell[1] >= 0 && cell[1] < nb[1] && cell[2] >= 0 && cell[2] < nb[2];
+                if (inside) {
+                    const int b = (cell[0] * M.nbx + cell[1]) * M.nbz + cell[2];
+                    n_ok += e - j;
+                    for (int j0 = j; j0 < e; j0 += SEG_MAX_CNT) {
+                        const int cnt = min(e - j0, SEG_MAX_CNT);
+                        const unsigned long long en = ((unsigned long long)b << STG_B_SHIFT) | ((unsigned long long)r << (SEG_CNT_BITS + SEG_J_BITS)) |
+                                                      ((unsigned long long)j0 << SEG_CNT_BITS) | (unsigned long long)cnt;
+                        const int idx = atomicAdd(&s_n, 1);
+                        const int hs = idx < SEG_LDS_CAP ? lh_slot(s_key, b) : -1;
+                        if (hs >= 0) { s_seg[idx] = en; atomicAdd(&s_cnt[hs], 1); }
+                        else {      // rare: block staging or hash full -> append and count directly
+                            if (idx < SEG_LDS_CAP) s_seg[idx] = ~0ull;
+                            const int pos = __hip_atomic_fetch_add(&F.counters[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (pos < F.seg_cap) {
+                                F.seg[pos] = en;
+                                if (__hip_atomic_fetch_add(&F.bhist[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                                    const int q = __hip_atomic_fetch_add(&F.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (q < F.max_frame_bricks) F.act_b[q] = b; else atomicOr(M.err, 2);
+                                }
+                            } else atomicOr(M.err, 4);
+                        }
+                    }
+                } else n_oob += e - j;
+                j = e;
+                if (j > jb) break;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) if (ev[a] == j) {
+                    cell[a] = axis_cell(axis_coord(d[a], P.T[a], P.vs, j), hh[a], NN[a], nb[a]);
+                    ev[a] = next_axis_event(d[a], P.T[a], P.vs, tv[a], j, jb, cell[a], hh[a], NN[a], nb[a]);
                 }
             }
-            run_cnt = 0;
-        };
-        for (int j = ja; j <= jb; ++j) {
-            float x[3]; int xi[3];
-            step_voxel(R, P, j, x, xi);
-            if (!in_volume(M, xi[0], xi[1], xi[2])) { emit(); run_b = -1; ++n_oob; continue; }
-            int l; const int b = brick_of(M, xi[0], xi[1], xi[2], &l);
-            if (b != run_b || run_cnt == SEG_MAX_CNT) { emit(); run_b = b; run_j0 = j; run_sl = F.slot_tab[b]; }
-            ++run_cnt;
         }
-        emit();
     }
+    TSL_TICK(F, 2);
     __syncthreads();
+    TSL_TICK(F, 3);
     const int n = min(s_n, SEG_LDS_CAP);
     if (threadIdx.x == 0) s_base = n ? __hip_atomic_fetch_add(&F.counters[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     __syncthreads();
+    TSL_TICK(F, 5);
     const int base = s_base;
     for (int i = threadIdx.x; i < n; i += 256) {
         if (base + i < F.seg_cap) F.seg[base + i] = s_seg[i];
         else { atomicOr(M.err, 4); }
     }
-    for (int i = threadIdx.x; i < SLOT_LDS; i += 256) {
-        const int c = s_hist[i];
-        if (c) __hip_atomic_fetch_add(&F.hist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < LH_SIZE; i += 256) {        // LH_SIZE is a multiple of 256: no lane leaves the loop early
+        const int c = s_cnt[i];
+        const int b = c ? s_key[i] : 0;
+        const bool first = c && __hip_atomic_fetch_add(&F.bhist[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        const int q = wave_reserve(&F.counters[1], first);      // the first block to count a brick this frame lists it as active
+        if (first) { if (q < F.max_frame_bricks) F.act_b[q] = b; else atomicOr(M.err, 2); }
     }
+    TSL_TICK(F, 6);
+#ifdef TSL_TIMING
+    if (lane_id() == 0 && _wv < 16384) F.dbg[_wv * 16 + 15] = working;
+#endif
+    (void)working;
     n_ok = wave_sum_ll(n_ok); n_oob = wave_sum_ll(n_oob);
     if (lane_id() == 0) {
         if (n_ok) atomic_add_i64(&F.stats->steps, n_ok);
@@ -288,8 +380,9 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FramePar
     }
 }
 
-// K4b: offset[s] = sum_{t<s} hist[t] (offset[nt] = total) and part_off[s] = sum_{t<s} ceil(hist[t]/PART_SEGS):
-// a brick with more than PART_SEGS segments is integrated by several workgroups.  Single block.
+// K4b (single block): exclusive scans over the frame's active bricks (listed by k_segments, <= 4096):
+// act_off[i] = first segment of brick i, act_part[i] = first integrate part (a brick with more than PART_SEGS
+// segments is integrated by several workgroups), boffset[brick] = act_off[i] for the scatter.
 #define PART_SEGS 1024
 __device__ __forceinline__ int block_excl_scan_1024(int s, int* s_wave, int* total)
 {
@@ -304,55 +397,73 @@ __device__ __forceinline__ int block_excl_scan_1024(int s, int* s_wave, int* tot
     *total = tot;
     return wbase + inc - s;
 }
-__global__ void __launch_bounds__(1024) k_scan(FrameDev F)
+__global__ void __launch_bounds__(1024) k_scan(MapDev M, FrameDev F)
 {
     __shared__ int s_wave[16];
-    const int nt = min(F.counters[1], F.max_frame_bricks);
     const int t = threadIdx.x;
-    int v[4], pv[4], s = 0, ps = 0;
-    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; v[q] = i < nt ? F.hist[i] : 0; pv[q] = (v[q] + PART_SEGS - 1) / PART_SEGS; s += v[q]; ps += pv[q]; }
-    int nz = 0;
-    for (int q = 0; q < 4; ++q) nz += v[q] > 0;
-    nz = (int)wave_sum_ll(nz);
-    if ((t & 63) == 0 && nz) atomic_add_i64(&F.stats->bricks, nz);
+    const int listed = F.counters[1];
+    const int nact = min(listed, F.max_frame_bricks);
+    int v[4], bb[4], s = 0, ps = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int i = t * 4 + q;
+        bb[q] = i < nact ? F.act_b[i] : -1;
+        v[q] = bb[q] >= 0 ? F.bhist[bb[q]] : 0;
+        s += v[q]; ps += (v[q] + PART_SEGS - 1) / PART_SEGS;
+    }
     int tot, ptot;
     int run = block_excl_scan_1024(s, s_wave, &tot);
     int prun = block_excl_scan_1024(ps, s_wave, &ptot);
-    for (int q = 0; q < 4; ++q) { const int i = t * 4 + q; if (i <= nt) { F.offset[i] = run; F.part_off[i] = prun; } run += v[q]; prun += pv[q]; }
+    for (int q = 0; q < 4; ++q) {
+        const int i = t * 4 + q;
+        if (i <= nact) { F.act_off[i] = run; F.act_part[i] = prun; }
+        if (bb[q] >= 0) F.boffset[bb[q]] = run;
+        run += v[q]; prun += (v[q] + PART_SEGS - 1) / PART_SEGS;
+    }
     if (t == 1023) {
-        if (nt == SLOT_LDS) { F.offset[SLOT_LDS] = run; F.part_off[SLOT_LDS] = prun; }
+        if (nact == 4096) { F.act_off[4096] = run; F.act_part[4096] = prun; }
+        F.counters[1] = nact;
         F.counters[3] = min(tot, F.seg_cap);                     // total segments
-        F.counters[5] = ptot;                                    // total parts
+        F.counters[5] = listed <= F.max_frame_bricks ? ptot : 0; // total parts (nothing is integrated when the frame overflows)
+        F.stats->bricks = listed;
     }
 }
 
-// K4c: counting sort by brick slot
+// K4c: counting sort by brick (LDS hash of the bricks seen in each 4096-segment tile, one global reservation per (tile, brick))
 __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 {
-    __shared__ int s_hist[SLOT_LDS];
-    __shared__ int s_base[SLOT_LDS];
+    __shared__ int s_key[LH_SIZE];
+    __shared__ int s_cnt[LH_SIZE];
+    __shared__ int s_base[LH_SIZE];
     const int total = min(F.counters[2], F.seg_cap);
     const int ntiles = (total + SCATTER_TILE - 1) / SCATTER_TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        for (int i = threadIdx.x; i < SLOT_LDS; i += 256) s_hist[i] = 0;
+        for (int i = threadIdx.x; i < LH_SIZE; i += 256) { s_key[i] = LH_EMPTY; s_cnt[i] = 0; }
         __syncthreads();
         const int t0 = tile * SCATTER_TILE;
-        unsigned long long key[SCATTER_TILE / 256]; int rank[SCATTER_TILE / 256];
+        unsigned long long key[SCATTER_TILE / 256]; int rank[SCATTER_TILE / 256]; int hs[SCATTER_TILE / 256];
 #pragma unroll
         for (int q = 0; q < SCATTER_TILE / 256; ++q) {
             const int i = t0 + q * 256 + threadIdx.x;
-            rank[q] = -1;
-            if (i < total) { key[q] = F.seg[i]; rank[q] = atomicAdd(&s_hist[(int)(key[q] >> SEG_SLOT_SHIFT)], 1); }
+            rank[q] = -1; hs[q] = -1;
+            if (i < total) {
+                key[q] = F.seg[i];
+                if (key[q] != ~0ull) {
+                    const int b = (int)(key[q] >> STG_B_SHIFT);
+                    hs[q] = lh_slot(s_key, b);
+                    if (hs[q] >= 0) rank[q] = atomicAdd(&s_cnt[hs[q]], 1);
+                    else rank[q] = F.boffset[b] + __hip_atomic_fetch_add(&F.bcursor[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // hash full (rare)
+                }
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < SLOT_LDS; i += 256) {
-            const int c = s_hist[i];
-            if (c) s_base[i] = F.offset[i] + __hip_atomic_fetch_add(&F.cursor[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = threadIdx.x; i < LH_SIZE; i += 256) {
+            const int c = s_cnt[i];
+            if (c) { const int b = s_key[i]; s_base[i] = F.boffset[b] + __hip_atomic_fetch_add(&F.bcursor[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < SCATTER_TILE / 256; ++q)
-            if (rank[q] >= 0) F.seg_sorted[s_base[(int)(key[q] >> SEG_SLOT_SHIFT)] + rank[q]] = key[q];
+            if (rank[q] >= 0) F.seg_sorted[(hs[q] >= 0 ? s_base[hs[q]] : 0) + rank[q]] = key[q];
         __syncthreads();
     }
 }
@@ -361,24 +472,26 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, FrameParams P)
 {
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
-    const int nt = min(F.counters[1], F.max_frame_bricks);
+    __shared__ int s_p;
+    const int nact = F.counters[1];
     const int nparts = F.counters[5];
     long long uniq = 0;
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
-        int lo = 0, hi = nt;                                  // largest sl with part_off[sl] <= part
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.part_off[mid] <= part) lo = mid; else hi = mid; }
-        const int sl = lo;
-        const int b0 = F.offset[sl], b1 = F.offset[sl + 1];
-        const int np = F.part_off[sl + 1] - F.part_off[sl], k = part - F.part_off[sl];
+        int lo = 0, hi = nact;                                // largest rank with act_part[rank] <= part
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.act_part[mid] <= part) lo = mid; else hi = mid; }
+        const int rk = lo;
+        const int b0 = F.act_off[rk], b1 = F.act_off[rk + 1];
+        const int np = F.act_part[rk + 1] - F.act_part[rk], k = part - F.act_part[rk];
         const int per = (b1 - b0 + np - 1) / np;
         const int pos = b0 + k * per, run_end = min(b1, pos + per);
         const bool whole = np == 1;
+        if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, F.act_b[rk]);       // allocate the brick on its first touch ever
         for (int i = threadIdx.x; i < TSL_BRK3 * 2; i += 256) s_acc[i] = 0ull;
         __syncthreads();
         for (int i = pos + threadIdx.x; i < run_end; i += 256) {
             const unsigned long long key = F.seg_sorted[i];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
-            const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << SEG_RAY_BITS) - 1));
+            const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
             const RayRegs R = load_ray(F, P, r);
             for (int j = j0; j < j0 + cnt; ++j) {
                 float x[3]; int xi[3];
@@ -390,8 +503,8 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
             }
         }
         __syncthreads();
-        const int p = F.touched[sl];
-        if (whole) {
+        const int p = s_p;
+        if (p >= 0 && whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
             int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
             uint32_t old[TSL_BRK3 / 256];
@@ -407,8 +520,8 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                     ++uniq;
                 }
             }
-        } else {
-            unsigned long long* acc = F.acc + (size_t)sl * (TSL_BRK3 * 2);
+        } else if (p >= 0) {
+            unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
             for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
                 const unsigned long long qd = s_acc[l * 2 + 1];
                 if (qd != 0ull) {
@@ -416,13 +529,46 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                     __hip_atomic_fetch_add(acc + l * 2 + 1, qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (threadIdx.x == 0 && atomicExch(&F.shared_flag[sl], 1) == 0) {
+            if (threadIdx.x == 0 && k == 0) {
                 const int q = __hip_atomic_fetch_add(&F.counters[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                F.shared_list[q] = sl;
+                F.shared_list[q] = rk;
             }
         }
         __syncthreads();
     }
+    uniq = wave_sum_ll(uniq);
+    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
+}
+
+// K4e: finalise the bricks that were integrated by several workgroups from the HBM scratch, and restore the
+// "all zero between frames" invariant of bhist / bcursor for the bricks this frame used.
+__global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, FrameParams P)
+{
+    const int nact = F.counters[1];
+    const int nwork = min(F.counters[4], F.max_frame_bricks);
+    long long uniq = 0;
+    for (int q = blockIdx.x; q < nwork; q += gridDim.x) {
+        const int rk = F.shared_list[q];
+        const int p = pool_lookup_ro(M, P.slot, F.act_b[rk]);
+        if (p < 0) continue;
+        ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)rk * (TSL_BRK3 * 2));
+        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+        int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+        ulonglong2 a[TSL_BRK3 / 256]; uint32_t old[TSL_BRK3 / 256];
+#pragma unroll
+        for (int i = 0; i < TSL_BRK3 / 256; ++i) { a[i] = acc[i * 256 + threadIdx.x]; old[i] = tw[i * 256 + threadIdx.x]; }
+#pragma unroll
+        for (int i = 0; i < TSL_BRK3 / 256; ++i) {
+            const int l = i * 256 + threadIdx.x;
+            if (a[i].y != 0ull) {
+                tw[l] = apply_update(old[i], (long long)a[i].x, (long long)a[i].y);
+                obs[l] = 1;
+                acc[l] = make_ulonglong2(0ull, 0ull);
+                ++uniq;
+            }
+        }
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nact; i += gridDim.x * 256) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
     uniq = wave_sum_ll(uniq);
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
@@ -433,22 +579,21 @@ int launch_integrate(tsl_tsdf* m, int total)
     FrameDev& F = m->F;
     const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
     if (P.variant == 2) {
-        TSL_REQUIRE(F.max_frame_bricks <= SLOT_LDS, "variant 2 needs max_frame_bricks <= 4096");
-        TSL_REQUIRE(P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << SEG_RAY_BITS), "variant 2: ray too long / too many points for the segment key");
-        const int nclear = 3 * SLOT_LDS + 8;                                                              // hist | cursor | shared_flag
-        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, nclear, 1);
+        TSL_REQUIRE(F.max_frame_bricks <= 4096 && P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
+                    "variant 2: ray too long / too many points / too many bricks for the segment key (use variant 1)");
+        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, 0, 0);
         prof_begin(m, TSL_K_SEGMENTS);
         hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
         prof_begin(m, TSL_K_BIN);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, F);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, m->M, F);
         hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, m->stream, F);
         prof_end(m);
         prof_begin(m, TSL_K_INTEGRATE);
         hipLaunchKernelGGL(k_integrate_bricks, dim3(1024), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
         prof_begin(m, TSL_K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, m->stream, m->M, F, (const int*)F.shared_list, (const int*)&F.counters[4]);
+        hipLaunchKernelGGL(k_finalize_shared, dim3(64), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
     } else {
         hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, 0, 0);

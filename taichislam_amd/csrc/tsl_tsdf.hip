@@ -554,6 +554,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.counters, sizeof(int) * 8, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
     {   // ray segments: ~ (steps/16 + 3 axis crossings) per ray; 32 per point is a generous bound
         const int64_t cap = (int64_t)F.max_points * 32;
         F.seg_cap = (int)(cap > (1ll << 30) ? (1ll << 30) : cap);
@@ -564,6 +565,12 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = dev_alloc(m, (void**)&F.offset, sizeof(int) * (4096 + 8), 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&F.part_off, sizeof(int) * (4096 + 8), 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&F.shared_list, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.bhist, sizeof(int) * (size_t)m->nb3, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.bcursor, sizeof(int) * (size_t)m->nb3, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.boffset, sizeof(int) * (size_t)m->nb3, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8), 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.act_off, sizeof(int) * (size_t)(F.max_frame_bricks + 8), 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&F.act_part, sizeof(int) * (size_t)(F.max_frame_bricks + 8), 0))) return rc;
     }
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
@@ -594,7 +601,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         for (void* p : ap) if (p) (void)hipFree(p);
         (void)hipEventDestroy(A.a_done); (void)hipEventDestroy(A.b_done);
     }
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.part_off, m->F.acc, m->F.counters, m->F.seg, m->F.seg_sorted, m->F.hist, m->F.offset, m->F.shared_list,
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.part_off, m->F.acc, m->F.counters, m->F.dbg, m->F.seg, m->F.seg_sorted, m->F.hist, m->F.offset, m->F.shared_list, m->F.bhist, m->F.bcursor, m->F.boffset, m->F.act_b, m->F.act_off, m->F.act_part,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -879,6 +886,16 @@ int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launche
     if (total_ms) *total_ms = m->prof_ms[kid];
     if (launches) *launches = m->prof_n[kid];
     m->prof_ms[kid] = 0.0; m->prof_n[kid] = 0;
+    return TSL_OK;
+}
+
+/* developer aid (not part of the public header): read and optionally clear the TSL_TIMING cycle counters */
+int tsl_tsdf_debug_counters(tsl_tsdf* m, int64_t* out, int reset)
+{
+    TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
+    int rc = tsl_tsdf_sync(m); if (rc) return rc;
+    TSL_HIP(hipMemcpy(out, m->F.dbg, sizeof(long long) * 16384 * 16, hipMemcpyDeviceToHost));
+    if (reset) TSL_HIP(hipMemset(m->F.dbg, 0, sizeof(long long) * 16384 * 16));
     return TSL_OK;
 }
 

@@ -37,8 +37,11 @@ struct FrameDev {
     int   *hist, *cursor, *shared_flag;          // [4096] each, contiguous, cleared per frame
     int   *offset;                               // [4097] exclusive scan of hist
     int   *part_off;                             // [4097] exclusive scan of ceil(hist/PART_SEGS)
-    int   *shared_list;                          // slots whose segment list straddles integrate chunks
+    int   *shared_list;                          // active-brick ranks integrated by several workgroups
+    int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between frames) / first segment
+    int   *act_b, *act_off, *act_part;           // [max_frame_bricks+1] active bricks of the frame in brick-id order
     tsl_frame_stats* stats;
+    long long* dbg;                              // [64] developer timing counters (TSL_TIMING builds)
     int    max_frame_bricks;
     int    max_points;
 };
