@@ -123,12 +123,13 @@ int  tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n);
 
 /* ---- submap fusion  (dense_tsdf.py:272-318) ------------------------------------------------------ */
 int  tsl_tsdf_fuse_submaps(tsl_tsdf* global, tsl_tsdf* submaps);
-/* multi-GPU form: splat this rank's submaps into exact int64 accumulators over the global grid,
- * all-reduce(sum) them with RCCL (caller side: torch.distributed / ncclAllReduce on the *_dev
- * buffers), then finalise.  Buffers: int64 [N*N*Nz] each (num, den) and int32 [N*N*Nz] (cnt_occ:
- * contribution count in the high 16 bits, occupancy sum in the low 16). */
-int  tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* global, tsl_tsdf* submaps, void* num_dev, void* den_dev, void* cnt_occ_dev);
-int  tsl_tsdf_fuse_finalize_dev(tsl_tsdf* global, const void* num_dev, const void* den_dev, const void* cnt_occ_dev);
+/* multi-GPU form: splat this rank's submaps into exact fixed-point accumulators over the dense global grid,
+ * all-reduce(sum) them with RCCL (caller side: torch.distributed / ncclAllReduce on the *_dev buffers), then finalise.
+ * acc_dev: int64 [N*N*Nz][2] = {sum w*tsdf, sum w} in 2^-24 fixed point; cnt_occ_dev: int32 [N*N*Nz] = contributions * 65536
+ * + occupancy sum.  Both must be zero before the first accumulate; integer sums make the result independent of the
+ * number of ranks and of the reduction order. */
+int  tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* global, tsl_tsdf* submaps, void* acc_dev, void* cnt_occ_dev);
+int  tsl_tsdf_fuse_finalize_dev(tsl_tsdf* global, const void* acc_dev, const void* cnt_occ_dev);
 
 /* ---- marching cubes  (marching_cube_mesher.py:127-193) ------------------------------------------- */
 /* generate_mesh(step): result stays on the device in the map's mesh buffers (3*max_tri rows each);

@@ -80,8 +80,8 @@ SIGNATURES = {
     "tsl_tsdf_num_particles": (C.c_int, [vp, pi32]),
     "tsl_tsdf_set_num_particles": (C.c_int, [vp, i32]),
     "tsl_tsdf_fuse_submaps": (C.c_int, [vp, vp]),
-    "tsl_tsdf_fuse_accumulate_dev": (C.c_int, [vp, vp, vp, vp, vp]),
-    "tsl_tsdf_fuse_finalize_dev": (C.c_int, [vp, vp, vp, vp]),
+    "tsl_tsdf_fuse_accumulate_dev": (C.c_int, [vp, vp, vp, vp]),
+    "tsl_tsdf_fuse_finalize_dev": (C.c_int, [vp, vp, vp]),
     "tsl_mesh_generate": (C.c_int, [vp, C.c_int, f32, i64, pi32]),
     "tsl_mesh_read": (C.c_int, [vp, vp, vp, vp, i64]),
     "tsl_esdf_update": (C.c_int, [vp, f32, f32, pi32]),

@@ -1,0 +1,190 @@
+// tsl_fuse.hip -- submap -> global map fusion.  Replaces fuse_submaps_kernel / fuse_with_interploation
+// (taichi_slam/mapping/dense_tsdf.py:272-318, reference root).
+//
+// Every observed voxel of every submap is transformed with its submap pose and splatted onto 7 of the 8 surrounding
+// global voxels (the (0,0,0) corner is skipped in the reference, Q8) with trilinear weights.  The reference applies the
+// weighted running average voxel by voxel in a racy read-modify-write; here the contributions {w*t, w} are summed in
+// exact 2^-24 fixed point (int64 atomics) plus a contribution/occupancy count, and the average is formed once per
+// voxel -- order-free, so N GPUs that each splat their own submaps and all-reduce(sum) the three arrays produce the
+// same bits as one GPU fusing everything (tsl_tsdf_fuse_accumulate_dev / _finalize_dev).
+#include "tsl_tsdf.hpp"
+
+namespace tsl {
+
+struct PoseTab { const float* p; };     // [npose][12]: R row-major, T
+
+template <bool DENSE>
+__global__ void __launch_bounds__(256) k_fuse_splat(MapDev S, MapDev G, PoseTab poses, float vs, int nused,
+                                                    unsigned long long* acc, int* cnt, int npose)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        const int owner = S.owner[p];
+        const int s = owner / S.nb3, b = owner - s * S.nb3;
+        if (s >= npose) continue;
+        const float* Rp = poses.p + (size_t)s * 12;
+        float R[9], T[3];
+        for (int a = 0; a < 9; ++a) R[a] = Rp[a];
+        for (int a = 0; a < 3; ++a) T[a] = Rp[9 + a];
+        const int bk = b % S.nbz, bj = (b / S.nbz) % S.nbx, bi = b / (S.nbz * S.nbx);
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            if (S.obs[v] <= 0) continue;                                                        // :292
+            const int i = bi * 16 + (l >> 8) - S.hN, j = bj * 16 + ((l >> 4) & 15) - S.hN, k = bk * 16 + (l & 15) - S.hNz;
+            const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;             // mapping_common.py:221-232 with the GLOBAL map's voxel scale
+            float f[3]; int lo[3];
+            for (int a = 0; a < 3; ++a) {
+                const float x = ((R[a * 3] * p0 + R[a * 3 + 1] * p1) + R[a * 3 + 2] * p2) + T[a];      // :293
+                f[a] = x / vs; lo[a] = (int)floorf(f[a]);                                     // :294-296
+            }
+            const uint32_t tw = S.tw[v];
+            const float tsdf = h2f((h16)(tw & 0xffffu)), wsrc = h2f((h16)(tw >> 16));
+            const int occ = (int)S.occ[v];
+            for (int c = 1; c < 8; ++c) {                                                        // :297-300 (corner 0 skipped)
+                const int ci = lo[0] + ((c >> 2) & 1), cj = lo[1] + ((c >> 1) & 1), ck = lo[2] + (c & 1);
+                const float wt = ((1.0f - fabsf((float)ci - f[0])) * (1.0f - fabsf((float)cj - f[1]))) * (1.0f - fabsf((float)ck - f[2]));   // :303
+                const float w_tsdf = wsrc * wt;                                                  // :307
+                if (!in_volume(G, ci, cj, ck)) continue;
+                size_t dst;
+                if (DENSE) dst = ((size_t)(ci + G.hN) * G.N + (size_t)(cj + G.hN)) * G.Nz + (size_t)(ck + G.hNz);
+                else {
+                    int gl; const int gb = brick_of(G, ci, cj, ck, &gl);
+                    const int gp = pool_claim<false>(G, 0, gb);
+                    if (gp < 0) continue;
+                    dst = (size_t)gp * TSL_BRK3 + gl;
+                }
+                __hip_atomic_fetch_add(acc + dst * 2, (unsigned long long)to_fix(w_tsdf * tsdf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :275 numerator
+                __hip_atomic_fetch_add(acc + dst * 2 + 1, (unsigned long long)to_fix(w_tsdf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // :274
+                __hip_atomic_fetch_add(cnt + dst, (1 << 16) + occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                 // :279-280
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void fuse_write(const MapDev& G, size_t v, long long qn, long long qd, int c)
+{
+    const int occ_sum = (int)(int16_t)(c & 0xffff);
+    const float num = from_fix(qn), den = from_fix(qd);
+    G.tw[v] = (uint32_t)f2h(num / den) | ((uint32_t)f2h(den) << 16);          // empty global map: T0 = W0 = 0  (:275,:278)
+    G.obs[v] = 1;
+    G.occ[v] = (int8_t)occ_sum;                                                // i8 wrap as in the reference (:280, Q7)
+}
+
+// finalise from the per-brick scratch of the global map
+__global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsigned long long* acc, int* cnt)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x)
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            const int c = cnt[v];
+            if (c == 0) continue;
+            fuse_write(G, v, (long long)acc[v * 2], (long long)acc[v * 2 + 1], c);
+            acc[v * 2] = 0ull; acc[v * 2 + 1] = 0ull; cnt[v] = 0;
+        }
+}
+
+// finalise from dense (all-reduced) arrays over the whole global grid
+__global__ void __launch_bounds__(256) k_fuse_finalize_dense(MapDev G, const long long* pair, const int* cnt, long long nvox)
+{
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nvox; q += (long long)gridDim.x * 256) {
+        const int c = cnt[q];
+        if (c == 0) continue;
+        const int uk = (int)(q % G.Nz), uj = (int)((q / G.Nz) % G.N), ui = (int)(q / ((long long)G.Nz * G.N));
+        int gl; const int gb = brick_of(G, ui - G.hN, uj - G.hN, uk - G.hNz, &gl);
+        const int gp = pool_claim<false>(G, 0, gb);
+        if (gp < 0) continue;
+        fuse_write(G, (size_t)gp * TSL_BRK3 + gl, pair[q * 2], pair[q * 2 + 1], c);
+    }
+}
+
+static int upload_poses(tsl_tsdf* g, const tsl_tsdf* sub)
+{
+    // dense_tsdf.py:286-290: the f32 pose fields of submaps [0, active) are refreshed from the float64 tables
+    const int nsub = sub->active;
+    for (int s = 0; s < nsub && s < g->npose; ++s) {
+        for (int a = 0; a < 9; ++a) g->baseRf[(size_t)s * 9 + a] = (float)g->baseR[(size_t)s * 9 + a];
+        for (int a = 0; a < 3; ++a) g->baseTf[(size_t)s * 3 + a] = (float)g->baseT[(size_t)s * 3 + a];
+    }
+    std::vector<float> tab((size_t)g->npose * 12);
+    for (int s = 0; s < g->npose; ++s) {
+        for (int a = 0; a < 9; ++a) tab[(size_t)s * 12 + a] = g->baseRf[(size_t)s * 9 + a];
+        for (int a = 0; a < 3; ++a) tab[(size_t)s * 12 + 9 + a] = g->baseTf[(size_t)s * 3 + a];
+    }
+    TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    TSL_HIP(hipStreamSynchronize(g->stream));
+    return TSL_OK;
+}
+
+static int used_bricks(tsl_tsdf* m, int* n) { return tsl_tsdf_bricks_in_use(m, n); }
+
+}  // namespace tsl
+
+using namespace tsl;
+
+extern "C" {
+
+int tsl_tsdf_fuse_submaps(tsl_tsdf* g, tsl_tsdf* sub)
+{
+    TSL_REQUIRE(g && sub, "fuse_submaps: null handle");
+    TSL_REQUIRE(g->cfg.is_global_map, "fuse_submaps: destination must be a global map (is_global_map=True)");
+    TSL_REQUIRE(g->device == sub->device, "fuse_submaps: maps live on different devices");
+    TSL_HIP(hipSetDevice(g->device));
+    int rc = tsl_tsdf_sync(sub); if (rc) return rc;
+    if ((rc = tsl_tsdf_reset(g))) return rc;                                                // :313
+    if (!g->fuse_acc) {
+        const size_t nv = (size_t)g->M.max_bricks * TSL_BRK3;
+        if ((rc = dev_alloc(g, &g->fuse_acc, nv * 16, 0))) return rc;
+        if ((rc = dev_alloc(g, &g->fuse_cnt, nv * 4, 0))) return rc;
+    }
+    if ((rc = upload_poses(g, sub))) return rc;
+    int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
+    if (nsrc > 0) {
+        PoseTab pt = { g->pose_dev };
+        hipLaunchKernelGGL(k_fuse_splat<false>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, pt, g->P.vs, nsrc,
+                           (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose);
+        int ndst = 0; if ((rc = used_bricks(g, &ndst))) return rc;
+        if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, g->stream, g->M, ndst,
+                                         (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt);
+    }
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(g->stream));
+    int e = 0;
+    TSL_HIP(hipMemcpy(&e, g->M.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) { (void)hipMemset(g->M.err, 0, sizeof(int)); set_error("fuse_submaps: global brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
+    return TSL_OK;
+}
+
+int tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* g, tsl_tsdf* sub, void* acc_dev, void* cnt_occ_dev)
+{
+    TSL_REQUIRE(g && sub && acc_dev && cnt_occ_dev, "fuse_accumulate: null argument");
+    TSL_REQUIRE(g->cfg.is_global_map && g->device == sub->device, "fuse_accumulate: bad destination");
+    TSL_HIP(hipSetDevice(g->device));
+    int rc = tsl_tsdf_sync(sub); if (rc) return rc;
+    if ((rc = upload_poses(g, sub))) return rc;
+    int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
+    if (nsrc > 0) {
+        PoseTab pt = { g->pose_dev };
+        hipLaunchKernelGGL(k_fuse_splat<true>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, pt, g->P.vs, nsrc,
+                           (unsigned long long*)acc_dev, (int*)cnt_occ_dev, g->npose);
+    }
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(g->stream));
+    return TSL_OK;
+}
+
+int tsl_tsdf_fuse_finalize_dev(tsl_tsdf* g, const void* acc_dev, const void* cnt_occ_dev)
+{
+    TSL_REQUIRE(g && acc_dev && cnt_occ_dev, "fuse_finalize: null argument");
+    TSL_REQUIRE(g->cfg.is_global_map, "fuse_finalize: destination must be a global map");
+    TSL_HIP(hipSetDevice(g->device));
+    int rc = tsl_tsdf_reset(g); if (rc) return rc;
+    const long long nvox = (long long)g->N * g->N * g->Nz;
+    hipLaunchKernelGGL(k_fuse_finalize_dense, dim3(8192), dim3(256), 0, g->stream, g->M, (const long long*)acc_dev, (const int*)cnt_occ_dev, nvox);
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(g->stream));
+    int e = 0;
+    TSL_HIP(hipMemcpy(&e, g->M.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) { (void)hipMemset(g->M.err, 0, sizeof(int)); set_error("fuse_finalize: global brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
+    return TSL_OK;
+}
+
+}  // extern "C"

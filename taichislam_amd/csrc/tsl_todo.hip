@@ -3,11 +3,6 @@
 #include "tsl_common.hpp"
 #define TSL_TODO(name) { tsl::set_error(name ": not implemented yet"); return TSL_ERR_ARG; }
 extern "C" {
-int  tsl_tsdf_fuse_submaps(tsl_tsdf*, tsl_tsdf*) TSL_TODO("tsl_tsdf_fuse_submaps")
-int  tsl_tsdf_fuse_accumulate_dev(tsl_tsdf*, tsl_tsdf*, void*, void*, void*) TSL_TODO("tsl_tsdf_fuse_accumulate_dev")
-int  tsl_tsdf_fuse_finalize_dev(tsl_tsdf*, const void*, const void*, const void*) TSL_TODO("tsl_tsdf_fuse_finalize_dev")
-int  tsl_mesh_generate(tsl_tsdf*, int, float, int64_t, int32_t*) TSL_TODO("tsl_mesh_generate")
-int  tsl_mesh_read(tsl_tsdf*, float*, float*, float*, int64_t) TSL_TODO("tsl_mesh_read")
 int  tsl_esdf_update(tsl_tsdf*, float, float, int32_t*) TSL_TODO("tsl_esdf_update")
 int  tsl_esdf_export(tsl_tsdf*, int16_t*, float*, int64_t, int64_t*) TSL_TODO("tsl_esdf_export")
 int  tsl_octo_create(const tsl_octo_cfg*, int, tsl_octo**) TSL_TODO("tsl_octo_create")
