@@ -1,0 +1,442 @@
+// tsl_octo.hip -- Octomap hit counter on MI355X.  Replaces taichi_slam/mapping/taichi_octomap.py:14-211 (reference root).
+//
+// The reference stores one f32 hit count per leaf of a K-ary pointer tree (11 pointer levels at 1024^3) and walks the
+// tree for every insert.  Here the leaves live in 16^3 bricks of f32 behind a direct-mapped brick table per submap
+// (tables are created lazily by the host when a submap becomes active); an insert is one table lookup + one f32 atomic.
+// Counts are small integers in f32, so the sums are exact and independent of the order of the atomics.
+#include "tsl_common.hpp"
+#include <cmath>
+
+namespace tsl {
+
+struct OctoDev {
+    int N, Nz, hN, hNz, ext_xy, ext_z, nbx, nbz, nb3;
+    int max_bricks;
+    int** tables;            // [nsub] -> brick table of the submap (nullptr until the host creates it)
+    float* cnt;              // [max_bricks][4096]
+    int* owner_s; int* owner_b;
+    int* pool_top; int* err;
+};
+
+struct OctoParams {
+    float R[9], T[3]; float fx, fy, cx, cy; float vs; float thr_max, thr_min; int step, hh, ww, W;
+};
+
+__device__ __forceinline__ bool octo_in_tree(const OctoDev& M, int i, int j, int k)
+{ return i >= -M.hN && i < M.ext_xy - M.hN && j >= -M.hN && j < M.ext_xy - M.hN && k >= -M.hNz && k < M.ext_z - M.hNz; }
+__device__ __forceinline__ int octo_brick_of(const OctoDev& M, int i, int j, int k, int* local)
+{
+    const int ui = i + M.hN, uj = j + M.hN, uk = k + M.hNz;
+    *local = ((ui & 15) << 8) | ((uj & 15) << 4) | (uk & 15);
+    return ((ui >> 4) * M.nbx + (uj >> 4)) * M.nbz + (uk >> 4);
+}
+__device__ __forceinline__ int octo_claim(const OctoDev& M, int s, int b)
+{
+    int* tab = M.tables[s];
+    if (!tab) return -1;
+    int v = __hip_atomic_load(tab + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= 0) return v;
+    v = claim_index_1(tab + b, M.pool_top, M.max_bricks);
+    if (v >= 0) { M.owner_s[v] = s; M.owner_b[v] = b; } else atomicOr(M.err, 1);
+    return v;
+}
+// process_point  taichi_octomap.py:116-124 (texture not stored: see DESIGN.md)
+__device__ __forceinline__ bool octo_point(const OctoDev& M, int s, float vs, float x, float y, float z)
+{
+    const int ci = rnd_i(x / vs), cj = rnd_i(y / vs), ck = rnd_i(z / vs);                    // mapping_common.py:252-266
+    if (!octo_in_tree(M, ci, cj, ck)) return false;
+    int l; const int b = octo_brick_of(M, ci, cj, ck, &l);
+    const int p = octo_claim(M, s, b);
+    if (p < 0) return false;
+    atomicAdd(M.cnt + (size_t)p * TSL_BRK3 + l, 1.0f);                                       // :119
+    return true;
+}
+
+// recast_depth_to_map_kernel  taichi_octomap.py:147-169
+__global__ void __launch_bounds__(256) k_octo_depth(OctoDev M, OctoParams P, int s, const uint16_t* __restrict__ depth, tsl_frame_stats* st)
+{
+    const int total = P.hh * P.ww;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool gate = false, ok = false;
+    if (p < total) {
+        const int jj = p / P.ww, ii = p - jj * P.ww;
+        const int j = jj * P.step, i = ii * P.step;
+        const uint16_t d = depth[(size_t)j * P.W + i];
+        const float df = (float)d;
+        if (d != 0 && !(df > P.thr_max) && !(df < P.thr_min)) {                               // :155
+            gate = true;
+            const float dep = df / 1000.0f;                                                   // :157
+            const float px = ((float)i - P.cx) * dep / P.fx, py = ((float)j - P.cy) * dep / P.fy, pz = dep;
+            const float mx = ((P.R[0] * px + P.R[1] * py) + P.R[2] * pz) + P.T[0];            // :159
+            const float my = ((P.R[3] * px + P.R[4] * py) + P.R[5] * pz) + P.T[1];
+            const float mz = ((P.R[6] * px + P.R[7] * py) + P.R[8] * pz) + P.T[2];
+            ok = octo_point(M, s, P.vs, mx, my, mz);
+        }
+    }
+    block_count_add(&st->p_valid, ok);
+    block_count_add(&st->p_oob, gate && !ok);
+}
+// recast_pcl_to_map_kernel  taichi_octomap.py:134-145 (no range gate)
+__global__ void __launch_bounds__(256) k_octo_points(OctoDev M, OctoParams P, int s, const float* __restrict__ xyz, int n, tsl_frame_stats* st)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool ok = false;
+    if (p < n) {
+        const float px = xyz[(size_t)p * 3], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
+        const float mx = ((P.R[0] * px + P.R[1] * py) + P.R[2] * pz) + P.T[0];                // :141
+        const float my = ((P.R[3] * px + P.R[4] * py) + P.R[5] * pz) + P.T[1];
+        const float mz = ((P.R[6] * px + P.R[7] * py) + P.R[8] * pz) + P.T[2];
+        ok = octo_point(M, s, P.vs, mx, my, mz);
+    }
+    block_count_add(&st->p_valid, ok);
+    block_count_add(&st->p_oob, p < n && !ok);
+}
+
+__device__ __forceinline__ void octo_ijk(const OctoDev& M, int b, int l, int* i, int* j, int* k)
+{
+    const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
+    *i = bi * 16 + (l >> 8) - M.hN; *j = bj * 16 + ((l >> 4) & 15) - M.hN; *k = bk * 16 + (l & 15) - M.hNz;
+}
+
+struct OctoPose { float R[9], T[3]; };
+// mode 0: every touched leaf -> (idx, count); mode 1: cvt_occupy_to_voxels(level) taichi_octomap.py:90-114 -> xyz
+__global__ void __launch_bounds__(256) k_octo_export(OctoDev M, int s, int nused, int mode, float thres, int gxy, int gz, OctoPose B, float vs,
+                                                     int32_t* idx, float* cnt, float* xyz, long long cap, int* counter)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        if (M.owner_s[p] != s) continue;
+        const int b = M.owner_b[p];
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
+            const int l = l0 + threadIdx.x;
+            const float c = M.cnt[(size_t)p * TSL_BRK3 + l];
+            int i, j, k; octo_ijk(M, b, l, &i, &j, &k);
+            bool pred;
+            if (mode == 0) pred = c != 0.0f;
+            else pred = (c > thres) && ((i + M.hN) % gxy == 0) && ((j + M.hN) % gxy == 0) && ((k + M.hNz) % gz == 0);   // :96-97, :86-88
+            const int o = wave_reserve(counter, pred);
+            if (pred && o < cap) {
+                if (mode == 0) { idx[(size_t)o * 3] = i; idx[(size_t)o * 3 + 1] = j; idx[(size_t)o * 3 + 2] = k; cnt[o] = c; }
+                else {
+                    const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;      // sijk_to_xyz mapping_common.py:234-238
+                    for (int a = 0; a < 3; ++a) xyz[(size_t)o * 3 + a] = ((B.R[a * 3] * p0 + B.R[a * 3 + 1] * p1) + B.R[a * 3 + 2] * p2) + B.T[a];
+                }
+            }
+        }
+    }
+}
+
+// fuse_submaps_kernel  taichi_octomap.py:171-189
+__global__ void __launch_bounds__(256) k_octo_fuse(OctoDev S, OctoDev G, int nused, const float* poses, int npose, float vs, float thres)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        const int s = S.owner_s[p], b = S.owner_b[p];
+        if (s >= npose) continue;
+        const float* Rp = poses + (size_t)s * 12;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const float c = S.cnt[(size_t)p * TSL_BRK3 + l];
+            if (!(c > thres)) continue;                                                      // :181
+            int i, j, k; octo_ijk(S, b, l, &i, &j, &k);
+            const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;
+            int cc[3];
+            for (int a = 0; a < 3; ++a) { const float x = ((Rp[a * 3] * p0 + Rp[a * 3 + 1] * p1) + Rp[a * 3 + 2] * p2) + Rp[9 + a]; cc[a] = rnd_i(x / vs); }   // :182-183
+            if (!octo_in_tree(G, cc[0], cc[1], cc[2])) continue;
+            int gl; const int gb = octo_brick_of(G, cc[0], cc[1], cc[2], &gl);
+            const int gp = octo_claim(G, 0, gb);
+            if (gp >= 0) atomicAdd(G.cnt + (size_t)gp * TSL_BRK3 + gl, c);                    // :186
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_octo_reset(OctoDev M, int nused)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        float* c = M.cnt + (size_t)p * TSL_BRK3;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) c[l] = 0.0f;
+        if (threadIdx.x == 0) M.tables[M.owner_s[p]][M.owner_b[p]] = TSL_EMPTY;
+    }
+}
+
+void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
+
+}  // namespace tsl
+
+struct tsl_octo {
+    tsl_octo_cfg cfg; int device; hipStream_t stream;
+    int Rxy, Rz, N, Nz, K, nsub;
+    double voxel_scale_recomputed;
+    tsl::OctoDev M; tsl::OctoParams P;
+    std::vector<int*> tables;                 // host copy of M.tables
+    std::vector<double> baseR, baseT; std::vector<float> baseRf, baseTf;
+    int active; float occ_thres;
+    tsl_frame_stats* stats; tsl_frame_stats* h_stats; int64_t p_used;
+    float *exp_xyz, *exp_rgb; int* num_particles; int64_t max_disp;
+    float* pose_dev;
+    void* stage; size_t stage_bytes; void* xbuf; size_t xbuf_bytes;
+};
+
+using namespace tsl;
+
+static int octo_ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+static int octo_ensure_table(tsl_octo* m, int s)
+{
+    if (m->tables[(size_t)s]) return TSL_OK;
+    int* t = nullptr;
+    TSL_HIP(hipMalloc((void**)&t, sizeof(int) * (size_t)m->M.nb3));
+    TSL_HIP(hipMemsetAsync(t, 0xff, sizeof(int) * (size_t)m->M.nb3, m->stream));
+    m->tables[(size_t)s] = t;
+    TSL_HIP(hipMemcpyAsync(m->M.tables + s, &m->tables[(size_t)s], sizeof(int*), hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    return TSL_OK;
+}
+static int octo_read_int(tsl_octo* m, const int* dev, int* out)
+{
+    TSL_HIP(hipMemcpyAsync(m->h_stats, dev, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    *out = *reinterpret_cast<int*>(m->h_stats);
+    return TSL_OK;
+}
+static int octo_used(tsl_octo* m, int* n)
+{ int v = 0; int rc = octo_read_int(m, m->M.pool_top, &v); if (rc) return rc; *n = v > m->M.max_bricks ? m->M.max_bricks : v; return TSL_OK; }
+static int octo_check_err(tsl_octo* m)
+{
+    int e = 0; int rc = octo_read_int(m, m->M.err, &e); if (rc) return rc;
+    if (e) { (void)hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream); set_error("octomap brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
+    return TSL_OK;
+}
+
+extern "C" {
+
+int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
+{
+    TSL_REQUIRE(cfg && out, "tsl_octo_create: null argument");
+    TSL_REQUIRE(cfg->voxel_scale > 0 && cfg->K >= 2 && cfg->recast_step >= 1, "tsl_octo_create: bad config");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available"); return TSL_ERR_NO_DEVICE; }
+    TSL_REQUIRE(device >= 0 && device < ndev, "tsl_octo_create: bad device index");
+    TSL_HIP(hipSetDevice(device));
+    tsl_octo* m = new tsl_octo();
+    m->cfg = *cfg; m->device = device;
+    TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    m->K = cfg->K;
+    m->Rxy = (int)std::ceil(std::log2(cfg->map_size_xy / cfg->voxel_scale) / std::log2((double)cfg->K));     // taichi_octomap.py:19
+    m->Rz = (int)std::ceil(std::log2(cfg->map_size_z / cfg->voxel_scale) / std::log2((double)cfg->K));      // :20
+    TSL_REQUIRE(m->Rxy >= 1 && m->Rz >= 1 && m->Rxy <= 20, "tsl_octo_create: bad tree depth");
+    m->N = octo_ipow(m->K, m->Rxy); m->Nz = octo_ipow(m->K, m->Rz);                                          // :26-27
+    m->voxel_scale_recomputed = cfg->map_size_xy / (double)m->N;                                             // :28 (Q15)
+    OctoDev& M = m->M; std::memset(&M, 0, sizeof(M));
+    M.N = m->N; M.Nz = m->Nz; M.hN = m->N / 2; M.hNz = m->Nz / 2;
+    M.ext_xy = octo_ipow(m->K, m->Rxy + 1);                                                                  // tree extent, :65-70 (Q16)
+    M.ext_z = octo_ipow(m->K, 1 + (m->Rz < m->Rxy ? m->Rz : m->Rxy));
+    M.nbx = (M.ext_xy + 15) / 16; M.nbz = (M.ext_z + 15) / 16;
+    const int64_t nb3 = (int64_t)M.nbx * M.nbx * M.nbz;
+    TSL_REQUIRE(nb3 < (1ll << 30), "tsl_octo_create: map too large");
+    M.nb3 = (int)nb3;
+    m->nsub = cfg->max_submap_num > 0 ? cfg->max_submap_num : 1;
+    M.max_bricks = cfg->max_bricks > 0 ? cfg->max_bricks : 65536;
+    TSL_HIP(hipMalloc((void**)&M.tables, sizeof(int*) * (size_t)m->nsub));
+    TSL_HIP(hipMemsetAsync(M.tables, 0, sizeof(int*) * (size_t)m->nsub, m->stream));
+    m->tables.assign((size_t)m->nsub, nullptr);
+    TSL_HIP(hipMalloc((void**)&M.cnt, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3));
+    TSL_HIP(hipMemsetAsync(M.cnt, 0, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+    TSL_HIP(hipMalloc((void**)&M.owner_s, sizeof(int) * (size_t)M.max_bricks));
+    TSL_HIP(hipMalloc((void**)&M.owner_b, sizeof(int) * (size_t)M.max_bricks));
+    TSL_HIP(hipMalloc((void**)&M.pool_top, sizeof(int) * 4));
+    TSL_HIP(hipMemsetAsync(M.pool_top, 0, sizeof(int) * 4, m->stream));
+    M.err = M.pool_top + 1;
+    OctoParams& P = m->P; std::memset(&P, 0, sizeof(P));
+    for (int i = 0; i < 3; ++i) P.R[i * 4] = 1.0f;
+    P.vs = (float)cfg->voxel_scale;                                                                          // voxel_scale_ cached from the ctor argument (Q15)
+    P.thr_max = (float)(cfg->max_ray_length * 1000.0); P.thr_min = (float)(cfg->min_ray_length * 1000.0);
+    P.step = cfg->recast_step;
+    m->occ_thres = (float)cfg->min_occupy_thres;
+    m->baseR.assign((size_t)m->nsub * 9, 0.0); m->baseT.assign((size_t)m->nsub * 3, 0.0);
+    m->baseRf.assign((size_t)m->nsub * 9, 0.0f); m->baseTf.assign((size_t)m->nsub * 3, 0.0f);
+    for (int s = 0; s < m->nsub; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }   // identity default
+    m->active = 0; m->p_used = 0;
+    TSL_HIP(hipMalloc((void**)&m->stats, sizeof(tsl_frame_stats)));
+    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
+    m->max_disp = cfg->max_disp_particles > 0 ? cfg->max_disp_particles : 1000000;
+    TSL_HIP(hipMalloc((void**)&m->exp_xyz, sizeof(float) * 3 * (size_t)m->max_disp));
+    TSL_HIP(hipMalloc((void**)&m->exp_rgb, sizeof(float) * 3 * (size_t)m->max_disp));
+    TSL_HIP(hipMalloc((void**)&m->num_particles, sizeof(int) * 4));
+    TSL_HIP(hipMemsetAsync(m->num_particles, 0, sizeof(int) * 4, m->stream));
+    TSL_HIP(hipMalloc((void**)&m->pose_dev, sizeof(float) * 12 * (size_t)m->nsub));
+    m->stage = nullptr; m->stage_bytes = 0; m->xbuf = nullptr; m->xbuf_bytes = 0;
+    int rc = octo_ensure_table(m, 0); if (rc) return rc;
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    *out = m;
+    return TSL_OK;
+}
+
+void tsl_octo_destroy(tsl_octo* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream);
+    for (int* t : m->tables) if (t) (void)hipFree(t);
+    void* ptrs[] = { m->M.tables, m->M.cnt, m->M.owner_s, m->M.owner_b, m->M.pool_top, m->stats, m->exp_xyz, m->exp_rgb, m->num_particles, m->pose_dev, m->stage, m->xbuf };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (m->h_stats) (void)hipHostFree(m->h_stats);
+    (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int tsl_octo_get_dims(const tsl_octo* m, int32_t* N, int32_t* Nz, int32_t* Rxy, int32_t* Rz, double* vs)
+{ TSL_REQUIRE(m, "null handle"); if (N) *N = m->N; if (Nz) *Nz = m->Nz; if (Rxy) *Rxy = m->Rxy; if (Rz) *Rz = m->Rz; if (vs) *vs = m->voxel_scale_recomputed; return TSL_OK; }
+int tsl_octo_sync(tsl_octo* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
+
+int tsl_octo_reset(tsl_octo* m)                                                              // taichi_octomap.py:210-211
+{
+    TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
+    int used = 0; int rc = octo_used(m, &used); if (rc) return rc;
+    if (used > 0) hipLaunchKernelGGL(k_octo_reset, dim3(used < 4096 ? used : 4096), dim3(256), 0, m->stream, m->M, used);
+    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, m->stream));
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+int tsl_octo_set_intrinsics(tsl_octo* m, const double Kd[9], const double Kc[9])
+{ TSL_REQUIRE(m, "null handle"); (void)Kc; if (Kd) { m->P.fx = (float)Kd[0]; m->P.fy = (float)Kd[4]; m->P.cx = (float)Kd[2]; m->P.cy = (float)Kd[5]; } return TSL_OK; }
+int tsl_octo_set_base_pose_submap(tsl_octo* m, int sid, const double R[9], const double T[3])
+{
+    TSL_REQUIRE(m && R && T, "null"); TSL_REQUIRE(sid >= 0 && sid < m->nsub, "set_base_pose_submap: submap id out of range");
+    std::memcpy(&m->baseR[(size_t)sid * 9], R, 72); std::memcpy(&m->baseT[(size_t)sid * 3], T, 24);
+    for (int a = 0; a < 9; ++a) m->baseRf[(size_t)sid * 9 + a] = (float)R[a];
+    for (int a = 0; a < 3; ++a) m->baseTf[(size_t)sid * 3 + a] = (float)T[a];
+    return TSL_OK;
+}
+int tsl_octo_get_active_submap(const tsl_octo* m, int32_t* sid) { TSL_REQUIRE(m && sid, "null"); *sid = m->active; return TSL_OK; }
+int tsl_octo_set_active_submap(tsl_octo* m, int32_t sid)
+{
+    TSL_REQUIRE(m, "null"); TSL_REQUIRE(sid >= 0 && sid < m->nsub, "set_active_submap: id out of range");
+    TSL_HIP(hipSetDevice(m->device));
+    m->active = sid;
+    return octo_ensure_table(m, sid);
+}
+
+static void octo_fill_pose(tsl_octo* m, const double R[9], const double T[3])
+{ convert_pose(&m->baseR[(size_t)m->active * 9], &m->baseT[(size_t)m->active * 3], R, T, m->P.R, m->P.T); }
+
+int tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[3], const void* depth_dev, int h, int w, const void* tex_dev, int th, int tw)
+{
+    TSL_REQUIRE(m && R && T && depth_dev, "octo integrate_depth: null argument"); TSL_REQUIRE(h > 0 && w > 0, "octo integrate_depth: bad image size");
+    (void)tex_dev; (void)th; (void)tw;
+    TSL_HIP(hipSetDevice(m->device));
+    octo_fill_pose(m, R, T);
+    OctoParams& P = m->P;
+    P.W = w; P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);   // taichi_octomap.py:151,153
+    const int total = P.hh * P.ww;
+    m->p_used = total;
+    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    if (total > 0) hipLaunchKernelGGL(k_octo_depth, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, m->active, (const uint16_t*)depth_dev, m->stats);
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+int tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w, const uint8_t* tex, int th, int tw)
+{
+    TSL_REQUIRE(m && depth, "octo integrate_depth: null argument"); TSL_REQUIRE(h > 0 && w > 0, "octo integrate_depth: bad image size");
+    (void)tex; TSL_HIP(hipSetDevice(m->device));
+    const size_t nb = (size_t)h * w * 2;
+    if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
+    TSL_HIP(hipMemcpyAsync(m->stage, depth, nb, hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    return tsl_octo_integrate_depth_dev(m, R, T, m->stage, h, w, nullptr, th, tw);
+}
+int tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n)
+{
+    TSL_REQUIRE(m && R && T, "octo integrate_points: null argument"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz) && n < (1ll << 31), "octo integrate_points: bad input");
+    (void)rgb; TSL_HIP(hipSetDevice(m->device));
+    octo_fill_pose(m, R, T);
+    m->p_used = n;
+    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    if (n == 0) return TSL_OK;
+    const size_t nb = (size_t)n * 12;
+    if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
+    TSL_HIP(hipMemcpyAsync(m->stage, xyz, nb, hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)m->stage, (int)n, m->stats);
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+int tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out)
+{
+    TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipMemcpyAsync(m->h_stats, m->stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    *out = *m->h_stats; out->p_used = m->p_used;
+    return octo_check_err(m);
+}
+
+static int octo_export(tsl_octo* m, tsl_octo* dst, int mode, int level, int keep, int32_t* idx, float* cnt, int64_t cap, int64_t* n)
+{
+    TSL_HIP(hipSetDevice(m->device));
+    int used = 0; int rc = octo_used(m, &used); if (rc) return rc;
+    int gxy = 1, gz = 1;
+    for (int up = 0; up < level - 1; ++up) { const int r = m->Rxy - 1 - up; if (r < 0) break; gxy *= m->K; if (r < m->Rz) gz *= m->K; }   // granularity of occupy.parent(level)
+    OctoPose B;
+    for (int a = 0; a < 9; ++a) B.R[a] = m->baseRf[(size_t)m->active * 9 + a];
+    for (int a = 0; a < 3; ++a) B.T[a] = m->baseTf[(size_t)m->active * 3 + a];
+    int* counter; int32_t* didx = nullptr; float* dcnt = nullptr; float* dxyz = nullptr; long long dcap;
+    if (mode == 0) {
+        const size_t need = (size_t)cap * 16 + 64;
+        if (m->xbuf_bytes < need) { if (m->xbuf) (void)hipFree(m->xbuf); m->xbuf = nullptr; TSL_HIP(hipMalloc(&m->xbuf, need + 4096)); m->xbuf_bytes = need + 4096; }
+        didx = (int32_t*)m->xbuf; dcnt = (float*)((char*)m->xbuf + (size_t)cap * 12);
+        counter = m->num_particles + 2; dcap = cap;
+        TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));
+    } else {
+        if (!dst) dst = m;
+        counter = dst->num_particles; dxyz = dst->exp_xyz; dcap = dst->max_disp;
+        if (!keep) TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));                // :93
+    }
+    if (used > 0) hipLaunchKernelGGL(k_octo_export, dim3(used < 8192 ? used : 8192), dim3(256), 0, m->stream, m->M, m->active, used, mode, m->occ_thres, gxy, gz, B, m->P.vs,
+                                     didx, dcnt, dxyz, dcap, counter);
+    int c = 0; rc = octo_read_int(m, counter, &c); if (rc) return rc;
+    *n = c;
+    if (mode == 0) {
+        const size_t k = (size_t)(c < cap ? c : cap);
+        if (k && idx) TSL_HIP(hipMemcpy(idx, didx, k * 12, hipMemcpyDeviceToHost));
+        if (k && cnt) TSL_HIP(hipMemcpy(cnt, dcnt, k * 4, hipMemcpyDeviceToHost));
+    }
+    return TSL_OK;
+}
+int tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, int64_t cap, int64_t* n)
+{ TSL_REQUIRE(m && n && cap >= 0, "octo export_leaves: bad argument"); return octo_export(m, nullptr, 0, 0, 0, idx, cnt, cap, n); }
+int tsl_octo_occupied_voxels(tsl_octo* m, tsl_octo* dst, int level, int add_to_cur, int32_t* n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(level >= 0, "bad level");
+    int64_t c = 0; int rc = octo_export(m, dst, 1, level, add_to_cur, nullptr, nullptr, 0, &c);
+    if (n) *n = (int32_t)c;
+    return rc;
+}
+int tsl_octo_read_exports(tsl_octo* m, float* xyz, float* rgb, int64_t n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "read_exports: n out of range"); TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipStreamSynchronize(m->stream));
+    if (n && xyz) TSL_HIP(hipMemcpy(xyz, m->exp_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    if (n && rgb) TSL_HIP(hipMemcpy(rgb, m->exp_rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    return TSL_OK;
+}
+int tsl_octo_num_particles(tsl_octo* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device)); int v = 0; int rc = octo_read_int(m, m->num_particles, &v); *n = v; return rc; }
+
+int tsl_octo_fuse_submaps(tsl_octo* g, tsl_octo* sub)
+{
+    TSL_REQUIRE(g && sub, "octo fuse_submaps: null handle"); TSL_REQUIRE(g->device == sub->device, "octo fuse_submaps: maps live on different devices");
+    TSL_HIP(hipSetDevice(g->device));
+    int rc = tsl_octo_sync(sub); if (rc) return rc;
+    if ((rc = tsl_octo_reset(g))) return rc;                                                   // :196
+    if ((rc = octo_ensure_table(g, 0))) return rc;
+    for (int s = 0; s < sub->active && s < g->nsub; ++s) {                                     // :174-178
+        for (int a = 0; a < 9; ++a) g->baseRf[(size_t)s * 9 + a] = (float)g->baseR[(size_t)s * 9 + a];
+        for (int a = 0; a < 3; ++a) g->baseTf[(size_t)s * 3 + a] = (float)g->baseT[(size_t)s * 3 + a];
+    }
+    std::vector<float> tab((size_t)g->nsub * 12);
+    for (int s = 0; s < g->nsub; ++s) { for (int a = 0; a < 9; ++a) tab[(size_t)s * 12 + a] = g->baseRf[(size_t)s * 9 + a]; for (int a = 0; a < 3; ++a) tab[(size_t)s * 12 + 9 + a] = g->baseTf[(size_t)s * 3 + a]; }
+    TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, g->stream));
+    TSL_HIP(hipStreamSynchronize(g->stream));
+    int nsrc = 0; if ((rc = octo_used(sub, &nsrc))) return rc;
+    if (nsrc > 0) hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres);
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(g->stream));
+    return octo_check_err(g);
+}
+
+}  // extern "C"

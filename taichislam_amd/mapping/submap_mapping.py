@@ -24,7 +24,7 @@ class SubmapMapping:
     global_map: BaseMap
 
     def __init__(self, submap_type=DenseTSDF, keyframe_step=20, sub_opts={}, global_opts={}, autosave_path=None):
-        self._is_tsdf = submap_type is DenseTSDF
+        self._is_tsdf = issubclass(submap_type, DenseTSDF)
         if self._is_tsdf:
             opts = {'map_scale': [10, 10], 'voxel_scale': 0.05, 'texture_enabled': False, 'min_ray_length': 0.3,
                     'max_ray_length': 3.0, 'max_disp_particles': 1024 * 1024, 'num_voxel_per_blk_axis': 10,

@@ -1,0 +1,127 @@
+"""Octomap: drop-in for taichi_slam.mapping.Octomap (reference taichi_slam/mapping/taichi_octomap.py:12-211): an f32
+hit counter per leaf voxel with a `> min_occupy_thres` occupancy test, on HIP kernels through the C-ABI."""
+import ctypes as C
+import math
+import time
+
+import numpy as np
+
+from .. import _lib
+from .fields import DeviceArrayField, MapFieldRef, ScalarField
+from .mapping_common import BaseMap, _dptr
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Octomap(BaseMap):
+    _prefix = "tsl_octo"
+
+    def __init__(self, map_scale=[10, 10], voxel_scale=0.05, min_occupy_thres=3, texture_enabled=False,
+                 min_ray_length=0.3, max_ray_length=3.0, max_disp_particles=1000000, K=2,
+                 max_submap_num=1024, disp_ceiling=10.0, disp_floor=-10.0,
+                 is_global_map=False, recast_step=2, color_same_proj=True, device=0, max_bricks=0, max_points=0):
+        super(Octomap, self).__init__(voxel_scale)
+        Rxy = math.ceil(math.log2(map_scale[0] / voxel_scale) / math.log2(K))
+        Rz = math.ceil(math.log2(map_scale[1] / voxel_scale) / math.log2(K))
+        self.Rxy, self.Rz = Rxy, Rz
+        self.map_size_xy, self.map_size_z = map_scale[0], map_scale[1]
+        self.K = K
+        self.N = self.K ** self.Rxy
+        self.Nz = self.K ** self.Rz
+        self.voxel_scale = self.map_size_xy / self.N          # recomputed as in the reference (:28); index math keeps voxel_scale_ (Q15)
+        self.max_disp_particles = max_disp_particles
+        self.min_occupy_thres = min_occupy_thres
+        self.max_ray_length, self.min_ray_length = max_ray_length, min_ray_length
+        self.enable_texture = texture_enabled
+        self.max_submap_num = max_submap_num
+        self.disp_ceiling, self.disp_floor = disp_ceiling, disp_floor
+        self.is_global_map = is_global_map
+        self.recast_step = recast_step
+        self.color_same_proj = color_same_proj
+        cfg = _lib.OctoCfg(float(map_scale[0]), float(map_scale[1]), float(voxel_scale), float(min_occupy_thres),
+                           int(bool(texture_enabled)), float(min_ray_length), float(max_ray_length), int(K),
+                           int(max_submap_num), float(disp_ceiling), float(disp_floor), int(bool(is_global_map)),
+                           int(recast_step), int(bool(color_same_proj)), int(max_disp_particles), int(max_bricks), int(max_points))
+        h = C.c_void_p()
+        _lib.check(self.L.tsl_octo_create(C.byref(cfg), int(device), C.byref(h)))
+        self.h = h
+        self.num_export_particles = ScalarField(self._get_num, None, "num_export_particles")
+        self.export_x = DeviceArrayField(self, lambda n: self._read(n)[0], max_disp_particles, 3, "export_x")
+        self.export_color = DeviceArrayField(self, lambda n: self._read(n)[1], max_disp_particles, 3, "export_color")
+        self.occupy = MapFieldRef(self, "occupy")
+        self.color = MapFieldRef(self, "color") if texture_enabled else None
+        self.initialize_submap_fields(self.max_submap_num)
+        print(f'The map voxel is:[{self.max_submap_num}x{self.N}x{self.N}x{self.Nz}] voxel scale {self.voxel_scale:3.3f}^3 '
+              f'map scale:[{self.map_size_xy}mx{self.map_size_xy}mx{self.map_size_z}m] tree depth [{self.Rxy}, {self.Rz}]')
+
+    def _get_num(self):
+        v = C.c_int32()
+        self._call("num_particles", C.byref(v))
+        return v.value
+
+    def _read(self, n):
+        n = int(max(0, min(n, self.max_disp_particles)))
+        xyz = np.empty((n, 3), np.float32)
+        self._call("read_exports", _vp(xyz), None, n)
+        return xyz, np.full((n, 3), 0.5, np.float32)
+
+    def last_frame_stats(self):
+        st = _lib.FrameStats()
+        self._call("last_frame_stats", C.byref(st))
+        return st.as_dict()
+
+    def is_occupy_count(self, count):
+        return count > self.min_occupy_thres
+
+    def recast_pcl_to_map(self, R, T, xyz_array, rgb_array=None, n=None):
+        xyz = np.ascontiguousarray(np.asarray(xyz_array, dtype=np.float32).reshape(-1, 3))
+        if n is not None:
+            xyz = xyz[:int(n)]
+        self._call("integrate_points", _dptr(R, 9)[1], _dptr(T, 3)[1], _vp(xyz), None, int(xyz.shape[0]))
+
+    def recast_depth_to_map(self, R, T, depthmap, texture=None):
+        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
+        if hasattr(depthmap, "data_ptr") and getattr(depthmap, "is_cuda", False):
+            self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]), int(depthmap.shape[1]), None, 0, 0)
+            return
+        depth = np.ascontiguousarray(np.asarray(depthmap, dtype=np.uint16))
+        self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], None, 0, 0)
+
+    def cvt_occupy_to_voxels(self, level=0):
+        n = C.c_int32()
+        self._call("occupied_voxels", None, int(level), 0, C.byref(n))
+
+    def cvt_occupy_voxels_to(self, level, cur_num, max_disp_particles, x, color):
+        n = C.c_int32()
+        self._call("occupied_voxels", x._owner.h, int(level), 1, C.byref(n))
+
+    def get_occupy_voxels(self, l):
+        self.cvt_occupy_to_voxels(l)
+        n = self.num_export_particles[None]
+        return self._read(n)
+
+    def export_leaves(self):
+        """(indices int32[n,3], counts f32[n]) of every touched leaf of the active submap (backend extra for tests)."""
+        n = C.c_int64()
+        self._call("export_leaves", None, None, 0, C.byref(n))
+        idx = np.zeros((n.value, 3), np.int32)
+        cnt = np.zeros(n.value, np.float32)
+        self._call("export_leaves", _vp(idx), _vp(cnt), n.value, C.byref(n))
+        return idx, cnt
+
+    def fuse_submaps(self, submaps):
+        t = time.time()
+        _lib.check(self.L.tsl_octo_fuse_submaps(self.h, submaps.h))
+        print(f"[OctoMap] Fuse submaps {(time.time() - t) * 1000:.1f}ms, active local: {submaps.active_submap_id[None]} "
+              f"remote: {submaps.remote_submap_num[None]}")
+
+    def reset(self):
+        self._call("reset")
+
+    def saveMap(self, path):
+        pass
+
+    def export_submap(self):
+        return {}

@@ -1,0 +1,80 @@
+"""GPU parity for the Octomap hit counter (taichi_slam/mapping/taichi_octomap.py:116-189)."""
+import numpy as np
+import pytest
+
+from taichislam_amd.utils import synthetic as syn
+from util import small_stream, sorted_rows
+
+pytestmark = pytest.mark.gpu
+CFG = dict(map_scale=[12.8, 12.8], voxel_scale=0.05, min_occupy_thres=2, min_ray_length=0.3, max_ray_length=5.0, K=2, max_submap_num=8)
+
+
+def _pair(**kw):
+    from oracle import OracleOctomap
+    from taichislam_amd.mapping import Octomap
+    cfg = dict(CFG, **kw)
+    return Octomap(**cfg), OracleOctomap(**cfg)
+
+
+def _leaves_equal(g, o):
+    gi, gc = g.export_leaves()
+    oi, oc = o.export_leaves()
+    a = sorted_rows(np.concatenate([gi.astype(np.float64), gc[:, None]], 1))
+    b = sorted_rows(np.concatenate([oi.astype(np.float64), oc[:, None]], 1))
+    assert a.shape == b.shape and a.shape[0] > 100 and np.array_equal(a, b)
+
+
+def test_octomap_depth_points_and_levels(hip_lib):
+    K, frames = small_stream(5)
+    g, o = _pair()
+    assert (g.N, g.Nz, g.Rxy, g.Rz) == (o.N, o.Nz, o.Rxy, o.Rz) == (256, 256, 8, 8)
+    g.set_dep_camera_intrinsic(K); o.set_intrinsics(K)
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, np.array([], dtype=int))
+        so = o.integrate_depth(R, T, d)
+        sg = g.last_frame_stats()
+        assert (sg["p_used"], sg["p_valid"], sg["p_oob"]) == (so["p_used"], so["p_valid"], so["p_oob"])
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-4, 4, size=(5000, 3)).astype(np.float32)
+    g.recast_pcl_to_map(frames[0][0], frames[0][1], pts, None, 5000)
+    o.integrate_points(frames[0][0], frames[0][1], pts)
+    _leaves_equal(g, o)
+    for level in (0, 1, 2, 3):
+        gx, _ = g.get_occupy_voxels(level)
+        ox, on = o.occupied_voxels(level)
+        assert gx.shape[0] == on and np.array_equal(sorted_rows(gx), sorted_rows(ox)), f"level {level}"
+    assert g.get_occupy_voxels(0)[0].shape[0] > g.get_occupy_voxels(3)[0].shape[0] > 0
+
+
+def test_octomap_c3_shape(hip_lib):
+    """BASELINE configs[2] geometry: 1024^3 / 5 cm, K=2 (tree depth 10); full-size frames, counts match the oracle."""
+    from oracle import OracleOctomap
+    from taichislam_amd.mapping import Octomap
+    cfg = dict(map_scale=[51.2, 51.2], voxel_scale=0.05, K=2, max_ray_length=5.0, max_submap_num=4)
+    g, o = Octomap(**cfg), OracleOctomap(**cfg)
+    assert (g.N, g.Rxy) == (1024, 10)
+    g.set_dep_camera_intrinsic(syn.K_DEPTH); o.set_intrinsics(syn.K_DEPTH)
+    for R, T, d in syn.sphere_room_stream(3):
+        g.recast_depth_to_map(R, T, d, None); o.integrate_depth(R, T, d)
+    _leaves_equal(g, o)
+
+
+def test_octomap_submaps_and_fusion(hip_lib):
+    from oracle import OracleOctomap
+    from taichislam_amd.mapping import Octomap
+    K, frames = small_stream(4)
+    g, o = _pair(min_occupy_thres=0)
+    g.set_dep_camera_intrinsic(K); o.set_intrinsics(K)
+    for sid, fr in ((0, frames[:2]), (1, frames[2:])):
+        g.set_base_pose_submap(sid, fr[0][0], fr[0][1]); o.set_base_pose_submap(sid, fr[0][0], fr[0][1])
+        for R, T, d in fr:
+            g.recast_depth_to_map(R, T, d, None); o.integrate_depth(R, T, d)
+        _leaves_equal(g, o)
+        g.switch_to_next_submap(); o.set_active_submap(sid + 1)
+    gg, og = Octomap(**dict(CFG, is_global_map=True, min_occupy_thres=0)), OracleOctomap(**dict(CFG, is_global_map=True, min_occupy_thres=0))
+    for sid, f in ((0, 0), (1, 2)):
+        gg.set_base_pose_submap(sid, frames[f][0], frames[f][1]); og.set_base_pose_submap(sid, frames[f][0], frames[f][1])
+    gg.fuse_submaps(g); og.fuse_submaps(o)
+    _leaves_equal(gg, og)
+    gg.reset()
+    assert gg.export_leaves()[0].shape[0] == 0
