@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--split", type=int, default=None)
     ap.add_argument("--overlap", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--merge", action="store_true", help="also run the config-5 global-map merge (default when --gpus > 1)")
     args = ap.parse_args()
 
     import torch
@@ -83,9 +84,11 @@ def main():
     depth_dev = torch.from_numpy(np.stack([d for _, _, d in host]).view(np.int16)).cuda(dev)   # resident in HBM
     poses = [(np.ascontiguousarray(R), np.ascontiguousarray(T)) for R, T, _ in host]
 
-    m = DenseTSDF(**C2, device=dev)
+    m = DenseTSDF(**C2, device=dev, max_submap_num=max(8, world))
     m.set_dep_camera_intrinsic(syn.K_DEPTH)
-    m.set_base_pose_submap(0, np.eye(3), np.zeros(3))
+    # config 5: rank r integrates into submap id r whose base pose is its first camera pose
+    m.active_submap_id[None] = rank
+    m.set_base_pose_submap(rank, poses[0][0], poses[0][1])
     if args.variant is not None:
         m.set_option("variant", args.variant)
     if args.split is not None:
@@ -120,6 +123,24 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    merge = None
+    if distributed or args.merge:
+        # outside the timed region: one exchange at merge time -- splat, RCCL all-reduce, finalise
+        try:
+            from taichislam_amd import distributed as D
+            g = DenseTSDF(**C2, device=dev, is_global_map=True, max_submap_num=max(8, world), max_bricks=32768)
+            for r in range(world):
+                Rb, Tb = syn.camera_pose(0, start_deg=D.stream_start_deg(r))
+                g.set_base_pose_submap(r, Rb, Tb)
+            m.switch_to_next_submap()
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            nbytes = D.allreduce_merge(g, m, device=f"cuda:{dev}")
+            torch.cuda.synchronize()
+            merge = {"ms": 1000.0 * (time.perf_counter() - tm), "allreduce_bytes_per_rank": nbytes, "global_voxels": g.count_active()}
+        except Exception as e:          # the merge is reported next to the headline metric, it never hides it
+            merge = {"error": repr(e)[:300]}
 
     kern = {}
     for kid, name in _lib.KERNEL_NAMES.items():
@@ -159,7 +180,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: single 640x480 u16 depth stream (sphere room r=3 m, 1 deg/frame) -> "
                                    "DenseTSDF 512^3 / 2 cm, recast_step 2, max_ray 5 m; one stream+submap per GPU",
                        "frame_stats": stats, "kernels_us": kern,
-                       "updates_per_s": stats["steps"] * fps},
+                       "updates_per_s": stats["steps"] * fps, "merge": merge},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -74,6 +74,8 @@ def lib():
         L.ora_tsdf_slice_voxels.restype = i64
         L.ora_tsdf_slice_voxels.argtypes = [vp, C.c_float, C.c_float, vp, vp, vp, i64]
         L.ora_tsdf_fuse_submaps.argtypes = [vp, vp, C.c_int]
+        L.ora_tsdf_fuse_accumulate_dense.argtypes = [vp, vp, vp, vp]
+        L.ora_tsdf_fuse_finalize_dense.argtypes = [vp, vp, vp]
         L.ora_mesh_generate.restype = i64
         L.ora_mesh_generate.argtypes = [vp, C.c_int, C.c_float, i64, vp, vp, vp]
         L.ora_esdf_compute.restype = i64
@@ -226,6 +228,13 @@ class OracleTSDF:
 
     def fuse_submaps(self, sub, mode=BATCHED):
         self.L.ora_tsdf_fuse_submaps(self.h, sub.h, mode)
+
+    # dense accumulate / finalize (multi-rank merge); same call shape as DenseTSDF.fuse_accumulate / fuse_finalize
+    def fuse_accumulate(self, sub, acc, cnt):
+        self.L.ora_tsdf_fuse_accumulate_dense(self.h, sub.h, _p(acc), _p(cnt))
+
+    def fuse_finalize(self, acc, cnt):
+        self.L.ora_tsdf_fuse_finalize_dense(self.h, _p(acc), _p(cnt))
 
     def generate_mesh(self, step=1, surface_thres=0.1, max_tri=1000000):
         v = np.zeros((max_tri * 3, 3), np.float32)

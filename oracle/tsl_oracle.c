@@ -718,6 +718,50 @@ int ora_tsdf_fuse_submaps(ora_tsdf* g, const ora_tsdf* sub, int mode)
     return 0;
 }
 
+/* Dense form of the BATCHED fusion used by the multi-rank merge (each rank splats its own submaps, the arrays are
+ * all-reduced, every rank finalises): acc int64 [N*N*Nz][2] = {sum w*t, sum w} in 2^-24 fixed point, cnt int32 [N*N*Nz]
+ * = contributions*65536 + occupancy sum. */
+typedef struct { ora_tsdf* g; int64_t* acc; int32_t* cnt; } fused_ctx;
+static void fuse_dense_fn(void* vctx, const ora_tsdf* sm, int s, int i, int j, int k, const brick_t* sb, int sl)
+{
+    fused_ctx* c = (fused_ctx*)vctx; ora_tsdf* g = c->g; (void)sm;
+    if (sb->obs[sl] <= 0) return;
+    const float vs = g->vs;
+    float p[3] = { (float)i * vs, (float)j * vs, (float)k * vs };
+    const float* R = g->baseRf + s * 9; const float* T = g->baseTf + s * 3;
+    float f[3]; int lo[3];
+    for (int a = 0; a < 3; ++a) { float x = ((R[a * 3] * p[0] + R[a * 3 + 1] * p[1]) + R[a * 3 + 2] * p[2]) + T[a]; f[a] = x / vs; lo[a] = (int)floorf(f[a]); }
+    float tsdf = F(sb->tsdf[sl]), wsrc = F(sb->w[sl]);
+    for (int di = 0; di < 2; ++di) for (int dj = 0; dj < 2; ++dj) for (int dk = 0; dk < 2; ++dk) {
+        if (di + dj + dk == 0) continue;
+        int ci = lo[0] + di, cj = lo[1] + dj, ck = lo[2] + dk;
+        float wt = ((1.0f - fabsf((float)ci - f[0])) * (1.0f - fabsf((float)cj - f[1]))) * (1.0f - fabsf((float)ck - f[2]));
+        float w_tsdf = wsrc * wt;
+        if (!in_volume(g, ci, cj, ck)) continue;
+        size_t q = ((size_t)(ci + g->N / 2) * g->N + (size_t)(cj + g->N / 2)) * g->Nz + (size_t)(ck + g->Nz / 2);
+        c->acc[q * 2] += to_fix(w_tsdf * tsdf); c->acc[q * 2 + 1] += to_fix(w_tsdf); c->cnt[q] += (1 << 16) + sb->occ[sl];
+    }
+}
+int ora_tsdf_fuse_accumulate_dense(ora_tsdf* g, const ora_tsdf* sub, int64_t* acc, int32_t* cnt)
+{
+    fused_ctx c = { g, acc, cnt };
+    for (int s = 0; s < sub->nsub; ++s) for_each_voxel(sub, s, fuse_dense_fn, &c);
+    return 0;
+}
+int ora_tsdf_fuse_finalize_dense(ora_tsdf* g, const int64_t* acc, const int32_t* cnt)
+{
+    ora_tsdf_reset(g);
+    size_t nv = (size_t)g->N * g->N * g->Nz;
+    for (size_t q = 0; q < nv; ++q) {
+        if (cnt[q] == 0) continue;
+        int uk = (int)(q % g->Nz), uj = (int)((q / g->Nz) % g->N), ui = (int)(q / ((size_t)g->Nz * g->N));
+        int l; brick_t* b = get_brick(g, 0, ui - g->N / 2, uj - g->N / 2, uk - g->Nz / 2, 1, &l);
+        float num = from_fix(acc[q * 2]), den = from_fix(acc[q * 2 + 1]);
+        b->tsdf[l] = H(num / den); b->w[l] = H(den); b->obs[l] = 1; b->occ[l] = (int8_t)(int16_t)(cnt[q] & 0xffff);
+    }
+    return 0;
+}
+
 #include "mc_tables.h"
 
 /* ------------------------------------------------------------------------------------------ */

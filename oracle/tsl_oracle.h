@@ -86,6 +86,8 @@ int64_t ora_tsdf_surface_voxels(const ora_tsdf* m, float* xyz, float* rgb, int64
 int64_t ora_tsdf_slice_voxels(const ora_tsdf* m, float z, float dz, float* xyz, float* val, float* rgb, int64_t cap);
 
 int ora_tsdf_fuse_submaps(ora_tsdf* global, const ora_tsdf* sub, int mode);
+int ora_tsdf_fuse_accumulate_dense(ora_tsdf* global, const ora_tsdf* sub, int64_t* acc, int32_t* cnt);
+int ora_tsdf_fuse_finalize_dense(ora_tsdf* global, const int64_t* acc, const int32_t* cnt);
 
 /* marching cubes over one map (active submap of a submap collection, or submap 0 of a global map).
  * verts/normals: [3*max_tri][3] f32, colors may be NULL.  returns triangle count (may exceed max_tri;

@@ -89,7 +89,7 @@ struct tsl_tsdf {
     float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap;
     void *fuse_acc, *fuse_cnt;           // global-map fusion scratch ({num,den} int64 pairs, count|occupancy)
     // esdf
-    float* esdf; int* esdf_flag; int64_t esdf_bricks;
+    float* esdf; int* esdf_flag; int64_t esdf_bricks; float esdf_gamma;
     // profiling
     bool prof_on; std::vector<tsl::ProfSlot> prof;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];

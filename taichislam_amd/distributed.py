@@ -1,0 +1,44 @@
+"""Multi-GPU operation: one submap (one depth stream) per GPU, one exchange at merge time.
+
+Integration shards by submap with no data-path collective.  The only exchange is the global-map
+merge: every rank splats its own submaps into exact int64 fixed-point accumulators over the dense global grid
+(`fuse_accumulate`), the accumulators are all-reduced (sum) -- RCCL over xGMI when the process group is "nccl" -- and
+every rank finalises the same global TSDF (`fuse_finalize`).  Integer sums make the result independent of the number
+of ranks and of the reduction order, i.e. bit-identical to a single GPU fusing all submaps
+(reference: taichi_slam/mapping/dense_tsdf.py:272-318 run once over every agent's submaps; the reference itself ships
+submaps between agents as zlib-compressed numpy dicts over LCM, submap_mapping.py:226-253)."""
+import numpy as np
+
+
+def stream_start_deg(rank):
+    """Start angle of rank `rank`'s synthetic stream (45 degrees apart)."""
+    return 45.0 * rank
+
+
+def merge_buffers(global_map, device=None):
+    """Zero-initialised accumulators for `global_map`: torch tensors on `device` (CUDA) or numpy arrays (device=None)."""
+    nvox = int(global_map.N) * int(global_map.N) * int(global_map.Nz)
+    if device is None:
+        return np.zeros((nvox, 2), np.int64), np.zeros(nvox, np.int32)
+    import torch
+    return (torch.zeros((nvox, 2), dtype=torch.int64, device=device), torch.zeros(nvox, dtype=torch.int32, device=device))
+
+
+def allreduce_merge(global_map, submaps, group=None, device=None):
+    """Merge every rank's `submaps` into every rank's `global_map`.  Returns the bytes all-reduced per rank.
+
+    `global_map` / `submaps` need `fuse_accumulate(submaps, acc, cnt)` and `fuse_finalize(acc, cnt)` (DenseTSDF on
+    the GPU; the CPU oracle in the gloo tests).  The global map's pose table must hold the base pose of every submap
+    id used by any rank (set_base_pose_submap), exactly as for a single-process fuse_submaps."""
+    import torch
+    import torch.distributed as dist
+    acc, cnt = merge_buffers(global_map, device)
+    global_map.fuse_accumulate(submaps, acc, cnt)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        tacc = acc if isinstance(acc, torch.Tensor) else torch.from_numpy(acc)
+        tcnt = cnt if isinstance(cnt, torch.Tensor) else torch.from_numpy(cnt)
+        dist.all_reduce(tacc, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(tcnt, op=dist.ReduceOp.SUM, group=group)
+    global_map.fuse_finalize(acc, cnt)
+    return int(acc.nbytes if not hasattr(acc, "element_size") else acc.numel() * acc.element_size()) + \
+        int(cnt.nbytes if not hasattr(cnt, "element_size") else cnt.numel() * cnt.element_size())
