@@ -155,10 +155,11 @@ def main():
         # algorithmic bytes (SURVEY.md section 8d / DESIGN.md): phase A = 2*P_used + 24*P_valid, phase B = 9*U + V_pcl
         bytes_a = 2 * stats["p_used"] + 24 * stats["p_valid"]
         bytes_b = 9 * stats["unique"] + stats["v_pcl"]
-        dom = max(kern, key=lambda k: kern[k]["avg_us"]) if kern else None
+        single = {k: v for k, v in kern.items() if k not in ("sort", "bin")}      # "sort"/"bin" time several launches each
+        dom = max(single, key=lambda k: single[k]["avg_us"]) if single else None
         roof = None
         if dom:
-            alg = bytes_b if dom in ("integrate", "finalize") else bytes_a
+            alg = 9 * stats["unique"] if dom in ("integrate", "finalize") else (stats["v_pcl"] * 20 + stats["steps"] // 10 * 8 if dom == "segments" else bytes_a)
             ach = alg / (kern[dom]["avg_us"] * 1e-6) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
