@@ -87,6 +87,7 @@ SIGNATURES = {
     "tsl_esdf_update": (C.c_int, [vp, f32, f32, pi32]),
     "tsl_esdf_export": (C.c_int, [vp, vp, vp, i64, pi64]),
     "tsl_tsdf_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "tsl_tsdf_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),
     "tsl_tsdf_prof_enable": (C.c_int, [vp, C.c_int]),
     "tsl_tsdf_prof_query": (C.c_int, [vp, C.c_int, dp, pi64]),
     "tsl_octo_create": (C.c_int, [C.POINTER(OctoCfg), C.c_int, C.POINTER(vp)]),

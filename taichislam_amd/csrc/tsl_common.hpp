@@ -50,12 +50,27 @@ __device__ __forceinline__ float rnd_f(float x)
 __device__ __forceinline__ int rnd_i(float x) { return (int)rnd_f(x); }
 __device__ __forceinline__ int sgn_f(float v) { return (0.0f < v) - (v < 0.0f); }     // mapping_common.py:5-7
 
+// x / vs with a loop-invariant divisor.  IEEE division costs ~10 VALU ops on gfx950; with y = RN(1/vs) the sequence
+// q0 = x*y, r = fma(-q0, vs, x), q = fma(r, y, q0) is the correctly rounded quotient (Markstein) -- and because the parity
+// contract is bit-exactness this is not assumed: tsl_tsdf_create checks it on the device against IEEE division for every
+// float x in the range that can reach an integer conversion and only then sets `fast`.
+__device__ __forceinline__ float div_vs(float x, float vs, float rvs, int fast)
+{
+    if (fast) { const float q0 = x * rvs; const float r = __builtin_fmaf(-q0, vs, x); return __builtin_fmaf(r, rvs, q0); }
+    return x / vs;
+}
+
 // ---- 2^-24 fixed point ------------------------------------------------------------------------------
 #define TSL_FIX_SCALE 16777216.0f
 #define TSL_FIX_INV   (1.0 / 16777216.0)
 #define TSL_W_CLAMP   65536.0f
 #define TSL_WMAX      1000.0f                                                             // dense_tsdf.py:8
-__device__ __forceinline__ long long to_fix(float v) { return __float2ll_rn(v * TSL_FIX_SCALE); }
+__device__ __forceinline__ long long to_fix(float v)
+{
+    const float q = rintf(v * TSL_FIX_SCALE);                  // integer-valued
+    if (fabsf(q) < 2147483648.0f) return (long long)(int)q;    // common case: one v_cvt_i32_f32 + sign extension
+    return __float2ll_rn(q);
+}
 __device__ __forceinline__ float from_fix(long long q) { return (float)((double)q * TSL_FIX_INV); }
 
 // ---- wave64 helpers -----------------------------------------------------------------------------------

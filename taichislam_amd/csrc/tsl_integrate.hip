@@ -9,18 +9,19 @@
 //                ~1 ms/frame at BASELINE configs[1].  Kept as the simple cross-check.
 //
 //   variant 2    "brick-binned LDS" (default): all updates of one 16^3 brick happen in LDS.
-//                K4a k_segments   : every ray is cut into runs of consecutive steps inside one brick
-//                                   ("segments", one u64 each), staged in LDS and appended block-wise; a
-//                                   per-brick histogram is kept in LDS and flushed once per block.
-//                K4b k_scan       : exclusive scan of the per-brick segment counts (<= 4096 bricks/frame).
-//                K4c k_scatter    : counting-sort the segments by brick (LDS histogram per 4096-segment tile,
-//                                   one global reservation per (tile, brick)).
-//                K4d k_integrate_bricks : one workgroup per chunk of the sorted list; the brick's 4096
-//                                   {num,den} int64 accumulators live in 64 KiB of LDS (ds_add_u64, >400 G
-//                                   pairs/s chip-wide), then the brick is finalised in place with coalesced
-//                                   row reads/writes.  Bricks whose segment list straddles chunks flush their
-//                                   partial sums to the HBM scratch (wave-coherent int64 atomics) and
-//                K4e k_finalize   : ... are finalised from there.
+//                phase A (per frame, own stream, independent of the map contents):
+//                K4a k_segments   : every ray is cut into runs of consecutive steps inside one brick ("segments", one
+//                                   u64 each) by searching the brick-boundary crossings per axis; staged in LDS and
+//                                   appended block-wise; per-brick counts in an LDS hash, flushed once per block.
+//                K4b k_scan       : exclusive scans over the frame's active bricks (<= 4096).
+//                K4c k_scatter    : counting-sort the segments by brick (LDS hash per 4096-segment tile, one global
+//                                   reservation per (tile, brick)).
+//                phase B (frame order, main stream):
+//                K4d k_integrate_bricks : one workgroup per brick part (<= 1024 segments); the brick's 4096 {num,den}
+//                                   int64 accumulators live in 64 KiB of LDS (ds_add_u64, >400 G pairs/s chip-wide),
+//                                   then the brick is finalised in place with all row loads in flight.  Bricks split
+//                                   over several workgroups flush partial sums to the HBM scratch and
+//                K4e k_finalize_shared : ... are finalised from there.
 #include "tsl_tsdf.hpp"
 
 namespace tsl {
@@ -46,11 +47,12 @@ namespace tsl {
 
 struct RayRegs { float pf0, pf1, pf2, d0, d1, d2, P0, P1, P2, w; long long qden; int n; };
 
+template <bool WITH_N = true>
 __device__ __forceinline__ RayRegs load_ray(const FrameDev& F, const FrameParams& P, int r)
 {
     RayRegs R;
     const uint4 rec = F.rayA[r];
-    R.n = F.rayN[r];
+    R.n = WITH_N ? F.rayN[r] : 0;
     R.pf0 = h2f((h16)(rec.x & 0xffffu)); R.pf1 = h2f((h16)(rec.x >> 16)); R.pf2 = h2f((h16)(rec.y & 0xffffu));
     R.d0 = h2f((h16)(rec.y >> 16)); R.d1 = h2f((h16)(rec.z & 0xffffu)); R.d2 = h2f((h16)(rec.z >> 16));
     R.w = __uint_as_float(rec.w);
@@ -63,7 +65,7 @@ __device__ __forceinline__ void step_voxel(const RayRegs& R, const FrameParams& 
 {
     const float jf = (float)j;
     x[0] = (R.d0 * jf) * P.vs + P.T[0]; x[1] = (R.d1 * jf) * P.vs + P.T[1]; x[2] = (R.d2 * jf) * P.vs + P.T[2];
-    xi[0] = rnd_i(x[0] / P.vs); xi[1] = rnd_i(x[1] / P.vs); xi[2] = rnd_i(x[2] / P.vs);
+    xi[0] = rnd_i(div_vs(x[0], P.vs, P.rvs, P.fastdiv)); xi[1] = rnd_i(div_vs(x[1], P.vs, P.rvs, P.fastdiv)); xi[2] = rnd_i(div_vs(x[2], P.vs, P.rvs, P.fastdiv));
 }
 // numerator term of the running average  (dense_tsdf.py:258-264)
 __device__ __forceinline__ long long step_term(const RayRegs& R, const float* x)
@@ -77,7 +79,7 @@ __device__ __forceinline__ long long step_term(const RayRegs& R, const float* x)
 // occupy[pos_p] = 1  (dense_tsdf.py:248)
 __device__ __forceinline__ void mark_occupied(const MapDev& M, const FrameParams& P, const RayRegs& R)
 {
-    const int oi = rnd_i(R.P0 / P.vs), oj = rnd_i(R.P1 / P.vs), ok = rnd_i(R.P2 / P.vs);
+    const int oi = rnd_i(div_vs(R.P0, P.vs, P.rvs, P.fastdiv)), oj = rnd_i(div_vs(R.P1, P.vs, P.rvs, P.fastdiv)), ok = rnd_i(div_vs(R.P2, P.vs, P.rvs, P.fastdiv));
     if (in_volume(M, oi, oj, ok)) {
         int l; const int b = brick_of(M, oi, oj, ok, &l);
         const int p = pool_claim(M, P.slot, b);
@@ -112,24 +114,6 @@ __device__ __forceinline__ uint32_t apply_update(uint32_t old, long long qnum, l
     const h16 Tn = f2h((h2f(hmul(T0, W0)) + num) / (h2f(W0) + den));
     float wn = h2f(W0) + den; if (TSL_WMAX < wn) wn = TSL_WMAX;
     return (uint32_t)Tn | ((uint32_t)f2h(wn) << 16);
-}
-
-// Frame prologue on the phase-B stream: clear the per-frame counters / histograms and pre-claim the 5^3 bricks
-// around the sensor.  Every ray starts at the sensor, so without this ~all waves of k_segments hit the same
-// EMPTY table entries in their first steps and pay a same-address CAS storm (~12 ns per wave and brick).
-__global__ void __launch_bounds__(1024) k_frame_begin(MapDev M, FrameDev F, FrameParams P, int nclear, int preclaim)
-{
-    for (int i = threadIdx.x; i < nclear; i += 1024) F.hist[i] = 0;          // hist | cursor | shared_flag
-    if (threadIdx.x >= 1 && threadIdx.x < 8) __hip_atomic_store(&F.counters[threadIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    __syncthreads();
-    if (preclaim && threadIdx.x < 125) {
-        const int t = threadIdx.x;
-        const int ci = rnd_i(P.T[0] / P.vs) + M.hN, cj = rnd_i(P.T[1] / P.vs) + M.hN, ck = rnd_i(P.T[2] / P.vs) + M.hNz;
-        const int bi = (ci >> 4) + (t % 5) - 2, bj = (cj >> 4) + ((t / 5) % 5) - 2, bk = (ck >> 4) + (t / 25) - 2;
-        if (bi >= 0 && bi < M.nbx && bj >= 0 && bj < M.nbx && bk >= 0 && bk < M.nbz)
-            (void)frame_slot_slow<false>(M, F, P.slot, (bi * M.nbx + bj) * M.nbz + bk);
-    }
 }
 
 // =====================================================================================================
@@ -230,14 +214,14 @@ __global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F, const in
 // variant 2: brick-binned segments, LDS accumulation
 // =====================================================================================================
 // exact voxel coordinate of step j along one axis  (dense_tsdf.py:253-254, one component)
-__device__ __forceinline__ int axis_coord(float d, float T, float vs, int j) { return rnd_i(((d * (float)j) * vs + T) / vs); }
+__device__ __forceinline__ int axis_coord(float d, float T, const FrameParams& P, int j) { return rnd_i(div_vs((d * (float)j) * P.vs + T, P.vs, P.rvs, P.fastdiv)); }
 // "cell" of a coordinate along one axis: -1 below the volume, nb above it, else the brick coordinate.  Monotone in c.
 __device__ __forceinline__ int axis_cell(int c, int h, int N, int nb) { const int u = c + h; return u < 0 ? -1 : (u >= N ? nb : (u >> 4)); }
 
 // Smallest step e in (j, jb] at which the ray's cell along one axis differs from `cell` (the cell at step j), or jb+1.
 // The coordinate is a monotone function of the step (every operation in axis_coord is monotone), so the event is
 // located from a real-arithmetic estimate and then fixed up with exact evaluations -- typically two.
-__device__ __forceinline__ int next_axis_event(float d, float T, float vs, float t_over_vs, int j, int jb, int cell, int h, int N, int nb)
+__device__ __forceinline__ int next_axis_event(float d, float T, const FrameParams& P, float t_over_vs, int j, int jb, int cell, int h, int N, int nb)
 {
     if (j >= jb) return jb + 1;
     int bound;                       // first coordinate that belongs to the next cell in the direction of travel
@@ -247,7 +231,7 @@ __device__ __forceinline__ int next_axis_event(float d, float T, float vs, float
     else return jb + 1;
     const float est = ((float)bound + (up ? -0.5f : 0.5f) - t_over_vs) / d;      // real-valued crossing step
     int e = (int)fminf(fmaxf(ceilf(est), (float)(j + 1)), (float)jb);
-    #define TSL_PRED(q) (up ? (axis_coord(d, T, vs, (q)) >= bound) : (axis_coord(d, T, vs, (q)) <= bound))
+    #define TSL_PRED(q) (up ? (axis_coord(d, T, P, (q)) >= bound) : (axis_coord(d, T, P, (q)) <= bound))
     if (TSL_PRED(e)) { while (e - 1 > j && TSL_PRED(e - 1)) --e; }
     else { ++e; while (e <= jb && !TSL_PRED(e)) ++e; }
     #undef TSL_PRED
@@ -309,8 +293,8 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FramePar
             int cell[3], ev[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                cell[a] = axis_cell(axis_coord(d[a], P.T[a], P.vs, ja), hh[a], NN[a], nb[a]);
-                ev[a] = next_axis_event(d[a], P.T[a], P.vs, tv[a], ja, jb, cell[a], hh[a], NN[a], nb[a]);
+                cell[a] = axis_cell(axis_coord(d[a], P.T[a], P, ja), hh[a], NN[a], nb[a]);
+                ev[a] = next_axis_event(d[a], P.T[a], P, tv[a], ja, jb, cell[a], hh[a], NN[a], nb[a]);
             }
             int j = ja;
             while (j <= jb) {
@@ -343,8 +327,8 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FramePar
                 if (j > jb) break;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) if (ev[a] == j) {
-                    cell[a] = axis_cell(axis_coord(d[a], P.T[a], P.vs, j), hh[a], NN[a], nb[a]);
-                    ev[a] = next_axis_event(d[a], P.T[a], P.vs, tv[a], j, jb, cell[a], hh[a], NN[a], nb[a]);
+                    cell[a] = axis_cell(axis_coord(d[a], P.T[a], P, j), hh[a], NN[a], nb[a]);
+                    ev[a] = next_axis_event(d[a], P.T[a], P, tv[a], j, jb, cell[a], hh[a], NN[a], nb[a]);
                 }
             }
         }
@@ -472,11 +456,15 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, FrameParams P)
 {
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
+    __shared__ unsigned long long s_keys[PART_SEGS];
+    __shared__ int s_bin[64];
     __shared__ int s_p;
     const int nact = F.counters[1];
     const int nparts = F.counters[5];
     long long uniq = 0;
+    TSL_T0();
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
+        TSL_TICK(F, 0);
         int lo = 0, hi = nact;                                // largest rank with act_part[rank] <= part
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.act_part[mid] <= part) lo = mid; else hi = mid; }
         const int rk = lo;
@@ -487,22 +475,47 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
         const bool whole = np == 1;
         if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, F.act_b[rk]);       // allocate the brick on its first touch ever
         for (int i = threadIdx.x; i < TSL_BRK3 * 2; i += 256) s_acc[i] = 0ull;
+        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         __syncthreads();
-        for (int i = pos + threadIdx.x; i < run_end; i += 256) {
-            const unsigned long long key = F.seg_sorted[i];
+        // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
+        // segments of (almost) equal length instead of idling behind the longest one
+        const int nseg = run_end - pos;
+        unsigned long long kk[PART_SEGS / 256]; int rr[PART_SEGS / 256];
+#pragma unroll
+        for (int q = 0; q < PART_SEGS / 256; ++q) {
+            const int i = q * 256 + threadIdx.x;
+            rr[q] = -1;
+            if (i < nseg) { kk[q] = F.seg_sorted[pos + i]; rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int c = s_bin[threadIdx.x];
+            int inc = c;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }
+            s_bin[threadIdx.x] = inc - c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PART_SEGS / 256; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
+        __syncthreads();
+        TSL_TICK(F, 1);
+        for (int i = threadIdx.x; i < nseg; i += 256) {
+            const unsigned long long key = s_keys[i];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
             const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
-            const RayRegs R = load_ray(F, P, r);
+            const RayRegs R = load_ray<false>(F, P, r);
             for (int j = j0; j < j0 + cnt; ++j) {
                 float x[3]; int xi[3];
                 step_voxel(R, P, j, x, xi);
-                int l; (void)brick_of(M, xi[0], xi[1], xi[2], &l);
+                const int l = (((xi[0] + M.hN) & 15) << 8) | (((xi[1] + M.hN) & 15) << 4) | ((xi[2] + M.hNz) & 15);
                 const long long qn = step_term(R, x);
                 atomicAdd(&s_acc[l * 2], (unsigned long long)qn);
                 atomicAdd(&s_acc[l * 2 + 1], (unsigned long long)R.qden);
             }
         }
+        TSL_TICK(F, 2);
         __syncthreads();
+        TSL_TICK(F, 3);
         const int p = s_p;
         if (p >= 0 && whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
@@ -516,7 +529,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 const unsigned long long qd = s_acc[l * 2 + 1];
                 if (qd != 0ull) {
                     tw[l] = apply_update(old[q], (long long)s_acc[l * 2], (long long)qd);
-                    obs[l] = 1;
+                    if ((old[q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
                     ++uniq;
                 }
             }
@@ -534,6 +547,10 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 F.shared_list[q] = rk;
             }
         }
+        TSL_TICK(F, 4);
+#ifdef TSL_TIMING
+        if (lane_id() == 0 && _wv < 16384) { F.dbg[_wv * 16 + 10] = nseg; F.dbg[_wv * 16 + 11] = whole; F.dbg[_wv * 16 + 12] = part; }
+#endif
         __syncthreads();
     }
     uniq = wave_sum_ll(uniq);
@@ -573,22 +590,29 @@ __global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, F
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
 
-int launch_integrate(tsl_tsdf* m, int total)
+int launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st)
 {
     FrameParams& P = m->P;
-    FrameDev& F = m->F;
+    FrameDev& F = S.F;
+    if (P.variant != 2) return TSL_OK;
+    TSL_REQUIRE(F.max_frame_bricks <= 4096 && P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
+                "variant 2: ray too long / too many points / too many bricks for the segment key (use variant 1)");
     const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
+    prof_begin(m, TSL_K_SEGMENTS, st);
+    hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, st, m->M, F, P);
+    prof_end(m, st);
+    prof_begin(m, TSL_K_BIN, st);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, m->M, F);
+    hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, st, F);
+    prof_end(m, st);
+    return TSL_OK;
+}
+
+int launch_apply(tsl_tsdf* m, FSet& S, int total)
+{
+    FrameParams& P = m->P;
+    FrameDev& F = S.F;
     if (P.variant == 2) {
-        TSL_REQUIRE(F.max_frame_bricks <= 4096 && P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
-                    "variant 2: ray too long / too many points / too many bricks for the segment key (use variant 1)");
-        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, 0, 0);
-        prof_begin(m, TSL_K_SEGMENTS);
-        hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
-        prof_end(m);
-        prof_begin(m, TSL_K_BIN);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, m->M, F);
-        hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, m->stream, F);
-        prof_end(m);
         prof_begin(m, TSL_K_INTEGRATE);
         hipLaunchKernelGGL(k_integrate_bricks, dim3(1024), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
@@ -596,7 +620,7 @@ int launch_integrate(tsl_tsdf* m, int total)
         hipLaunchKernelGGL(k_finalize_shared, dim3(64), dim3(256), 0, m->stream, m->M, F, P);
         prof_end(m);
     } else {
-        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(1024), 0, m->stream, m->M, F, P, 0, 0);
+        const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
         prof_begin(m, TSL_K_INTEGRATE);
         if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
         else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(FrameParams P, FrameDev 
             const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;               // :203 (rotation only)
             const float my = (P.R[3] * px + P.R[4] * py) + P.R[5] * pz;
             const float mz = (P.R[6] * px + P.R[7] * py) + P.R[8] * pz;
-            const int cx = rnd_i(mx / P.vs) - P.pcl_lo, cy = rnd_i(my / P.vs) - P.pcl_lo, cz = rnd_i(mz / P.vs) - P.pcl_lo;   // :229
+            const int cx = rnd_i(div_vs(mx, P.vs, P.rvs, P.fastdiv)) - P.pcl_lo, cy = rnd_i(div_vs(my, P.vs, P.rvs, P.fastdiv)) - P.pcl_lo, cz = rnd_i(div_vs(mz, P.vs, P.rvs, P.fastdiv)) - P.pcl_lo;   // :229
             if (cx >= 0 && cx < P.pcl_ext && cy >= 0 && cy < P.pcl_ext && cz >= 0 && cz < P.pcl_ext) {
                 inside = true;
                 key = KeyOps<K>::make(cx, cy, cz);
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_voxelize_points(FrameParams P, FrameDev
         uint2 payload = make_uint2(0u, 0u);
         if (len < P.max_ray_f) {                                                      // :177
             gate = true;
-            const int cx = rnd_i(mx / P.vs) - P.pcl_lo, cy = rnd_i(my / P.vs) - P.pcl_lo, cz = rnd_i(mz / P.vs) - P.pcl_lo;
+            const int cx = rnd_i(div_vs(mx, P.vs, P.rvs, P.fastdiv)) - P.pcl_lo, cy = rnd_i(div_vs(my, P.vs, P.rvs, P.fastdiv)) - P.pcl_lo, cz = rnd_i(div_vs(mz, P.vs, P.rvs, P.fastdiv)) - P.pcl_lo;
             if (cx >= 0 && cx < P.pcl_ext && cy >= 0 && cy < P.pcl_ext && cz >= 0 && cz < P.pcl_ext) {
                 inside = true;
                 key = KeyOps<K>::make(cx, cy, cz);
@@ -310,6 +310,22 @@ __global__ void __launch_bounds__(256) k_reset_bricks(MapDev M, int nused)
     }
 }
 
+// Verify on the device that the fma-refined reciprocal division equals IEEE division bit for bit for every float x whose
+// quotient can reach an integer conversion (2^-100 <= |x|, |x/vs| < 2^31) -- 2^32 candidates, ~1 ms.  *bad counts mismatches.
+__global__ void __launch_bounds__(256) k_verify_div(float vs, float rvs, unsigned long long* bad)
+{
+    unsigned long long nbad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * 256) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float ax = fabsf(x);
+        if (!(ax >= 7.8886090522101181e-31f) || !(ax < 2147483648.0f * vs)) continue;
+        const float q = x / vs;
+        const float f = div_vs(x, vs, rvs, 1);
+        if (__float_as_uint(q) != __float_as_uint(f)) ++nbad;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
@@ -376,22 +392,21 @@ template <typename K>
 static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
 {
     FrameParams& P = m->P;
-    FrameDev& F = m->F;
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
-    TSL_REQUIRE(total <= F.max_points, "integrate: more pixels/points than max_points");
-    // ---- phase A (depth -> rays) on stream A into working set `si`; it never touches the map ----
-    const int si = (int)(m->frame_no & 1);
-    ASet& A = m->aset[si];
-    hipStream_t sa = m->overlap ? m->streamA : m->stream;
-    F.keys = (uint32_t*)A.keys; F.keys_s = (uint32_t*)A.keys_s; F.vals = A.vals; F.vals_s = A.vals_s; F.pix = A.pix;
-    F.rayA = A.rayA; F.rayN = A.rayN; F.nrays = A.nrays; F.stats = A.stats;
-    if (m->overlap && A.b_pending) TSL_HIP(hipStreamWaitEvent(sa, A.b_done, 0));      // phase B of frame f-2 still reads this set
-    TSL_HIP(hipMemsetAsync(A.stats, 0, sizeof(tsl_frame_stats), sa));
-    TSL_HIP(hipMemsetAsync(A.nrays, 0, sizeof(int), sa));
+    TSL_REQUIRE(total <= m->F.max_points, "integrate: more pixels/points than max_points");
+    // ---- phase A: depth -> rays -> brick-sorted segments, into working set `si` on its own stream.  It depends on the
+    //      image, the pose and the map GEOMETRY only, so several frames are in flight; the only map access is first-touch
+    //      brick allocation and the occupancy byte (atomic claims, safe next to phase B of older frames). ----
+    const int si = m->overlap ? (int)(m->frame_no % TSL_NSETS) : 0;
+    FSet& S = m->fset[si];
+    FrameDev& F = S.F;
+    hipStream_t sa = m->overlap ? S.st : m->stream;
+    if (m->overlap && S.b_pending) TSL_HIP(hipStreamWaitEvent(sa, S.b_done, 0));      // phase B of frame f-NSETS still reads this set
+    TSL_HIP(hipMemsetAsync(S.header, 0, S.header_bytes, sa));                         // stats | nrays | counters
     m->last_set = si; m->frame_no++;
     if (total > 0) {
-        K* keys = reinterpret_cast<K*>(A.keys);
-        K* keys_s = reinterpret_cast<K*>(A.keys_s);
+        K* keys = reinterpret_cast<K*>(F.keys);
+        K* keys_s = reinterpret_cast<K*>(F.keys_s);
         const int blocks = (total + 255) / 256;
         prof_begin(m, TSL_K_VOXELIZE, sa);
         if (xyz_dev) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const float*)xyz_dev, total, keys);
@@ -399,19 +414,20 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
         prof_end(m, sa);
         prof_begin(m, TSL_K_SORT, sa);
         size_t tb = m->sort_temp_bytes;
-        TSL_HIP(rocprim::radix_sort_pairs(A.sort_temp, tb, keys, keys_s, A.vals, A.vals_s, (size_t)total, 0u, (unsigned)(3 * P.pcl_bits + 1), sa));
+        TSL_HIP(rocprim::radix_sort_pairs(S.sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * P.pcl_bits + 1), sa));
         prof_end(m, sa);
         prof_begin(m, TSL_K_RAYS, sa);
         hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const K*)keys_s, total);
         prof_end(m, sa);
+        { int rc = launch_segments(m, S, total, sa); if (rc) return rc; }
     }
     if (m->overlap) {
-        TSL_HIP(hipEventRecord(A.a_done, sa));
-        TSL_HIP(hipStreamWaitEvent(m->stream, A.a_done, 0));
+        TSL_HIP(hipEventRecord(S.a_done, sa));
+        TSL_HIP(hipStreamWaitEvent(m->stream, S.a_done, 0));
     }
-    // ---- phase B (rays -> map) on the main stream ----
-    if (total > 0) { int rc = launch_integrate(m, total); if (rc) return rc; }
-    if (m->overlap) { TSL_HIP(hipEventRecord(A.b_done, m->stream)); A.b_pending = true; }
+    // ---- phase B: apply to the map, in frame order on the main stream ----
+    if (total > 0) { int rc = launch_apply(m, S, total); if (rc) return rc; }
+    if (m->overlap) { TSL_HIP(hipEventRecord(S.b_done, m->stream)); S.b_pending = true; }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -466,8 +482,8 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     tsl_tsdf* m = new tsl_tsdf();
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    TSL_HIP(hipStreamCreateWithFlags(&m->streamA, hipStreamNonBlocking));
     m->frame_no = 0; m->overlap = 1; m->last_set = 0;
+    for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; }
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
     m->Nz = (int)std::ceil(cfg->map_size_z / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:25
@@ -488,6 +504,13 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     FrameParams& P = m->P; std::memset(&P, 0, sizeof(P));
     for (int i = 0; i < 3; ++i) P.R[i * 4] = 1.0f;
     P.vs = (float)cfg->voxel_scale;
+    {   // RN(1/vs): take the float neighbour whose product with vs is closest to 1 (products of two floats are exact in double)
+        const float y0 = (float)(1.0 / (double)P.vs);
+        float best = y0; double err = std::fabs(1.0 - (double)y0 * (double)P.vs);
+        const float cand[2] = { std::nextafterf(y0, 0.0f), std::nextafterf(y0, INFINITY) };
+        for (float c : cand) { const double e = std::fabs(1.0 - (double)c * (double)P.vs); if (e < err) { err = e; best = c; } }
+        P.rvs = best; P.fastdiv = 0;
+    }
     P.thr_max = (float)(cfg->max_ray_length * 1000.0); P.thr_min = (float)(cfg->min_ray_length * 1000.0);
     P.max_ray_f = (float)cfg->max_ray_length;
     P.max_steps_f = (float)(cfg->max_ray_length / cfg->voxel_scale);
@@ -526,52 +549,53 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
     M.err = M.pool_top + 1;
 
-    // ---- frame scratch ----
+    // ---- frame scratch: shared part + TSL_NSETS per-frame working sets ----
     FrameDev& F = m->F; std::memset(&F, 0, sizeof(F));
     F.max_points = cfg->max_points > 0 ? cfg->max_points : 640 * 480;
     F.max_frame_bricks = cfg->max_frame_bricks > 0 ? cfg->max_frame_bricks : 4096;
     if (F.max_frame_bricks > M.max_bricks) F.max_frame_bricks = M.max_bricks;
+    {   // ray segments: ~ (steps/16 + 3 axis crossings) per ray; 32 per point is a generous bound
+        const int64_t cap = (int64_t)F.max_points * 32;
+        F.seg_cap = (int)(cap > (1ll << 30) ? (1ll << 30) : cap);
+    }
     const size_t np = (size_t)F.max_points;
     if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
-    for (int si = 0; si < 2; ++si) {
-        ASet& A = m->aset[si];
-        if ((rc = dev_alloc(m, &A.keys, 8 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, &A.keys_s, 8 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.vals, 4 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.vals_s, 4 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.pix, 8 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.rayA, 16 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.rayN, 4 * np, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.nrays, sizeof(int) * 4, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&A.stats, sizeof(tsl_frame_stats), 0))) return rc;
-        if ((rc = dev_alloc(m, &A.sort_temp, m->sort_temp_bytes + 256, 0))) return rc;
-        TSL_HIP(hipEventCreateWithFlags(&A.a_done, hipEventDisableTiming));
-        TSL_HIP(hipEventCreateWithFlags(&A.b_done, hipEventDisableTiming));
-        A.b_pending = false;
-    }
-    F.stats = m->aset[0].stats; F.nrays = m->aset[0].nrays;
     if ((rc = dev_alloc(m, (void**)&F.slot_tab, sizeof(int) * (size_t)m->nb3, 0xff))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.touched, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.counters, sizeof(int) * 8, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
-    {   // ray segments: ~ (steps/16 + 3 axis crossings) per ray; 32 per point is a generous bound
-        const int64_t cap = (int64_t)F.max_points * 32;
-        F.seg_cap = (int)(cap > (1ll << 30) ? (1ll << 30) : cap);
-        if ((rc = dev_alloc(m, (void**)&F.seg, 8 * (size_t)F.seg_cap, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.seg_sorted, 8 * (size_t)F.seg_cap, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.hist, sizeof(int) * (3 * 4096 + 8), 0))) return rc;
-        F.cursor = F.hist + 4096; F.shared_flag = F.hist + 2 * 4096;
-        if ((rc = dev_alloc(m, (void**)&F.offset, sizeof(int) * (4096 + 8), 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.part_off, sizeof(int) * (4096 + 8), 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.shared_list, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.bhist, sizeof(int) * (size_t)m->nb3, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.bcursor, sizeof(int) * (size_t)m->nb3, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.boffset, sizeof(int) * (size_t)m->nb3, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8), 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.act_off, sizeof(int) * (size_t)(F.max_frame_bricks + 8), 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&F.act_part, sizeof(int) * (size_t)(F.max_frame_bricks + 8), 0))) return rc;
+    for (int si = 0; si < TSL_NSETS; ++si) {
+        FSet& S = m->fset[si];
+        S.F = F;
+        FrameDev& G = S.F;
+        auto own = [&](void** p, size_t bytes) -> int { int r = dev_alloc(m, p, bytes, 0); if (!r) S.owned.push_back(*p); return r; };
+        if ((rc = own((void**)&G.keys, 8 * np))) return rc;
+        if ((rc = own((void**)&G.keys_s, 8 * np))) return rc;
+        if ((rc = own((void**)&G.vals, 4 * np))) return rc;
+        if ((rc = own((void**)&G.vals_s, 4 * np))) return rc;
+        if ((rc = own((void**)&G.pix, 8 * np))) return rc;
+        if ((rc = own((void**)&G.rayA, 16 * np))) return rc;
+        if ((rc = own((void**)&G.rayN, 4 * np))) return rc;
+        S.header_bytes = 128;
+        if ((rc = own(&S.header, S.header_bytes))) return rc;
+        G.stats = reinterpret_cast<tsl_frame_stats*>(S.header);
+        G.nrays = reinterpret_cast<int*>((char*)S.header + 80);
+        G.counters = reinterpret_cast<int*>((char*)S.header + 96);
+        if ((rc = own((void**)&G.seg, 8 * (size_t)F.seg_cap))) return rc;
+        if ((rc = own((void**)&G.seg_sorted, 8 * (size_t)F.seg_cap))) return rc;
+        if ((rc = own((void**)&G.shared_list, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
+        if ((rc = own((void**)&G.bhist, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.bcursor, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.boffset, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
+        if ((rc = own((void**)&G.act_off, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
+        if ((rc = own((void**)&G.act_part, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
+        if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
+        TSL_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+        TSL_HIP(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&S.b_done, hipEventDisableTiming));
+        S.b_pending = false;
     }
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
@@ -585,6 +609,16 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&m->num_particles, sizeof(int) * 4, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&m->colormap, sizeof(float) * 3 * 1024, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&m->pose_dev, sizeof(float) * 12 * (size_t)m->npose, 0))) return rc;
+    {   // enable the fast exact division only if the device proves it equal to IEEE division for this voxel size
+        unsigned long long* bad = reinterpret_cast<unsigned long long*>(m->num_particles + 2);
+        TSL_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), m->stream));
+        hipLaunchKernelGGL(k_verify_div, dim3(8192), dim3(256), 0, m->stream, P.vs, P.rvs, bad);
+        unsigned long long nbad = 1;
+        TSL_HIP(hipMemcpyAsync(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost, m->stream));
+        TSL_HIP(hipStreamSynchronize(m->stream));
+        TSL_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), m->stream));
+        P.fastdiv = nbad == 0 ? 1 : 0;
+    }
     TSL_HIP(hipStreamSynchronize(m->stream));
     *out = m;
     return TSL_OK;
@@ -595,21 +629,20 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    (void)hipStreamSynchronize(m->streamA);
-    for (int si = 0; si < 2; ++si) {
-        ASet& A = m->aset[si];
-        void* ap[] = { A.keys, A.keys_s, A.vals, A.vals_s, A.pix, A.rayA, A.rayN, A.nrays, A.stats, A.sort_temp };
-        for (void* p : ap) if (p) (void)hipFree(p);
-        (void)hipEventDestroy(A.a_done); (void)hipEventDestroy(A.b_done);
+    for (auto& S : m->fset) {
+        if (S.st) { (void)hipStreamSynchronize(S.st); (void)hipStreamDestroy(S.st); }
+        for (void* p : S.owned) if (p) (void)hipFree(p);
+        if (S.a_done) (void)hipEventDestroy(S.a_done);
+        if (S.b_done) (void)hipEventDestroy(S.b_done);
     }
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.part_off, m->F.acc, m->F.counters, m->F.dbg, m->F.seg, m->F.seg_sorted, m->F.hist, m->F.offset, m->F.shared_list, m->F.bhist, m->F.bcursor, m->F.boffset, m->F.act_b, m->F.act_off, m->F.act_part,
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.dbg,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag, m->fuse_acc, m->fuse_cnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
     if (m->h_ints) (void)hipHostFree(m->h_ints);
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
-    (void)hipStreamDestroy(m->stream); (void)hipStreamDestroy(m->streamA);
+    (void)hipStreamDestroy(m->stream);
     delete m;
 }
 
@@ -621,7 +654,7 @@ int tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* bxy, 
     if (bxy) *bxy = m->N / blk; if (bz) *bz = m->Nz / blk;                                   // dense_tsdf.py:27-28
     return TSL_OK;
 }
-int tsl_tsdf_sync(tsl_tsdf* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(m->streamA)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
+int tsl_tsdf_sync(tsl_tsdf* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); for (auto& S : m->fset) if (S.st) TSL_HIP(hipStreamSynchronize(S.st)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
 int tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* b) { TSL_REQUIRE(m && b, "null"); *b = m->bytes; return TSL_OK; }
 
 static int read_int(tsl_tsdf* m, const int* dev, int* out)
@@ -641,6 +674,14 @@ static int check_dev_err(tsl_tsdf* m)
     }
     return TSL_OK;
 }
+int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
+{
+    TSL_REQUIRE(m && name && value, "null");
+    if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
+    if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
+    if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }
+    set_error("unknown option"); return TSL_ERR_ARG;
+}
 int tsl_tsdf_bricks_in_use(tsl_tsdf* m, int32_t* n)
 {
     TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device));
@@ -652,7 +693,8 @@ int tsl_tsdf_bricks_in_use(tsl_tsdf* m, int32_t* n)
 int tsl_tsdf_reset(tsl_tsdf* m)
 {
     TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
-    int used = 0; int rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
+    int rc = tsl_tsdf_sync(m); if (rc) return rc;
+    int used = 0; rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
     if (used > 0) hipLaunchKernelGGL(k_reset_bricks, dim3(used < 4096 ? used : 4096), dim3(256), 0, m->stream, m->M, used);
     TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, m->stream));
     TSL_HIP(hipGetLastError());
@@ -711,7 +753,8 @@ int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], 
     TSL_HIP(hipSetDevice(m->device));
     const size_t nb = (size_t)h * w * sizeof(uint16_t);
     int rc = grow(&m->stage_in, &m->stage_in_bytes, nb); if (rc) return rc;
-    hipStream_t sa = m->overlap ? m->streamA : m->stream;
+    { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }      // host-buffer path: the single staging buffer must be free again
+    hipStream_t sa = m->stream;
     TSL_HIP(hipMemcpyAsync(m->stage_in, depth, nb, hipMemcpyHostToDevice, sa));
     void* tdev = nullptr;
     if (tex && m->cfg.texture_enabled && th > 0 && tw > 0) {
@@ -740,7 +783,8 @@ int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
     TSL_HIP(hipSetDevice(m->device));
     const size_t nb = (size_t)n * 3 * sizeof(float);
     int rc = grow(&m->stage_in, &m->stage_in_bytes, nb + 16); if (rc) return rc;
-    hipStream_t sa = m->overlap ? m->streamA : m->stream;
+    { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }
+    hipStream_t sa = m->stream;
     if (n) TSL_HIP(hipMemcpyAsync(m->stage_in, xyz, nb, hipMemcpyHostToDevice, sa));
     void* cdev = nullptr;
     if (rgb && m->cfg.texture_enabled && n) {
@@ -757,8 +801,8 @@ int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
     TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
     const int64_t used = m->h_stats->p_used;
     tsl_frame_stats tmp;
-    TSL_HIP(hipStreamSynchronize(m->streamA));
-    TSL_HIP(hipMemcpyAsync(m->h_ints, m->aset[m->last_set].stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
+    { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->fset[m->last_set].F.stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
     TSL_HIP(hipStreamSynchronize(m->stream));
     std::memcpy(&tmp, m->h_ints, sizeof(tmp));
     tmp.p_used = used;
@@ -905,7 +949,8 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
 {
     TSL_REQUIRE(m && name, "null");
     if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
-    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value != 0; for (auto& A : m->aset) A.b_pending = false; return TSL_OK; }
+    if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }      // can only be switched off
+    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value != 0; for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
 }

@@ -10,6 +10,7 @@ struct FrameParams {
     float fx, fy, cx, cy;              // depth intrinsics   (mapping_common.py:31-41)
     float fxc, fyc, cxc, cyc;          // colour intrinsics  (mapping_common.py:43-58)
     float vs;                          // voxel_scale as f32
+    float rvs; int fastdiv;            // RN(1/vs) and whether x/vs == fma-refined x*rvs was verified for every float (div_vs)
     float thr_max, thr_min;            // max/min_ray_length*1000  (dense_tsdf.py:198)
     float max_ray_f;                   // dense_tsdf.py:177
     float max_steps_f;                 // max_ray_length/voxel_scale (dense_tsdf.py:249)
@@ -21,38 +22,41 @@ struct FrameParams {
     int   variant, split;              // integrate kernel variant / lanes per ray
 };
 
+// Device-side view of ONE frame's working set.  Everything up to the brick-sorted ray segments depends only on the
+// depth image, the pose and the map geometry -- not on the map contents -- so it is computed per frame in its own set
+// on its own stream ("phase A"), several frames in flight; only the LDS integration + finalise ("phase B") runs in
+// frame order on the main stream.
 struct FrameDev {
+    // ---- per set ----
     uint32_t *keys, *keys_s, *vals, *vals_s;     // sensor-grid Morton key + pixel id, unsorted / sorted
     uint2* pix;                                  // per pixel: f16 bits {x,y | z,depth}
     uint4* rayA;                                 // per ray: {p01, p2|d0, d12, w bits}
     int*   rayN;                                 // per ray: step count
-    int*   nrays;                                // ray count of this frame (phase-A set)
-    int*   slot_tab;                             // [nb3] brick id (inside the written submap) -> frame scratch slot, EMPTY between frames
-    int*   touched;                              // [max_frame_bricks] -> pool brick
-    int*   touched_b;                            // [max_frame_bricks] -> brick id
-    unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
-    int*   counters;                             // [0] rays [1] touched bricks [2] segments appended [3] segments sorted [4] shared bricks [5] parts
-    unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick slot
-    int    seg_cap;
-    int   *hist, *cursor, *shared_flag;          // [4096] each, contiguous, cleared per frame
-    int   *offset;                               // [4097] exclusive scan of hist
-    int   *part_off;                             // [4097] exclusive scan of ceil(hist/PART_SEGS)
+    tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
+    int*   nrays;                                // ray count of this frame
+    int*   counters;                             // [1] active bricks [2] segments appended [3] segments sorted [4] shared bricks [5] parts
+    unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick
     int   *shared_list;                          // active-brick ranks integrated by several workgroups
-    int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between frames) / first segment
-    int   *act_b, *act_off, *act_part;           // [max_frame_bricks+1] active bricks of the frame in brick-id order
-    tsl_frame_stats* stats;
-    long long* dbg;                              // [64] developer timing counters (TSL_TIMING builds)
+    int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment
+    int   *act_b, *act_off, *act_part;           // [max_frame_bricks+1] active bricks of the frame
+    // ---- shared by all sets (only touched in phase B, i.e. serially on the main stream) ----
+    int*   slot_tab;                             // variants 0/1: [nb3] brick id -> frame scratch slot, EMPTY between frames
+    int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
+    int*   touched_b;                            // variants 0/1: [max_frame_bricks] -> brick id
+    unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
+    long long* dbg;                              // developer timing counters (TSL_TIMING builds)
+    int    seg_cap;
     int    max_frame_bricks;
     int    max_points;
 };
 
 struct ProfSlot { hipEvent_t a, b; int kid; };
 
-// phase-A working set (depth -> rays).  Two of them, so phase A of frame f+1 (stream A) overlaps phase B of frame f.
-struct ASet {
-    void *keys, *keys_s; uint32_t *vals, *vals_s; uint2* pix; uint4* rayA; int* rayN; int* nrays;
-    tsl_frame_stats* stats; void* sort_temp;
-    hipEvent_t a_done, b_done; bool b_pending;
+#define TSL_NSETS 4
+struct FSet {
+    FrameDev F; void* sort_temp; void* header; size_t header_bytes;
+    hipStream_t st; hipEvent_t a_done, b_done; bool b_pending;
+    std::vector<void*> owned;
 };
 
 }  // namespace tsl
@@ -61,8 +65,7 @@ struct tsl_tsdf {
     tsl_tsdf_cfg cfg;
     int device;
     hipStream_t stream;                  // phase B + everything else
-    hipStream_t streamA;                 // phase A (depth -> rays) of the next frame
-    tsl::ASet aset[2]; int64_t frame_no; int overlap; int last_set;
+    tsl::FSet fset[TSL_NSETS]; int64_t frame_no; int overlap; int last_set;      // phase-A sets / streams, round robin
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;
     tsl::MapDev M;
@@ -103,5 +106,6 @@ void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr);
 void prof_end(tsl_tsdf* m, hipStream_t st = nullptr);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
-int  launch_integrate(tsl_tsdf* m, int total);
+int  launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
+int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B: apply to the map
 }

@@ -113,6 +113,11 @@ class DenseTSDF(BaseMap):
     def set_option(self, name, value):
         self._call("set_option", name.encode(), int(value))
 
+    def get_option(self, name):
+        v = C.c_int()
+        self._call("get_option", name.encode(), C.byref(v))
+        return v.value
+
     def enable_profiling(self, on=True):
         self._call("prof_enable", int(bool(on)))
 

@@ -43,6 +43,22 @@ def test_kernel_variants_agree(hip_lib, variant, split):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"variant {variant} split {split}")
 
 
+def test_fast_division_is_verified_and_optional(hip_lib):
+    """x / voxel_scale is replaced by an fma-refined reciprocal product only after the device has checked it against IEEE
+    division for every float; forcing IEEE division must give the same map."""
+    from taichislam_amd.mapping import DenseTSDF
+    K, frames = small_stream(2)
+    for vs in (0.02, 0.04, 0.05, 0.1):
+        m = DenseTSDF(map_scale=[5.12, 5.12], voxel_scale=vs, num_voxel_per_blk_axis=16, max_ray_length=3.0)
+        assert m.get_option("fastdiv") in (0, 1)
+    g, o = make_pair(SMALL, K)
+    assert g.get_option("fastdiv") == 1
+    g.set_option("fastdiv", 0)
+    assert g.get_option("fastdiv") == 0
+    _run_both(g, o, frames)
+    assert_export_equal(g.export_submap(), o.export_sparse(), "IEEE division path")
+
+
 def test_full_size_c2_bit_exact(hip_lib):
     """BASELINE.json configs[1]: 640x480 depth into 512^3 @ 2 cm; two frames against the oracle."""
     g, o = make_pair(C2, syn.K_DEPTH)
