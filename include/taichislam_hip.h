@@ -146,7 +146,7 @@ int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);
 int  tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value);   /* also "fastdiv": 1 when the device verified the fma-refined division */
 
 /* ---- profiling: HIP-event timing of the per-frame kernels on the handle's stream ----------------- */
-int  tsl_tsdf_prof_enable(tsl_tsdf* m, int on);
+int  tsl_tsdf_prof_enable(tsl_tsdf* m, int on);   /* 0 off, 1 every kernel, 2*mask: only the kernel ids whose bit is set in mask */
 int  tsl_tsdf_prof_query(tsl_tsdf* m, int kernel_id, double* total_ms, int64_t* launches);   /* synchronises, resets */
 
 /* ======== Octomap hit counter (taichi_octomap.py) =================================================== */

@@ -350,16 +350,20 @@ int dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill)
 
 void prof_begin(tsl_tsdf* m, int kid, hipStream_t st)
 {
-    if (!m->prof_on) return;
+    m->prof_open = false;
+    if (!m->prof_on || !((m->prof_mask >> kid) & 1)) return;
     ProfSlot s; s.kid = kid;
-    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    if (m->prof_free.size() >= 2) { s.a = m->prof_free.back(); m->prof_free.pop_back(); s.b = m->prof_free.back(); m->prof_free.pop_back(); }
+    else if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
     (void)hipEventRecord(s.a, st ? st : m->stream);
     m->prof.push_back(s);
+    m->prof_open = true;
 }
 void prof_end(tsl_tsdf* m, hipStream_t st)
 {
-    if (!m->prof_on || m->prof.empty()) return;
+    if (!m->prof_open) return;
     (void)hipEventRecord(m->prof.back().b, st ? st : m->stream);
+    m->prof_open = false;
 }
 
 // set_pose + convert_by_base  mapping_common.py:91-100,149-156 (float64, fixed summation order, then f32)
@@ -526,7 +530,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
     m->active = 0; m->variant = 2; m->split = 2;
-    m->prof_on = false; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
+    m->prof_on = false; m->prof_open = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0; m->stage_in = nullptr; m->stage_in_bytes = 0; m->stage_tex = nullptr; m->stage_tex_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr;
@@ -642,6 +646,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (m->h_stats) (void)hipHostFree(m->h_stats);
     if (m->h_ints) (void)hipHostFree(m->h_ints);
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto& e : m->prof_free) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -917,7 +922,13 @@ int tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n)
     return TSL_OK;
 }
 
-int tsl_tsdf_prof_enable(tsl_tsdf* m, int on) { TSL_REQUIRE(m, "null"); m->prof_on = on != 0; return TSL_OK; }
+int tsl_tsdf_prof_enable(tsl_tsdf* m, int on)
+{
+    TSL_REQUIRE(m, "null");
+    m->prof_on = on != 0;
+    m->prof_mask = (on == 0 || on == 1) ? ~0u : (unsigned)on >> 1;      // on = 1: every kernel; on = 2*mask: only the kernel ids in mask
+    return TSL_OK;
+}
 int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launches)
 {
     TSL_REQUIRE(m, "null"); TSL_REQUIRE(kid >= 0 && kid < TSL_K_COUNT, "bad kernel id"); TSL_HIP(hipSetDevice(m->device));
@@ -925,7 +936,7 @@ int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launche
     for (auto& s : m->prof) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { m->prof_ms[s.kid] += ms; m->prof_n[s.kid] += 1; }
-        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+        m->prof_free.push_back(s.a); m->prof_free.push_back(s.b);
     }
     m->prof.clear();
     if (total_ms) *total_ms = m->prof_ms[kid];

@@ -94,7 +94,7 @@ struct tsl_tsdf {
     // esdf
     float* esdf; int* esdf_flag; int64_t esdf_bricks; float esdf_gamma;
     // profiling
-    bool prof_on; std::vector<tsl::ProfSlot> prof;
+    bool prof_on, prof_open; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int variant, split;
     int64_t bytes;

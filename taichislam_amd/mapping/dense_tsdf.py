@@ -118,8 +118,15 @@ class DenseTSDF(BaseMap):
         self._call("get_option", name.encode(), C.byref(v))
         return v.value
 
-    def enable_profiling(self, on=True):
-        self._call("prof_enable", int(bool(on)))
+    def enable_profiling(self, on=True, only=None):
+        """HIP-event timing of the per-frame kernels; `only` = iterable of kernel ids restricts it (less host overhead)."""
+        if on and only is not None:
+            mask = 0
+            for k in only:
+                mask |= 1 << int(k)
+            self._call("prof_enable", 2 * mask)
+        else:
+            self._call("prof_enable", int(bool(on)))
 
     def kernel_time(self, kernel_id):
         """(total_ms, launches) recorded by HIP events since the last query; synchronises."""
