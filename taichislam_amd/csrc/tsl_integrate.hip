@@ -120,8 +120,9 @@ __device__ __forceinline__ uint32_t apply_update(uint32_t old, long long qnum, l
 // variant 0/1: global int64 atomics
 // =====================================================================================================
 template <int VARIANT>
-__global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, FrameParams P)
+__global__ void __launch_bounds__(256) k_integrate(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
+    const FrameParams& P = *Pp;
     const int split = P.split;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int r = gid / split, sub = gid - r * split;
@@ -261,8 +262,9 @@ __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-inse
 // segment: [0,6) count [6,18) first step [18,40) ray [40,64) brick id
 #define STG_RAY_BITS 22
 #define STG_B_SHIFT (SEG_CNT_BITS + SEG_J_BITS + STG_RAY_BITS)
-__global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, FrameParams P)
+__global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
+    const FrameParams& P = *Pp;
     __shared__ unsigned long long s_seg[SEG_LDS_CAP];
     __shared__ int s_key[LH_SIZE];
     __shared__ int s_cnt[LH_SIZE];
@@ -381,33 +383,45 @@ __device__ __forceinline__ int block_excl_scan_1024(int s, int* s_wave, int* tot
     *total = tot;
     return wbase + inc - s;
 }
+// parts are handed to workgroups longest first (3 size classes), so the tail of k_integrate_bricks is made of short parts
+__device__ __forceinline__ int part_class(int per) { return per >= 640 ? 0 : (per >= 256 ? 1 : 2); }
 __global__ void __launch_bounds__(1024) k_scan(MapDev M, FrameDev F)
 {
     __shared__ int s_wave[16];
     const int t = threadIdx.x;
     const int listed = F.counters[1];
     const int nact = min(listed, F.max_frame_bricks);
-    int v[4], bb[4], s = 0, ps = 0;
+    int v[4], bb[4], np[4], cls[4], s = 0, pc[3] = {0, 0, 0};
     for (int q = 0; q < 4; ++q) {
         const int i = t * 4 + q;
         bb[q] = i < nact ? F.act_b[i] : -1;
         v[q] = bb[q] >= 0 ? F.bhist[bb[q]] : 0;
-        s += v[q]; ps += (v[q] + PART_SEGS - 1) / PART_SEGS;
+        np[q] = (v[q] + PART_SEGS - 1) / PART_SEGS;
+        cls[q] = np[q] ? part_class((v[q] + np[q] - 1) / np[q]) : 2;
+        s += v[q]; pc[cls[q]] += np[q];
     }
-    int tot, ptot;
+    int tot, ctot[3], crun[3];
     int run = block_excl_scan_1024(s, s_wave, &tot);
-    int prun = block_excl_scan_1024(ps, s_wave, &ptot);
+    for (int c = 0; c < 3; ++c) crun[c] = block_excl_scan_1024(pc[c], s_wave, &ctot[c]);
+    const int cbase[3] = { 0, ctot[0], ctot[0] + ctot[1] };
     for (int q = 0; q < 4; ++q) {
         const int i = t * 4 + q;
-        if (i <= nact) { F.act_off[i] = run; F.act_part[i] = prun; }
-        if (bb[q] >= 0) F.boffset[bb[q]] = run;
-        run += v[q]; prun += (v[q] + PART_SEGS - 1) / PART_SEGS;
+        if (i <= nact) F.act_off[i] = run;
+        if (bb[q] >= 0) {
+            F.boffset[bb[q]] = run;
+            const int p0 = cbase[cls[q]] + crun[cls[q]];
+            for (int k = 0; k < np[q]; ++k) if (p0 + k < F.part_cap) F.part_tab[p0 + k] = make_int4(i, k, np[q], 0);
+            crun[cls[q]] += np[q];
+        }
+        run += v[q];
     }
     if (t == 1023) {
-        if (nact == 4096) { F.act_off[4096] = run; F.act_part[4096] = prun; }
+        const int ptot = ctot[0] + ctot[1] + ctot[2];
+        if (nact == 4096) F.act_off[4096] = run;
+        if (ptot > F.part_cap) atomicOr(M.err, 2);
         F.counters[1] = nact;
         F.counters[3] = min(tot, F.seg_cap);                     // total segments
-        F.counters[5] = listed <= F.max_frame_bricks ? ptot : 0; // total parts (nothing is integrated when the frame overflows)
+        F.counters[5] = (listed <= F.max_frame_bricks && ptot <= F.part_cap) ? ptot : 0;   // total parts (nothing is integrated when the frame overflows)
         F.stats->bricks = listed;
     }
 }
@@ -453,39 +467,42 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 }
 
 // K4d: LDS accumulation per brick, in-place finalise
-__global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, FrameParams P)
+__global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
+    const FrameParams& P = *Pp;
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
     __shared__ unsigned long long s_keys[PART_SEGS];
     __shared__ int s_bin[64];
     __shared__ int s_p;
-    const int nact = F.counters[1];
     const int nparts = F.counters[5];
     long long uniq = 0;
     TSL_T0();
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
         TSL_TICK(F, 0);
-        int lo = 0, hi = nact;                                // largest rank with act_part[rank] <= part
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.act_part[mid] <= part) lo = mid; else hi = mid; }
-        const int rk = lo;
+        const int4 pt = F.part_tab[part];
+        const int rk = pt.x, k = pt.y, np = pt.z;
         const int b0 = F.act_off[rk], b1 = F.act_off[rk + 1];
-        const int np = F.act_part[rk + 1] - F.act_part[rk], k = part - F.act_part[rk];
         const int per = (b1 - b0 + np - 1) / np;
         const int pos = b0 + k * per, run_end = min(b1, pos + per);
         const bool whole = np == 1;
+        const int nseg = run_end - pos;
+        unsigned long long kk[PART_SEGS / 256]; int rr[PART_SEGS / 256];
+#pragma unroll
+        for (int q = 0; q < PART_SEGS / 256; ++q) { const int i = q * 256 + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
         if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, F.act_b[rk]);       // allocate the brick on its first touch ever
-        for (int i = threadIdx.x; i < TSL_BRK3 * 2; i += 256) s_acc[i] = 0ull;
+        {
+            ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
+            for (int i = threadIdx.x; i < TSL_BRK3; i += 256) z[i] = make_ulonglong2(0ull, 0ull);
+        }
         if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         __syncthreads();
         // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
         // segments of (almost) equal length instead of idling behind the longest one
-        const int nseg = run_end - pos;
-        unsigned long long kk[PART_SEGS / 256]; int rr[PART_SEGS / 256];
 #pragma unroll
         for (int q = 0; q < PART_SEGS / 256; ++q) {
             const int i = q * 256 + threadIdx.x;
             rr[q] = -1;
-            if (i < nseg) { kk[q] = F.seg_sorted[pos + i]; rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1); }
+            if (i < nseg) rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1);
         }
         __syncthreads();
         if (threadIdx.x < 64) {
@@ -559,8 +576,9 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
 
 // K4e: finalise the bricks that were integrated by several workgroups from the HBM scratch, and restore the
 // "all zero between frames" invariant of bhist / bcursor for the bricks this frame used.
-__global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, FrameParams P)
+__global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
+    const FrameParams& P = *Pp;
     const int nact = F.counters[1];
     const int nwork = min(F.counters[4], F.max_frame_bricks);
     long long uniq = 0;
@@ -590,16 +608,21 @@ __global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, F
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
 
+int check_variant2(tsl_tsdf* m)
+{
+    TSL_REQUIRE(m->F.max_frame_bricks <= 4096 && m->P.max_steps_f < (float)(1 << SEG_J_BITS) && m->F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
+                "variant 2: ray too long / too many points / too many bricks for the segment key (use variant 1)");
+    return TSL_OK;
+}
+
 int launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st)
 {
     FrameParams& P = m->P;
     FrameDev& F = S.F;
     if (P.variant != 2) return TSL_OK;
-    TSL_REQUIRE(F.max_frame_bricks <= 4096 && P.max_steps_f < (float)(1 << SEG_J_BITS) && F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
-                "variant 2: ray too long / too many points / too many bricks for the segment key (use variant 1)");
     const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
     prof_begin(m, TSL_K_SEGMENTS, st);
-    hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, st, m->M, F, P);
+    hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, m->M, F);
@@ -614,16 +637,16 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
     FrameDev& F = S.F;
     if (P.variant == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
-        hipLaunchKernelGGL(k_integrate_bricks, dim3(1024), dim3(256), 0, m->stream, m->M, F, P);
+        hipLaunchKernelGGL(k_integrate_bricks, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
         prof_begin(m, TSL_K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_shared, dim3(64), dim3(256), 0, m->stream, m->M, F, P);
+        hipLaunchKernelGGL(k_finalize_shared, dim3(64), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
         prof_begin(m, TSL_K_INTEGRATE);
-        if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
-        else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, P);
+        if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
         prof_begin(m, TSL_K_FINALIZE);
         hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const int*)nullptr, (const int*)nullptr);

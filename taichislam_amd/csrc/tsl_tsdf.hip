@@ -11,6 +11,7 @@
 #include "tsl_tsdf.hpp"
 #include <rocprim/rocprim.hpp>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -56,8 +57,10 @@ template <> struct KeyOps<uint64_t> {
 // K1: depth image -> sensor-centred voxel key + f16 payload       dense_tsdf.py:188-213, process_point :227-229
 // ------------------------------------------------------------------------------------------------------
 template <typename K>
-__global__ void __launch_bounds__(256) k_voxelize_depth(FrameParams P, FrameDev F, const uint16_t* __restrict__ depth, K* __restrict__ keys)
+__global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __restrict__ Pp, FrameDev F, K* __restrict__ keys)
 {
+    const FrameParams& P = *Pp;
+    const uint16_t* __restrict__ depth = static_cast<const uint16_t*>(P.input);
     const int total = P.hh * P.ww;
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool gate = false, inside = false;
@@ -95,8 +98,11 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(FrameParams P, FrameDev 
 
 // recast_pcl_to_map_kernel  dense_tsdf.py:167-186 (z := range, gate on the range)
 template <typename K>
-__global__ void __launch_bounds__(256) k_voxelize_points(FrameParams P, FrameDev F, const float* __restrict__ xyz, int n, K* __restrict__ keys)
+__global__ void __launch_bounds__(256) k_voxelize_points(const FrameParams* __restrict__ Pp, FrameDev F, K* __restrict__ keys)
 {
+    const FrameParams& P = *Pp;
+    const float* __restrict__ xyz = static_cast<const float*>(P.input);
+    const int n = P.total;
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool gate = false, inside = false;
     if (p < n) {
@@ -130,8 +136,10 @@ __global__ void __launch_bounds__(256) k_voxelize_points(FrameParams P, FrameDev
 // rounding (process_point :230-232) and emit the ray record (process_new_pcl :242-249)
 // ------------------------------------------------------------------------------------------------------
 template <typename K>
-__global__ void __launch_bounds__(256) k_build_rays(FrameParams P, FrameDev F, const K* __restrict__ keys_s, int total)
+__global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restrict__ Pp, FrameDev F, const K* __restrict__ keys_s)
 {
+    const FrameParams& P = *Pp;
+    const int total = P.total;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const K bad = KeyOps<K>::invalid(P.pcl_bits);
     bool head = false, ok = false;
@@ -392,45 +400,100 @@ static PoseF pose_of(const tsl_tsdf* m, int s)
     return B;
 }
 
+__global__ void k_set_params(FrameParams P, FrameParams* dst) { if (threadIdx.x == 0) *dst = P; }
+
+// phase A of one frame on stream `sa`: depth -> rays -> brick-sorted segments.  Every argument is constant for a given
+// (image shape, options), the per-frame values live in *S.Pd -- so the same sequence can be captured into a hipGraph.
+template <typename K>
+static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStream_t sa)
+{
+    FrameDev& F = S.F;
+    TSL_HIP(hipMemsetAsync(S.header, 0, S.header_bytes, sa));                         // stats | nrays | counters
+    if (total <= 0) return TSL_OK;
+    K* keys = reinterpret_cast<K*>(F.keys);
+    K* keys_s = reinterpret_cast<K*>(F.keys_s);
+    const int blocks = (total + 255) / 256;
+    prof_begin(m, TSL_K_VOXELIZE, sa);
+    if (points) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
+    else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
+    prof_end(m, sa);
+    prof_begin(m, TSL_K_SORT, sa);
+    size_t tb = m->sort_temp_bytes;
+    TSL_HIP(rocprim::radix_sort_pairs(S.sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * m->P.pcl_bits + 1), sa));
+    prof_end(m, sa);
+    prof_begin(m, TSL_K_RAYS, sa);
+    hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, (const K*)keys_s);
+    prof_end(m, sa);
+    return launch_segments(m, S, total, sa);
+}
+
+static void drop_graphs(FSet& S)
+{
+    if (S.execA) { (void)hipGraphExecDestroy(S.execA); S.execA = nullptr; }
+    if (S.execB) { (void)hipGraphExecDestroy(S.execB); S.execB = nullptr; }
+    S.graph_key = -1;
+}
+
+template <typename K>
+static int build_graphs(tsl_tsdf* m, FSet& S, int total, long long key)
+{
+    drop_graphs(S);
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(S.st, hipStreamCaptureModeThreadLocal) != hipSuccess) return TSL_ERR_HIP;
+    int rc = enqueue_phase_a<K>(m, S, total, false, S.st);
+    hipError_t e = hipStreamEndCapture(S.st, &g);
+    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return TSL_ERR_HIP; }
+    e = hipGraphInstantiate(&S.execA, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g); g = nullptr;
+    if (e != hipSuccess) { S.execA = nullptr; (void)hipGetLastError(); return TSL_ERR_HIP; }
+    if (hipStreamBeginCapture(S.st, hipStreamCaptureModeThreadLocal) != hipSuccess) { drop_graphs(S); return TSL_ERR_HIP; }
+    hipStream_t keep = m->stream; m->stream = S.st;                 // phase B is captured on the set's stream, replayed on the main stream
+    rc = launch_apply(m, S, total);
+    m->stream = keep;
+    e = hipStreamEndCapture(S.st, &g);
+    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); drop_graphs(S); (void)hipGetLastError(); return TSL_ERR_HIP; }
+    e = hipGraphInstantiate(&S.execB, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { S.execB = nullptr; drop_graphs(S); (void)hipGetLastError(); return TSL_ERR_HIP; }
+    S.graph_key = key;
+    return TSL_OK;
+}
+
 template <typename K>
 static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
 {
     FrameParams& P = m->P;
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
     TSL_REQUIRE(total <= m->F.max_points, "integrate: more pixels/points than max_points");
+    if (P.variant == 2) { int rc = check_variant2(m); if (rc) return rc; }
+    P.input = xyz_dev ? xyz_dev : depth_dev; P.total = total;
     // ---- phase A: depth -> rays -> brick-sorted segments, into working set `si` on its own stream.  It depends on the
     //      image, the pose and the map GEOMETRY only, so several frames are in flight; the only map access is first-touch
     //      brick allocation and the occupancy byte (atomic claims, safe next to phase B of older frames). ----
     const int si = m->overlap ? (int)(m->frame_no % TSL_NSETS) : 0;
     FSet& S = m->fset[si];
-    FrameDev& F = S.F;
     hipStream_t sa = m->overlap ? S.st : m->stream;
     if (m->overlap && S.b_pending) TSL_HIP(hipStreamWaitEvent(sa, S.b_done, 0));      // phase B of frame f-NSETS still reads this set
-    TSL_HIP(hipMemsetAsync(S.header, 0, S.header_bytes, sa));                         // stats | nrays | counters
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sa, P, S.Pd);
     m->last_set = si; m->frame_no++;
-    if (total > 0) {
-        K* keys = reinterpret_cast<K*>(F.keys);
-        K* keys_s = reinterpret_cast<K*>(F.keys_s);
-        const int blocks = (total + 255) / 256;
-        prof_begin(m, TSL_K_VOXELIZE, sa);
-        if (xyz_dev) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const float*)xyz_dev, total, keys);
-        else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const uint16_t*)depth_dev, keys);
-        prof_end(m, sa);
-        prof_begin(m, TSL_K_SORT, sa);
-        size_t tb = m->sort_temp_bytes;
-        TSL_HIP(rocprim::radix_sort_pairs(S.sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * P.pcl_bits + 1), sa));
-        prof_end(m, sa);
-        prof_begin(m, TSL_K_RAYS, sa);
-        hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, P, F, (const K*)keys_s, total);
-        prof_end(m, sa);
-        { int rc = launch_segments(m, S, total, sa); if (rc) return rc; }
+    // replay captured graphs for same-shaped depth frames: 7 host calls per frame instead of ~22
+    bool graph = m->use_graph && m->overlap && !m->prof_on && !xyz_dev && total > 0;
+    if (graph) {
+        const long long key = ((long long)P.H << 40) ^ ((long long)P.W << 24) ^ ((long long)P.step << 16) ^ ((long long)P.variant << 8) ^ (long long)P.split ^ ((long long)sizeof(K) << 60);
+        if (S.graph_key != key && build_graphs<K>(m, S, total, key) != TSL_OK) { m->use_graph = 0; graph = false; }
+    }
+    if (graph) {
+        TSL_HIP(hipGraphLaunch(S.execA, sa));
+    } else {
+        int rc = enqueue_phase_a<K>(m, S, total, xyz_dev != nullptr, sa); if (rc) return rc;
     }
     if (m->overlap) {
         TSL_HIP(hipEventRecord(S.a_done, sa));
         TSL_HIP(hipStreamWaitEvent(m->stream, S.a_done, 0));
     }
     // ---- phase B: apply to the map, in frame order on the main stream ----
-    if (total > 0) { int rc = launch_apply(m, S, total); if (rc) return rc; }
+    if (graph) { TSL_HIP(hipGraphLaunch(S.execB, m->stream)); }
+    else if (total > 0) { int rc = launch_apply(m, S, total); if (rc) return rc; }
     if (m->overlap) { TSL_HIP(hipEventRecord(S.b_done, m->stream)); S.b_pending = true; }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -487,7 +550,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     m->frame_no = 0; m->overlap = 1; m->last_set = 0;
-    for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; }
+    for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.execA = nullptr; S.execB = nullptr; S.graph_key = -1; }
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
     m->Nz = (int)std::ceil(cfg->map_size_z / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:25
@@ -529,7 +592,8 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->active = 0; m->variant = 2; m->split = 2;
+    m->active = 0; m->variant = 2; m->split = 2; m->use_graph = std::getenv("TSL_GRAPH") ? 1 : 0;      // hipGraph replay is opt-in: it halves the host enqueue time but the
+                                                               // pipeline is GPU-bound, and replay aborted once inside a long multi-handle test session
     m->prof_on = false; m->prof_open = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0; m->stage_in = nullptr; m->stage_in_bytes = 0; m->stage_tex = nullptr; m->stage_tex_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
@@ -595,7 +659,11 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
         if ((rc = own((void**)&G.act_off, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
         if ((rc = own((void**)&G.act_part, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
+        G.part_cap = F.seg_cap / 256 + F.max_frame_bricks + 8;
+        if ((rc = own((void**)&G.part_tab, sizeof(int4) * (size_t)G.part_cap))) return rc;
         if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
+        if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
+        S.execA = nullptr; S.execB = nullptr; S.graph_key = -1;
         TSL_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
         TSL_HIP(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
         TSL_HIP(hipEventCreateWithFlags(&S.b_done, hipEventDisableTiming));
@@ -633,8 +701,12 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
+    for (auto& S : m->fset) if (S.st) (void)hipStreamSynchronize(S.st);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipDeviceSynchronize();
     for (auto& S : m->fset) {
-        if (S.st) { (void)hipStreamSynchronize(S.st); (void)hipStreamDestroy(S.st); }
+        drop_graphs(S);
+        if (S.st) { (void)hipStreamDestroy(S.st); }
         for (void* p : S.owned) if (p) (void)hipFree(p);
         if (S.a_done) (void)hipEventDestroy(S.a_done);
         if (S.b_done) (void)hipEventDestroy(S.b_done);
@@ -960,7 +1032,8 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
 {
     TSL_REQUIRE(m && name, "null");
     if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
-    if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }      // can only be switched off
+    if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
+    if (!std::strcmp(name, "graph")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->use_graph = value != 0; return TSL_OK; }      // can only be switched off
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value != 0; for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;

@@ -20,6 +20,7 @@ struct FrameParams {
     int   th, tw, tex, same_proj;
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
+    const void* input; int total;      // device pointer of the depth image / point array of this frame, pixels or points to visit
 };
 
 // Device-side view of ONE frame's working set.  Everything up to the brick-sorted ray segments depends only on the
@@ -39,6 +40,7 @@ struct FrameDev {
     int   *shared_list;                          // active-brick ranks integrated by several workgroups
     int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment
     int   *act_b, *act_off, *act_part;           // [max_frame_bricks+1] active bricks of the frame
+    int4  *part_tab; int part_cap;               // integrate work list: {active rank, part k, parts of the brick, -}, longest first
     // ---- shared by all sets (only touched in phase B, i.e. serially on the main stream) ----
     int*   slot_tab;                             // variants 0/1: [nb3] brick id -> frame scratch slot, EMPTY between frames
     int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
@@ -56,6 +58,9 @@ struct ProfSlot { hipEvent_t a, b; int kid; };
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
     hipStream_t st; hipEvent_t a_done, b_done; bool b_pending;
+    FrameParams* Pd;                       // this frame's parameters in device memory (kernels read them through the pointer, so the
+                                           // launch sequence has constant arguments and can be replayed as a hipGraph)
+    hipGraphExec_t execA, execB; long long graph_key;
     std::vector<void*> owned;
 };
 
@@ -97,6 +102,7 @@ struct tsl_tsdf {
     bool prof_on, prof_open; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int variant, split;
+    int use_graph;                       // 1: replay captured hipGraphs for same-shaped depth frames (when profiling is off)
     int64_t bytes;
 };
 
@@ -106,6 +112,7 @@ void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr);
 void prof_end(tsl_tsdf* m, hipStream_t st = nullptr);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
+int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B: apply to the map
 }
