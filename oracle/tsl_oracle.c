@@ -102,6 +102,7 @@ typedef struct {
     int8_t  obs[BRK3], occ[BRK3];
     f16     col[BRK3][3];
     int64_t num[BRK3], den[BRK3];      /* per-frame accumulators (zero between frames) */
+    int64_t cnum[BRK3][3];             /* fusion: sum of w*colour per channel (texture)  */
     uint32_t win[BRK3];                /* per-frame colour winner (ray order + 1)      */
     int     touched;                   /* in the frame touched list                    */
 } brick_t;
@@ -282,6 +283,7 @@ static void set_pose(ora_tsdf* m, const double R[9], const double T[3])
 typedef struct {
     int c[3];
     int cnt;
+    int first;                         /* index of the first pixel / point that fell into the cell (raster order) */
     f16 sum[3], z, csum[3];
 } pcl_cell;
 typedef struct {
@@ -320,12 +322,13 @@ static pcl_cell* pcl_get(pcl_grid* g, int cx, int cy, int cz)
 }
 
 /* process_point  dense_tsdf.py:227-234 : f16 accumulators, value cast to f16 before the add (A5) */
-static int process_point(ora_tsdf* m, pcl_grid* g, const float pt[3], float z, const uint8_t* rgb)
+static int process_point(ora_tsdf* m, pcl_grid* g, const float pt[3], float z, const uint8_t* rgb, int index)
 {
     int c[3];
     for (int a = 0; a < 3; ++a) c[a] = rnd_i(pt[a] / m->vs);                       /* mapping_common.py:241-243,264-266 */
     for (int a = 0; a < 3; ++a) if (c[a] < m->pcl_lo || c[a] >= m->pcl_hi) return 0;   /* outside the 800^3 scratch grid: undefined in the reference, skipped (Q20) */
     pcl_cell* cell = pcl_get(g, c[0], c[1], c[2]);
+    if (cell->cnt == 0) cell->first = index;
     cell->cnt += 1;
     for (int a = 0; a < 3; ++a) cell->sum[a] = hadd(cell->sum[a], H(pt[a]));
     cell->z = hadd(cell->z, H(z));
@@ -400,7 +403,6 @@ static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats*
             st->steps++;
             b->num[l] += to_fix(w * sd);
             b->den[l] += qden;
-            if (tex) { b->win[l] = (uint32_t)r + 1u; }
             if (mode == ORA_FAITHFUL) {
                 f16 T0 = b->tsdf[l], W0 = b->w[l];
                 b->tsdf[l] = H((F(hmul(T0, W0)) + w * sd) / (F(W0) + w));             /* :264 */
@@ -408,8 +410,10 @@ static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats*
                 float wn = F(W0) + w; if (WMAX < wn) wn = WMAX;
                 b->w[l] = H(wn);                                                       /* :267 */
                 if (tex) for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];             /* :268-269 */
-            } else if (tex) {
-                /* BATCHED colour: the last ray in struct-for order wins (deterministic stand-in for the race) */
+            } else if (tex && (uint32_t)cell->first + 1u > b->win[l]) {
+                /* BATCHED colour: of the rays that reach a voxel in this frame, the one whose sensor cell was opened by the
+                 * latest pixel wins -- an order-free stand-in for the reference's "last writer" race (:268-269) */
+                b->win[l] = (uint32_t)cell->first + 1u;
                 for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];
             }
         }
@@ -471,7 +475,7 @@ int ora_tsdf_integrate_depth(ora_tsdf* m, int mode, const double R[9], const dou
                     rgb = tex + ((size_t)cj * tw + ci) * 3;
                 }
             }
-            if (process_point(m, &g, pm, dep, rgb)) st.p_valid++; else st.p_oob++;
+            if (process_point(m, &g, pm, dep, rgb, jj * ww + ii)) st.p_valid++; else st.p_oob++;
         }
     }
     process_new_pcl(m, &g, mode, &st);
@@ -495,7 +499,7 @@ int ora_tsdf_integrate_points(ora_tsdf* m, int mode, const double R[9], const do
         for (int a = 0; a < 3; ++a) pm[a] = (m->inR[a * 3] * pt[0] + m->inR[a * 3 + 1] * pt[1]) + m->inR[a * 3 + 2] * pt[2];   /* :175 */
         float len = sqrtf((pm[0] * pm[0] + pm[1] * pm[1]) + pm[2] * pm[2]);            /* :176 */
         if (!(len < m->max_ray_f)) continue;                                           /* :177 */
-        if (process_point(m, &g, pm, len, use_tex ? rgb + idx * 3 : NULL)) st.p_valid++; else st.p_oob++;   /* :183-185 (z := range, Q5) */
+        if (process_point(m, &g, pm, len, use_tex ? rgb + idx * 3 : NULL, (int)idx)) st.p_valid++; else st.p_oob++;   /* :183-185 (z := range, Q5) */
     }
     process_new_pcl(m, &g, mode, &st);
     pcl_free(&g);
@@ -676,6 +680,8 @@ static void fuse_fn(void* vctx, const ora_tsdf* sm, int s, int i, int j, int k, 
         int l; brick_t* b = get_brick(g, 0, ci, cj, ck, 1, &l);
         if (c->mode == ORA_FAITHFUL) {                                                /* fuse_with_interploation :272-280 */
             float w_new = w_tsdf + F(b->w[l]);
+            if (g->cfg.texture_enabled) for (int a = 0; a < 3; ++a)                  /* :277 */
+                b->col[l][a] = H((F(hmul(b->w[l], b->col[l][a])) + w_tsdf * F(sb->col[sl][a])) / w_new);
             b->tsdf[l] = H((F(hmul(b->w[l], b->tsdf[l])) + w_tsdf * tsdf) / w_new);
             b->w[l] = H(w_new);
             b->obs[l] = 1;
@@ -684,6 +690,7 @@ static void fuse_fn(void* vctx, const ora_tsdf* sm, int s, int i, int j, int k, 
             touch_brick(g, b);
             b->num[l] += to_fix(w_tsdf * tsdf);
             b->den[l] += to_fix(w_tsdf);
+            if (g->cfg.texture_enabled) for (int a = 0; a < 3; ++a) b->cnum[l][a] += to_fix(w_tsdf * F(sb->col[sl][a]));
             b->win[l] += 1;                       /* contribution count: observed even if the weights quantise to 0 */
             b->occ[l] = (int8_t)(b->occ[l] + sb->occ[sl]);
         }
@@ -709,6 +716,7 @@ int ora_tsdf_fuse_submaps(ora_tsdf* g, const ora_tsdf* sub, int mode)
                 b->tsdf[l] = H(num / den);                /* global map starts empty: T0 = W0 = 0 */
                 b->w[l] = H(den);
                 b->obs[l] = 1;
+                if (g->cfg.texture_enabled) for (int a = 0; a < 3; ++a) { b->col[l][a] = H(from_fix(b->cnum[l][a]) / den); b->cnum[l][a] = 0; }
                 b->num[l] = 0; b->den[l] = 0; b->win[l] = 0;
             }
             b->touched = 0;

@@ -467,10 +467,12 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 }
 
 // K4d: LDS accumulation per brick, in-place finalise
+template <bool TEX>
 __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
     const FrameParams& P = *Pp;
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
+    __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
     __shared__ unsigned long long s_keys[PART_SEGS];
     __shared__ int s_bin[64];
     __shared__ int s_p;
@@ -495,6 +497,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
             for (int i = threadIdx.x; i < TSL_BRK3; i += 256) z[i] = make_ulonglong2(0ull, 0ull);
         }
         if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+        if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += 256) s_win[i] = 0u;
         __syncthreads();
         // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
         // segments of (almost) equal length instead of idling behind the longest one
@@ -521,6 +524,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
             const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
             const RayRegs R = load_ray<false>(F, P, r);
+            const uint32_t wid = TEX ? F.rayFirst[r] + 1u : 0u;
             for (int j = j0; j < j0 + cnt; ++j) {
                 float x[3]; int xi[3];
                 step_voxel(R, P, j, x, xi);
@@ -528,6 +532,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 const long long qn = step_term(R, x);
                 atomicAdd(&s_acc[l * 2], (unsigned long long)qn);
                 atomicAdd(&s_acc[l * 2 + 1], (unsigned long long)R.qden);
+                if (TEX) atomicMax(&s_win[l], wid);                                            // dense_tsdf.py:268-269, order-free winner
             }
         }
         TSL_TICK(F, 2);
@@ -547,6 +552,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 if (qd != 0ull) {
                     tw[l] = apply_update(old[q], (long long)s_acc[l * 2], (long long)qd);
                     if ((old[q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
+                    if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[l] - 1u];
                     ++uniq;
                 }
             }
@@ -557,6 +563,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 if (qd != 0ull) {
                     __hip_atomic_fetch_add(acc + l * 2, s_acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(acc + l * 2 + 1, qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[l]);
                 }
             }
             if (threadIdx.x == 0 && k == 0) {
@@ -599,6 +606,11 @@ __global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, c
                 tw[l] = apply_update(old[i], (long long)a[i].x, (long long)a[i].y);
                 obs[l] = 1;
                 acc[l] = make_ulonglong2(0ull, 0ull);
+                if (P.tex) {
+                    uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
+                    reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[*wv - 1u];
+                    *wv = 0u;
+                }
                 ++uniq;
             }
         }
@@ -637,7 +649,8 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
     FrameDev& F = S.F;
     if (P.variant == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
-        hipLaunchKernelGGL(k_integrate_bricks, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        if (P.tex) hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        else hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
         prof_begin(m, TSL_K_FINALIZE);
         hipLaunchKernelGGL(k_finalize_shared, dim3(64), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);

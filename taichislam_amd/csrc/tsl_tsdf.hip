@@ -145,14 +145,34 @@ __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restric
     bool head = false, ok = false;
     uint4 rec = make_uint4(0, 0, 0, 0);
     int nsteps = 0;
+    uint32_t first_pix = 0;
     if (i < total) {
         const K k = keys_s[i];
         head = (k != bad) && (i == 0 || keys_s[i - 1] != k);
         if (head) {
             int cnt = 0;
-            h16 sx = 0, sy = 0, sz = 0, zs = 0;
+            h16 sx = 0, sy = 0, sz = 0, zs = 0, cr = 0, cg = 0, cb = 0;
+            const uint32_t first = F.vals_s[i];                                              // stable sort: the run starts with its lowest pixel id
             for (int q = i; q < total && keys_s[q] == k; ++q) {
-                const uint2 pl = F.pix[F.vals_s[q]];
+                const uint32_t pid = F.vals_s[q];
+                if (P.tex) {                                                                 // new_pcl_sum_color += rgb  (:234)
+                    const uint8_t* rgb;
+                    if (P.points) rgb = P.tex_input + (size_t)pid * 3;                       // :179-183
+                    else {
+                        const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
+                        const int pj = jj * P.step, pi = ii * P.step;
+                        if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;   // :206
+                        else {                                                               // color_ind_from_depth_pt  mapping_common.py:43-58
+                            int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
+                            int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
+                            if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }      // the reference tests column against rows (:56)
+                            if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                        // keep the read inside the buffer
+                            rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
+                        }
+                    }
+                    cr = hadd(cr, f2h((float)rgb[0])); cg = hadd(cg, f2h((float)rgb[1])); cb = hadd(cb, f2h((float)rgb[2]));
+                }
+                const uint2 pl = F.pix[pid];
                 sx = hadd(sx, (h16)(pl.x & 0xffffu)); sy = hadd(sy, (h16)(pl.x >> 16));      // :231
                 sz = hadd(sz, (h16)(pl.y & 0xffffu)); zs = hadd(zs, (h16)(pl.y >> 16));      // :232
                 ++cnt;                                                                       // :230
@@ -174,11 +194,16 @@ __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restric
                 rec.y = (uint32_t)pz | ((uint32_t)dx << 16);
                 rec.z = (uint32_t)dy | ((uint32_t)dz << 16);
                 rec.w = __float_as_uint(w);
+                if (P.tex) {                                                                 // color = sum_color/c/255  (:269)
+                    const h16 r16 = f2h(h2f(hdiv(cr, c)) / 255.0f), g16 = f2h(h2f(hdiv(cg, c)) / 255.0f), b16 = f2h(h2f(hdiv(cb, c)) / 255.0f);
+                    F.colpix[first] = make_uint2((uint32_t)r16 | ((uint32_t)g16 << 16), (uint32_t)b16);
+                }
+                first_pix = first;
             }
         }
     }
     const int r = block_reserve(F.nrays, ok);
-    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; }
+    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = first_pix; }
     block_count_add(&F.stats->v_pcl, head);
     block_count_add(&F.stats->v_skipped, head && !ok);
 }
@@ -466,7 +491,8 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
     TSL_REQUIRE(total <= m->F.max_points, "integrate: more pixels/points than max_points");
     if (P.variant == 2) { int rc = check_variant2(m); if (rc) return rc; }
-    P.input = xyz_dev ? xyz_dev : depth_dev; P.total = total;
+    P.input = xyz_dev ? xyz_dev : depth_dev; P.total = total; P.points = xyz_dev ? 1 : 0;
+    TSL_REQUIRE(!P.tex || P.variant == 2, "texture integration needs the brick-binned path (variant 2)");
     // ---- phase A: depth -> rays -> brick-sorted segments, into working set `si` on its own stream.  It depends on the
     //      image, the pose and the map GEOMETRY only, so several frames are in flight; the only map access is first-touch
     //      brick allocation and the occupancy byte (atomic claims, safe next to phase B of older frames). ----
@@ -479,7 +505,7 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     // replay captured graphs for same-shaped depth frames: 7 host calls per frame instead of ~22
     bool graph = m->use_graph && m->overlap && !m->prof_on && !xyz_dev && total > 0;
     if (graph) {
-        const long long key = ((long long)P.H << 40) ^ ((long long)P.W << 24) ^ ((long long)P.step << 16) ^ ((long long)P.variant << 8) ^ (long long)P.split ^ ((long long)sizeof(K) << 60);
+        const long long key = ((long long)P.H << 40) ^ ((long long)P.W << 24) ^ ((long long)P.step << 16) ^ ((long long)P.variant << 8) ^ (long long)P.split ^ ((long long)sizeof(K) << 60) ^ ((long long)P.tex << 59);
         if (S.graph_key != key && build_graphs<K>(m, S, total, key) != TSL_OK) { m->use_graph = 0; graph = false; }
     }
     if (graph) {
@@ -633,6 +659,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
+    if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&F.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc; }
     for (int si = 0; si < TSL_NSETS; ++si) {
         FSet& S = m->fset[si];
         S.F = F;
@@ -645,6 +672,8 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&G.pix, 8 * np))) return rc;
         if ((rc = own((void**)&G.rayA, 16 * np))) return rc;
         if ((rc = own((void**)&G.rayN, 4 * np))) return rc;
+        if ((rc = own((void**)&G.rayFirst, 4 * np))) return rc;
+        if (cfg->texture_enabled) { if ((rc = own((void**)&G.colpix, 8 * np))) return rc; }
         S.header_bytes = 128;
         if ((rc = own(&S.header, S.header_bytes))) return rc;
         G.stats = reinterpret_cast<tsl_frame_stats*>(S.header);
@@ -711,7 +740,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         if (S.a_done) (void)hipEventDestroy(S.a_done);
         if (S.b_done) (void)hipEventDestroy(S.b_done);
     }
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.dbg,
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag, m->fuse_acc, m->fuse_cnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -818,7 +847,8 @@ int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[
     FrameParams& P = m->P;
     P.H = h; P.W = w;
     P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);           // dense_tsdf.py:192,194
-    P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0;
+    P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0; P.tex_input = (const uint8_t*)tex_dev;
+    TSL_REQUIRE(!P.tex || (th > 0 && tw > 0 && (!P.same_proj || (th >= h && tw >= w))), "integrate_depth: texture smaller than the depth image");
     m->h_stats->p_used = (int64_t)P.hh * P.ww;
     return m->pcl_bits <= 10 ? run_frame<uint32_t>(m, depth_dev, nullptr, 0) : run_frame<uint64_t>(m, depth_dev, nullptr, 0);
 }
@@ -849,7 +879,7 @@ int tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T
     TSL_REQUIRE(m && R && T, "integrate_points: null argument"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz_dev), "integrate_points: bad input");
     TSL_HIP(hipSetDevice(m->device));
     fill_frame_params(m, R, T);
-    m->P.tex = (m->cfg.texture_enabled && rgb_dev) ? 1 : 0;
+    m->P.tex = (m->cfg.texture_enabled && rgb_dev) ? 1 : 0; m->P.tex_input = (const uint8_t*)rgb_dev;
     m->h_stats->p_used = n;
     return m->pcl_bits <= 10 ? run_frame<uint32_t>(m, nullptr, xyz_dev, n) : run_frame<uint64_t>(m, nullptr, xyz_dev, n);
 }

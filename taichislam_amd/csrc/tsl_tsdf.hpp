@@ -21,6 +21,7 @@ struct FrameParams {
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
     const void* input; int total;      // device pointer of the depth image / point array of this frame, pixels or points to visit
+    const uint8_t* tex_input; int points;   // texture [th][tw][3] (depth input) or rgb [n][3] (point input); input kind
 };
 
 // Device-side view of ONE frame's working set.  Everything up to the brick-sorted ray segments depends only on the
@@ -33,6 +34,8 @@ struct FrameDev {
     uint2* pix;                                  // per pixel: f16 bits {x,y | z,depth}
     uint4* rayA;                                 // per ray: {p01, p2|d0, d12, w bits}
     int*   rayN;                                 // per ray: step count
+    uint32_t* rayFirst;                          // per ray: index of the first pixel / point of its sensor voxel (texture: colour winner order)
+    uint2* colpix;                               // [pixel] f16 colour {r|g<<16, b} of the ray opened by that pixel (texture)
     tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
     int*   nrays;                                // ray count of this frame
     int*   counters;                             // [1] active bricks [2] segments appended [3] segments sorted [4] shared bricks [5] parts
@@ -46,6 +49,7 @@ struct FrameDev {
     int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
     int*   touched_b;                            // variants 0/1: [max_frame_bricks] -> brick id
     unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
+    uint32_t* accw;                              // [max_frame_bricks][4096] colour winner (first pixel + 1) of bricks split over workgroups (texture)
     long long* dbg;                              // developer timing counters (TSL_TIMING builds)
     int    seg_cap;
     int    max_frame_bricks;
