@@ -15,7 +15,7 @@ struct PoseTab { const float* p; };     // [npose][12]: R row-major, T
 
 template <bool DENSE>
 __global__ void __launch_bounds__(256) k_fuse_splat(MapDev S, MapDev G, PoseTab poses, float vs, int nused,
-                                                    unsigned long long* acc, int* cnt, int npose)
+                                                    unsigned long long* acc, int* cnt, int npose, unsigned long long* cacc)
 {
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         const int owner = S.owner[p];
@@ -55,6 +55,12 @@ __global__ void __launch_bounds__(256) k_fuse_splat(MapDev S, MapDev G, PoseTab 
                 __hip_atomic_fetch_add(acc + dst * 2, (unsigned long long)to_fix(w_tsdf * tsdf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :275 numerator
                 __hip_atomic_fetch_add(acc + dst * 2 + 1, (unsigned long long)to_fix(w_tsdf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // :274
                 __hip_atomic_fetch_add(cnt + dst, (1 << 16) + occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                 // :279-280
+                if (!DENSE && cacc) {                                                            // :277 colour, exact weighted sums per channel
+                    const uint2 cs = reinterpret_cast<const uint2*>(S.col)[v];
+                    const float cf[3] = { h2f((h16)(cs.x & 0xffffu)), h2f((h16)(cs.x >> 16)), h2f((h16)(cs.y & 0xffffu)) };
+                    for (int a = 0; a < 3; ++a)
+                        __hip_atomic_fetch_add(cacc + dst * 3 + a, (unsigned long long)to_fix(w_tsdf * cf[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -70,7 +76,7 @@ __device__ __forceinline__ void fuse_write(const MapDev& G, size_t v, long long 
 }
 
 // finalise from the per-brick scratch of the global map
-__global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsigned long long* acc, int* cnt)
+__global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsigned long long* acc, int* cnt, unsigned long long* cacc)
 {
     for (int p = blockIdx.x; p < nused; p += gridDim.x)
         for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
@@ -78,6 +84,12 @@ __global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsi
             const int c = cnt[v];
             if (c == 0) continue;
             fuse_write(G, v, (long long)acc[v * 2], (long long)acc[v * 2 + 1], c);
+            if (cacc) {
+                const float den = from_fix((long long)acc[v * 2 + 1]);
+                h16 cc[3];
+                for (int a = 0; a < 3; ++a) { cc[a] = f2h(from_fix((long long)cacc[v * 3 + a]) / den); cacc[v * 3 + a] = 0ull; }
+                reinterpret_cast<uint2*>(G.col)[v] = make_uint2((uint32_t)cc[0] | ((uint32_t)cc[1] << 16), (uint32_t)cc[2]);
+            }
             acc[v * 2] = 0ull; acc[v * 2 + 1] = 0ull; cnt[v] = 0;
         }
 }
@@ -134,16 +146,18 @@ int tsl_tsdf_fuse_submaps(tsl_tsdf* g, tsl_tsdf* sub)
         const size_t nv = (size_t)g->M.max_bricks * TSL_BRK3;
         if ((rc = dev_alloc(g, &g->fuse_acc, nv * 16, 0))) return rc;
         if ((rc = dev_alloc(g, &g->fuse_cnt, nv * 4, 0))) return rc;
+        if (g->M.col) { if ((rc = dev_alloc(g, &g->fuse_cacc, nv * 24, 0))) return rc; }
     }
+    unsigned long long* cacc = (g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
     if ((rc = upload_poses(g, sub))) return rc;
     int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
     if (nsrc > 0) {
         PoseTab pt = { g->pose_dev };
         hipLaunchKernelGGL(k_fuse_splat<false>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, pt, g->P.vs, nsrc,
-                           (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose);
+                           (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose, cacc);
         int ndst = 0; if ((rc = used_bricks(g, &ndst))) return rc;
         if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, g->stream, g->M, ndst,
-                                         (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt);
+                                         (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, cacc);
     }
     TSL_HIP(hipGetLastError());
     TSL_HIP(hipStreamSynchronize(g->stream));
@@ -164,7 +178,7 @@ int tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* g, tsl_tsdf* sub, void* acc_dev, void
     if (nsrc > 0) {
         PoseTab pt = { g->pose_dev };
         hipLaunchKernelGGL(k_fuse_splat<true>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, pt, g->P.vs, nsrc,
-                           (unsigned long long*)acc_dev, (int*)cnt_occ_dev, g->npose);
+                           (unsigned long long*)acc_dev, (int*)cnt_occ_dev, g->npose, (unsigned long long*)nullptr);
     }
     TSL_HIP(hipGetLastError());
     TSL_HIP(hipStreamSynchronize(g->stream));

@@ -49,8 +49,16 @@ __device__ __forceinline__ void edge_corners(int e, int* a, int* b)
     else { *a = e - 8; *b = e - 4; }
 }
 
+__device__ __forceinline__ uint2 rd_col(const MapDev& M, int s, int i, int j, int k)
+{
+    if (!in_volume(M, i, j, k)) return make_uint2(0u, 0u);
+    int l; const int b = brick_of(M, i, j, k, &l);
+    const int p = pool_lookup_ro(M, s, b);
+    return p < 0 ? make_uint2(0u, 0u) : reinterpret_cast<const uint2*>(M.col)[(size_t)p * TSL_BRK3 + l];
+}
+
 __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int step, float thres, float vs, long long max_tri,
-                                                        float* __restrict__ verts, float* __restrict__ normals, int* counter)
+                                                        float* __restrict__ verts, float* __restrict__ normals, float* __restrict__ colors, int* counter)
 {
     __shared__ unsigned long long s_tri[256];
     __shared__ float s_val[8][256];
@@ -100,10 +108,21 @@ __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int
                         const float v0 = s_val[ca][threadIdx.x], v1 = s_val[cb][threadIdx.x];
                         const float p0[3] = { (float)(i + da[0] * step), (float)(j + da[1] * step), (float)(k + da[2] * step) };
                         const float p1[3] = { (float)(i + db[0] * step), (float)(j + db[1] * step), (float)(k + db[2] * step) };
-                        float pv[3];
+                        float pv[3], mu = 0.0f;
                         if (fabsf(0.0f - v0) < MC_EPS) { pv[0] = p0[0]; pv[1] = p0[1]; pv[2] = p0[2]; }            // vertexInterp :44-60
                         else if (fabsf(0.0f - v1) < MC_EPS) { pv[0] = p1[0]; pv[1] = p1[1]; pv[2] = p1[2]; }
-                        else { const float mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
+                        else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
+                        if (colors) {                                                            // vertexInterp_color :62-82 (Q13: only channel 0 is tested)
+                            const uint2 ca2 = rd_col(M, s, i + da[0] * step, j + da[1] * step, k + da[2] * step);
+                            const uint2 cb2 = rd_col(M, s, i + db[0] * step, j + db[1] * step, k + db[2] * step);
+                            const h16 c0[3] = { (h16)(ca2.x & 0xffffu), (h16)(ca2.x >> 16), (h16)(ca2.y & 0xffffu) };
+                            const h16 c1[3] = { (h16)(cb2.x & 0xffffu), (h16)(cb2.x >> 16), (h16)(cb2.y & 0xffffu) };
+                            float vc[3] = { h2f(c0[0]), h2f(c0[1]), h2f(c0[2]) };
+                            if (h2f(c0[0]) == 0.0f) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c1[a]); }
+                            else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])); }
+                            const size_t oc = ((size_t)idx * 3 + q) * 3;
+                            for (int a = 0; a < 3; ++a) colors[oc + a] = vc[a];
+                        }
                         float nn[3]; gen_normal(M, s, pv, nn);                                   // :100-102
                         const size_t o = ((size_t)idx * 3 + q) * 3;
                         for (int a = 0; a < 3; ++a) { verts[o + a] = pv[a] * vs; normals[o + a] = nn[a]; }   // :41-42,:97-99
@@ -127,9 +146,10 @@ int tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tr
     TSL_HIP(hipSetDevice(m->device));
     int rc;
     if (m->mesh_cap < max_tri) {
-        if (m->mesh_v) { (void)hipFree(m->mesh_v); (void)hipFree(m->mesh_n); m->mesh_v = m->mesh_n = nullptr; }
+        if (m->mesh_v) { (void)hipFree(m->mesh_v); (void)hipFree(m->mesh_n); if (m->mesh_c) (void)hipFree(m->mesh_c); m->mesh_v = m->mesh_n = m->mesh_c = nullptr; }
         if ((rc = dev_alloc(m, (void**)&m->mesh_v, sizeof(float) * 9 * (size_t)max_tri, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->mesh_n, sizeof(float) * 9 * (size_t)max_tri, 0))) return rc;
+        if (m->M.col) { if ((rc = dev_alloc(m, (void**)&m->mesh_c, sizeof(float) * 9 * (size_t)max_tri, 0))) return rc; }
         m->mesh_cap = max_tri;
     }
     if (!m->mesh_count) { if ((rc = dev_alloc(m, (void**)&m->mesh_count, sizeof(int) * 4, 0))) return rc; }
@@ -137,7 +157,7 @@ int tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tr
     TSL_HIP(hipMemsetAsync(m->mesh_count, 0, sizeof(int), m->stream));                          // :182
     prof_begin(m, TSL_K_MESH);
     if (nused > 0) hipLaunchKernelGGL(k_marching_cubes, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, m->stream, m->M, nused, step,
-                                      surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->mesh_count);
+                                      surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);
     prof_end(m);
     TSL_HIP(hipGetLastError());
     TSL_HIP(hipMemcpyAsync(m->h_ints, m->mesh_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -149,12 +169,12 @@ int tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tr
 int tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int64_t n_vertices)
 {
     TSL_REQUIRE(m, "mesh_read: null handle"); TSL_REQUIRE(n_vertices >= 0 && n_vertices <= 3 * m->mesh_cap, "mesh_read: more vertices than the mesh buffers hold");
-    (void)colors;
     TSL_HIP(hipSetDevice(m->device));
     TSL_HIP(hipStreamSynchronize(m->stream));
     if (n_vertices == 0) return TSL_OK;
     if (verts) TSL_HIP(hipMemcpy(verts, m->mesh_v, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost));
     if (normals) TSL_HIP(hipMemcpy(normals, m->mesh_n, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost));
+    if (colors && m->mesh_c) TSL_HIP(hipMemcpy(colors, m->mesh_c, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost));
     return TSL_OK;
 }
 

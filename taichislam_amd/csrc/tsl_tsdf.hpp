@@ -99,7 +99,7 @@ struct tsl_tsdf {
     void* xbuf; size_t xbuf_bytes;
     // mesh buffers (mesh_vertices / mesh_normals / mesh_colors, num_facelets)  marching_cube_mesher.py:16-22
     float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap;
-    void *fuse_acc, *fuse_cnt;           // global-map fusion scratch ({num,den} int64 pairs, count|occupancy)
+    void *fuse_acc, *fuse_cnt, *fuse_cacc;           // global-map fusion scratch ({num,den} int64 pairs, count|occupancy)
     // esdf
     float* esdf; int* esdf_flag; int64_t esdf_bricks; float esdf_gamma;
     // profiling

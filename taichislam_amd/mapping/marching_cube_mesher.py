@@ -31,8 +31,10 @@ class MarchingCubeMesher:
         n = int(max(0, min(n, 3 * min(self._n_tri, self.max_triangles))))
         v = np.empty((n, 3), np.float32)
         nr = np.empty((n, 3), np.float32)
-        _lib.check(_lib.lib().tsl_mesh_read(self.mapping.h, v.ctypes.data_as(C.c_void_p), nr.ctypes.data_as(C.c_void_p), None, n))
-        return v, nr, np.full((n, 3), 0.5, np.float32)
+        col = np.full((n, 3), 0.5, np.float32)
+        _lib.check(_lib.lib().tsl_mesh_read(self.mapping.h, v.ctypes.data_as(C.c_void_p), nr.ctypes.data_as(C.c_void_p),
+                                            col.ctypes.data_as(C.c_void_p) if self.enable_texture else None, n))
+        return v, nr, col
 
     def vertice_num(self):
         return self.num_facelets[None] * 3

@@ -70,3 +70,37 @@ def test_texture_round_trip_and_untextured_input(hip_lib):
     # a textured map fed without a texture integrates geometry only (colours stay as they were)
     g.recast_depth_to_map(R, T, d, np.array([], dtype=int))
     assert g.count_active() == e["TSDF"].shape[0]
+
+
+def test_textured_mesh_and_fusion(hip_lib):
+    """vertexInterp_color (marching_cube_mesher.py:62-82) and colour fusion (dense_tsdf.py:276-277)."""
+    from oracle import BATCHED, OracleTSDF
+    from taichislam_amd.mapping import DenseTSDF, MarchingCubeMesher
+    from util import sort_export, sorted_rows
+    K, frames = small_stream(3)
+    cfg = dict(TEX, max_submap_num=4)
+    g, o = make_pair(cfg, K)
+    g.set_base_pose_submap(0, frames[0][0], frames[0][1]); o.set_base_pose_submap(0, frames[0][0], frames[0][1])
+    for f, (R, T, d) in enumerate(frames):
+        tex = _texture(d.shape[0], d.shape[1], f)
+        g.recast_depth_to_map(R, T, d, tex); o.integrate_depth(R, T, d, tex, mode=BATCHED)
+    mesher = MarchingCubeMesher(g, 300000, tsdf_surface_thres=0.2)
+    mesher.generate_mesh(1)
+    ov, on, oc, ontri = o.generate_mesh(1, 0.2, 300000)
+    gv, gn, gc = mesher.get_mesh()
+    assert mesher.num_facelets[None] == ontri > 1000 and gc is not None
+    a = sorted_rows(np.concatenate([gv.reshape(-1, 9), gc.reshape(-1, 9)], 1))
+    b = sorted_rows(np.concatenate([ov.reshape(-1, 9), oc.reshape(-1, 9)], 1))
+    assert np.array_equal(a, b)
+    g.switch_to_next_submap(); o.set_active_submap(1)
+    gcfg = dict(cfg, is_global_map=True)
+    gg, og = DenseTSDF(**gcfg), OracleTSDF(**gcfg)
+    gg.set_base_pose_submap(0, frames[0][0], frames[0][1]); og.set_base_pose_submap(0, frames[0][0], frames[0][1])
+    gg.fuse_submaps(g); og.fuse_submaps(o, mode=BATCHED)
+    eg, eo = sort_export(gg.export_submap()), sort_export(og.export_sparse())
+    assert np.array_equal(eg["indices"], eo["indices"]) and eg["indices"].shape[0] > 10000
+    ok = ~np.isnan(eg["TSDF"].view(np.float16))
+    assert np.array_equal(eg["TSDF"][ok], eo["TSDF"][ok]) and np.array_equal(eg["W_TSDF"], eo["W_TSDF"])
+    cg, co = eg["color"].view(np.float16), eo["color"].view(np.float16)
+    okc = ~(np.isnan(cg).any(1) | np.isnan(co).any(1))
+    assert np.array_equal(np.isnan(cg), np.isnan(co)) and np.array_equal(eg["color"][okc], eo["color"][okc])
