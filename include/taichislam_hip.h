@@ -137,6 +137,12 @@ int  tsl_tsdf_fuse_finalize_dev(tsl_tsdf* global, const void* acc_dev, const voi
 int  tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tri, int32_t* n_tri);
 int  tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int64_t n_vertices);
 
+/* ---- batched map queries  (mapping_common.py:165-204, dense_tsdf.py:148-155; consumers: topo_graph.py:444-507) ---------- */
+/* mode 0: is_pos_occupy, 1: is_pos_unobserved, 2: is_near_pos_occupy(param voxels); xyz f32 [n][3] in the active submap's frame */
+int  tsl_tsdf_query_points(tsl_tsdf* m, int mode, int param, const float* xyz, int64_t n, uint8_t* out);
+/* raycast(pos, dir, max_dist) per query: hit flag, last evaluated position, length travelled */
+int  tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, float max_dist, int64_t n, uint8_t* hit, float* end_xyz, float* len);
+
 /* ---- ESDF  (dense_esdf.py:228-333, see DESIGN.md for the definition used) ------------------------ */
 int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters);
 int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);

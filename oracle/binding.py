@@ -76,6 +76,8 @@ def lib():
         L.ora_tsdf_fuse_submaps.argtypes = [vp, vp, C.c_int]
         L.ora_tsdf_fuse_accumulate_dense.argtypes = [vp, vp, vp, vp]
         L.ora_tsdf_fuse_finalize_dense.argtypes = [vp, vp, vp]
+        L.ora_tsdf_query_points.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp]
+        L.ora_tsdf_query_raycast.argtypes = [vp, vp, vp, C.c_float, i64, vp, vp, vp]
         L.ora_mesh_generate.restype = i64
         L.ora_mesh_generate.argtypes = [vp, C.c_int, C.c_float, i64, vp, vp, vp]
         L.ora_esdf_compute.restype = i64
@@ -243,6 +245,20 @@ class OracleTSDF:
         n = int(self.L.ora_mesh_generate(self.h, step, surface_thres, max_tri, _p(v), _p(nrm), _p(col)))
         k = min(n, max_tri) * 3
         return v[:k], nrm[:k], (col[:k] if col is not None else None), n
+
+    def query_points(self, mode, xyz, param=0):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(xyz.shape[0], np.uint8)
+        self.L.ora_tsdf_query_points(self.h, mode, param, _p(xyz), xyz.shape[0], _p(out))
+        return out.astype(bool)
+
+    def raycast(self, pos, dir, max_dist):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        n = pos.shape[0]
+        hit = np.zeros(n, np.uint8); end = np.zeros((n, 3), np.float32); ln = np.zeros(n, np.float32)
+        self.L.ora_tsdf_query_raycast(self.h, _p(pos), _p(dir), max_dist, n, _p(hit), _p(end), _p(ln))
+        return hit.astype(bool), end, ln
 
     def esdf(self, gamma=None, max_dist=None):
         n = self.count_active()

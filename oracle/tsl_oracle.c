@@ -871,6 +871,38 @@ int64_t ora_mesh_generate(const ora_tsdf* m, int step, float surface_thres, int6
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* map queries  mapping_common.py:165-204, dense_tsdf.py:148-155                               */
+/* ------------------------------------------------------------------------------------------ */
+static int q_occupied(const ora_tsdf* m, int s, int i, int j, int k) { int o; float t = rd_tsdf(m, s, i, j, k, &o); return t < m->surf_thres; }
+void ora_tsdf_query_points(const ora_tsdf* m, int mode, int param, const float* xyz, int64_t n, uint8_t* out)
+{
+    int s = map_slot(m, m->active);
+    for (int64_t q = 0; q < n; ++q) {
+        int i = rnd_i(xyz[q * 3] / m->vs), j = rnd_i(xyz[q * 3 + 1] / m->vs), k = rnd_i(xyz[q * 3 + 2] / m->vs);
+        int r = 0;
+        if (mode == 0) r = q_occupied(m, s, i, j, k);
+        else if (mode == 1) { int o; (void)rd_tsdf(m, s, i, j, k, &o); r = o == 0; }
+        else for (int a = -param; a < param; ++a) for (int b = -param; b < param; ++b) for (int c = -param; c < param; ++c) r |= q_occupied(m, s, i + a, j + b, k + c);
+        out[q] = (uint8_t)r;
+    }
+}
+void ora_tsdf_query_raycast(const ora_tsdf* m, const float* pos, const float* dir, float max_dist, int64_t n, uint8_t* hit, float* end_xyz, float* len)
+{
+    int s = map_slot(m, m->active);
+    float vs_len = (float)m->cfg.voxel_scale;
+    for (int64_t q = 0; q < n; ++q) {
+        int steps = (int)(max_dist / m->vs);
+        float x[3] = {0, 0, 0}, l = 0.0f; int succ = 0;
+        for (int jj = 0; jj < steps; ++jj) {
+            l = (float)jj * vs_len;
+            for (int a = 0; a < 3; ++a) x[a] = dir[q * 3 + a] * l + pos[q * 3 + a];
+            if (q_occupied(m, s, rnd_i(x[0] / m->vs), rnd_i(x[1] / m->vs), rnd_i(x[2] / m->vs))) { succ = 1; break; }
+        }
+        hit[q] = (uint8_t)succ; for (int a = 0; a < 3; ++a) end_xyz[q * 3 + a] = x[a]; len[q] = l;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* ESDF: definition from dense_esdf.py:228-333 evaluated non-incrementally         */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { float d; int32_t v; } heap_item;

@@ -95,6 +95,9 @@ int ora_tsdf_fuse_finalize_dense(ora_tsdf* global, const int64_t* acc, const int
 int64_t ora_mesh_generate(const ora_tsdf* m, int step, float surface_thres, int64_t max_tri,
                           float* verts, float* normals, float* colors);
 
+void ora_tsdf_query_points(const ora_tsdf* m, int mode, int param, const float* xyz, int64_t n, uint8_t* out);
+void ora_tsdf_query_raycast(const ora_tsdf* m, const float* pos, const float* dir, float max_dist, int64_t n, uint8_t* hit, float* end_xyz, float* len);
+
 /* ---- Octomap hit counter (taichi_octomap.py) ---- */
 typedef struct {
     double map_size_xy, map_size_z, voxel_scale;

@@ -84,6 +84,8 @@ SIGNATURES = {
     "tsl_tsdf_fuse_finalize_dev": (C.c_int, [vp, vp, vp]),
     "tsl_mesh_generate": (C.c_int, [vp, C.c_int, f32, i64, pi32]),
     "tsl_mesh_read": (C.c_int, [vp, vp, vp, vp, i64]),
+    "tsl_tsdf_query_points": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp]),
+    "tsl_tsdf_query_raycast": (C.c_int, [vp, vp, vp, f32, i64, vp, vp, vp]),
     "tsl_esdf_update": (C.c_int, [vp, f32, f32, pi32]),
     "tsl_esdf_export": (C.c_int, [vp, vp, vp, i64, pi64]),
     "tsl_tsdf_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),

@@ -315,6 +315,32 @@ class DenseTSDF(BaseMap):
         self.set_base_pose_submap(idx, R, T)
         return idx
 
+    # ---- batched map queries (mapping_common.py:165-204; the reference exposes them as ti.funcs for TopoGraphGen) ----
+    def _query_points(self, mode, xyz, param=0):
+        xyz = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32).reshape(-1, 3))
+        out = np.zeros(xyz.shape[0], np.uint8)
+        _lib.check(self.L.tsl_tsdf_query_points(self.h, mode, int(param), _vp(xyz), xyz.shape[0], _vp(out)))
+        return out.astype(bool)
+
+    def is_pos_occupy(self, xyz):
+        return self._query_points(0, xyz)
+
+    def is_pos_unobserved(self, xyz):
+        return self._query_points(1, xyz)
+
+    def is_near_pos_occupy(self, xyz, voxel):
+        return self._query_points(2, xyz, voxel)
+
+    def raycast(self, pos, dir, max_dist):
+        """Batched BaseMap.raycast: returns (hit bool[n], end xyz f32[n,3], length f32[n])."""
+        pos = np.ascontiguousarray(np.asarray(pos, dtype=np.float32).reshape(-1, 3))
+        dir = np.ascontiguousarray(np.asarray(dir, dtype=np.float32).reshape(-1, 3))
+        assert pos.shape == dir.shape
+        n = pos.shape[0]
+        hit = np.zeros(n, np.uint8); end = np.zeros((n, 3), np.float32); ln = np.zeros(n, np.float32)
+        _lib.check(self.L.tsl_tsdf_query_raycast(self.h, _vp(pos), _vp(dir), float(max_dist), n, _vp(hit), _vp(end), _vp(ln)))
+        return hit.astype(bool), end, ln
+
     # ---- ESDF (definition from the legacy dense_esdf.py:228-333; see DESIGN.md) -----------------------------------
     def update_esdf(self, gamma=None, max_dist=None):
         """Recompute the ESDF of the active submap; returns the number of relaxation launches."""
