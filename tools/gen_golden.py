@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the CPU oracle (BATCHED mode).
+
+The reference ships no golden vectors and cannot be executed here (no Taichi), so these fixtures do not pin the oracle
+to the reference -- they freeze the oracle's own output so that an accidental change of the restated semantics (or of the
+HIP path that is compared against the same files on the GPU box) is caught.  Inputs are the deterministic synthetic stream."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import BATCHED, OracleOctomap, OracleTSDF  # noqa: E402
+from taichislam_amd.utils import synthetic as syn  # noqa: E402
+from util import lin  # noqa: E402
+
+CFG = dict(map_scale=[10.24, 10.24], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=5.0, min_ray_length=0.3,
+           internal_voxels=10, recast_step=2)
+H, W, NF = 60, 80, 3
+
+
+def frames():
+    K = syn.scaled_intrinsics(H, W)
+    out = []
+    for f in range(NF):
+        R, T = syn.camera_pose(f)
+        out.append((R, T, syn.sphere_room_depth(R, T, H, W, K=K)))
+    return K, out
+
+
+def main():
+    K, fr = frames()
+    o = OracleTSDF(**CFG)
+    o.set_intrinsics(K)
+    stats = [o.integrate_depth(R, T, d, mode=BATCHED) for R, T, d in fr]
+    e = o.export_sparse()
+    order = np.argsort(lin(e["indices"]))
+    v, n, _, ntri = o.generate_mesh(1, 0.4, 200000)
+    tri = np.concatenate([v.reshape(-1, 9), n.reshape(-1, 9)], 1)
+    tri = tri[np.lexsort(tri.T[::-1])]
+    oc = OracleOctomap(map_scale=[12.8, 12.8], voxel_scale=0.1, min_occupy_thres=1, max_ray_length=5.0, K=2, max_submap_num=4)
+    oc.set_intrinsics(K)
+    for R, T, d in fr:
+        oc.integrate_depth(R, T, d)
+    li, lc = oc.export_leaves()
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "tsdf_small.npz"),
+                        indices=e["indices"][order], tsdf_bits=e["TSDF"].view(np.uint16)[order], w_bits=e["W_TSDF"].view(np.uint16)[order],
+                        occupy=e["occupy"][order], stats=np.array([[s[k] for k in sorted(s)] for s in stats], np.int64),
+                        stat_keys=np.array(sorted(stats[0])), mesh=tri.astype(np.float32), ntri=ntri,
+                        octo_idx=li, octo_cnt=lc)
+    print("wrote tests/golden/tsdf_small.npz:", e["TSDF"].shape[0], "voxels,", ntri, "triangles,", li.shape[0], "octomap leaves")
+
+
+if __name__ == "__main__":
+    main()
