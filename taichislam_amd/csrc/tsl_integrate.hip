@@ -475,10 +475,14 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
     __shared__ unsigned long long s_keys[PART_SEGS];
     __shared__ int s_bin[64];
-    __shared__ int s_p;
+    __shared__ int s_p, s_last;
     const int nparts = F.counters[5];
     long long uniq = 0;
     TSL_T0();
+    {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
+        const int nact = F.counters[1];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nact; i += gridDim.x * 256) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
+    }
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
         TSL_TICK(F, 0);
         const int4 pt = F.part_tab[part];
@@ -525,7 +529,12 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
             const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
             const RayRegs R = load_ray<false>(F, P, r);
             const uint32_t wid = TEX ? F.rayFirst[r] + 1u : 0u;
-            for (int j = j0; j < j0 + cnt; ++j) {
+            // lanes start at different offsets inside their (equally long) segments: rays that enter a brick together -- all
+            // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration (64-way LDS conflicts)
+            int off = (int)(threadIdx.x & 63u) % cnt;
+            for (int t = 0; t < cnt; ++t) {
+                const int j = j0 + off;
+                if (++off == cnt) off = 0;
                 float x[3]; int xi[3];
                 step_voxel(R, P, j, x, xi);
                 const int l = (((xi[0] + M.hN) & 15) << 8) | (((xi[1] + M.hN) & 15) << 4) | ((xi[2] + M.hNz) & 15);
@@ -557,6 +566,8 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 }
             }
         } else if (p >= 0) {
+            // brick split over `np` workgroups: add the partial sums into the HBM scratch; the last workgroup to arrive
+            // (arrival ticket, agent-scope release/acquire) applies them.
             unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
             for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
                 const unsigned long long qd = s_acc[l * 2 + 1];
@@ -566,9 +577,38 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                     if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[l]);
                 }
             }
-            if (threadIdx.x == 0 && k == 0) {
-                const int q = __hip_atomic_fetch_add(&F.counters[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                F.shared_list[q] = rk;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int tk = __hip_atomic_fetch_add(&F.ticket[rk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (tk == np - 1) ? 1 : 0;
+                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); F.ticket[rk] = 0; }
+            }
+            __syncthreads();
+            if (s_last) {
+                ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
+                uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+                int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+                for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+                    // the sums were produced by L2 atomics of other CUs: read them at L2 as well
+                    const unsigned long long qn = __hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long qd = __hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (qd != 0ull) {
+                        const uint32_t old = tw[l];
+                        tw[l] = apply_update(old, (long long)qn, (long long)qd);
+                        if ((old >> 16) == 0u) obs[l] = 1;
+                        acc2[l] = make_ulonglong2(0ull, 0ull);
+                        if (TEX) {
+                            uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
+                            const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[wsel - 1u];
+                            *wv = 0u;
+                        }
+                        ++uniq;
+                    }
+                }
             }
         }
         TSL_TICK(F, 4);
@@ -651,9 +691,6 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
         prof_begin(m, TSL_K_INTEGRATE);
         if (P.tex) hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         else hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-        prof_end(m);
-        prof_begin(m, TSL_K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_shared, dim3(64), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);

@@ -496,7 +496,7 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     // ---- phase A: depth -> rays -> brick-sorted segments, into working set `si` on its own stream.  It depends on the
     //      image, the pose and the map GEOMETRY only, so several frames are in flight; the only map access is first-touch
     //      brick allocation and the occupancy byte (atomic claims, safe next to phase B of older frames). ----
-    const int si = m->overlap ? (int)(m->frame_no % TSL_NSETS) : 0;
+    const int si = m->overlap ? (int)(m->frame_no % m->overlap) : 0;      // m->overlap = number of phase-A sets in flight
     FSet& S = m->fset[si];
     hipStream_t sa = m->overlap ? S.st : m->stream;
     if (m->overlap && S.b_pending) TSL_HIP(hipStreamWaitEvent(sa, S.b_done, 0));      // phase B of frame f-NSETS still reads this set
@@ -575,7 +575,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     tsl_tsdf* m = new tsl_tsdf();
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    m->frame_no = 0; m->overlap = 1; m->last_set = 0;
+    m->frame_no = 0; m->overlap = TSL_NSETS; m->last_set = 0;   // phase-A sets in flight (3 is marginally better without per-kernel events, 4 with them)
     for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.execA = nullptr; S.execB = nullptr; S.graph_key = -1; }
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
@@ -659,6 +659,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.ticket, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&F.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc; }
     for (int si = 0; si < TSL_NSETS; ++si) {
         FSet& S = m->fset[si];
@@ -740,7 +741,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         if (S.a_done) (void)hipEventDestroy(S.a_done);
         if (S.b_done) (void)hipEventDestroy(S.b_done);
     }
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag, m->fuse_acc, m->fuse_cnt, m->fuse_cacc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1064,7 +1065,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "graph")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->use_graph = value != 0; return TSL_OK; }      // can only be switched off
-    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value != 0; for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
+    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NSETS ? TSL_NSETS : value); for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
 }
