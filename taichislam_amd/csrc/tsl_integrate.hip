@@ -467,8 +467,8 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 }
 
 // K4d: LDS accumulation per brick, in-place finalise
-template <bool TEX>
-__global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+template <bool TEX, int NT>
+__global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
     const FrameParams& P = *Pp;
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
     TSL_T0();
     {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
         const int nact = F.counters[1];
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < nact; i += gridDim.x * 256) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
+        for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
     }
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
         TSL_TICK(F, 0);
@@ -492,22 +492,22 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
         const int pos = b0 + k * per, run_end = min(b1, pos + per);
         const bool whole = np == 1;
         const int nseg = run_end - pos;
-        unsigned long long kk[PART_SEGS / 256]; int rr[PART_SEGS / 256];
+        unsigned long long kk[PART_SEGS / NT]; int rr[PART_SEGS / NT];
 #pragma unroll
-        for (int q = 0; q < PART_SEGS / 256; ++q) { const int i = q * 256 + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
+        for (int q = 0; q < PART_SEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
         if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, F.act_b[rk]);       // allocate the brick on its first touch ever
         {
             ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
-            for (int i = threadIdx.x; i < TSL_BRK3; i += 256) z[i] = make_ulonglong2(0ull, 0ull);
+            for (int i = threadIdx.x; i < TSL_BRK3; i += NT) z[i] = make_ulonglong2(0ull, 0ull);
         }
         if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
-        if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += 256) s_win[i] = 0u;
+        if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         __syncthreads();
         // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
         // segments of (almost) equal length instead of idling behind the longest one
 #pragma unroll
-        for (int q = 0; q < PART_SEGS / 256; ++q) {
-            const int i = q * 256 + threadIdx.x;
+        for (int q = 0; q < PART_SEGS / NT; ++q) {
+            const int i = q * NT + threadIdx.x;
             rr[q] = -1;
             if (i < nseg) rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1);
         }
@@ -520,10 +520,10 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PART_SEGS / 256; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
+        for (int q = 0; q < PART_SEGS / NT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
         __syncthreads();
         TSL_TICK(F, 1);
-        for (int i = threadIdx.x; i < nseg; i += 256) {
+        for (int i = threadIdx.x; i < nseg; i += NT) {
             const unsigned long long key = s_keys[i];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
             const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
@@ -551,12 +551,12 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
         if (p >= 0 && whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
             int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-            uint32_t old[TSL_BRK3 / 256];
+            uint32_t old[TSL_BRK3 / NT];
 #pragma unroll
-            for (int q = 0; q < TSL_BRK3 / 256; ++q) old[q] = tw[q * 256 + threadIdx.x];      // all row loads in flight at once
+            for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = tw[q * NT + threadIdx.x];      // all row loads in flight at once
 #pragma unroll
-            for (int q = 0; q < TSL_BRK3 / 256; ++q) {
-                const int l = q * 256 + threadIdx.x;
+            for (int q = 0; q < TSL_BRK3 / NT; ++q) {
+                const int l = q * NT + threadIdx.x;
                 const unsigned long long qd = s_acc[l * 2 + 1];
                 if (qd != 0ull) {
                     tw[l] = apply_update(old[q], (long long)s_acc[l * 2], (long long)qd);
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
             // brick split over `np` workgroups: add the partial sums into the HBM scratch; the last workgroup to arrive
             // (arrival ticket, agent-scope release/acquire) applies them.
             unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
-            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            for (int l = threadIdx.x; l < TSL_BRK3; l += NT) {
                 const unsigned long long qd = s_acc[l * 2 + 1];
                 if (qd != 0ull) {
                     __hip_atomic_fetch_add(acc + l * 2, s_acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(MapDev M, FrameDev F, 
                 ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
                 uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
                 int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-                for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+                for (int l = threadIdx.x; l < TSL_BRK3; l += NT) {
                     // the sums were produced by L2 atomics of other CUs: read them at L2 as well
                     const unsigned long long qn = __hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long qd = __hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -689,8 +689,10 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
     FrameDev& F = S.F;
     if (P.variant == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
-        if (P.tex) hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-        else hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 256>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        else if (m->wg == 1024) hipLaunchKernelGGL((k_integrate_bricks<false, 1024>), dim3(1024), dim3(1024), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        else if (m->wg == 512) hipLaunchKernelGGL((k_integrate_bricks<false, 512>), dim3(1024), dim3(512), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        else hipLaunchKernelGGL((k_integrate_bricks<false, 256>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);

@@ -56,6 +56,8 @@ template <> struct KeyOps<uint64_t> {
 // ------------------------------------------------------------------------------------------------------
 // K1: depth image -> sensor-centred voxel key + f16 payload       dense_tsdf.py:188-213, process_point :227-229
 // ------------------------------------------------------------------------------------------------------
+template <typename K> __device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first);
+
 template <typename K>
 __global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __restrict__ Pp, FrameDev F, K* __restrict__ keys)
 {
@@ -63,7 +65,8 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __res
     const uint16_t* __restrict__ depth = static_cast<const uint16_t*>(P.input);
     const int total = P.hh * P.ww;
     const int p = blockIdx.x * 256 + threadIdx.x;
-    bool gate = false, inside = false;
+    bool gate = false, inside = false, opened = false;
+    int slot = -1;
     if (p < total) {
         const int jj = p / P.ww, ii = p - jj * P.ww;
         const int j = jj * P.step, i = ii * P.step;
@@ -88,10 +91,11 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __res
                 payload.y = (uint32_t)f2h(mz) | ((uint32_t)f2h(dep) << 16);
             }
         }
-        keys[p] = key;
-        F.vals[p] = (uint32_t)p;
         F.pix[p] = payload;
+        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened); F.slot_of_pix[p] = slot; }
+        else { keys[p] = key; F.vals[p] = (uint32_t)p; }
     }
+    if (P.group) { const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot; }
     block_count_add(&F.stats->p_valid, inside);
     block_count_add(&F.stats->p_oob, gate && !inside);
 }
@@ -104,7 +108,8 @@ __global__ void __launch_bounds__(256) k_voxelize_points(const FrameParams* __re
     const float* __restrict__ xyz = static_cast<const float*>(P.input);
     const int n = P.total;
     const int p = blockIdx.x * 256 + threadIdx.x;
-    bool gate = false, inside = false;
+    bool gate = false, inside = false, opened = false;
+    int slot = -1;
     if (p < n) {
         const float px = xyz[(size_t)p * 3], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
         const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;                   // :175
@@ -123,18 +128,73 @@ __global__ void __launch_bounds__(256) k_voxelize_points(const FrameParams* __re
                 payload.y = (uint32_t)f2h(mz) | ((uint32_t)f2h(len) << 16);
             }
         }
-        keys[p] = key;
-        F.vals[p] = (uint32_t)p;
         F.pix[p] = payload;
+        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened); F.slot_of_pix[p] = slot; }
+        else { keys[p] = key; F.vals[p] = (uint32_t)p; }
     }
+    if (P.group) { const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot; }
     block_count_add(&F.stats->p_valid, inside);
     block_count_add(&F.stats->p_oob, gate && !inside);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K3: one thread per sorted entry; segment heads replay their pixels in raster order with per-add f16
-// rounding (process_point :230-232) and emit the ray record (process_new_pcl :242-249)
+// K3: one ray per sensor voxel.  The voxel's pixels are replayed in raster order with per-add f16 rounding
+// (process_point :230-234) and turned into a ray record (process_new_pcl :242-249).
 // ------------------------------------------------------------------------------------------------------
+struct PixAcc { int cnt; h16 sx, sy, sz, zs, cr, cg, cb; };
+
+__device__ __forceinline__ void acc_pixel(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
+{
+    if (P.tex) {                                                                     // new_pcl_sum_color += rgb  (:234)
+        const uint8_t* rgb;
+        if (P.points) rgb = P.tex_input + (size_t)pid * 3;                           // :179-183
+        else {
+            const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
+            const int pj = jj * P.step, pi = ii * P.step;
+            if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;       // :206
+            else {                                                                   // color_ind_from_depth_pt  mapping_common.py:43-58
+                int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
+                int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
+                if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }          // the reference tests column against rows (:56)
+                if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                            // keep the read inside the buffer
+                rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
+            }
+        }
+        A.cr = hadd(A.cr, f2h((float)rgb[0])); A.cg = hadd(A.cg, f2h((float)rgb[1])); A.cb = hadd(A.cb, f2h((float)rgb[2]));
+    }
+    const uint2 pl = F.pix[pid];
+    A.sx = hadd(A.sx, (h16)(pl.x & 0xffffu)); A.sy = hadd(A.sy, (h16)(pl.x >> 16));              // :231
+    A.sz = hadd(A.sz, (h16)(pl.y & 0xffffu)); A.zs = hadd(A.zs, (h16)(pl.y >> 16));              // :232
+    ++A.cnt;                                                                                       // :230
+}
+
+// mean point -> ray record; false for degenerate rays (zero length / z^2 not in (0, inf))
+__device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev& F, const PixAcc& A, uint32_t first, uint4* rec, int* nsteps)
+{
+    const h16 c = f2h((float)A.cnt);                                                 // :242
+    const h16 px = hdiv(A.sx, c), py = hdiv(A.sy, c), pz = hdiv(A.sz, c);            // :243
+    const h16 len = hsqrt(hadd(hadd(hmul(px, px), hmul(py, py)), hmul(pz, pz)));     // :244
+    const h16 zbar = hdiv(A.zs, c);                                                  // :247
+    const float lenf = h2f(len), zzf = h2f(hmul(zbar, zbar));
+    if (!((lenf > 0.0f) && isfinite(lenf) && (zzf > 0.0f) && isfinite(zzf))) return false;
+    const h16 dx = hdiv(px, len), dy = hdiv(py, len), dz = hdiv(pz, len);            // :245
+    float nf = lenf / P.vs + P.internal_f;                                           // :249
+    if (P.max_steps_f < nf) nf = P.max_steps_f;
+    *nsteps = (int)nf;
+    float w = 1.0f / zzf;                                                            // w_x_p :216-225 (d >= 0 always, Q3)
+    if (w > TSL_W_CLAMP) w = TSL_W_CLAMP;
+    rec->x = (uint32_t)px | ((uint32_t)py << 16);
+    rec->y = (uint32_t)pz | ((uint32_t)dx << 16);
+    rec->z = (uint32_t)dy | ((uint32_t)dz << 16);
+    rec->w = __float_as_uint(w);
+    if (P.tex) {                                                                     // color = sum_color/c/255  (:269)
+        const h16 r16 = f2h(h2f(hdiv(A.cr, c)) / 255.0f), g16 = f2h(h2f(hdiv(A.cg, c)) / 255.0f), b16 = f2h(h2f(hdiv(A.cb, c)) / 255.0f);
+        F.colpix[first] = make_uint2((uint32_t)r16 | ((uint32_t)g16 << 16), (uint32_t)b16);
+    }
+    return true;
+}
+
+// (a) pixels grouped by a stable radix sort of the sensor-voxel keys: one thread per sorted entry, segment heads work
 template <typename K>
 __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restrict__ Pp, FrameDev F, const K* __restrict__ keys_s)
 {
@@ -145,67 +205,164 @@ __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restric
     bool head = false, ok = false;
     uint4 rec = make_uint4(0, 0, 0, 0);
     int nsteps = 0;
-    uint32_t first_pix = 0;
+    uint32_t first = 0;
     if (i < total) {
         const K k = keys_s[i];
         head = (k != bad) && (i == 0 || keys_s[i - 1] != k);
         if (head) {
-            int cnt = 0;
-            h16 sx = 0, sy = 0, sz = 0, zs = 0, cr = 0, cg = 0, cb = 0;
-            const uint32_t first = F.vals_s[i];                                              // stable sort: the run starts with its lowest pixel id
-            for (int q = i; q < total && keys_s[q] == k; ++q) {
-                const uint32_t pid = F.vals_s[q];
-                if (P.tex) {                                                                 // new_pcl_sum_color += rgb  (:234)
-                    const uint8_t* rgb;
-                    if (P.points) rgb = P.tex_input + (size_t)pid * 3;                       // :179-183
-                    else {
-                        const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
-                        const int pj = jj * P.step, pi = ii * P.step;
-                        if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;   // :206
-                        else {                                                               // color_ind_from_depth_pt  mapping_common.py:43-58
-                            int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
-                            int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
-                            if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }      // the reference tests column against rows (:56)
-                            if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                        // keep the read inside the buffer
-                            rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
-                        }
-                    }
-                    cr = hadd(cr, f2h((float)rgb[0])); cg = hadd(cg, f2h((float)rgb[1])); cb = hadd(cb, f2h((float)rgb[2]));
-                }
-                const uint2 pl = F.pix[pid];
-                sx = hadd(sx, (h16)(pl.x & 0xffffu)); sy = hadd(sy, (h16)(pl.x >> 16));      // :231
-                sz = hadd(sz, (h16)(pl.y & 0xffffu)); zs = hadd(zs, (h16)(pl.y >> 16));      // :232
-                ++cnt;                                                                       // :230
-            }
-            const h16 c = f2h((float)cnt);                                                   // :242
-            const h16 px = hdiv(sx, c), py = hdiv(sy, c), pz = hdiv(sz, c);                  // :243
-            const h16 len = hsqrt(hadd(hadd(hmul(px, px), hmul(py, py)), hmul(pz, pz)));     // :244
-            const h16 zbar = hdiv(zs, c);                                                    // :247
-            const float lenf = h2f(len), zzf = h2f(hmul(zbar, zbar));
-            ok = (lenf > 0.0f) && isfinite(lenf) && (zzf > 0.0f) && isfinite(zzf);
-            if (ok) {
-                const h16 dx = hdiv(px, len), dy = hdiv(py, len), dz = hdiv(pz, len);        // :245
-                float nf = lenf / P.vs + P.internal_f;                                       // :249
-                if (P.max_steps_f < nf) nf = P.max_steps_f;
-                nsteps = (int)nf;
-                float w = 1.0f / zzf;                                                        // w_x_p :216-225 (d >= 0 always, Q3)
-                if (w > TSL_W_CLAMP) w = TSL_W_CLAMP;
-                rec.x = (uint32_t)px | ((uint32_t)py << 16);
-                rec.y = (uint32_t)pz | ((uint32_t)dx << 16);
-                rec.z = (uint32_t)dy | ((uint32_t)dz << 16);
-                rec.w = __float_as_uint(w);
-                if (P.tex) {                                                                 // color = sum_color/c/255  (:269)
-                    const h16 r16 = f2h(h2f(hdiv(cr, c)) / 255.0f), g16 = f2h(h2f(hdiv(cg, c)) / 255.0f), b16 = f2h(h2f(hdiv(cb, c)) / 255.0f);
-                    F.colpix[first] = make_uint2((uint32_t)r16 | ((uint32_t)g16 << 16), (uint32_t)b16);
-                }
-                first_pix = first;
-            }
+            PixAcc A = {};
+            first = F.vals_s[i];                                                     // stable sort: the run starts with its lowest pixel id
+            for (int q = i; q < total && keys_s[q] == k; ++q) acc_pixel(P, F, F.vals_s[q], A);
+            ok = finish_ray(P, F, A, first, &rec, &nsteps);
         }
     }
     const int r = block_reserve(F.nrays, ok);
-    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = first_pix; }
+    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = first; }
     block_count_add(&F.stats->v_pcl, head);
     block_count_add(&F.stats->v_skipped, head && !ok);
+}
+
+// (b) pixels grouped through a hash table of sensor voxels (no sort): k_voxelize_* insert every pixel and count per voxel,
+// k_group_scan lays the groups out, k_group_fill writes each pixel id into its group (arrival order), and here one thread
+// per voxel walks its group in ASCENDING pixel id -- i.e. raster order -- by repeated selection of the next larger id.
+// Groups are small (a sensor voxel rarely sees more than a dozen pixels); groups above GROUP_SMALL are sorted by a whole
+// workgroup in k_build_rays_big.
+#define GROUP_SMALL 48
+#define GROUP_BIG_CAP 16384
+#define H_EMPTY32 0xffffffffu
+template <typename K> __device__ __forceinline__ K h_empty() { return (K)~(K)0; }
+template <typename K> __device__ __forceinline__ uint32_t h_hash(K key, int log2n)
+{ return (uint32_t)(((unsigned long long)key * 0x9E3779B97F4A7C15ull) >> (64 - log2n)); }
+
+// insert pixel p's sensor voxel; returns the table slot.  *first = this pixel opened the voxel in this frame
+template <typename K>
+__device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first)
+{
+    K* tab = reinterpret_cast<K*>(F.hkey);
+    const uint32_t mask = (1u << F.hlog2) - 1u;
+    uint32_t h = h_hash<K>(key, F.hlog2);
+    for (;;) {
+        const K cur = atomicCAS(&tab[h], h_empty<K>(), key);
+        if (cur == h_empty<K>() || cur == key) break;
+        h = (h + 1u) & mask;
+    }
+    *first = atomicAdd(&F.hcnt[h], 1) == 0;
+    return (int)h;
+}
+
+__global__ void __launch_bounds__(256) k_group_scan(FrameDev F)
+{
+    // list position of every group: groups only have to be contiguous, not ordered, so a block-aggregated reservation
+    // of `count` entries replaces a prefix scan
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nact = F.counters[6];
+    if (blockIdx.x * 256 >= nact) return;
+    const int sl = i < nact ? F.act[i] : 0;
+    const int c = i < nact ? F.hcnt[sl] : 0;
+    int inc = c;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = atomicAdd(&F.counters[0], s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+    __syncthreads();
+    int off = s_base + inc - c;
+    for (int q = 0; q < w; ++q) off += s_wave[q];
+    if (i < nact) F.hoff[sl] = off;
+}
+
+__global__ void __launch_bounds__(256) k_group_fill(const FrameParams* __restrict__ Pp, FrameDev F)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Pp->total) return;
+    const int sl = F.slot_of_pix[p];
+    if (sl < 0) return;
+    F.plist[F.hoff[sl] + atomicAdd(&F.hfill[sl], 1)] = (uint32_t)p;
+}
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_build_rays_hash(const FrameParams* __restrict__ Pp, FrameDev F)
+{
+    const FrameParams& P = *Pp;
+    const int nact = F.counters[6];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool head = false, ok = false, big = false;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    int nsteps = 0;
+    uint32_t first = 0;
+    if (i < nact) {
+        const int sl = F.act[i];
+        const int n = F.hcnt[sl];
+        const uint32_t* ids = F.plist + F.hoff[sl];
+        if (n > GROUP_SMALL) big = true;
+        else {
+            head = true;
+            PixAcc A = {};
+            long long last = -1;
+            for (int k = 0; k < n; ++k) {                                            // next pixel in raster order
+                uint32_t best = 0xffffffffu;
+                for (int q = 0; q < n; ++q) { const uint32_t v = ids[q]; if ((long long)v > last && v < best) best = v; }
+                if (k == 0) first = best;
+                acc_pixel(P, F, best, A);
+                last = (long long)best;
+            }
+            ok = finish_ray(P, F, A, first, &rec, &nsteps);
+            reinterpret_cast<K*>(F.hkey)[sl] = h_empty<K>(); F.hcnt[sl] = 0; F.hfill[sl] = 0;      // table is empty again for the next frame of this set
+        }
+    }
+    const int bq = block_reserve(&F.counters[7], big);
+    if (big) F.big[bq] = F.act[i];
+    const int r = block_reserve(F.nrays, ok);
+    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = first; }
+    block_count_add(&F.stats->v_pcl, head);
+    block_count_add(&F.stats->v_skipped, head && !ok);
+}
+
+// big groups: one workgroup per sensor voxel, ids bitonic-sorted in LDS, thread 0 replays them
+template <typename K>
+__global__ void __launch_bounds__(256) k_build_rays_big(const FrameParams* __restrict__ Pp, FrameDev F, MapDev M)
+{
+    const FrameParams& P = *Pp;
+    __shared__ uint32_t s_id[GROUP_BIG_CAP];
+    const int nbig = F.counters[7];
+    for (int g = blockIdx.x; g < nbig; g += gridDim.x) {
+        const int sl = F.big[g];
+        const int n = F.hcnt[sl];
+        const uint32_t* ids = F.plist + F.hoff[sl];
+        if (n > GROUP_BIG_CAP) { if (threadIdx.x == 0) atomicOr(M.err, 8); }
+        else {
+            int m2 = 1; while (m2 < n) m2 <<= 1;
+            for (int q = threadIdx.x; q < m2; q += 256) s_id[q] = q < n ? ids[q] : 0xffffffffu;
+            __syncthreads();
+            for (int k = 2; k <= m2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int q = threadIdx.x; q < m2; q += 256) {
+                        const int x = q ^ j;
+                        if (x > q) {
+                            const uint32_t a = s_id[q], b = s_id[x];
+                            const bool up = (q & k) == 0;
+                            if ((a > b) == up) { s_id[q] = b; s_id[x] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            if (threadIdx.x == 0) {
+                PixAcc A = {};
+                for (int q = 0; q < n; ++q) acc_pixel(P, F, s_id[q], A);
+                uint4 rec; int nsteps = 0;
+                const bool ok = finish_ray(P, F, A, s_id[0], &rec, &nsteps);
+                if (ok) {
+                    const int r = __hip_atomic_fetch_add(F.nrays, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = s_id[0];
+                } else atomic_add_i64(&F.stats->v_skipped, 1);
+                atomic_add_i64(&F.stats->v_pcl, 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { reinterpret_cast<K*>(F.hkey)[sl] = h_empty<K>(); F.hcnt[sl] = 0; F.hfill[sl] = 0; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -442,13 +599,24 @@ static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStre
     if (points) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
     else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
     prof_end(m, sa);
-    prof_begin(m, TSL_K_SORT, sa);
-    size_t tb = m->sort_temp_bytes;
-    TSL_HIP(rocprim::radix_sort_pairs(S.sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * m->P.pcl_bits + 1), sa));
-    prof_end(m, sa);
-    prof_begin(m, TSL_K_RAYS, sa);
-    hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, (const K*)keys_s);
-    prof_end(m, sa);
+    if (m->P.group) {
+        prof_begin(m, TSL_K_SORT, sa);
+        hipLaunchKernelGGL(k_group_scan, dim3(blocks), dim3(256), 0, sa, F);
+        hipLaunchKernelGGL(k_group_fill, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
+        prof_end(m, sa);
+        prof_begin(m, TSL_K_RAYS, sa);
+        hipLaunchKernelGGL(k_build_rays_hash<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
+        hipLaunchKernelGGL(k_build_rays_big<K>, dim3(64), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, m->M);
+        prof_end(m, sa);
+    } else {
+        prof_begin(m, TSL_K_SORT, sa);
+        size_t tb = m->sort_temp_bytes;
+        TSL_HIP(rocprim::radix_sort_pairs(S.sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * m->P.pcl_bits + 1), sa));
+        prof_end(m, sa);
+        prof_begin(m, TSL_K_RAYS, sa);
+        hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, (const K*)keys_s);
+        prof_end(m, sa);
+    }
     return launch_segments(m, S, total, sa);
 }
 
@@ -505,13 +673,13 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     // replay captured graphs for same-shaped depth frames: 7 host calls per frame instead of ~22
     bool graph = m->use_graph && m->overlap && !m->prof_on && !xyz_dev && total > 0;
     if (graph) {
-        const long long key = ((long long)P.H << 40) ^ ((long long)P.W << 24) ^ ((long long)P.step << 16) ^ ((long long)P.variant << 8) ^ (long long)P.split ^ ((long long)sizeof(K) << 60) ^ ((long long)P.tex << 59);
+        const long long key = ((long long)P.H << 40) ^ ((long long)P.W << 24) ^ ((long long)P.step << 16) ^ ((long long)P.variant << 8) ^ (long long)P.split ^ ((long long)sizeof(K) << 60) ^ ((long long)P.tex << 59) ^ ((long long)P.group << 58);
         if (S.graph_key != key && build_graphs<K>(m, S, total, key) != TSL_OK) { m->use_graph = 0; graph = false; }
     }
     if (graph) {
         TSL_HIP(hipGraphLaunch(S.execA, sa));
     } else {
-        int rc = enqueue_phase_a<K>(m, S, total, xyz_dev != nullptr, sa); if (rc) return rc;
+        if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, S, total, xyz_dev != nullptr, sa); if (rc) return rc; }
     }
     if (m->overlap) {
         TSL_HIP(hipEventRecord(S.a_done, sa));
@@ -519,7 +687,7 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     }
     // ---- phase B: apply to the map, in frame order on the main stream ----
     if (graph) { TSL_HIP(hipGraphLaunch(S.execB, m->stream)); }
-    else if (total > 0) { int rc = launch_apply(m, S, total); if (rc) return rc; }
+    else if (total > 0 && (m->phases & 2)) { int rc = launch_apply(m, S, total); if (rc) return rc; }
     if (m->overlap) { TSL_HIP(hipEventRecord(S.b_done, m->stream)); S.b_pending = true; }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -618,6 +786,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256;
     m->active = 0; m->variant = 2; m->split = 2; m->use_graph = std::getenv("TSL_GRAPH") ? 1 : 0;      // hipGraph replay is opt-in: it halves the host enqueue time but the
                                                                // pipeline is GPU-bound, and replay aborted once inside a long multi-handle test session
     m->prof_on = false; m->prof_open = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -674,6 +843,19 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&G.rayA, 16 * np))) return rc;
         if ((rc = own((void**)&G.rayN, 4 * np))) return rc;
         if ((rc = own((void**)&G.rayFirst, 4 * np))) return rc;
+        {   // sensor-voxel hash table (>= 4 entries per possible point) and the group lists
+            int lg = 10; while ((1ll << lg) < 4 * (long long)np) ++lg;
+            G.hlog2 = lg;
+            const size_t hs = (size_t)1 << lg;
+            if ((rc = dev_alloc(m, &G.hkey, 8 * hs, 0xff))) return rc; S.owned.push_back(G.hkey);
+            if ((rc = own((void**)&G.hcnt, 4 * hs))) return rc;
+            if ((rc = own((void**)&G.hoff, 4 * hs))) return rc;
+            if ((rc = own((void**)&G.hfill, 4 * hs))) return rc;
+            if ((rc = own((void**)&G.slot_of_pix, 4 * np))) return rc;
+            if ((rc = own((void**)&G.act, 4 * np))) return rc;
+            if ((rc = own((void**)&G.plist, 4 * np))) return rc;
+            if ((rc = own((void**)&G.big, 4 * (np / GROUP_SMALL + 16)))) return rc;
+        }
         if (cfg->texture_enabled) { if ((rc = own((void**)&G.colpix, 8 * np))) return rc; }
         S.header_bytes = 128;
         if ((rc = own(&S.header, S.header_bytes))) return rc;
@@ -775,7 +957,7 @@ static int check_dev_err(tsl_tsdf* m)
 {
     int e = 0; int rc = read_int(m, m->M.err, &e); if (rc) return rc;
     if (e) {
-        set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : ""));
+        set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : "") + ((e & 4) ? " ray segments" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : ""));
         (void)hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream);
         return TSL_ERR_CAPACITY;
     }
@@ -784,6 +966,7 @@ static int check_dev_err(tsl_tsdf* m)
 int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
 {
     TSL_REQUIRE(m && name && value, "null");
+    if (!std::strcmp(name, "group")) { *value = m->P.group; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
     if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }
@@ -1063,7 +1246,10 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
 {
     TSL_REQUIRE(m && name, "null");
     if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
+    if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; for (auto& S : m->fset) drop_graphs(S); return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
+    if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); m->wg = value; return TSL_OK; }
+    if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
     if (!std::strcmp(name, "graph")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->use_graph = value != 0; return TSL_OK; }      // can only be switched off
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NSETS ? TSL_NSETS : value); for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }

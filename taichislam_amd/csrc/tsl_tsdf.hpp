@@ -20,6 +20,7 @@ struct FrameParams {
     int   th, tw, tex, same_proj;
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
+    int   group;                       // 1: group pixels per sensor voxel through a hash table, 0: stable radix sort (rocPRIM)
     const void* input; int total;      // device pointer of the depth image / point array of this frame, pixels or points to visit
     const uint8_t* tex_input; int points;   // texture [th][tw][3] (depth input) or rgb [n][3] (point input); input kind
 };
@@ -35,6 +36,11 @@ struct FrameDev {
     uint4* rayA;                                 // per ray: {p01, p2|d0, d12, w bits}
     int*   rayN;                                 // per ray: step count
     uint32_t* rayFirst;                          // per ray: index of the first pixel / point of its sensor voxel (texture: colour winner order)
+    void*  hkey; int *hcnt, *hoff, *hfill; int hlog2;   // sensor-voxel hash table: key, pixel count, first list position, fill cursor
+    int*   slot_of_pix;                          // [pixel] -> table slot or -1
+    int*   act;                                  // sensor voxels opened in this frame (arrival order), count in counters[6]
+    uint32_t* plist;                             // pixel ids grouped per sensor voxel (arrival order inside a group)
+    int*   big;                                  // groups larger than GROUP_SMALL, count in counters[7]
     uint2* colpix;                               // [pixel] f16 colour {r|g<<16, b} of the ray opened by that pixel (texture)
     tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
     int*   nrays;                                // ray count of this frame
@@ -106,7 +112,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split;
+    int variant, split, phases, wg;
     int use_graph;                       // 1: replay captured hipGraphs for same-shaped depth frames (when profiling is off)
     int64_t bytes;
 };

@@ -44,10 +44,12 @@ def test_depth_with_texture(hip_lib, same_proj):
     assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
 
 
-def test_points_with_colour(hip_lib):
+@pytest.mark.parametrize("group", [0, 1])
+def test_points_with_colour(hip_lib, group):
     from oracle import BATCHED
     rng = np.random.default_rng(11)
     g, o = make_pair(TEX, syn.K_DEPTH)
+    g.set_option("group", group)
     R, T = syn.camera_pose(2)
     d = rng.normal(size=(15000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     pts = (d * rng.uniform(0.5, 4.0, size=(15000, 1))).astype(np.float32)

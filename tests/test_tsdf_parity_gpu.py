@@ -43,6 +43,15 @@ def test_kernel_variants_agree(hip_lib, variant, split):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"variant {variant} split {split}")
 
 
+@pytest.mark.parametrize("wg", [256, 512, 1024])
+def test_integrate_workgroup_sizes(hip_lib, wg):
+    K, frames = small_stream(2)
+    g, o = make_pair(SMALL, K)
+    g.set_option("wg", wg)
+    _run_both(g, o, frames)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"workgroup size {wg}")
+
+
 def test_fast_division_is_verified_and_optional(hip_lib):
     """x / voxel_scale is replaced by an fma-refined reciprocal product only after the device has checked it against IEEE
     division for every float; forcing IEEE division must give the same map."""
@@ -111,6 +120,43 @@ def test_points_input(hip_lib):
     assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
     assert so["v_skipped"] >= 1
     assert_export_equal(g.export_submap(), o.export_sparse(), "points")
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_pixel_grouping_paths(hip_lib, group):
+    """Pixels of one sensor voxel are summed in raster order with per-add f16 rounding (dense_tsdf.py:230-234) whether the
+    groups come from the stable radix sort (group=0) or from the sensor-voxel hash table (group=1)."""
+    K, frames = small_stream(3)
+    g, o = make_pair(SMALL, K)
+    g.set_option("group", group)
+    assert g.get_option("group") == group
+    _run_both(g, o, frames)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"group {group}")
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_crowded_sensor_voxels(hip_lib, group):
+    """Point clouds that put tens to thousands of points into one sensor voxel: per-thread replay, the workgroup-sorted
+    path for big groups, and the f16 saturation of the sums that goes with them."""
+    from oracle import BATCHED
+    rng = np.random.default_rng(23)
+    g, o = make_pair(SMALL, syn.K_DEPTH)
+    g.set_option("group", group)
+    R, T = syn.camera_pose(1)
+    centres = np.array([[1.0, 0.3, 0.2], [-0.8, 1.1, 0.1], [0.5, -1.4, 0.3], [2.0, 2.0, 0.5], [-1.5, -0.7, 0.4]])
+    sizes = [40, 49, 300, 5000, 9]
+    blobs = [c + rng.uniform(-0.015, 0.015, size=(n, 3)) for c, n in zip(centres, sizes)]
+    d = rng.normal(size=(3000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = np.concatenate(blobs + [d * rng.uniform(0.5, 4.0, size=(3000, 1))]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    g.recast_pcl_to_map(R, T, pts, np.array([]))
+    so = o.integrate_points(R, T, pts, None, mode=BATCHED)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"crowded voxels, group {group}")
+    g.recast_pcl_to_map(R, T, pts[::-1].copy(), np.array([]))                   # the hash table must be clean again
+    o.integrate_points(R, T, pts[::-1].copy(), None, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"crowded voxels second frame, group {group}")
 
 
 @pytest.mark.parametrize("h,w,step", [(121, 163, 2), (120, 160, 3), (97, 131, 1)])
