@@ -118,6 +118,27 @@ __device__ __forceinline__ int wave_reserve(int* ctr, bool pred)
     return pred ? base + rank_below(m) : -1;
 }
 
+// block-aggregated reservation of n items per thread (256-thread blocks): returns the first index of this thread's range
+__device__ __forceinline__ int block_reserve_n(int* ctr, int n)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_b;
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    int inc = n;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        s_b = tot ? __hip_atomic_fetch_add(ctr, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+    __syncthreads();
+    int off = s_b + inc - n;
+    for (int w = 0; w < wid; ++w) off += s_w[w];
+    __syncthreads();
+    return off;
+}
+
 // block-aggregated reservation (256-thread blocks): ONE global atomic per block; must be reached by every thread
 __device__ __forceinline__ int block_reserve(int* ctr, bool pred)
 {

@@ -77,12 +77,13 @@ __device__ __forceinline__ long long step_term(const RayRegs& R, const float* x)
     return to_fix(R.w * sd);
 }
 // occupy[pos_p] = 1  (dense_tsdf.py:248)
+template <bool COOP = true>
 __device__ __forceinline__ void mark_occupied(const MapDev& M, const FrameParams& P, const RayRegs& R)
 {
     const int oi = rnd_i(div_vs(R.P0, P.vs, P.rvs, P.fastdiv)), oj = rnd_i(div_vs(R.P1, P.vs, P.rvs, P.fastdiv)), ok = rnd_i(div_vs(R.P2, P.vs, P.rvs, P.fastdiv));
     if (in_volume(M, oi, oj, ok)) {
         int l; const int b = brick_of(M, oi, oj, ok, &l);
-        const int p = pool_claim(M, P.slot, b);
+        const int p = pool_claim<COOP>(M, P.slot, b);
         if (p >= 0) M.occ[(size_t)p * TSL_BRK3 + l] = 1;
     }
 }
@@ -242,14 +243,15 @@ __device__ __forceinline__ int next_axis_event(float d, float T, const FramePara
 // ---- small open-addressing hash in LDS: brick id -> counter (a block / tile only touches ~100 distinct bricks) ----
 #define LH_SIZE 1024
 #define LH_EMPTY (-1)
+template <int LOG2 = 10>
 __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-insert; returns the table index or -1 when full
 {
-    unsigned h = ((unsigned)b * 2654435761u) >> 22;
-    for (int probe = 0; probe < LH_SIZE; ++probe) {
+    unsigned h = ((unsigned)b * 2654435761u) >> (32 - LOG2);
+    for (int probe = 0; probe < (1 << LOG2); ++probe) {
         const int k = keys[h];
         if (k == b) return (int)h;
         if (k == LH_EMPTY) { const int old = atomicCAS(&keys[h], LH_EMPTY, b); if (old == LH_EMPTY || old == b) return (int)h; }
-        h = (h + 1) & (LH_SIZE - 1);
+        h = (h + 1) & ((1u << LOG2) - 1u);
     }
     return -1;
 }
@@ -261,18 +263,18 @@ __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-inse
 // once per block.
 // segment: [0,6) count [6,18) first step [18,40) ray [40,64) brick id
 #define STG_RAY_BITS 22
+#define SEG_RAY_SLOTS 16        // private segment slots per ray (split evenly over its lanes); further segments are appended behind them
+#define SEG_LH_LOG2 9
+#define SEG_LH (1 << SEG_LH_LOG2)
 #define STG_B_SHIFT (SEG_CNT_BITS + SEG_J_BITS + STG_RAY_BITS)
 __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
     const FrameParams& P = *Pp;
-    __shared__ unsigned long long s_seg[SEG_LDS_CAP];
-    __shared__ int s_key[LH_SIZE];
-    __shared__ int s_cnt[LH_SIZE];
-    __shared__ int s_n, s_base;
+    __shared__ int s_key[SEG_LH];
+    __shared__ int s_cnt[SEG_LH];
     TSL_T0();
     TSL_TICK(F, 8);
-    for (int i = threadIdx.x; i < LH_SIZE; i += 256) { s_key[i] = LH_EMPTY; s_cnt[i] = 0; }
-    if (threadIdx.x == 0) s_n = 0;
+    for (int i = threadIdx.x; i < SEG_LH; i += 256) { s_key[i] = LH_EMPTY; s_cnt[i] = 0; }
     __syncthreads();
     TSL_TICK(F, 0);
 
@@ -282,6 +284,9 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
     const int nrays = *F.nrays;
     long long n_ok = 0, n_oob = 0;
     const bool working = __any(r < nrays);
+    const int spl = SEG_RAY_SLOTS / split;                              // private slots of this lane in the frame's segment array
+    unsigned long long* myseg = F.seg + (size_t)gid * spl;
+    int nslot = 0;
     if (r < nrays) {
         const RayRegs R = load_ray(F, P, r);
         if (sub == 0) mark_occupied(M, P, R);
@@ -309,19 +314,19 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
                         const int cnt = min(e - j0, SEG_MAX_CNT);
                         const unsigned long long en = ((unsigned long long)b << STG_B_SHIFT) | ((unsigned long long)r << (SEG_CNT_BITS + SEG_J_BITS)) |
                                                       ((unsigned long long)j0 << SEG_CNT_BITS) | (unsigned long long)cnt;
-                        const int idx = atomicAdd(&s_n, 1);
-                        const int hs = idx < SEG_LDS_CAP ? lh_slot(s_key, b) : -1;
-                        if (hs >= 0) { s_seg[idx] = en; atomicAdd(&s_cnt[hs], 1); }
-                        else {      // rare: block staging or hash full -> append and count directly
-                            if (idx < SEG_LDS_CAP) s_seg[idx] = ~0ull;
-                            const int pos = __hip_atomic_fetch_add(&F.counters[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (pos < F.seg_cap) {
-                                F.seg[pos] = en;
-                                if (__hip_atomic_fetch_add(&F.bhist[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                                    const int q = __hip_atomic_fetch_add(&F.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if (q < F.max_frame_bricks) F.act_b[q] = b; else atomicOr(M.err, 2);
-                                }
-                            } else atomicOr(M.err, 4);
+                        bool stored = true;
+                        if (nslot < spl) myseg[nslot++] = en;
+                        else {      // more brick crossings than private slots: append behind the per-ray slots
+                            const long long pos = (long long)nrays * SEG_RAY_SLOTS + __hip_atomic_fetch_add(&F.counters[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (pos < F.seg_cap) F.seg[pos] = en; else { stored = false; atomicOr(M.err, 4); }
+                        }
+                        if (stored) {
+                            const int hs = lh_slot<SEG_LH_LOG2>(s_key, b);
+                            if (hs >= 0) atomicAdd(&s_cnt[hs], 1);
+                            else if (__hip_atomic_fetch_add(&F.bhist[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // hash full (incoherent rays)
+                                const int q = __hip_atomic_fetch_add(&F.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (q < F.max_frame_bricks) F.act_b[q] = b; else atomicOr(M.err, 2);
+                            }
                         }
                     }
                 } else n_oob += e - j;
@@ -335,19 +340,12 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
             }
         }
     }
+    if (r < nrays) for (int q = nslot; q < spl; ++q) myseg[q] = ~0ull;        // unused private slots
     TSL_TICK(F, 2);
     __syncthreads();
     TSL_TICK(F, 3);
-    const int n = min(s_n, SEG_LDS_CAP);
-    if (threadIdx.x == 0) s_base = n ? __hip_atomic_fetch_add(&F.counters[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    __syncthreads();
     TSL_TICK(F, 5);
-    const int base = s_base;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        if (base + i < F.seg_cap) F.seg[base + i] = s_seg[i];
-        else { atomicOr(M.err, 4); }
-    }
-    for (int i = threadIdx.x; i < LH_SIZE; i += 256) {        // LH_SIZE is a multiple of 256: no lane leaves the loop early
+    for (int i = threadIdx.x; i < SEG_LH; i += 256) {        // SEG_LH is a multiple of 256: no lane leaves the loop early
         const int c = s_cnt[i];
         const int b = c ? s_key[i] : 0;
         const bool first = c && __hip_atomic_fetch_add(&F.bhist[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
@@ -432,7 +430,7 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
     __shared__ int s_key[LH_SIZE];
     __shared__ int s_cnt[LH_SIZE];
     __shared__ int s_base[LH_SIZE];
-    const int total = min(F.counters[2], F.seg_cap);
+    const int total = (int)min((long long)*F.nrays * SEG_RAY_SLOTS + F.counters[2], (long long)F.seg_cap);
     const int ntiles = (total + SCATTER_TILE - 1) / SCATTER_TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < LH_SIZE; i += 256) { s_key[i] = LH_EMPTY; s_cnt[i] = 0; }
@@ -447,7 +445,7 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
                 key[q] = F.seg[i];
                 if (key[q] != ~0ull) {
                     const int b = (int)(key[q] >> STG_B_SHIFT);
-                    hs[q] = lh_slot(s_key, b);
+                    hs[q] = lh_slot<10>(s_key, b);
                     if (hs[q] >= 0) rank[q] = atomicAdd(&s_cnt[hs[q]], 1);
                     else rank[q] = F.boffset[b] + __hip_atomic_fetch_add(&F.bcursor[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // hash full (rare)
                 }

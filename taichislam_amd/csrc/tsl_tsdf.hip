@@ -63,12 +63,15 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __res
 {
     const FrameParams& P = *Pp;
     const uint16_t* __restrict__ depth = static_cast<const uint16_t*>(P.input);
-    const int total = P.hh * P.ww;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    // a workgroup visits a 16x16 tile of the sampled pixels: the voxels it opens are listed together (block_reserve), so
+    // neighbouring rays -- which cross the same bricks -- are walked and binned by the same workgroup later on
+    const int tiles_x = (P.ww + 15) >> 4;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int jj = ty * 16 + ((int)threadIdx.x >> 4), ii = tx * 16 + ((int)threadIdx.x & 15);
+    const int p = jj * P.ww + ii;                                                    // pixel id = raster order
     bool gate = false, inside = false, opened = false;
     int slot = -1;
-    if (p < total) {
-        const int jj = p / P.ww, ii = p - jj * P.ww;
+    if (jj < P.hh && ii < P.ww) {
         const int j = jj * P.step, i = ii * P.step;
         const uint16_t d = depth[(size_t)j * P.W + i];
         K key = KeyOps<K>::invalid(P.pcl_bits);
@@ -141,59 +144,6 @@ __global__ void __launch_bounds__(256) k_voxelize_points(const FrameParams* __re
 // K3: one ray per sensor voxel.  The voxel's pixels are replayed in raster order with per-add f16 rounding
 // (process_point :230-234) and turned into a ray record (process_new_pcl :242-249).
 // ------------------------------------------------------------------------------------------------------
-struct PixAcc { int cnt; h16 sx, sy, sz, zs, cr, cg, cb; };
-
-__device__ __forceinline__ void acc_pixel(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
-{
-    if (P.tex) {                                                                     // new_pcl_sum_color += rgb  (:234)
-        const uint8_t* rgb;
-        if (P.points) rgb = P.tex_input + (size_t)pid * 3;                           // :179-183
-        else {
-            const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
-            const int pj = jj * P.step, pi = ii * P.step;
-            if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;       // :206
-            else {                                                                   // color_ind_from_depth_pt  mapping_common.py:43-58
-                int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
-                int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
-                if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }          // the reference tests column against rows (:56)
-                if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                            // keep the read inside the buffer
-                rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
-            }
-        }
-        A.cr = hadd(A.cr, f2h((float)rgb[0])); A.cg = hadd(A.cg, f2h((float)rgb[1])); A.cb = hadd(A.cb, f2h((float)rgb[2]));
-    }
-    const uint2 pl = F.pix[pid];
-    A.sx = hadd(A.sx, (h16)(pl.x & 0xffffu)); A.sy = hadd(A.sy, (h16)(pl.x >> 16));              // :231
-    A.sz = hadd(A.sz, (h16)(pl.y & 0xffffu)); A.zs = hadd(A.zs, (h16)(pl.y >> 16));              // :232
-    ++A.cnt;                                                                                       // :230
-}
-
-// mean point -> ray record; false for degenerate rays (zero length / z^2 not in (0, inf))
-__device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev& F, const PixAcc& A, uint32_t first, uint4* rec, int* nsteps)
-{
-    const h16 c = f2h((float)A.cnt);                                                 // :242
-    const h16 px = hdiv(A.sx, c), py = hdiv(A.sy, c), pz = hdiv(A.sz, c);            // :243
-    const h16 len = hsqrt(hadd(hadd(hmul(px, px), hmul(py, py)), hmul(pz, pz)));     // :244
-    const h16 zbar = hdiv(A.zs, c);                                                  // :247
-    const float lenf = h2f(len), zzf = h2f(hmul(zbar, zbar));
-    if (!((lenf > 0.0f) && isfinite(lenf) && (zzf > 0.0f) && isfinite(zzf))) return false;
-    const h16 dx = hdiv(px, len), dy = hdiv(py, len), dz = hdiv(pz, len);            // :245
-    float nf = lenf / P.vs + P.internal_f;                                           // :249
-    if (P.max_steps_f < nf) nf = P.max_steps_f;
-    *nsteps = (int)nf;
-    float w = 1.0f / zzf;                                                            // w_x_p :216-225 (d >= 0 always, Q3)
-    if (w > TSL_W_CLAMP) w = TSL_W_CLAMP;
-    rec->x = (uint32_t)px | ((uint32_t)py << 16);
-    rec->y = (uint32_t)pz | ((uint32_t)dx << 16);
-    rec->z = (uint32_t)dy | ((uint32_t)dz << 16);
-    rec->w = __float_as_uint(w);
-    if (P.tex) {                                                                     // color = sum_color/c/255  (:269)
-        const h16 r16 = f2h(h2f(hdiv(A.cr, c)) / 255.0f), g16 = f2h(h2f(hdiv(A.cg, c)) / 255.0f), b16 = f2h(h2f(hdiv(A.cb, c)) / 255.0f);
-        F.colpix[first] = make_uint2((uint32_t)r16 | ((uint32_t)g16 << 16), (uint32_t)b16);
-    }
-    return true;
-}
-
 // (a) pixels grouped by a stable radix sort of the sensor-voxel keys: one thread per sorted entry, segment heads work
 template <typename K>
 __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restrict__ Pp, FrameDev F, const K* __restrict__ keys_s)
@@ -597,7 +547,7 @@ static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStre
     const int blocks = (total + 255) / 256;
     prof_begin(m, TSL_K_VOXELIZE, sa);
     if (points) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
-    else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
+    else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(((m->P.ww + 15) / 16) * ((m->P.hh + 15) / 16)), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
     prof_end(m, sa);
     if (m->P.group) {
         prof_begin(m, TSL_K_SORT, sa);
@@ -709,7 +659,7 @@ static void fill_frame_params(tsl_tsdf* m, const double R[9], const double T[3])
     const int s = m->active;
     convert_pose(&m->baseR[(size_t)s * 9], &m->baseT[(size_t)s * 3], R, T, m->P.R, m->P.T);   // submap_enabled is always True for DenseTSDF
     m->P.slot = map_slot(m, s);
-    m->P.variant = m->variant; m->P.split = m->split;
+    m->P.variant = m->variant; m->P.split = (m->variant == 2 && m->split > 8) ? 8 : m->split;      // variant 2: a ray's 16 private segment slots are split over its lanes
 }
 
 }  // namespace tsl
@@ -845,7 +795,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&G.rayFirst, 4 * np))) return rc;
         {   // sensor-voxel hash table (>= 4 entries per possible point) and the group lists
             int lg = 10; while ((1ll << lg) < 4 * (long long)np) ++lg;
-            G.hlog2 = lg;
+            G.hlog2 = lg; G.hwide = m->pcl_bits > 10;
             const size_t hs = (size_t)1 << lg;
             if ((rc = dev_alloc(m, &G.hkey, 8 * hs, 0xff))) return rc; S.owned.push_back(G.hkey);
             if ((rc = own((void**)&G.hcnt, 4 * hs))) return rc;

@@ -60,8 +60,64 @@ struct FrameDev {
     long long* dbg;                              // developer timing counters (TSL_TIMING builds)
     int    seg_cap;
     int    max_frame_bricks;
+    int    hwide;                                // sensor-voxel keys are 64 bit
     int    max_points;
 };
+
+// ---- sensor voxel -> ray  (process_point dense_tsdf.py:230-234, process_new_pcl :242-249); citations are to dense_tsdf.py ----
+struct PixAcc { int cnt; h16 sx, sy, sz, zs, cr, cg, cb; };
+
+__device__ __forceinline__ void acc_pixel(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
+{
+    if (P.tex) {                                                                     // new_pcl_sum_color += rgb  (:234)
+        const uint8_t* rgb;
+        if (P.points) rgb = P.tex_input + (size_t)pid * 3;                           // :179-183
+        else {
+            const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
+            const int pj = jj * P.step, pi = ii * P.step;
+            if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;       // :206
+            else {                                                                   // color_ind_from_depth_pt  mapping_common.py:43-58
+                int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
+                int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
+                if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }          // the reference tests column against rows (:56)
+                if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                            // keep the read inside the buffer
+                rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
+            }
+        }
+        A.cr = hadd(A.cr, f2h((float)rgb[0])); A.cg = hadd(A.cg, f2h((float)rgb[1])); A.cb = hadd(A.cb, f2h((float)rgb[2]));
+    }
+    const uint2 pl = F.pix[pid];
+    A.sx = hadd(A.sx, (h16)(pl.x & 0xffffu)); A.sy = hadd(A.sy, (h16)(pl.x >> 16));              // :231
+    A.sz = hadd(A.sz, (h16)(pl.y & 0xffffu)); A.zs = hadd(A.zs, (h16)(pl.y >> 16));              // :232
+    ++A.cnt;                                                                                       // :230
+}
+
+// mean point -> ray record; false for degenerate rays (zero length / z^2 not in (0, inf))
+__device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev& F, const PixAcc& A, uint32_t first, uint4* rec, int* nsteps, bool write_colour = true)
+{
+    const h16 c = f2h((float)A.cnt);                                                 // :242
+    const h16 px = hdiv(A.sx, c), py = hdiv(A.sy, c), pz = hdiv(A.sz, c);            // :243
+    const h16 len = hsqrt(hadd(hadd(hmul(px, px), hmul(py, py)), hmul(pz, pz)));     // :244
+    const h16 zbar = hdiv(A.zs, c);                                                  // :247
+    const float lenf = h2f(len), zzf = h2f(hmul(zbar, zbar));
+    if (!((lenf > 0.0f) && isfinite(lenf) && (zzf > 0.0f) && isfinite(zzf))) return false;
+    const h16 dx = hdiv(px, len), dy = hdiv(py, len), dz = hdiv(pz, len);            // :245
+    float nf = lenf / P.vs + P.internal_f;                                           // :249
+    if (P.max_steps_f < nf) nf = P.max_steps_f;
+    *nsteps = (int)nf;
+    float w = 1.0f / zzf;                                                            // w_x_p :216-225 (d >= 0 always, Q3)
+    if (w > TSL_W_CLAMP) w = TSL_W_CLAMP;
+    rec->x = (uint32_t)px | ((uint32_t)py << 16);
+    rec->y = (uint32_t)pz | ((uint32_t)dx << 16);
+    rec->z = (uint32_t)dy | ((uint32_t)dz << 16);
+    rec->w = __float_as_uint(w);
+    if (P.tex && write_colour) {                                                     // color = sum_color/c/255  (:269)
+        const h16 r16 = f2h(h2f(hdiv(A.cr, c)) / 255.0f), g16 = f2h(h2f(hdiv(A.cg, c)) / 255.0f), b16 = f2h(h2f(hdiv(A.cb, c)) / 255.0f);
+        F.colpix[first] = make_uint2((uint32_t)r16 | ((uint32_t)g16 << 16), (uint32_t)b16);
+    }
+    return true;
+}
+
 
 struct ProfSlot { hipEvent_t a, b; int kid; };
 
