@@ -13,7 +13,7 @@
 //                K4a k_segments   : every ray is cut into runs of consecutive steps inside one brick ("segments", one
 //                                   u64 each) by searching the brick-boundary crossings per axis; staged in LDS and
 //                                   appended block-wise; per-brick counts in an LDS hash, flushed once per block.
-//                K4b k_scan       : exclusive scans over the frame's active bricks (<= 4096).
+//                K4b k_plan       : segment range and integrate parts of every active brick (block-aggregated reservations).
 //                K4c k_scatter    : counting-sort the segments by brick (LDS hash per 4096-segment tile, one global
 //                                   reservation per (tile, brick)).
 //                phase B (frame order, main stream):
@@ -47,12 +47,15 @@ namespace tsl {
 
 struct RayRegs { float pf0, pf1, pf2, d0, d1, d2, P0, P1, P2, w; long long qden; int n; };
 
-template <bool WITH_N = true>
-__device__ __forceinline__ RayRegs load_ray(const FrameDev& F, const FrameParams& P, int r)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ RayRegs make_ray(const uint4 rec, int n, const FrameParams& P)
 {
     RayRegs R;
-    const uint4 rec = F.rayA[r];
-    R.n = WITH_N ? F.rayN[r] : 0;
+    R.n = n;
     R.pf0 = h2f((h16)(rec.x & 0xffffu)); R.pf1 = h2f((h16)(rec.x >> 16)); R.pf2 = h2f((h16)(rec.y & 0xffffu));
     R.d0 = h2f((h16)(rec.y >> 16)); R.d1 = h2f((h16)(rec.z & 0xffffu)); R.d2 = h2f((h16)(rec.z >> 16));
     R.w = __uint_as_float(rec.w);
@@ -60,6 +63,8 @@ __device__ __forceinline__ RayRegs load_ray(const FrameDev& F, const FrameParams
     R.P0 = R.pf0 + P.T[0]; R.P1 = R.pf1 + P.T[1]; R.P2 = R.pf2 + P.T[2];                      // dense_tsdf.py:246
     return R;
 }
+template <bool WITH_N = true>
+__device__ __forceinline__ RayRegs load_ray(const FrameDev& F, const FrameParams& P, int r) { return make_ray(F.rayA[r], WITH_N ? F.rayN[r] : 0, P); }
 // voxel visited at step j  (dense_tsdf.py:253-254)
 __device__ __forceinline__ void step_voxel(const RayRegs& R, const FrameParams& P, int j, float* x, int* xi)
 {
@@ -259,7 +264,7 @@ __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-inse
 // K4a: cut rays into per-brick segments without visiting every step: per axis the next brick/volume boundary
 // crossing is searched directly (next_axis_event), so a ray costs ~12 crossings x ~2 exact coordinate evaluations
 // instead of ~135 full voxel evaluations.  Segments are keyed by BRICK id (no per-frame slot claims anywhere: the
-// dense renumbering of the frame's bricks falls out of k_scan); per-brick counts are kept in an LDS hash and flushed
+// dense renumbering of the frame's bricks is the order in which they are listed); per-brick counts are kept in an LDS hash and flushed
 // once per block.
 // segment: [0,6) count [6,18) first step [18,40) ray [40,64) brick id
 #define STG_RAY_BITS 22
@@ -267,6 +272,10 @@ __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-inse
 #define SEG_LH_LOG2 9
 #define SEG_LH (1 << SEG_LH_LOG2)
 #define STG_B_SHIFT (SEG_CNT_BITS + SEG_J_BITS + STG_RAY_BITS)
+// FUSED: the rays are built here as well -- lane 0 of every ray replays the pixels of its sensor voxel in raster order
+// (dense_tsdf.py:230-249; crowded voxels by the whole wave) and hands the ray to the other lanes; ray id = position of the
+// sensor voxel in the frame's list.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
     const FrameParams& P = *Pp;
@@ -281,14 +290,73 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
     const int split = P.split;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int r = gid / split, sub = gid - r * split;
-    const int nrays = *F.nrays;
+    const int nrays = FUSED ? F.counters[6] : *F.nrays;
     long long n_ok = 0, n_oob = 0;
     const bool working = __any(r < nrays);
     const int spl = SEG_RAY_SLOTS / split;                              // private slots of this lane in the frame's segment array
     unsigned long long* myseg = F.seg + (size_t)gid * spl;
     int nslot = 0;
-    if (r < nrays) {
-        const RayRegs R = load_ray(F, P, r);
+    bool ok = r < nrays;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    int nsteps = 0;
+    if (FUSED) {
+        const int lane = threadIdx.x & 63;
+        bool big = false;
+        int gn = 0, sl = 0;
+        uint32_t first = 0;
+        ok = false;
+        if (r < nrays && sub == 0) {
+            sl = F.act[r];
+            gn = F.hcnt[sl];
+            if (gn > GROUP_SMALL) big = true;
+            else {
+                const uint32_t* ids = F.plist + F.hoff[sl];
+                PixAcc A = {};
+                long long last = -1;
+                for (int k = 0; k < gn; ++k) {                                   // next pixel in raster order
+                    uint32_t best = 0xffffffffu;
+                    for (int q = 0; q < gn; ++q) { const uint32_t v = ids[q]; if ((long long)v > last && v < best) best = v; }
+                    if (k == 0) first = best;
+                    acc_pixel(P, F, best, A);
+                    last = (long long)best;
+                }
+                ok = finish_ray(P, F, A, first, &rec, &nsteps);
+            }
+        }
+        for (unsigned long long bm = __ballot(big); bm; bm &= bm - 1ull) {       // crowded voxels: the whole wave selects the next id
+            const int src = (int)__builtin_ctzll(bm);
+            const int n = __shfl(gn, src);
+            const uint32_t* gid_list = F.plist + F.hoff[__shfl(sl, src)];
+            PixAcc A = {};
+            long long last = -1; uint32_t f0 = 0;
+            for (int k = 0; k < n; ++k) {
+                uint32_t best = 0xffffffffu;
+                for (int q = lane; q < n; q += 64) { const uint32_t v = gid_list[q]; if ((long long)v > last && v < best) best = v; }
+                best = wave_min_u32(best);
+                if (k == 0) f0 = best;
+                acc_pixel(P, F, best, A);
+                last = (long long)best;
+            }
+            uint4 rc; int ns = 0;
+            const bool k2 = finish_ray(P, F, A, f0, &rc, &ns, lane == src);
+            if (lane == src) { rec = rc; nsteps = ns; ok = k2; first = f0; }
+        }
+        if (r < nrays && sub == 0) {
+            F.rayA[r] = rec; F.rayFirst[r] = first;
+            if (F.hwide) reinterpret_cast<unsigned long long*>(F.hkey)[sl] = ~0ull; else reinterpret_cast<uint32_t*>(F.hkey)[sl] = ~0u;
+            F.hcnt[sl] = 0; F.hfill[sl] = 0;                                     // the table is empty again for the next frame of this set
+        }
+        block_count_add(&F.stats->v_pcl, r < nrays && sub == 0);
+        block_count_add(&F.stats->v_skipped, r < nrays && sub == 0 && !ok);
+        if (gid == 0) *F.nrays = nrays;
+        // hand the ray to the other lanes of its group (a group never straddles a wave: split divides 64)
+        const int src = lane - sub;
+        rec.x = (uint32_t)__shfl((int)rec.x, src); rec.y = (uint32_t)__shfl((int)rec.y, src); rec.z = (uint32_t)__shfl((int)rec.z, src); rec.w = (uint32_t)__shfl((int)rec.w, src);
+        nsteps = __shfl(nsteps, src);
+        ok = __shfl((int)ok, src) != 0;
+    }
+    if (ok) {
+        const RayRegs R = FUSED ? make_ray(rec, nsteps, P) : load_ray(F, P, r);
         if (sub == 0) mark_occupied(M, P, R);
         TSL_TICK(F, 1);
         const int len = (R.n + split - 1) / split;
@@ -364,64 +432,39 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
     }
 }
 
-// K4b (single block): exclusive scans over the frame's active bricks (listed by k_segments, <= 4096):
-// act_off[i] = first segment of brick i, act_part[i] = first integrate part (a brick with more than PART_SEGS
-// segments is integrated by several workgroups), boffset[brick] = act_off[i] for the scatter.
+// K4b: lay out the frame's active bricks (listed by k_segments): a range of the sorted segment array per brick and its
+// integrate parts (a brick with more than PART_SEGS segments is integrated by several workgroups).  Neither has to be in
+// any particular order, so block-aggregated reservations replace a prefix scan.  Parts go to three tables by length, so
+// k_integrate_bricks starts the long ones first and its tail is made of short ones.
+// part = { first segment, segments | parts of the brick << 16, brick, active rank }
 #define PART_SEGS 1024
-__device__ __forceinline__ int block_excl_scan_1024(int s, int* s_wave, int* total)
-{
-    const int t = threadIdx.x;
-    int inc = s;
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((t & 63) >= d) inc += o; }
-    __syncthreads();
-    if ((t & 63) == 63) s_wave[t >> 6] = inc;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) { if (w < (t >> 6)) wbase += s_wave[w]; tot += s_wave[w]; }
-    *total = tot;
-    return wbase + inc - s;
-}
-// parts are handed to workgroups longest first (3 size classes), so the tail of k_integrate_bricks is made of short parts
 __device__ __forceinline__ int part_class(int per) { return per >= 640 ? 0 : (per >= 256 ? 1 : 2); }
-__global__ void __launch_bounds__(1024) k_scan(MapDev M, FrameDev F)
+__global__ void __launch_bounds__(256) k_plan(MapDev M, FrameDev F)
 {
-    __shared__ int s_wave[16];
-    const int t = threadIdx.x;
     const int listed = F.counters[1];
     const int nact = min(listed, F.max_frame_bricks);
-    int v[4], bb[4], np[4], cls[4], s = 0, pc[3] = {0, 0, 0};
-    for (int q = 0; q < 4; ++q) {
-        const int i = t * 4 + q;
-        bb[q] = i < nact ? F.act_b[i] : -1;
-        v[q] = bb[q] >= 0 ? F.bhist[bb[q]] : 0;
-        np[q] = (v[q] + PART_SEGS - 1) / PART_SEGS;
-        cls[q] = np[q] ? part_class((v[q] + np[q] - 1) / np[q]) : 2;
-        s += v[q]; pc[cls[q]] += np[q];
+    if ((int)blockIdx.x * 256 >= nact && blockIdx.x) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int v = 0, b = 0, np = 0, cls = 2;
+    if (i < nact) {
+        b = F.act_b[i];
+        v = F.bhist[b];
+        np = (v + PART_SEGS - 1) / PART_SEGS;
+        cls = np ? part_class((v + np - 1) / np) : 2;
     }
-    int tot, ctot[3], crun[3];
-    int run = block_excl_scan_1024(s, s_wave, &tot);
-    for (int c = 0; c < 3; ++c) crun[c] = block_excl_scan_1024(pc[c], s_wave, &ctot[c]);
-    const int cbase[3] = { 0, ctot[0], ctot[0] + ctot[1] };
-    for (int q = 0; q < 4; ++q) {
-        const int i = t * 4 + q;
-        if (i <= nact) F.act_off[i] = run;
-        if (bb[q] >= 0) {
-            F.boffset[bb[q]] = run;
-            const int p0 = cbase[cls[q]] + crun[cls[q]];
-            for (int k = 0; k < np[q]; ++k) if (p0 + k < F.part_cap) F.part_tab[p0 + k] = make_int4(i, k, np[q], 0);
-            crun[cls[q]] += np[q];
+    const int off = block_reserve_n(&F.counters[3], v);
+    int p0 = 0;
+    for (int c = 0; c < 3; ++c) { const int q = block_reserve_n(&F.counters[8 + c], cls == c ? np : 0); if (cls == c) p0 = q; }
+    if (i < nact) {
+        F.boffset[b] = off;
+        const int per = np ? (v + np - 1) / np : 0;
+        int4* tab = F.part_tab + (size_t)cls * F.part_cap;
+        for (int k = 0; k < np; ++k) {
+            const int pos = k * per, n = min(v, pos + per) - pos;
+            if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, n | (np << 16), b, i); else atomicOr(M.err, 2);
         }
-        run += v[q];
     }
-    if (t == 1023) {
-        const int ptot = ctot[0] + ctot[1] + ctot[2];
-        if (nact == 4096) F.act_off[4096] = run;
-        if (ptot > F.part_cap) atomicOr(M.err, 2);
-        F.counters[1] = nact;
-        F.counters[3] = min(tot, F.seg_cap);                     // total segments
-        F.counters[5] = (listed <= F.max_frame_bricks && ptot <= F.part_cap) ? ptot : 0;   // total parts (nothing is integrated when the frame overflows)
-        F.stats->bricks = listed;
-    }
+    if (i == 0) { F.stats->bricks = listed; if (listed > F.max_frame_bricks) atomicOr(M.err, 2); }
 }
 
 // K4c: counting sort by brick (LDS hash of the bricks seen in each 4096-segment tile, one global reservation per (tile, brick))
@@ -474,26 +517,23 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
     __shared__ unsigned long long s_keys[PART_SEGS];
     __shared__ int s_bin[64];
     __shared__ int s_p, s_last;
-    const int nparts = F.counters[5];
+    const int nA = min(F.counters[8], F.part_cap), nB = min(F.counters[9], F.part_cap), nC = min(F.counters[10], F.part_cap);
+    const int nparts = (*M.err & 2) ? 0 : nA + nB + nC;          // nothing is integrated when the frame overflows its scratch
     long long uniq = 0;
     TSL_T0();
     {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
-        const int nact = F.counters[1];
+        const int nact = min(F.counters[1], F.max_frame_bricks);
         for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
     }
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
         TSL_TICK(F, 0);
-        const int4 pt = F.part_tab[part];
-        const int rk = pt.x, k = pt.y, np = pt.z;
-        const int b0 = F.act_off[rk], b1 = F.act_off[rk + 1];
-        const int per = (b1 - b0 + np - 1) / np;
-        const int pos = b0 + k * per, run_end = min(b1, pos + per);
+        const int4 pt = part < nA ? F.part_tab[part] : (part < nA + nB ? F.part_tab[F.part_cap + part - nA] : F.part_tab[2 * (size_t)F.part_cap + part - nA - nB]);
+        const int pos = pt.x, nseg = pt.y & 0xffff, np = pt.y >> 16, rk = pt.w;
         const bool whole = np == 1;
-        const int nseg = run_end - pos;
         unsigned long long kk[PART_SEGS / NT]; int rr[PART_SEGS / NT];
 #pragma unroll
         for (int q = 0; q < PART_SEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
-        if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, F.act_b[rk]);       // allocate the brick on its first touch ever
+        if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, pt.z);       // allocate the brick on its first touch ever
         {
             ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
             for (int i = threadIdx.x; i < TSL_BRK3; i += NT) z[i] = make_ulonglong2(0ull, 0ull);
@@ -619,45 +659,6 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
 
-// K4e: finalise the bricks that were integrated by several workgroups from the HBM scratch, and restore the
-// "all zero between frames" invariant of bhist / bcursor for the bricks this frame used.
-__global__ void __launch_bounds__(256) k_finalize_shared(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
-{
-    const FrameParams& P = *Pp;
-    const int nact = F.counters[1];
-    const int nwork = min(F.counters[4], F.max_frame_bricks);
-    long long uniq = 0;
-    for (int q = blockIdx.x; q < nwork; q += gridDim.x) {
-        const int rk = F.shared_list[q];
-        const int p = pool_lookup_ro(M, P.slot, F.act_b[rk]);
-        if (p < 0) continue;
-        ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)rk * (TSL_BRK3 * 2));
-        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
-        int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-        ulonglong2 a[TSL_BRK3 / 256]; uint32_t old[TSL_BRK3 / 256];
-#pragma unroll
-        for (int i = 0; i < TSL_BRK3 / 256; ++i) { a[i] = acc[i * 256 + threadIdx.x]; old[i] = tw[i * 256 + threadIdx.x]; }
-#pragma unroll
-        for (int i = 0; i < TSL_BRK3 / 256; ++i) {
-            const int l = i * 256 + threadIdx.x;
-            if (a[i].y != 0ull) {
-                tw[l] = apply_update(old[i], (long long)a[i].x, (long long)a[i].y);
-                obs[l] = 1;
-                acc[l] = make_ulonglong2(0ull, 0ull);
-                if (P.tex) {
-                    uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
-                    reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[*wv - 1u];
-                    *wv = 0u;
-                }
-                ++uniq;
-            }
-        }
-    }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nact; i += gridDim.x * 256) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
-    uniq = wave_sum_ll(uniq);
-    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
-}
-
 int check_variant2(tsl_tsdf* m)
 {
     TSL_REQUIRE(m->F.max_frame_bricks <= 4096 && m->P.max_steps_f < (float)(1 << SEG_J_BITS) && m->F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
@@ -672,10 +673,11 @@ int launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st)
     if (P.variant != 2) return TSL_OK;
     const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
     prof_begin(m, TSL_K_SEGMENTS, st);
-    hipLaunchKernelGGL(k_segments, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
+    if (P.group) hipLaunchKernelGGL(k_segments<true>, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
+    else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, m->M, F);
+    hipLaunchKernelGGL(k_plan, dim3((F.max_frame_bricks + 255) / 256), dim3(256), 0, st, m->M, F);
     hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, st, F);
     prof_end(m, st);
     return TSL_OK;

@@ -177,7 +177,6 @@ __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restric
 // per voxel walks its group in ASCENDING pixel id -- i.e. raster order -- by repeated selection of the next larger id.
 // Groups are small (a sensor voxel rarely sees more than a dozen pixels); groups above GROUP_SMALL are sorted by a whole
 // workgroup in k_build_rays_big.
-#define GROUP_SMALL 48
 #define GROUP_BIG_CAP 16384
 #define H_EMPTY32 0xffffffffu
 template <typename K> __device__ __forceinline__ K h_empty() { return (K)~(K)0; }
@@ -532,7 +531,8 @@ static PoseF pose_of(const tsl_tsdf* m, int s)
     return B;
 }
 
-__global__ void k_set_params(FrameParams P, FrameParams* dst) { if (threadIdx.x == 0) *dst = P; }
+// per-frame prologue of a working set: publish the frame's parameters, clear stats | nrays | counters (256 bytes)
+__global__ void k_set_params(FrameParams P, FrameParams* dst, int* header) { if (threadIdx.x == 0) *dst = P; header[threadIdx.x] = 0; }
 
 // phase A of one frame on stream `sa`: depth -> rays -> brick-sorted segments.  Every argument is constant for a given
 // (image shape, options), the per-frame values live in *S.Pd -- so the same sequence can be captured into a hipGraph.
@@ -540,7 +540,6 @@ template <typename K>
 static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStream_t sa)
 {
     FrameDev& F = S.F;
-    TSL_HIP(hipMemsetAsync(S.header, 0, S.header_bytes, sa));                         // stats | nrays | counters
     if (total <= 0) return TSL_OK;
     K* keys = reinterpret_cast<K*>(F.keys);
     K* keys_s = reinterpret_cast<K*>(F.keys_s);
@@ -554,10 +553,12 @@ static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStre
         hipLaunchKernelGGL(k_group_scan, dim3(blocks), dim3(256), 0, sa, F);
         hipLaunchKernelGGL(k_group_fill, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
         prof_end(m, sa);
-        prof_begin(m, TSL_K_RAYS, sa);
-        hipLaunchKernelGGL(k_build_rays_hash<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
-        hipLaunchKernelGGL(k_build_rays_big<K>, dim3(64), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, m->M);
-        prof_end(m, sa);
+        if (m->P.variant != 2) {      // variant 2 builds the rays inside k_segments
+            prof_begin(m, TSL_K_RAYS, sa);
+            hipLaunchKernelGGL(k_build_rays_hash<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
+            hipLaunchKernelGGL(k_build_rays_big<K>, dim3(64), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, m->M);
+            prof_end(m, sa);
+        }
     } else {
         prof_begin(m, TSL_K_SORT, sa);
         size_t tb = m->sort_temp_bytes;
@@ -618,7 +619,7 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     FSet& S = m->fset[si];
     hipStream_t sa = m->overlap ? S.st : m->stream;
     if (m->overlap && S.b_pending) TSL_HIP(hipStreamWaitEvent(sa, S.b_done, 0));      // phase B of frame f-NSETS still reads this set
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sa, P, S.Pd);
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sa, P, S.Pd, reinterpret_cast<int*>(S.header));
     m->last_set = si; m->frame_no++;
     // replay captured graphs for same-shaped depth frames: 7 host calls per frame instead of ~22
     bool graph = m->use_graph && m->overlap && !m->prof_on && !xyz_dev && total > 0;
@@ -807,22 +808,19 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
             if ((rc = own((void**)&G.big, 4 * (np / GROUP_SMALL + 16)))) return rc;
         }
         if (cfg->texture_enabled) { if ((rc = own((void**)&G.colpix, 8 * np))) return rc; }
-        S.header_bytes = 128;
+        S.header_bytes = 256;
         if ((rc = own(&S.header, S.header_bytes))) return rc;
         G.stats = reinterpret_cast<tsl_frame_stats*>(S.header);
         G.nrays = reinterpret_cast<int*>((char*)S.header + 80);
         G.counters = reinterpret_cast<int*>((char*)S.header + 96);
         if ((rc = own((void**)&G.seg, 8 * (size_t)F.seg_cap))) return rc;
         if ((rc = own((void**)&G.seg_sorted, 8 * (size_t)F.seg_cap))) return rc;
-        if ((rc = own((void**)&G.shared_list, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
         if ((rc = own((void**)&G.bhist, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.bcursor, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.boffset, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
-        if ((rc = own((void**)&G.act_off, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
-        if ((rc = own((void**)&G.act_part, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
         G.part_cap = F.seg_cap / 256 + F.max_frame_bricks + 8;
-        if ((rc = own((void**)&G.part_tab, sizeof(int4) * (size_t)G.part_cap))) return rc;
+        if ((rc = own((void**)&G.part_tab, sizeof(int4) * 3 * (size_t)G.part_cap))) return rc;
         if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
         S.execA = nullptr; S.execB = nullptr; S.graph_key = -1;

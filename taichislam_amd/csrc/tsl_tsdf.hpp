@@ -44,12 +44,11 @@ struct FrameDev {
     uint2* colpix;                               // [pixel] f16 colour {r|g<<16, b} of the ray opened by that pixel (texture)
     tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
     int*   nrays;                                // ray count of this frame
-    int*   counters;                             // [1] active bricks [2] segments appended [3] segments sorted [4] shared bricks [5] parts
+    int*   counters;                             // [0] grouped pixels [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] crowded voxels [8..10] parts per table
     unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick
-    int   *shared_list;                          // active-brick ranks integrated by several workgroups
     int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment
-    int   *act_b, *act_off, *act_part;           // [max_frame_bricks+1] active bricks of the frame
-    int4  *part_tab; int part_cap;               // integrate work list: {active rank, part k, parts of the brick, -}, longest first
+    int   *act_b;                                // [max_frame_bricks] active bricks of the frame, in the order they were listed
+    int4  *part_tab; int part_cap;               // integrate work list, three tables (long, medium, short parts): {first segment, segments | parts << 16, brick, active rank}
     // ---- shared by all sets (only touched in phase B, i.e. serially on the main stream) ----
     int*   slot_tab;                             // variants 0/1: [nb3] brick id -> frame scratch slot, EMPTY between frames
     int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
@@ -65,6 +64,7 @@ struct FrameDev {
 };
 
 // ---- sensor voxel -> ray  (process_point dense_tsdf.py:230-234, process_new_pcl :242-249); citations are to dense_tsdf.py ----
+#define GROUP_SMALL 48        // sensor voxels with more pixels are replayed by a whole wave / workgroup
 struct PixAcc { int cnt; h16 sx, sy, sz, zs, cr, cg, cb; };
 
 __device__ __forceinline__ void acc_pixel(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
