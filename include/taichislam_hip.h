@@ -69,6 +69,10 @@ enum { TSL_K_VOXELIZE = 0, TSL_K_SORT = 1, TSL_K_RAYS = 2, TSL_K_INTEGRATE = 3, 
 const char* tsl_version(void);
 const char* tsl_last_error(void);
 int  tsl_device_count(int* n);
+/* Exhaustive device check (all 2^32 float patterns) of an arithmetic shortcut the kernels rely on for bit-exactness:
+   which = 0: three-instruction round-half-away == ti.round (mapping_common.py:263-266, dense_tsdf.py:254);
+   which = 1: rescale-free correctly rounded sqrt == sqrtf on [2^-96, inf).  *mismatches must come back 0. */
+int  tsl_selftest(int which, int64_t* mismatches);
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 int  tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out);        /* dense_tsdf.py:13-50,52-118 */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tsl_version": (C.c_char_p, []),
     "tsl_last_error": (C.c_char_p, []),
     "tsl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "tsl_selftest": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
     "tsl_tsdf_create": (C.c_int, [C.POINTER(TsdfCfg), C.c_int, C.POINTER(vp)]),
     "tsl_tsdf_destroy": (None, [vp]),
     "tsl_tsdf_get_dims": (C.c_int, [vp, pi32, pi32, pi32, pi32]),

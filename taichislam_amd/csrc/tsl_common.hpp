@@ -37,6 +37,17 @@ __device__ __forceinline__ h16 hdiv(h16 a, h16 b) { return f2h(h2f(a) / h2f(b));
 // sqrtf() is the correctly rounded form under -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn lowers to a bare
 // v_sqrt_f32 (1 ulp) on gfx950 and breaks bit parity with the CPU oracle.
 __device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+// the same correctly rounded root for x >= 2^-96 (or 0) without the library's rescaling of tiny inputs: hardware estimate,
+// then one step down / one step up decided by the exact residuals (tsl_selftest(1) compares it with sqrtf for every float)
+__device__ __forceinline__ float sqrt_rn_norm(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float yd = __uint_as_float(__float_as_uint(y) - 1u), yu = __uint_as_float(__float_as_uint(y) + 1u);
+    const float ed = __builtin_fmaf(-yd, y, x), eu = __builtin_fmaf(-yu, y, x);
+    float r = (ed <= 0.0f) ? yd : y;
+    r = (eu > 0.0f) ? yu : r;
+    return r;
+}
 __device__ __forceinline__ h16 hsqrt(h16 a) { return f2h(sqrt_rn(h2f(a))); }
 
 // ti.round(x, ti.i32): round half away from zero (mapping_common.py:263-266, assumption A1)
@@ -47,7 +58,11 @@ __device__ __forceinline__ float rnd_f(float x)
     if (d >= 0.5f) r += copysignf(1.0f, x);
     return r;
 }
-__device__ __forceinline__ int rnd_i(float x) { return (int)rnd_f(x); }
+// the same integer in three instructions: adding the float just below one half (with the sign of x) never carries a value
+// from below a tie over it, and carries every value from the tie on; the conversion truncates.  tsl_selftest(0) checks the
+// identity against rnd_f for every float.
+__device__ __forceinline__ int rnd_i(float x) { return (int)(x + copysignf(0.49999997f, x)); }
+__device__ __forceinline__ int rnd_i_ref(float x) { return (int)rnd_f(x); }
 __device__ __forceinline__ int sgn_f(float v) { return (0.0f < v) - (v < 0.0f); }     // mapping_common.py:5-7
 
 // x / vs with a loop-invariant divisor.  IEEE division costs ~10 VALU ops on gfx950; with y = RN(1/vs) the sequence
@@ -70,6 +85,13 @@ __device__ __forceinline__ long long to_fix(float v)
     const float q = rintf(v * TSL_FIX_SCALE);                  // integer-valued
     if (fabsf(q) < 2147483648.0f) return (long long)(int)q;    // common case: one v_cvt_i32_f32 + sign extension
     return __float2ll_rn(q);
+}
+// inside hot loops: the 64-bit conversion is only executed when some lane of the wave needs it
+__device__ __forceinline__ long long to_fix_wave(float v)
+{
+    const float q = rintf(v * TSL_FIX_SCALE);
+    if (__builtin_expect(__any(!(fabsf(q) < 2147483648.0f)), 0)) return __float2ll_rn(q);
+    return (long long)(int)q;
 }
 __device__ __forceinline__ float from_fix(long long q) { return (float)((double)q * TSL_FIX_INV); }
 

@@ -76,10 +76,11 @@ __device__ __forceinline__ void step_voxel(const RayRegs& R, const FrameParams& 
 __device__ __forceinline__ long long step_term(const RayRegs& R, const float* x)
 {
     const float v0 = R.P0 - x[0], v1 = R.P1 - x[1], v2 = R.P2 - x[2];
-    const float dist = sqrt_rn((v0 * v0 + v1 * v1) + v2 * v2);
+    const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
+    const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);        // 2^-96: below it sqrtf rescales
     const float dot = (v0 * R.pf0 + v1 * R.pf1) + v2 * R.pf2;
     const float sd = dist * (float)sgn_f(dot);
-    return to_fix(R.w * sd);
+    return to_fix_wave(R.w * sd);
 }
 // occupy[pos_p] = 1  (dense_tsdf.py:248)
 template <bool COOP = true>
@@ -437,9 +438,8 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
 // any particular order, so block-aggregated reservations replace a prefix scan.  Parts go to three tables by length, so
 // k_integrate_bricks starts the long ones first and its tail is made of short ones.
 // part = { first segment, segments | parts of the brick << 16, brick, active rank }
-#define PART_SEGS 1024
-__device__ __forceinline__ int part_class(int per) { return per >= 640 ? 0 : (per >= 256 ? 1 : 2); }
-__global__ void __launch_bounds__(256) k_plan(MapDev M, FrameDev F)
+__device__ __forceinline__ int part_class(int per, int psegs) { return per * 8 >= psegs * 5 ? 0 : (per * 4 >= psegs ? 1 : 2); }
+__global__ void __launch_bounds__(256) k_plan(MapDev M, FrameDev F, int psegs)
 {
     const int listed = F.counters[1];
     const int nact = min(listed, F.max_frame_bricks);
@@ -449,8 +449,8 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, FrameDev F)
     if (i < nact) {
         b = F.act_b[i];
         v = F.bhist[b];
-        np = (v + PART_SEGS - 1) / PART_SEGS;
-        cls = np ? part_class((v + np - 1) / np) : 2;
+        np = (v + psegs - 1) / psegs;
+        cls = np ? part_class((v + np - 1) / np, psegs) : 2;
     }
     const int off = block_reserve_n(&F.counters[3], v);
     int p0 = 0;
@@ -508,13 +508,18 @@ __global__ void __launch_bounds__(256) k_scatter(FrameDev F)
 }
 
 // K4d: LDS accumulation per brick, in-place finalise
-template <bool TEX, int NT>
-__global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+// LDS position of a voxel's sums: an entry is 16 bytes = 4 of the 64 banks, so the z digit alone picks the banks.  Rays that
+// cross a brick side by side hit voxels that differ in x or y at equal z -- XOR-ing those digits into the z digit spreads
+// them over the banks.
+__device__ __forceinline__ int acc_swz(int l) { return l ^ (((l >> 4) ^ (l >> 8)) & 15); }
+
+template <bool TEX, int NT, int PSEGS, bool SORT>
+__global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
     const FrameParams& P = *Pp;
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
-    __shared__ unsigned long long s_keys[PART_SEGS];
+    __shared__ unsigned long long s_keys[SORT ? PSEGS : 1];
     __shared__ int s_bin[64];
     __shared__ int s_p, s_last;
     const int nA = min(F.counters[8], F.part_cap), nB = min(F.counters[9], F.part_cap), nC = min(F.counters[10], F.part_cap);
@@ -530,21 +535,22 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
         const int4 pt = part < nA ? F.part_tab[part] : (part < nA + nB ? F.part_tab[F.part_cap + part - nA] : F.part_tab[2 * (size_t)F.part_cap + part - nA - nB]);
         const int pos = pt.x, nseg = pt.y & 0xffff, np = pt.y >> 16, rk = pt.w;
         const bool whole = np == 1;
-        unsigned long long kk[PART_SEGS / NT]; int rr[PART_SEGS / NT];
+        unsigned long long kk[PSEGS / NT]; int rr[PSEGS / NT];
 #pragma unroll
-        for (int q = 0; q < PART_SEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
+        for (int q = 0; q < PSEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
         if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, pt.z);       // allocate the brick on its first touch ever
         {
             ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
             for (int i = threadIdx.x; i < TSL_BRK3; i += NT) z[i] = make_ulonglong2(0ull, 0ull);
         }
-        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+        if (SORT && threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         __syncthreads();
+        if (SORT) {
         // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
         // segments of (almost) equal length instead of idling behind the longest one
 #pragma unroll
-        for (int q = 0; q < PART_SEGS / NT; ++q) {
+        for (int q = 0; q < PSEGS / NT; ++q) {
             const int i = q * NT + threadIdx.x;
             rr[q] = -1;
             if (i < nseg) rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1);
@@ -558,15 +564,30 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PART_SEGS / NT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
+        for (int q = 0; q < PSEGS / NT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PSEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = s_keys[i]; }
+        }
         TSL_TICK(F, 1);
-        for (int i = threadIdx.x; i < nseg; i += NT) {
-            const unsigned long long key = s_keys[i];
+        uint4 recs[PSEGS / NT]; uint32_t wids[PSEGS / NT];
+#pragma unroll
+        for (int q = 0; q < PSEGS / NT; ++q) {                           // all ray records of this thread in flight at once
+            const int i = q * NT + threadIdx.x;
+            if (i < nseg) {
+                const int r = (int)((kk[q] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
+                recs[q] = F.rayA[r];
+                wids[q] = TEX ? F.rayFirst[r] + 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PSEGS / NT; ++q) {
+            const int i = q * NT + threadIdx.x;
+            if (i >= nseg) continue;
+            const unsigned long long key = kk[q];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
-            const int r = (int)((key >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
-            const RayRegs R = load_ray<false>(F, P, r);
-            const uint32_t wid = TEX ? F.rayFirst[r] + 1u : 0u;
+            const RayRegs R = make_ray(recs[q], 0, P);
+            const uint32_t wid = wids[q];
             // lanes start at different offsets inside their (equally long) segments: rays that enter a brick together -- all
             // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration (64-way LDS conflicts)
             int off = (int)(threadIdx.x & 63u) % cnt;
@@ -575,10 +596,16 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
                 if (++off == cnt) off = 0;
                 float x[3]; int xi[3];
                 step_voxel(R, P, j, x, xi);
-                const int l = (((xi[0] + M.hN) & 15) << 8) | (((xi[1] + M.hN) & 15) << 4) | ((xi[2] + M.hNz) & 15);
+                const int l = acc_swz((((xi[0] + M.hN) & 15) << 8) | (((xi[1] + M.hN) & 15) << 4) | ((xi[2] + M.hNz) & 15));
                 const long long qn = step_term(R, x);
+#if defined(TSL_EXP) && TSL_EXP == 1
+                s_acc[l * 2] = (unsigned long long)qn; s_acc[l * 2 + 1] = (unsigned long long)R.qden;
+#elif defined(TSL_EXP) && TSL_EXP == 2
+                { const int l2 = (l & ~63) | (threadIdx.x & 63); atomicAdd(&s_acc[l2 * 2], (unsigned long long)qn); atomicAdd(&s_acc[l2 * 2 + 1], (unsigned long long)R.qden); }
+#else
                 atomicAdd(&s_acc[l * 2], (unsigned long long)qn);
                 atomicAdd(&s_acc[l * 2 + 1], (unsigned long long)R.qden);
+#endif
                 if (TEX) atomicMax(&s_win[l], wid);                                            // dense_tsdf.py:268-269, order-free winner
             }
         }
@@ -594,25 +621,27 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
             for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = tw[q * NT + threadIdx.x];      // all row loads in flight at once
 #pragma unroll
             for (int q = 0; q < TSL_BRK3 / NT; ++q) {
-                const int l = q * NT + threadIdx.x;
-                const unsigned long long qd = s_acc[l * 2 + 1];
+                const int l = q * NT + threadIdx.x, ls = acc_swz(l);
+                const unsigned long long qd = s_acc[ls * 2 + 1];
                 if (qd != 0ull) {
-                    tw[l] = apply_update(old[q], (long long)s_acc[l * 2], (long long)qd);
+                    tw[l] = apply_update(old[q], (long long)s_acc[ls * 2], (long long)qd);
                     if ((old[q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
-                    if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[l] - 1u];
+                    if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[ls] - 1u];
                     ++uniq;
                 }
             }
         } else if (p >= 0) {
-            // brick split over `np` workgroups: add the partial sums into the HBM scratch; the last workgroup to arrive
-            // (arrival ticket, agent-scope release/acquire) applies them.
+            // brick split over `np` workgroups: add the partial sums into the brick's HBM scratch slab; the last workgroup
+            // to arrive (arrival ticket, agent-scope release/acquire) applies them and leaves the slab zeroed.
             unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
-            for (int l = threadIdx.x; l < TSL_BRK3; l += NT) {
-                const unsigned long long qd = s_acc[l * 2 + 1];
+#pragma unroll
+            for (int q = 0; q < TSL_BRK3 / NT; ++q) {
+                const int l = q * NT + threadIdx.x, ls = acc_swz(l);
+                const unsigned long long qd = s_acc[ls * 2 + 1];
                 if (qd != 0ull) {
-                    __hip_atomic_fetch_add(acc + l * 2, s_acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + l * 2, s_acc[ls * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(acc + l * 2 + 1, qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[l]);
+                    if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -629,14 +658,22 @@ __global__ void __launch_bounds__(NT) k_integrate_bricks(MapDev M, FrameDev F, c
                 ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
                 uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
                 int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-                for (int l = threadIdx.x; l < TSL_BRK3; l += NT) {
-                    // the sums were produced by L2 atomics of other CUs: read them at L2 as well
-                    const unsigned long long qn = __hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long qd = __hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (qd != 0ull) {
-                        const uint32_t old = tw[l];
-                        tw[l] = apply_update(old, (long long)qn, (long long)qd);
-                        if ((old >> 16) == 0u) obs[l] = 1;
+                // the sums were produced by L2 atomics of other CUs: read them at L2 as well -- every load of this thread is
+                // issued before the first one is used (they are device-coherent loads, a couple of microseconds each)
+                unsigned long long qn[TSL_BRK3 / NT], qd[TSL_BRK3 / NT]; uint32_t old[TSL_BRK3 / NT];
+#pragma unroll
+                for (int q = 0; q < TSL_BRK3 / NT; ++q) {
+                    const int l = q * NT + threadIdx.x;
+                    qn[q] = __hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qd[q] = __hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old[q] = tw[l];
+                }
+#pragma unroll
+                for (int q = 0; q < TSL_BRK3 / NT; ++q) {
+                    const int l = q * NT + threadIdx.x;
+                    if (qd[q] != 0ull) {
+                        tw[l] = apply_update(old[q], (long long)qn[q], (long long)qd[q]);
+                        if ((old[q] >> 16) == 0u) obs[l] = 1;
                         acc2[l] = make_ulonglong2(0ull, 0ull);
                         if (TEX) {
                             uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
@@ -677,7 +714,7 @@ int launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st)
     else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((F.max_frame_bricks + 255) / 256), dim3(256), 0, st, m->M, F);
+    hipLaunchKernelGGL(k_plan, dim3((F.max_frame_bricks + 255) / 256), dim3(256), 0, st, m->M, F, m->wg == 1024 ? 4096 : (m->wg == 512 ? 2048 : 1024));
     hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, st, F);
     prof_end(m, st);
     return TSL_OK;
@@ -689,10 +726,16 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
     FrameDev& F = S.F;
     if (P.variant == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
-        if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 256>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-        else if (m->wg == 1024) hipLaunchKernelGGL((k_integrate_bricks<false, 1024>), dim3(1024), dim3(1024), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-        else if (m->wg == 512) hipLaunchKernelGGL((k_integrate_bricks<false, 512>), dim3(1024), dim3(512), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-        else hipLaunchKernelGGL((k_integrate_bricks<false, 256>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        if (m->wg == 1024) {       // 4 segments per thread, bricks up to 4096 segments in one workgroup, no length sort
+            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+            else hipLaunchKernelGGL((k_integrate_bricks<false, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        } else if (m->wg == 512) {
+            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+            else hipLaunchKernelGGL((k_integrate_bricks<false, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        } else {
+            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+            else hipLaunchKernelGGL((k_integrate_bricks<false, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        }
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);

@@ -465,6 +465,24 @@ __global__ void __launch_bounds__(256) k_verify_div(float vs, float rvs, unsigne
     if (nbad) atomicAdd(bad, nbad);
 }
 
+// Exhaustive checks of the two arithmetic shortcuts that do not depend on any parameter (tsl_selftest):
+// which 0: rnd_i == round-half-away for every float; which 1: sqrt_rn_norm == sqrtf for every float in [2^-96, inf).
+__global__ void __launch_bounds__(256) k_selftest(int which, unsigned long long* bad)
+{
+    unsigned long long nbad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * 256) {
+        const float x = __uint_as_float((uint32_t)i);
+        if (which == 0) {
+            if (!(fabsf(x) < 2147483648.0f)) continue;
+            if (rnd_i(x) != rnd_i_ref(x)) ++nbad;
+        } else {
+            if (!(x >= 1.2621774483536189e-29f) || !(x < INFINITY)) continue;
+            if (__float_as_uint(sqrt_rn_norm(x)) != __float_as_uint(sqrt_rn(x))) ++nbad;
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
@@ -674,6 +692,20 @@ extern "C" {
 
 const char* tsl_version(void) { return "taichislam_hip 0.1 (gfx950)"; }
 const char* tsl_last_error(void) { return g_err.c_str(); }
+int tsl_selftest(int which, int64_t* mismatches)
+{
+    TSL_REQUIRE(mismatches && (which == 0 || which == 1), "tsl_selftest: bad argument");
+    unsigned long long* bad = nullptr;
+    TSL_HIP(hipMalloc((void**)&bad, sizeof(unsigned long long)));
+    TSL_HIP(hipMemset(bad, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest, dim3(8192), dim3(256), 0, 0, which, bad);
+    unsigned long long h = ~0ull;
+    hipError_t e = hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(bad);
+    TSL_HIP(e);
+    *mismatches = (int64_t)h;
+    return TSL_OK;
+}
 int tsl_device_count(int* n)
 {
     int c = 0;
@@ -1193,7 +1225,10 @@ int tsl_tsdf_debug_counters(tsl_tsdf* m, int64_t* out, int reset)
 int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
 {
     TSL_REQUIRE(m && name, "null");
-    if (!std::strcmp(name, "variant")) { TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2"); m->variant = value; return TSL_OK; }
+    if (!std::strcmp(name, "variant")) {
+        TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2");
+        m->variant = value; return TSL_OK;
+    }
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; for (auto& S : m->fset) drop_graphs(S); return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); m->wg = value; return TSL_OK; }

@@ -53,7 +53,7 @@ struct FrameDev {
     int*   slot_tab;                             // variants 0/1: [nb3] brick id -> frame scratch slot, EMPTY between frames
     int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
     int*   touched_b;                            // variants 0/1: [max_frame_bricks] -> brick id
-    unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point
+    unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point (zero between frames)
     int* ticket;                                 // [max_frame_bricks] arrival tickets of split bricks (zero between frames)
     uint32_t* accw;                              // [max_frame_bricks][4096] colour winner (first pixel + 1) of bricks split over workgroups (texture)
     long long* dbg;                              // developer timing counters (TSL_TIMING builds)

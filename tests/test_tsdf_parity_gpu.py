@@ -52,6 +52,17 @@ def test_integrate_workgroup_sizes(hip_lib, wg):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"workgroup size {wg}")
 
 
+@pytest.mark.parametrize("which", [0, 1])
+def test_arithmetic_shortcuts_hold_for_every_float(hip_lib, which):
+    """The kernels round half away from zero with add+truncate and take square roots without the library's rescaling;
+    both must agree with the plain forms (ti.round, sqrtf) for all 2^32 float patterns."""
+    import ctypes
+    from taichislam_amd import _lib
+    bad = ctypes.c_int64(-1)
+    _lib.check(_lib.lib().tsl_selftest(which, ctypes.byref(bad)))
+    assert bad.value == 0
+
+
 def test_fast_division_is_verified_and_optional(hip_lib):
     """x / voxel_scale is replaced by an fma-refined reciprocal product only after the device has checked it against IEEE
     division for every float; forcing IEEE division must give the same map."""

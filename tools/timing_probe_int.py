@@ -29,3 +29,11 @@ for lo, hi in ((0, 64), (64, 256), (256, 600), (600, 1025)):
     sel = (ns >= lo) & (ns < hi)
     if sel.any():
         print(f"  parts with {lo:4d}<=nseg<{hi:4d}: {sel.sum():5d} waves, compute mean {(o[sel, 2] - o[sel, 1]).mean():8.1f}, flush mean {(o[sel, 4] - o[sel, 3]).mean():7.1f}, whole frac {o[sel, 11].mean():.2f}")
+print("timeline (us from first wave start): bucket, waves, start p10/p50/p90/max, end p10/p50/p90/max")
+for lo, hi in ((0, 64), (64, 256), (256, 600), (600, 1025)):
+    for wh in (1, 0):
+        sel = (ns >= lo) & (ns < hi) & (o[:, 11] == wh)
+        if not sel.any(): continue
+        st = (o[sel, 0] - t0) / 100.0; en = (o[sel, 4] - t0) / 100.0
+        f = lambda a: "%.1f/%.1f/%.1f/%.1f" % (np.percentile(a, 10), np.percentile(a, 50), np.percentile(a, 90), a.max())
+        print(f"  nseg [{lo},{hi}) whole={wh}: {sel.sum():5d} waves  start {f(st)}  end {f(en)}  | sort {np.mean(o[sel,1]-o[sel,0])/100:.1f} compute {np.mean(o[sel,2]-o[sel,1])/100:.1f} barrier {np.mean(o[sel,3]-o[sel,2])/100:.1f} flush {np.mean(o[sel,4]-o[sel,3])/100:.1f}")
