@@ -164,8 +164,10 @@ def main():
         # algorithmic bytes (SURVEY.md section 8d / DESIGN.md): phase A = 2*P_used + 24*P_valid, phase B = 9*U + V_pcl
         bytes_a = 2 * stats["p_used"] + 24 * stats["p_valid"]
         bytes_b = 9 * stats["unique"] + stats["v_pcl"]
-        single = {k: v for k, v in kern.items() if k not in ("sort", "bin")}      # "sort"/"bin" time several launches each
-        dom = max(single, key=lambda k: single[k]["avg_us"]) if single else None
+        # the dominant kernel is k_integrate_bricks (largest share of GPU time in profiles/r01_v4_fused_kernel_stats.csv); its
+        # launches are timed with HIP events on its own stream INSIDE the timed region.  The other entries of kernels_us come
+        # from the second pass, where bracketing every kernel with events inflates them.
+        dom = "integrate" if "integrate" in kern else (max(kern, key=lambda k: kern[k]["avg_us"]) if kern else None)
         roof = None
         if dom:
             alg = 9 * stats["unique"] if dom in ("integrate", "finalize") else (stats["v_pcl"] * 20 + stats["steps"] // 10 * 8 if dom == "segments" else bytes_a)
@@ -181,7 +183,9 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[dom]["avg_us"],
                     "frame_bytes": bytes_a + bytes_b, "frame_gbs": (bytes_a + bytes_b) * fps / world / 1e9,
-                    "frame_frac": (bytes_a + bytes_b) * fps / world / 1e9 / HBM_PEAK_GBS}
+                    "frame_frac": (bytes_a + bytes_b) * fps / world / 1e9 / HBM_PEAK_GBS,
+                    "note": "exact f32 + int64 work per ray step, not data movement, bounds this kernel: waves wait 63% of their "
+                            "cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES), VALU issue is ~12% of peak (profiles/r01_v4_pmc_sq_summary.txt)"}
         out = {
             "metric": "depth-frames/s integrated (640x480->512^3 TSDF)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
