@@ -9,19 +9,20 @@
 //                ~1 ms/frame at BASELINE configs[1].  Kept as the simple cross-check.
 //
 //   variant 2    "brick-binned LDS" (default): all updates of one 16^3 brick happen in LDS.
-//                phase A (per frame, own stream, independent of the map contents):
-//                K4a k_segments   : every ray is cut into runs of consecutive steps inside one brick ("segments", one
-//                                   u64 each) by searching the brick-boundary crossings per axis; staged in LDS and
-//                                   appended block-wise; per-brick counts in an LDS hash, flushed once per block.
-//                K4b k_plan       : segment range and integrate parts of every active brick (block-aggregated reservations).
-//                K4c k_scatter    : counting-sort the segments by brick (LDS hash per 4096-segment tile, one global
-//                                   reservation per (tile, brick)).
+//                phase A (per frame, on the stream of its working set, independent of the map contents):
+//                k_segments   : every ray is cut into runs of consecutive steps inside one brick ("segments", one u64
+//                               each) by searching the brick-boundary crossings per axis; with the hash grouping of
+//                               pixels the rays themselves are built here too.  Segments go to private slots of the ray,
+//                               per-brick counts to an LDS hash that is flushed once per workgroup.
+//                k_plan       : segment range and integrate parts of every active brick (block-aggregated reservations).
+//                k_scatter    : counting-sort the segments by brick (LDS hash per 4096-slot tile, one global
+//                               reservation per (tile, brick)).
 //                phase B (frame order, main stream):
-//                K4d k_integrate_bricks : one workgroup per brick part (<= 1024 segments); the brick's 4096 {num,den}
-//                                   int64 accumulators live in 64 KiB of LDS (ds_add_u64, >400 G pairs/s chip-wide),
-//                                   then the brick is finalised in place with all row loads in flight.  Bricks split
-//                                   over several workgroups flush partial sums to the HBM scratch and
-//                K4e k_finalize_shared : ... are finalised from there.
+//                k_integrate_bricks : one workgroup per brick part (<= 1024 segments); the brick's 4096 {num,den}
+//                               int64 accumulators live in 64 KiB of LDS (ds_add_u64, >400 G pairs/s chip-wide), then
+//                               the brick is finalised in place with all row loads in flight.  Bricks split over several
+//                               workgroups add their partial sums to an HBM slab; the last workgroup to arrive (ticket)
+//                               finalises from there.
 #include "tsl_tsdf.hpp"
 
 namespace tsl {
@@ -35,7 +36,7 @@ namespace tsl {
 #define TSL_TICK(F, k) do {} while (0)
 #endif
 
-// segment key: [0,6) step count  [6,18) first step  [18,42) ray id  [42,58) frame slot of the brick
+// segment key (variants 0/1 staging): [0,6) step count  [6,18) first step  [18,42) ray id  [42,58) frame slot of the brick
 #define SEG_CNT_BITS 6
 #define SEG_J_BITS   12
 #define SEG_RAY_BITS 24
