@@ -151,7 +151,14 @@ int  tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, flo
 int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters);
 int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);
 
-/* backend knobs for A/B-ing kernel variants: name in {"variant" (0|1|2), "overlap" (0 = single stream, n = number of frames whose phase A may be in flight, max 4), "group" (1 = hash grouping of pixels per sensor voxel, 0 = stable radix sort), "graph" (0|1: hipGraph replay of same-shaped depth frames), "fastdiv" (0 = force IEEE division), "split" (lanes per ray, divides 64)} */
+/* backend knobs for A/B-ing kernel variants: name in
+     "variant"  0|1: one global int64 atomic pair per ray step, 2 (default): brick-binned LDS accumulation
+     "overlap"  0 = single stream, n = number of frames whose phase A may be in flight (default and maximum 4)
+     "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
+     "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
+     "wg"       threads per workgroup of the brick integrate kernel: 256 (default, 1024 segments per part), 512, 1024
+     "fastdiv"  0 = force IEEE division
+     "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);
 int  tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value);   /* also "fastdiv": 1 when the device verified the fma-refined division */
 

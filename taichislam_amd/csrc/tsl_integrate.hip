@@ -533,7 +533,9 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
     }
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
         TSL_TICK(F, 0);
-        const int4 pt = part < nA ? F.part_tab[part] : (part < nA + nB ? F.part_tab[F.part_cap + part - nA] : F.part_tab[2 * (size_t)F.part_cap + part - nA - nB]);
+        // order of issue: long parts, then the short ones (they retire within a few microseconds and free their slots for the
+        // medium parts, which still finish under the tail of the long ones)
+        const int4 pt = part < nA ? F.part_tab[part] : (part < nA + nC ? F.part_tab[2 * (size_t)F.part_cap + part - nA] : F.part_tab[F.part_cap + part - nA - nC]);
         const int pos = pt.x, nseg = pt.y & 0xffff, np = pt.y >> 16, rk = pt.w;
         const bool whole = np == 1;
         unsigned long long kk[PSEGS / NT]; int rr[PSEGS / NT];

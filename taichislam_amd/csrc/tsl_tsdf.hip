@@ -553,7 +553,7 @@ static PoseF pose_of(const tsl_tsdf* m, int s)
 __global__ void k_set_params(FrameParams P, FrameParams* dst, int* header) { if (threadIdx.x == 0) *dst = P; header[threadIdx.x] = 0; }
 
 // phase A of one frame on stream `sa`: depth -> rays -> brick-sorted segments.  Every argument is constant for a given
-// (image shape, options), the per-frame values live in *S.Pd -- so the same sequence can be captured into a hipGraph.
+// (image shape, options); the per-frame values live in *S.Pd.
 template <typename K>
 static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStream_t sa)
 {
@@ -589,38 +589,6 @@ static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStre
     return launch_segments(m, S, total, sa);
 }
 
-static void drop_graphs(FSet& S)
-{
-    if (S.execA) { (void)hipGraphExecDestroy(S.execA); S.execA = nullptr; }
-    if (S.execB) { (void)hipGraphExecDestroy(S.execB); S.execB = nullptr; }
-    S.graph_key = -1;
-}
-
-template <typename K>
-static int build_graphs(tsl_tsdf* m, FSet& S, int total, long long key)
-{
-    drop_graphs(S);
-    hipGraph_t g = nullptr;
-    if (hipStreamBeginCapture(S.st, hipStreamCaptureModeThreadLocal) != hipSuccess) return TSL_ERR_HIP;
-    int rc = enqueue_phase_a<K>(m, S, total, false, S.st);
-    hipError_t e = hipStreamEndCapture(S.st, &g);
-    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return TSL_ERR_HIP; }
-    e = hipGraphInstantiate(&S.execA, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g); g = nullptr;
-    if (e != hipSuccess) { S.execA = nullptr; (void)hipGetLastError(); return TSL_ERR_HIP; }
-    if (hipStreamBeginCapture(S.st, hipStreamCaptureModeThreadLocal) != hipSuccess) { drop_graphs(S); return TSL_ERR_HIP; }
-    hipStream_t keep = m->stream; m->stream = S.st;                 // phase B is captured on the set's stream, replayed on the main stream
-    rc = launch_apply(m, S, total);
-    m->stream = keep;
-    e = hipStreamEndCapture(S.st, &g);
-    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); drop_graphs(S); (void)hipGetLastError(); return TSL_ERR_HIP; }
-    e = hipGraphInstantiate(&S.execB, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { S.execB = nullptr; drop_graphs(S); (void)hipGetLastError(); return TSL_ERR_HIP; }
-    S.graph_key = key;
-    return TSL_OK;
-}
-
 template <typename K>
 static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
 {
@@ -639,24 +607,13 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     if (m->overlap && S.b_pending) TSL_HIP(hipStreamWaitEvent(sa, S.b_done, 0));      // phase B of frame f-NSETS still reads this set
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sa, P, S.Pd, reinterpret_cast<int*>(S.header));
     m->last_set = si; m->frame_no++;
-    // replay captured graphs for same-shaped depth frames: 7 host calls per frame instead of ~22
-    bool graph = m->use_graph && m->overlap && !m->prof_on && !xyz_dev && total > 0;
-    if (graph) {
-        const long long key = ((long long)P.H << 40) ^ ((long long)P.W << 24) ^ ((long long)P.step << 16) ^ ((long long)P.variant << 8) ^ (long long)P.split ^ ((long long)sizeof(K) << 60) ^ ((long long)P.tex << 59) ^ ((long long)P.group << 58);
-        if (S.graph_key != key && build_graphs<K>(m, S, total, key) != TSL_OK) { m->use_graph = 0; graph = false; }
-    }
-    if (graph) {
-        TSL_HIP(hipGraphLaunch(S.execA, sa));
-    } else {
-        if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, S, total, xyz_dev != nullptr, sa); if (rc) return rc; }
-    }
+    if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, S, total, xyz_dev != nullptr, sa); if (rc) return rc; }
     if (m->overlap) {
         TSL_HIP(hipEventRecord(S.a_done, sa));
         TSL_HIP(hipStreamWaitEvent(m->stream, S.a_done, 0));
     }
     // ---- phase B: apply to the map, in frame order on the main stream ----
-    if (graph) { TSL_HIP(hipGraphLaunch(S.execB, m->stream)); }
-    else if (total > 0 && (m->phases & 2)) { int rc = launch_apply(m, S, total); if (rc) return rc; }
+    if (total > 0 && (m->phases & 2)) { int rc = launch_apply(m, S, total); if (rc) return rc; }
     if (m->overlap) { TSL_HIP(hipEventRecord(S.b_done, m->stream)); S.b_pending = true; }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -727,7 +684,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     m->frame_no = 0; m->overlap = TSL_NSETS; m->last_set = 0;   // phase-A sets in flight (3 is marginally better without per-kernel events, 4 with them)
-    for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.execA = nullptr; S.execB = nullptr; S.graph_key = -1; }
+    for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; }
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
     m->Nz = (int)std::ceil(cfg->map_size_z / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:25
@@ -770,8 +727,7 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
     m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256;
-    m->active = 0; m->variant = 2; m->split = 2; m->use_graph = std::getenv("TSL_GRAPH") ? 1 : 0;      // hipGraph replay is opt-in: it halves the host enqueue time but the
-                                                               // pipeline is GPU-bound, and replay aborted once inside a long multi-handle test session
+    m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0; m->stage_in = nullptr; m->stage_in_bytes = 0; m->stage_tex = nullptr; m->stage_tex_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
@@ -855,7 +811,6 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&G.part_tab, sizeof(int4) * 3 * (size_t)G.part_cap))) return rc;
         if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
-        S.execA = nullptr; S.execB = nullptr; S.graph_key = -1;
         TSL_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
         TSL_HIP(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
         TSL_HIP(hipEventCreateWithFlags(&S.b_done, hipEventDisableTiming));
@@ -897,7 +852,6 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     (void)hipStreamSynchronize(m->stream);
     (void)hipDeviceSynchronize();
     for (auto& S : m->fset) {
-        drop_graphs(S);
         if (S.st) { (void)hipStreamDestroy(S.st); }
         for (void* p : S.owned) if (p) (void)hipFree(p);
         if (S.a_done) (void)hipEventDestroy(S.a_done);
@@ -1229,11 +1183,10 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
         TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2");
         m->variant = value; return TSL_OK;
     }
-    if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; for (auto& S : m->fset) drop_graphs(S); return TSL_OK; }
+    if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
-    if (!std::strcmp(name, "graph")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->use_graph = value != 0; return TSL_OK; }      // can only be switched off
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NSETS ? TSL_NSETS : value); for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;

@@ -125,9 +125,7 @@ struct ProfSlot { hipEvent_t a, b; int kid; };
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
     hipStream_t st; hipEvent_t a_done, b_done; bool b_pending;
-    FrameParams* Pd;                       // this frame's parameters in device memory (kernels read them through the pointer, so the
-                                           // launch sequence has constant arguments and can be replayed as a hipGraph)
-    hipGraphExec_t execA, execB; long long graph_key;
+    FrameParams* Pd;                       // this frame's parameters in device memory (written by the frame's prologue kernel)
     std::vector<void*> owned;
 };
 
@@ -169,7 +167,6 @@ struct tsl_tsdf {
     bool prof_on, prof_open; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int variant, split, phases, wg;
-    int use_graph;                       // 1: replay captured hipGraphs for same-shaped depth frames (when profiling is off)
     int64_t bytes;
 };
 

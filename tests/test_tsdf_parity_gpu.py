@@ -146,6 +146,20 @@ def test_pixel_grouping_paths(hip_lib, group):
 
 
 @pytest.mark.parametrize("group", [0, 1])
+def test_wide_sensor_grid_keys(hip_lib, group):
+    """max_ray_length / voxel_scale = 500: the sensor-centred grid needs 11 bits per axis, so sensor voxels are keyed with
+    64-bit Morton codes (sort path) / 64-bit hash keys, and most of every ray lies outside the 2.56 m map."""
+    cfg = dict(map_scale=[2.56, 2.56], voxel_scale=0.01, num_voxel_per_blk_axis=16, max_ray_length=5.0, min_ray_length=0.3,
+               internal_voxels=10, recast_step=2, texture_enabled=False)
+    K, frames = small_stream(2, radius=1.6, orbit=0.1)
+    g, o = make_pair(cfg, K)
+    g.set_option("group", group)
+    _run_both(g, o, frames)
+    assert g.last_frame_stats()["steps_oob"] > 0
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"wide keys, group {group}")
+
+
+@pytest.mark.parametrize("group", [0, 1])
 def test_crowded_sensor_voxels(hip_lib, group):
     """Point clouds that put tens to thousands of points into one sensor voxel: per-thread replay, the workgroup-sorted
     path for big groups, and the f16 saturation of the sums that goes with them."""
