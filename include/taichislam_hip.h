@@ -193,12 +193,13 @@ int  tsl_octo_set_base_pose_submap(tsl_octo* m, int sid, const double R[9], cons
 int  tsl_octo_get_active_submap(const tsl_octo* m, int32_t* sid);
 int  tsl_octo_set_active_submap(tsl_octo* m, int32_t sid);
 int  tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
-                              const uint8_t* tex, int th, int tw);                   /* :130-132,147-169 */
+                              const uint8_t* tex, int th, int tw);                   /* :130-132,147-169; tex u8[th][tw][3] BGR (:120-124) or NULL */
 int  tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
                                   const void* tex_dev, int th, int tw);
 int  tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n);   /* :126-128,134-145 */
 int  tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out);
-int  tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, int64_t cap, int64_t* n);
+/* every touched leaf of the active submap: index, hit count and (textured maps; else zeros) colour f32[n][3]; rgb may be NULL */
+int  tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, float* rgb, int64_t cap, int64_t* n);
 /* cvt_occupy_to_voxels(level) / cvt_occupy_voxels_to(...)  :90-114 */
 int  tsl_octo_occupied_voxels(tsl_octo* m, tsl_octo* dst /* NULL = m */, int level, int add_to_cur, int32_t* n);
 int  tsl_octo_read_exports(tsl_octo* m, float* xyz, float* rgb, int64_t n);

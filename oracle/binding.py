@@ -98,9 +98,9 @@ def lib():
                                                C.POINTER(FrameStats)]
         L.ora_octo_integrate_points.argtypes = [vp, dp, dp, vp, vp, i64, C.POINTER(FrameStats)]
         L.ora_octo_export_leaves.restype = i64
-        L.ora_octo_export_leaves.argtypes = [vp, vp, vp, i64]
+        L.ora_octo_export_leaves.argtypes = [vp, vp, vp, vp, i64]
         L.ora_octo_occupied_voxels.restype = i64
-        L.ora_octo_occupied_voxels.argtypes = [vp, C.c_int, vp, i64]
+        L.ora_octo_occupied_voxels.argtypes = [vp, C.c_int, vp, vp, i64]
         L.ora_octo_fuse_submaps.argtypes = [vp, vp]
         _LIB = L
     return _LIB
@@ -296,7 +296,8 @@ class OracleOctomap:
 
     def set_intrinsics(self, Kdep, Kcol=None):
         _, kd = _d(Kdep, 9)
-        self.L.ora_octo_set_intrinsics(self.h, kd, kd)
+        _, kc = _d(Kdep if Kcol is None else Kcol, 9)
+        self.L.ora_octo_set_intrinsics(self.h, kd, kc)
 
     def set_base_pose_submap(self, sid, R, T):
         _, r = _d(R, 9)
@@ -314,29 +315,36 @@ class OracleOctomap:
         _, r = _d(R, 9)
         _, t = _d(T, 3)
         st = FrameStats()
-        self.L.ora_octo_integrate_depth(self.h, r, t, _p(depth), depth.shape[0], depth.shape[1], None, 0, 0,
-                                        C.byref(st))
+        if texture is not None and np.size(texture):
+            tex = np.ascontiguousarray(texture, dtype=np.uint8)
+            self.L.ora_octo_integrate_depth(self.h, r, t, _p(depth), depth.shape[0], depth.shape[1], _p(tex), tex.shape[0], tex.shape[1],
+                                            C.byref(st))
+        else:
+            self.L.ora_octo_integrate_depth(self.h, r, t, _p(depth), depth.shape[0], depth.shape[1], None, 0, 0, C.byref(st))
         return st.as_dict()
 
-    def integrate_points(self, R, T, xyz):
+    def integrate_points(self, R, T, xyz, rgb=None):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         _, r = _d(R, 9)
         _, t = _d(T, 3)
         st = FrameStats()
-        self.L.ora_octo_integrate_points(self.h, r, t, _p(xyz), None, xyz.shape[0], C.byref(st))
+        c = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3) if rgb is not None and np.size(rgb) else None
+        self.L.ora_octo_integrate_points(self.h, r, t, _p(xyz), _p(c) if c is not None else None, xyz.shape[0], C.byref(st))
         return st.as_dict()
 
-    def export_leaves(self):
-        n = int(self.L.ora_octo_export_leaves(self.h, None, None, 0))
+    def export_leaves(self, with_color=False):
+        n = int(self.L.ora_octo_export_leaves(self.h, None, None, None, 0))
         idx = np.zeros((n, 3), np.int32)
         cnt = np.zeros(n, np.float32)
-        self.L.ora_octo_export_leaves(self.h, _p(idx), _p(cnt), n)
-        return idx, cnt
+        rgb = np.zeros((n, 3), np.float32)
+        self.L.ora_octo_export_leaves(self.h, _p(idx), _p(cnt), _p(rgb), n)
+        return (idx, cnt, rgb) if with_color else (idx, cnt)
 
-    def occupied_voxels(self, level=0, cap=1 << 22):
+    def occupied_voxels(self, level=0, cap=1 << 22, with_color=False):
         xyz = np.zeros((cap, 3), np.float32)
-        n = int(self.L.ora_octo_occupied_voxels(self.h, level, _p(xyz), cap))
-        return xyz[:min(n, cap)], n
+        rgb = np.zeros((cap, 3), np.float32) if with_color else None
+        n = int(self.L.ora_octo_occupied_voxels(self.h, level, _p(xyz), _p(rgb) if with_color else None, cap))
+        return (xyz[:min(n, cap)], rgb[:min(n, cap)], n) if with_color else (xyz[:min(n, cap)], n)
 
     def fuse_submaps(self, sub):
         self.L.ora_octo_fuse_submaps(self.h, sub.h)

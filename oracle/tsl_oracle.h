@@ -125,9 +125,9 @@ int       ora_octo_integrate_depth(ora_octo* m, const double R[9], const double 
 int       ora_octo_integrate_points(ora_octo* m, const double R[9], const double T[3],
                                     const float* xyz, const uint8_t* rgb, int64_t n, ora_frame_stats* st);
 /* leaf export (sorted by index) of the active submap: idx int32[n][3], count f32[n] */
-int64_t   ora_octo_export_leaves(const ora_octo* m, int32_t* idx, float* cnt, int64_t cap);
+int64_t   ora_octo_export_leaves(const ora_octo* m, int32_t* idx, float* cnt, float* rgb /* nullable, f32[n][3] */, int64_t cap);
 /* taichi_octomap.py:90-102 at tree level `level` (0 = leaf); xyz f32[n][3] sorted by node index */
-int64_t   ora_octo_occupied_voxels(const ora_octo* m, int level, float* xyz, int64_t cap);
+int64_t   ora_octo_occupied_voxels(const ora_octo* m, int level, float* xyz, float* rgb /* nullable */, int64_t cap);
 int       ora_octo_fuse_submaps(ora_octo* global, const ora_octo* sub);
 
 /* ---- ESDF (definitions from dense_esdf.py:228-333) ---- */

@@ -16,7 +16,7 @@ static inline float rnd_f(float x)
 }
 static inline int rnd_i(float x) { return (int)rnd_f(x); }
 
-typedef struct { int32_t c[3]; float cnt; float col[3]; int used; } leaf_t;
+typedef struct { int32_t c[3]; float cnt; float col[3]; int used; int32_t wkey[4]; } leaf_t;      /* wkey: source of col after a fusion (submap, i, j, k) */
 typedef struct { leaf_t* a; int nslots, n; } leafmap;
 
 struct ora_octo {
@@ -25,7 +25,7 @@ struct ora_octo {
     int ext_xy, ext_z;                 /* tree extent in cells: K^(Rxy+1), K^(1+min(Rxy,Rz))  taichi_octomap.py:65-70 (Q16) */
     double voxel_scale_recomputed;     /* :28 (Q15) */
     float vs;                          /* voxel_scale_ cached from the ctor argument  mapping_common.py:22-23 */
-    float fx, fy, cx, cy;
+    float fx, fy, cx, cy, fxc, fyc, cxc, cyc;
     float thr_max, thr_min, occ_thres;
     int nsub, active;
     leafmap* sub;
@@ -63,7 +63,10 @@ void ora_octo_destroy(ora_octo* m)
 void ora_octo_get_dims(const ora_octo* m, int* N, int* Nz, int* Rxy, int* Rz, double* vs)
 { if (N) *N = m->N; if (Nz) *Nz = m->Nz; if (Rxy) *Rxy = m->Rxy; if (Rz) *Rz = m->Rz; if (vs) *vs = m->voxel_scale_recomputed; }
 void ora_octo_set_intrinsics(ora_octo* m, const double Kd[9], const double Kc[9])
-{ (void)Kc; if (Kd) { m->fx = (float)Kd[0]; m->fy = (float)Kd[4]; m->cx = (float)Kd[2]; m->cy = (float)Kd[5]; } }
+{
+    if (Kd) { m->fx = (float)Kd[0]; m->fy = (float)Kd[4]; m->cx = (float)Kd[2]; m->cy = (float)Kd[5]; }
+    if (Kc) { m->fxc = (float)Kc[0]; m->fyc = (float)Kc[4]; m->cxc = (float)Kc[2]; m->cyc = (float)Kc[5]; }     /* mapping_common.py:25-29 */
+}
 void ora_octo_set_base_pose_submap(ora_octo* m, int sid, const double R[9], const double T[3])
 {
     memcpy(m->baseR + sid * 9, R, 72); memcpy(m->baseT + sid * 3, T, 24);
@@ -121,7 +124,6 @@ static int octo_point(ora_octo* m, const float pt[3], const uint8_t* rgb)
 int ora_octo_integrate_depth(ora_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
                              const uint8_t* tex, int th, int tw, ora_frame_stats* st_out)     /* :130-132,147-169 */
 {
-    (void)th;
     ora_frame_stats st; memset(&st, 0, sizeof(st));
     set_pose(m, R, T);
     const int step = m->cfg.recast_step;
@@ -135,8 +137,18 @@ int ora_octo_integrate_depth(ora_octo* m, const double R[9], const double T[3], 
         float pt[3] = { ((float)i - m->cx) * dep / m->fx, ((float)j - m->cy) * dep / m->fy, dep };
         float pm[3];
         for (int a = 0; a < 3; ++a) pm[a] = ((m->inR[a * 3] * pt[0] + m->inR[a * 3 + 1] * pt[1]) + m->inR[a * 3 + 2] * pt[2]) + m->inT[a];   /* :159 */
-        const uint8_t* rgb = (tex && m->cfg.texture_enabled) ? tex + ((size_t)j * tw + i) * 3 : NULL;
-        if (octo_point(m, pm, rgb)) st.p_valid++; else st.p_oob++;
+        const uint8_t* rgb = NULL;
+        if (tex && m->cfg.texture_enabled) {
+            if (m->cfg.color_same_proj) rgb = tex + ((size_t)j * tw + i) * 3;                 /* :161 */
+            else {                                                                             /* :164-165, mapping_common.py:43-58 (as in the TSDF path) */
+                int ci = (int)((((float)i - m->cx) / m->fx) * m->fxc + m->cxc);
+                int cj = (int)((((float)j - m->cy) / m->fy) * m->fyc + m->cyc);
+                if (ci < 0 || ci >= th || cj < 0 || cj >= tw) { ci = 0; cj = 0; }
+                if (cj >= th || ci >= tw) { ci = 0; cj = 0; }
+                rgb = tex + ((size_t)cj * tw + ci) * 3;
+            }
+        }
+        if (octo_point(m, pm, rgb)) st.p_valid++; else st.p_oob++;                            /* pixels in raster order: the last one to hit a leaf colours it */
     }
     if (st_out) *st_out = st;
     return 0;
@@ -169,17 +181,20 @@ static leaf_t* sorted_leaves(const leafmap* lm, int* n)
     qsort(out, (size_t)k, sizeof(leaf_t), cmp_leaf); *n = k; return out;
 }
 
-int64_t ora_octo_export_leaves(const ora_octo* m, int32_t* idx, float* cnt, int64_t cap)
+int64_t ora_octo_export_leaves(const ora_octo* m, int32_t* idx, float* cnt, float* rgb, int64_t cap)
 {
     int n; leaf_t* l = sorted_leaves(&m->sub[m->active], &n);
-    for (int i = 0; i < n && i < cap; ++i) { idx[i * 3] = l[i].c[0]; idx[i * 3 + 1] = l[i].c[1]; idx[i * 3 + 2] = l[i].c[2]; cnt[i] = l[i].cnt; }
+    for (int i = 0; i < n && i < cap; ++i) {
+        idx[i * 3] = l[i].c[0]; idx[i * 3 + 1] = l[i].c[1]; idx[i * 3 + 2] = l[i].c[2]; cnt[i] = l[i].cnt;
+        if (rgb) memcpy(rgb + (size_t)i * 3, l[i].col, sizeof(l[i].col));
+    }
     free(l); return n;
 }
 
 /* cvt_occupy_to_voxels(level) :90-102.  occupy.parent(level) for level>=1 is the pointer SNode
  * `level-1` steps above the leaf cells; its active cells are reported with the coordinate of
  * their lowest leaf, and is_occupy() reads that leaf (:97, :86-88). */
-int64_t ora_octo_occupied_voxels(const ora_octo* m, int level, float* xyz, int64_t cap)
+int64_t ora_octo_occupied_voxels(const ora_octo* m, int level, float* xyz, float* rgb, int64_t cap)
 {
     int gxy = 1, gz = 1;
     for (int up = 0; up < level - 1; ++up) {          /* tree level r = Rxy-1-up splits z iff r < Rz  (:66-70) */
@@ -196,6 +211,7 @@ int64_t ora_octo_occupied_voxels(const ora_octo* m, int level, float* xyz, int64
         if (cnt < cap) {
             float p[3] = { (float)l[i].c[0] * m->vs, (float)l[i].c[1] * m->vs, (float)l[i].c[2] * m->vs };
             for (int a = 0; a < 3; ++a) xyz[cnt * 3 + a] = ((R[a * 3] * p[0] + R[a * 3 + 1] * p[1]) + R[a * 3 + 2] * p[2]) + T[a];   /* sijk_to_xyz mapping_common.py:234-238 */
+            if (rgb) memcpy(rgb + (size_t)cnt * 3, l[i].col, sizeof(l[i].col));                /* :100-101 */
         }
         cnt++;
     }
@@ -222,8 +238,14 @@ int ora_octo_fuse_submaps(ora_octo* g, const ora_octo* sub)
             for (int a = 0; a < 3; ++a) { float x = ((R[a * 3] * p[0] + R[a * 3 + 1] * p[1]) + R[a * 3 + 2] * p[2]) + T[a]; c[a] = rnd_i(x / g->vs); }   /* :182-183 */
             if (!in_tree(g, c)) continue;
             leaf_t* d = leaf_get(&g->sub[0], c, 1);
+            const int first = d->cnt == 0.0f;
             d->cnt += l->cnt;                                                                  /* :186 */
-            if (g->cfg.texture_enabled) memcpy(d->col, l->col, sizeof(d->col));                /* :189 */
+            if (g->cfg.texture_enabled) {       /* :189 is a race between source leaves: here the largest (submap, i, j, k) wins */
+                const int32_t key[4] = { s, l->c[0], l->c[1], l->c[2] };
+                int bigger = first;
+                for (int a = 0; a < 4 && !bigger; ++a) { if (key[a] != d->wkey[a]) { bigger = key[a] > d->wkey[a]; break; } }
+                if (bigger) { memcpy(d->col, l->col, sizeof(d->col)); memcpy(d->wkey, key, sizeof(key)); }
+            }
         }
     }
     return 0;

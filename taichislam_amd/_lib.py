@@ -106,7 +106,7 @@ SIGNATURES = {
     "tsl_octo_integrate_depth_dev": (C.c_int, [vp, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     "tsl_octo_integrate_points": (C.c_int, [vp, dp, dp, vp, vp, i64]),
     "tsl_octo_last_frame_stats": (C.c_int, [vp, C.POINTER(FrameStats)]),
-    "tsl_octo_export_leaves": (C.c_int, [vp, vp, vp, i64, pi64]),
+    "tsl_octo_export_leaves": (C.c_int, [vp, vp, vp, vp, i64, pi64]),
     "tsl_octo_occupied_voxels": (C.c_int, [vp, vp, C.c_int, C.c_int, pi32]),
     "tsl_octo_read_exports": (C.c_int, [vp, vp, vp, i64]),
     "tsl_octo_num_particles": (C.c_int, [vp, pi32]),

@@ -3,7 +3,8 @@
 // The reference stores one f32 hit count per leaf of a K-ary pointer tree (11 pointer levels at 1024^3) and walks the
 // tree for every insert.  Here the leaves live in 16^3 bricks of f32 behind a direct-mapped brick table per submap
 // (tables are created lazily by the host when a submap becomes active); an insert is one table lookup + one f32 atomic.
-// Counts are small integers in f32, so the sums are exact and independent of the order of the atomics.
+// Counts are small integers in f32, so the sums are exact and independent of the order of the atomics.  Textured maps keep one
+// f32 colour per leaf; who colours a leaf is decided by an atomicMax over the writer's index instead of the reference's race.
 #include "tsl_common.hpp"
 #include <cmath>
 
@@ -14,12 +15,15 @@ struct OctoDev {
     int max_bricks;
     int** tables;            // [nsub] -> brick table of the submap (nullptr until the host creates it)
     float* cnt;              // [max_bricks][4096]
+    float* col;              // [max_bricks][4096][3] leaf colour (texture_enabled only)
+    unsigned long long* win; // [max_bricks][4096] winner of the current frame / fusion (zero in between)
     int* owner_s; int* owner_b;
     int* pool_top; int* err;
 };
 
 struct OctoParams {
-    float R[9], T[3]; float fx, fy, cx, cy; float vs; float thr_max, thr_min; int step, hh, ww, W;
+    float R[9], T[3]; float fx, fy, cx, cy; float fxc, fyc, cxc, cyc; float vs; float thr_max, thr_min; int step, hh, ww, W;
+    int th, tw, same_proj;
 };
 
 __device__ __forceinline__ bool octo_in_tree(const OctoDev& M, int i, int j, int k)
@@ -40,25 +44,53 @@ __device__ __forceinline__ int octo_claim(const OctoDev& M, int s, int b)
     if (v >= 0) { M.owner_s[v] = s; M.owner_b[v] = b; } else atomicOr(M.err, 1);
     return v;
 }
-// process_point  taichi_octomap.py:116-124 (texture not stored: see DESIGN.md)
-__device__ __forceinline__ bool octo_point(const OctoDev& M, int s, float vs, float x, float y, float z)
+// process_point  taichi_octomap.py:116-124.  Returns the leaf (pool brick * 4096 + cell) or -1.  The reference lets the last
+// writer colour a leaf (:120-124, a race); here the pixel / point with the largest index wins: `id1` = index + 1 enters an
+// atomicMax and k_octo_colour lets the winner write (the oracle inserts in index order, so its last writer is the same one).
+__device__ __forceinline__ long long octo_point(const OctoDev& M, int s, float vs, float x, float y, float z, unsigned id1)
 {
     const int ci = rnd_i(x / vs), cj = rnd_i(y / vs), ck = rnd_i(z / vs);                    // mapping_common.py:252-266
-    if (!octo_in_tree(M, ci, cj, ck)) return false;
+    if (!octo_in_tree(M, ci, cj, ck)) return -1;
     int l; const int b = octo_brick_of(M, ci, cj, ck, &l);
     const int p = octo_claim(M, s, b);
-    if (p < 0) return false;
-    atomicAdd(M.cnt + (size_t)p * TSL_BRK3 + l, 1.0f);                                       // :119
-    return true;
+    if (p < 0) return -1;
+    const long long leaf = (long long)p * TSL_BRK3 + l;
+    atomicAdd(M.cnt + leaf, 1.0f);                                                           // :119
+    if (id1) atomicMax(M.win + leaf, (unsigned long long)id1);
+    return leaf;
+}
+// texel of a depth pixel (taichi_octomap.py:160-165 with the index mapping of mapping_common.py:43-58, as in the TSDF path)
+__device__ __forceinline__ const uint8_t* octo_texel(const OctoParams& P, const uint8_t* tex, int i, int j)
+{
+    if (P.same_proj) return tex + ((size_t)j * P.tw + i) * 3;
+    int ci = (int)((((float)i - P.cx) / P.fx) * P.fxc + P.cxc);
+    int cj = (int)((((float)j - P.cy) / P.fy) * P.fyc + P.cyc);
+    if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }
+    if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }
+    return tex + ((size_t)cj * P.tw + ci) * 3;
+}
+// second pass of a textured insert: the winner of every leaf writes its colour (BGR -> RGB, :121-124) and clears the mark
+__global__ void __launch_bounds__(256) k_octo_colour(OctoDev M, OctoParams P, const uint8_t* __restrict__ tex, const long long* __restrict__ leaf_of, int total, int points)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const long long leaf = leaf_of[p];
+    if (leaf < 0 || M.win[leaf] != (unsigned long long)(p + 1)) return;
+    const uint8_t* rgb;
+    if (points) rgb = tex + (size_t)p * 3;
+    else { const int jj = p / P.ww, ii = p - jj * P.ww; rgb = octo_texel(P, tex, ii * P.step, jj * P.step); }
+    M.col[leaf * 3] = (float)rgb[2] / 255.0f; M.col[leaf * 3 + 1] = (float)rgb[1] / 255.0f; M.col[leaf * 3 + 2] = (float)rgb[0] / 255.0f;
+    M.win[leaf] = 0ull;
 }
 
 // recast_depth_to_map_kernel  taichi_octomap.py:147-169
-__global__ void __launch_bounds__(256) k_octo_depth(OctoDev M, OctoParams P, int s, const uint16_t* __restrict__ depth, tsl_frame_stats* st)
+__global__ void __launch_bounds__(256) k_octo_depth(OctoDev M, OctoParams P, int s, const uint16_t* __restrict__ depth, tsl_frame_stats* st, long long* leaf_of)
 {
     const int total = P.hh * P.ww;
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool gate = false, ok = false;
     if (p < total) {
+        long long leaf = -1;
         const int jj = p / P.ww, ii = p - jj * P.ww;
         const int j = jj * P.step, i = ii * P.step;
         const uint16_t d = depth[(size_t)j * P.W + i];
@@ -70,14 +102,16 @@ __global__ void __launch_bounds__(256) k_octo_depth(OctoDev M, OctoParams P, int
             const float mx = ((P.R[0] * px + P.R[1] * py) + P.R[2] * pz) + P.T[0];            // :159
             const float my = ((P.R[3] * px + P.R[4] * py) + P.R[5] * pz) + P.T[1];
             const float mz = ((P.R[6] * px + P.R[7] * py) + P.R[8] * pz) + P.T[2];
-            ok = octo_point(M, s, P.vs, mx, my, mz);
+            leaf = octo_point(M, s, P.vs, mx, my, mz, leaf_of ? (unsigned)(p + 1) : 0u);
+            ok = leaf >= 0;
         }
+        if (leaf_of) leaf_of[p] = leaf;
     }
     block_count_add(&st->p_valid, ok);
     block_count_add(&st->p_oob, gate && !ok);
 }
 // recast_pcl_to_map_kernel  taichi_octomap.py:134-145 (no range gate)
-__global__ void __launch_bounds__(256) k_octo_points(OctoDev M, OctoParams P, int s, const float* __restrict__ xyz, int n, tsl_frame_stats* st)
+__global__ void __launch_bounds__(256) k_octo_points(OctoDev M, OctoParams P, int s, const float* __restrict__ xyz, int n, tsl_frame_stats* st, long long* leaf_of)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool ok = false;
@@ -86,7 +120,9 @@ __global__ void __launch_bounds__(256) k_octo_points(OctoDev M, OctoParams P, in
         const float mx = ((P.R[0] * px + P.R[1] * py) + P.R[2] * pz) + P.T[0];                // :141
         const float my = ((P.R[3] * px + P.R[4] * py) + P.R[5] * pz) + P.T[1];
         const float mz = ((P.R[6] * px + P.R[7] * py) + P.R[8] * pz) + P.T[2];
-        ok = octo_point(M, s, P.vs, mx, my, mz);
+        const long long leaf = octo_point(M, s, P.vs, mx, my, mz, leaf_of ? (unsigned)(p + 1) : 0u);
+        ok = leaf >= 0;
+        if (leaf_of) leaf_of[p] = leaf;
     }
     block_count_add(&st->p_valid, ok);
     block_count_add(&st->p_oob, p < n && !ok);
@@ -101,7 +137,7 @@ __device__ __forceinline__ void octo_ijk(const OctoDev& M, int b, int l, int* i,
 struct OctoPose { float R[9], T[3]; };
 // mode 0: every touched leaf -> (idx, count); mode 1: cvt_occupy_to_voxels(level) taichi_octomap.py:90-114 -> xyz
 __global__ void __launch_bounds__(256) k_octo_export(OctoDev M, int s, int nused, int mode, float thres, int gxy, int gz, OctoPose B, float vs,
-                                                     int32_t* idx, float* cnt, float* xyz, long long cap, int* counter)
+                                                     int32_t* idx, float* cnt, float* xyz, float* rgb, long long cap, int* counter)
 {
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         if (M.owner_s[p] != s) continue;
@@ -115,6 +151,7 @@ __global__ void __launch_bounds__(256) k_octo_export(OctoDev M, int s, int nused
             else pred = (c > thres) && ((i + M.hN) % gxy == 0) && ((j + M.hN) % gxy == 0) && ((k + M.hNz) % gz == 0);   // :96-97, :86-88
             const int o = wave_reserve(counter, pred);
             if (pred && o < cap) {
+                if (rgb && M.col) for (int a = 0; a < 3; ++a) rgb[(size_t)o * 3 + a] = M.col[((size_t)p * TSL_BRK3 + l) * 3 + a];      // :100-101
                 if (mode == 0) { idx[(size_t)o * 3] = i; idx[(size_t)o * 3 + 1] = j; idx[(size_t)o * 3 + 2] = k; cnt[o] = c; }
                 else {
                     const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;      // sijk_to_xyz mapping_common.py:234-238
@@ -126,8 +163,11 @@ __global__ void __launch_bounds__(256) k_octo_export(OctoDev M, int s, int nused
 }
 
 // fuse_submaps_kernel  taichi_octomap.py:171-189
-__global__ void __launch_bounds__(256) k_octo_fuse(OctoDev S, OctoDev G, int nused, const float* poses, int npose, float vs, float thres)
+// pass 0 adds the counts (:186) and, when textured, lets the source leaf with the largest (submap, i, j, k) mark the target
+// (the reference's `color = submap_color` :189 is a race between the sources); pass 1 lets the marked source copy its colour.
+__global__ void __launch_bounds__(256) k_octo_fuse(OctoDev S, OctoDev G, int nused, const float* poses, int npose, float vs, float thres, int pass)
 {
+    const bool tex = S.col && G.col;
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         const int s = S.owner_s[p], b = S.owner_b[p];
         if (s >= npose) continue;
@@ -141,8 +181,21 @@ __global__ void __launch_bounds__(256) k_octo_fuse(OctoDev S, OctoDev G, int nus
             for (int a = 0; a < 3; ++a) { const float x = ((Rp[a * 3] * p0 + Rp[a * 3 + 1] * p1) + Rp[a * 3 + 2] * p2) + Rp[9 + a]; cc[a] = rnd_i(x / vs); }   // :182-183
             if (!octo_in_tree(G, cc[0], cc[1], cc[2])) continue;
             int gl; const int gb = octo_brick_of(G, cc[0], cc[1], cc[2], &gl);
-            const int gp = octo_claim(G, 0, gb);
-            if (gp >= 0) atomicAdd(G.cnt + (size_t)gp * TSL_BRK3 + gl, c);                    // :186
+            const unsigned long long key1 = 1ull + (((unsigned long long)s << 54) | ((unsigned long long)(i + S.hN) << 36) | ((unsigned long long)(j + S.hN) << 18) | (unsigned long long)(k + S.hNz));
+            if (pass == 0) {
+                const int gp = octo_claim(G, 0, gb);
+                if (gp >= 0) {
+                    atomicAdd(G.cnt + (size_t)gp * TSL_BRK3 + gl, c);                          // :186
+                    if (tex) atomicMax(G.win + (size_t)gp * TSL_BRK3 + gl, key1);
+                }
+            } else {
+                const int gp = G.tables[0][gb];
+                if (gp >= 0 && G.win[(size_t)gp * TSL_BRK3 + gl] == key1) {
+                    const size_t src = ((size_t)p * TSL_BRK3 + l) * 3, dst = ((size_t)gp * TSL_BRK3 + gl) * 3;
+                    for (int a = 0; a < 3; ++a) G.col[dst + a] = S.col[src + a];
+                    G.win[(size_t)gp * TSL_BRK3 + gl] = 0ull;
+                }
+            }
         }
     }
 }
@@ -152,6 +205,7 @@ __global__ void __launch_bounds__(256) k_octo_reset(OctoDev M, int nused)
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         float* c = M.cnt + (size_t)p * TSL_BRK3;
         for (int l = threadIdx.x; l < TSL_BRK3; l += 256) c[l] = 0.0f;
+        if (M.col) for (int l = threadIdx.x; l < TSL_BRK3 * 3; l += 256) M.col[(size_t)p * TSL_BRK3 * 3 + l] = 0.0f;
         if (threadIdx.x == 0) M.tables[M.owner_s[p]][M.owner_b[p]] = TSL_EMPTY;
     }
 }
@@ -172,6 +226,7 @@ struct tsl_octo {
     float *exp_xyz, *exp_rgb; int* num_particles; int64_t max_disp;
     float* pose_dev;
     void* stage; size_t stage_bytes; void* xbuf; size_t xbuf_bytes;
+    void* stage_tex; size_t stage_tex_bytes; long long* leaf_of; size_t leaf_of_n;      // texture staging, leaf of every pixel / point of the frame
 };
 
 using namespace tsl;
@@ -201,6 +256,18 @@ static int octo_check_err(tsl_octo* m)
 {
     int e = 0; int rc = octo_read_int(m, m->M.err, &e); if (rc) return rc;
     if (e) { (void)hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream); set_error("octomap brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
+    return TSL_OK;
+}
+
+static int octo_stage_tex(tsl_octo* m, const uint8_t* tex, size_t bytes)
+{
+    if (m->stage_tex_bytes < bytes) { if (m->stage_tex) (void)hipFree(m->stage_tex); m->stage_tex = nullptr; TSL_HIP(hipMalloc(&m->stage_tex, bytes + 4096)); m->stage_tex_bytes = bytes + 4096; }
+    TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, bytes, hipMemcpyHostToDevice, m->stream));
+    return TSL_OK;
+}
+static int octo_leaf_scratch(tsl_octo* m, size_t n)
+{
+    if (m->leaf_of_n < n) { if (m->leaf_of) (void)hipFree(m->leaf_of); m->leaf_of = nullptr; TSL_HIP(hipMalloc((void**)&m->leaf_of, sizeof(long long) * (n + 1024))); m->leaf_of_n = n + 1024; }
     return TSL_OK;
 }
 
@@ -238,6 +305,14 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     m->tables.assign((size_t)m->nsub, nullptr);
     TSL_HIP(hipMalloc((void**)&M.cnt, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3));
     TSL_HIP(hipMemsetAsync(M.cnt, 0, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+    M.col = nullptr; M.win = nullptr;
+    if (cfg->texture_enabled) {
+        TSL_REQUIRE(M.ext_xy <= (1 << 18) && m->nsub <= 1024, "tsl_octo_create: textured maps are limited to 2^18 cells per axis and 1024 submaps");
+        TSL_HIP(hipMalloc((void**)&M.col, sizeof(float) * 3 * (size_t)M.max_bricks * TSL_BRK3));
+        TSL_HIP(hipMemsetAsync(M.col, 0, sizeof(float) * 3 * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+        TSL_HIP(hipMalloc((void**)&M.win, sizeof(unsigned long long) * (size_t)M.max_bricks * TSL_BRK3));
+        TSL_HIP(hipMemsetAsync(M.win, 0, sizeof(unsigned long long) * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+    }
     TSL_HIP(hipMalloc((void**)&M.owner_s, sizeof(int) * (size_t)M.max_bricks));
     TSL_HIP(hipMalloc((void**)&M.owner_b, sizeof(int) * (size_t)M.max_bricks));
     TSL_HIP(hipMalloc((void**)&M.pool_top, sizeof(int) * 4));
@@ -247,7 +322,7 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     for (int i = 0; i < 3; ++i) P.R[i * 4] = 1.0f;
     P.vs = (float)cfg->voxel_scale;                                                                          // voxel_scale_ cached from the ctor argument (Q15)
     P.thr_max = (float)(cfg->max_ray_length * 1000.0); P.thr_min = (float)(cfg->min_ray_length * 1000.0);
-    P.step = cfg->recast_step;
+    P.step = cfg->recast_step; P.same_proj = cfg->color_same_proj;
     m->occ_thres = (float)cfg->min_occupy_thres;
     m->baseR.assign((size_t)m->nsub * 9, 0.0); m->baseT.assign((size_t)m->nsub * 3, 0.0);
     m->baseRf.assign((size_t)m->nsub * 9, 0.0f); m->baseTf.assign((size_t)m->nsub * 3, 0.0f);
@@ -263,6 +338,7 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     TSL_HIP(hipMemsetAsync(m->num_particles, 0, sizeof(int) * 4, m->stream));
     TSL_HIP(hipMalloc((void**)&m->pose_dev, sizeof(float) * 12 * (size_t)m->nsub));
     m->stage = nullptr; m->stage_bytes = 0; m->xbuf = nullptr; m->xbuf_bytes = 0;
+    m->stage_tex = nullptr; m->stage_tex_bytes = 0; m->leaf_of = nullptr; m->leaf_of_n = 0;
     int rc = octo_ensure_table(m, 0); if (rc) return rc;
     TSL_HIP(hipStreamSynchronize(m->stream));
     *out = m;
@@ -274,7 +350,7 @@ void tsl_octo_destroy(tsl_octo* m)
     if (!m) return;
     (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream);
     for (int* t : m->tables) if (t) (void)hipFree(t);
-    void* ptrs[] = { m->M.tables, m->M.cnt, m->M.owner_s, m->M.owner_b, m->M.pool_top, m->stats, m->exp_xyz, m->exp_rgb, m->num_particles, m->pose_dev, m->stage, m->xbuf };
+    void* ptrs[] = { m->M.col, m->M.win, m->stage_tex, m->leaf_of, m->M.tables, m->M.cnt, m->M.owner_s, m->M.owner_b, m->M.pool_top, m->stats, m->exp_xyz, m->exp_rgb, m->num_particles, m->pose_dev, m->stage, m->xbuf };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
     (void)hipStreamDestroy(m->stream);
@@ -295,7 +371,12 @@ int tsl_octo_reset(tsl_octo* m)                                                 
     return TSL_OK;
 }
 int tsl_octo_set_intrinsics(tsl_octo* m, const double Kd[9], const double Kc[9])
-{ TSL_REQUIRE(m, "null handle"); (void)Kc; if (Kd) { m->P.fx = (float)Kd[0]; m->P.fy = (float)Kd[4]; m->P.cx = (float)Kd[2]; m->P.cy = (float)Kd[5]; } return TSL_OK; }
+{
+    TSL_REQUIRE(m, "null handle");
+    if (Kd) { m->P.fx = (float)Kd[0]; m->P.fy = (float)Kd[4]; m->P.cx = (float)Kd[2]; m->P.cy = (float)Kd[5]; }
+    if (Kc) { m->P.fxc = (float)Kc[0]; m->P.fyc = (float)Kc[4]; m->P.cxc = (float)Kc[2]; m->P.cyc = (float)Kc[5]; }      // mapping_common.py:25-29
+    return TSL_OK;
+}
 int tsl_octo_set_base_pose_submap(tsl_octo* m, int sid, const double R[9], const double T[3])
 {
     TSL_REQUIRE(m && R && T, "null"); TSL_REQUIRE(sid >= 0 && sid < m->nsub, "set_base_pose_submap: submap id out of range");
@@ -319,41 +400,54 @@ static void octo_fill_pose(tsl_octo* m, const double R[9], const double T[3])
 int tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[3], const void* depth_dev, int h, int w, const void* tex_dev, int th, int tw)
 {
     TSL_REQUIRE(m && R && T && depth_dev, "octo integrate_depth: null argument"); TSL_REQUIRE(h > 0 && w > 0, "octo integrate_depth: bad image size");
-    (void)tex_dev; (void)th; (void)tw;
     TSL_HIP(hipSetDevice(m->device));
     octo_fill_pose(m, R, T);
     OctoParams& P = m->P;
     P.W = w; P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);   // taichi_octomap.py:151,153
     const int total = P.hh * P.ww;
     m->p_used = total;
+    const bool tex = m->M.col && tex_dev && th > 0 && tw > 0;
+    if (tex) {
+        TSL_REQUIRE(!P.same_proj || (th >= h && tw >= w), "octo integrate_depth: texture smaller than the depth image");
+        P.th = th; P.tw = tw;
+        int rc = octo_leaf_scratch(m, (size_t)total); if (rc) return rc;
+    }
     TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
-    if (total > 0) hipLaunchKernelGGL(k_octo_depth, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, m->active, (const uint16_t*)depth_dev, m->stats);
+    if (total > 0) {
+        hipLaunchKernelGGL(k_octo_depth, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, m->active, (const uint16_t*)depth_dev, m->stats, tex ? m->leaf_of : nullptr);
+        if (tex) hipLaunchKernelGGL(k_octo_colour, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, (const uint8_t*)tex_dev, (const long long*)m->leaf_of, total, 0);
+    }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
 int tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w, const uint8_t* tex, int th, int tw)
 {
     TSL_REQUIRE(m && depth, "octo integrate_depth: null argument"); TSL_REQUIRE(h > 0 && w > 0, "octo integrate_depth: bad image size");
-    (void)tex; TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipSetDevice(m->device));
     const size_t nb = (size_t)h * w * 2;
     if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
     TSL_HIP(hipMemcpyAsync(m->stage, depth, nb, hipMemcpyHostToDevice, m->stream));
+    const bool use_tex = m->M.col && tex && th > 0 && tw > 0;
+    if (use_tex) { int rc = octo_stage_tex(m, tex, (size_t)th * tw * 3); if (rc) return rc; }
     TSL_HIP(hipStreamSynchronize(m->stream));
-    return tsl_octo_integrate_depth_dev(m, R, T, m->stage, h, w, nullptr, th, tw);
+    return tsl_octo_integrate_depth_dev(m, R, T, m->stage, h, w, use_tex ? m->stage_tex : nullptr, th, tw);
 }
 int tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n)
 {
     TSL_REQUIRE(m && R && T, "octo integrate_points: null argument"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz) && n < (1ll << 31), "octo integrate_points: bad input");
-    (void)rgb; TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipSetDevice(m->device));
     octo_fill_pose(m, R, T);
     m->p_used = n;
+    const bool use_tex = m->M.col && rgb && n > 0;
     TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
     if (n == 0) return TSL_OK;
     const size_t nb = (size_t)n * 12;
     if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
     TSL_HIP(hipMemcpyAsync(m->stage, xyz, nb, hipMemcpyHostToDevice, m->stream));
+    if (use_tex) { int rc = octo_stage_tex(m, rgb, (size_t)n * 3); if (rc) return rc; rc = octo_leaf_scratch(m, (size_t)n); if (rc) return rc; }
     TSL_HIP(hipStreamSynchronize(m->stream));
-    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)m->stage, (int)n, m->stats);
+    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)m->stage, (int)n, m->stats, use_tex ? m->leaf_of : nullptr);
+    if (use_tex) hipLaunchKernelGGL(k_octo_colour, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, (const uint8_t*)m->stage_tex, (const long long*)m->leaf_of, (int)n, 1);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -366,7 +460,7 @@ int tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out)
     return octo_check_err(m);
 }
 
-static int octo_export(tsl_octo* m, tsl_octo* dst, int mode, int level, int keep, int32_t* idx, float* cnt, int64_t cap, int64_t* n)
+static int octo_export(tsl_octo* m, tsl_octo* dst, int mode, int level, int keep, int32_t* idx, float* cnt, float* rgb, int64_t cap, int64_t* n)
 {
     TSL_HIP(hipSetDevice(m->device));
     int used = 0; int rc = octo_used(m, &used); if (rc) return rc;
@@ -375,35 +469,36 @@ static int octo_export(tsl_octo* m, tsl_octo* dst, int mode, int level, int keep
     OctoPose B;
     for (int a = 0; a < 9; ++a) B.R[a] = m->baseRf[(size_t)m->active * 9 + a];
     for (int a = 0; a < 3; ++a) B.T[a] = m->baseTf[(size_t)m->active * 3 + a];
-    int* counter; int32_t* didx = nullptr; float* dcnt = nullptr; float* dxyz = nullptr; long long dcap;
+    int* counter; int32_t* didx = nullptr; float* dcnt = nullptr; float* dxyz = nullptr; float* drgb = nullptr; long long dcap;
     if (mode == 0) {
-        const size_t need = (size_t)cap * 16 + 64;
+        const size_t need = (size_t)cap * 28 + 64;
         if (m->xbuf_bytes < need) { if (m->xbuf) (void)hipFree(m->xbuf); m->xbuf = nullptr; TSL_HIP(hipMalloc(&m->xbuf, need + 4096)); m->xbuf_bytes = need + 4096; }
-        didx = (int32_t*)m->xbuf; dcnt = (float*)((char*)m->xbuf + (size_t)cap * 12);
+        didx = (int32_t*)m->xbuf; dcnt = (float*)((char*)m->xbuf + (size_t)cap * 12); drgb = (float*)((char*)m->xbuf + (size_t)cap * 16);
         counter = m->num_particles + 2; dcap = cap;
         TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));
     } else {
         if (!dst) dst = m;
-        counter = dst->num_particles; dxyz = dst->exp_xyz; dcap = dst->max_disp;
+        counter = dst->num_particles; dxyz = dst->exp_xyz; drgb = dst->exp_rgb; dcap = dst->max_disp;
         if (!keep) TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));                // :93
     }
     if (used > 0) hipLaunchKernelGGL(k_octo_export, dim3(used < 8192 ? used : 8192), dim3(256), 0, m->stream, m->M, m->active, used, mode, m->occ_thres, gxy, gz, B, m->P.vs,
-                                     didx, dcnt, dxyz, dcap, counter);
+                                     didx, dcnt, dxyz, drgb, dcap, counter);
     int c = 0; rc = octo_read_int(m, counter, &c); if (rc) return rc;
     *n = c;
     if (mode == 0) {
         const size_t k = (size_t)(c < cap ? c : cap);
         if (k && idx) TSL_HIP(hipMemcpy(idx, didx, k * 12, hipMemcpyDeviceToHost));
         if (k && cnt) TSL_HIP(hipMemcpy(cnt, dcnt, k * 4, hipMemcpyDeviceToHost));
+        if (k && rgb) { if (m->M.col) TSL_HIP(hipMemcpy(rgb, drgb, k * 12, hipMemcpyDeviceToHost)); else std::memset(rgb, 0, k * 12); }
     }
     return TSL_OK;
 }
-int tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, int64_t cap, int64_t* n)
-{ TSL_REQUIRE(m && n && cap >= 0, "octo export_leaves: bad argument"); return octo_export(m, nullptr, 0, 0, 0, idx, cnt, cap, n); }
+int tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, float* rgb, int64_t cap, int64_t* n)
+{ TSL_REQUIRE(m && n && cap >= 0, "octo export_leaves: bad argument"); return octo_export(m, nullptr, 0, 0, 0, idx, cnt, rgb, cap, n); }
 int tsl_octo_occupied_voxels(tsl_octo* m, tsl_octo* dst, int level, int add_to_cur, int32_t* n)
 {
     TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(level >= 0, "bad level");
-    int64_t c = 0; int rc = octo_export(m, dst, 1, level, add_to_cur, nullptr, nullptr, 0, &c);
+    int64_t c = 0; int rc = octo_export(m, dst, 1, level, add_to_cur, nullptr, nullptr, nullptr, 0, &c);
     if (n) *n = (int32_t)c;
     return rc;
 }
@@ -433,7 +528,10 @@ int tsl_octo_fuse_submaps(tsl_octo* g, tsl_octo* sub)
     TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, g->stream));
     TSL_HIP(hipStreamSynchronize(g->stream));
     int nsrc = 0; if ((rc = octo_used(sub, &nsrc))) return rc;
-    if (nsrc > 0) hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres);
+    if (nsrc > 0) {
+        hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres, 0);
+        if (sub->M.col && g->M.col) hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres, 1);
+    }
     TSL_HIP(hipGetLastError());
     TSL_HIP(hipStreamSynchronize(g->stream));
     return octo_check_err(g);

@@ -64,6 +64,10 @@ class Octomap(BaseMap):
     def _read(self, n):
         n = int(max(0, min(n, self.max_disp_particles)))
         xyz = np.empty((n, 3), np.float32)
+        if self.enable_texture:
+            rgb = np.empty((n, 3), np.float32)
+            self._call("read_exports", _vp(xyz), _vp(rgb), n)
+            return xyz, rgb
         self._call("read_exports", _vp(xyz), None, n)
         return xyz, np.full((n, 3), 0.5, np.float32)
 
@@ -79,15 +83,27 @@ class Octomap(BaseMap):
         xyz = np.ascontiguousarray(np.asarray(xyz_array, dtype=np.float32).reshape(-1, 3))
         if n is not None:
             xyz = xyz[:int(n)]
-        self._call("integrate_points", _dptr(R, 9)[1], _dptr(T, 3)[1], _vp(xyz), None, int(xyz.shape[0]))
+        rgb = None
+        if self.enable_texture and rgb_array is not None and np.size(rgb_array) >= 3 * xyz.shape[0] > 0:
+            rgb = np.ascontiguousarray(np.asarray(rgb_array, dtype=np.uint8).reshape(-1, 3)[:xyz.shape[0]])     # BGR as delivered by OpenCV (:120)
+        self._call("integrate_points", _dptr(R, 9)[1], _dptr(T, 3)[1], _vp(xyz), _vp(rgb) if rgb is not None else None, int(xyz.shape[0]))
 
     def recast_depth_to_map(self, R, T, depthmap, texture=None):
         r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
+        use_tex = self.enable_texture and texture is not None and np.ndim(texture) == 3
         if hasattr(depthmap, "data_ptr") and getattr(depthmap, "is_cuda", False):
-            self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]), int(depthmap.shape[1]), None, 0, 0)
+            if use_tex and hasattr(texture, "data_ptr") and getattr(texture, "is_cuda", False):
+                self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]), int(depthmap.shape[1]),
+                           C.c_void_p(texture.data_ptr()), int(texture.shape[0]), int(texture.shape[1]))
+            else:
+                self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]), int(depthmap.shape[1]), None, 0, 0)
             return
         depth = np.ascontiguousarray(np.asarray(depthmap, dtype=np.uint16))
-        self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], None, 0, 0)
+        if use_tex:
+            tex = np.ascontiguousarray(np.asarray(texture, dtype=np.uint8))
+            self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], _vp(tex), tex.shape[0], tex.shape[1])
+        else:
+            self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], None, 0, 0)
 
     def cvt_occupy_to_voxels(self, level=0):
         n = C.c_int32()
@@ -102,14 +118,24 @@ class Octomap(BaseMap):
         n = self.num_export_particles[None]
         return self._read(n)
 
-    def export_leaves(self):
-        """(indices int32[n,3], counts f32[n]) of every touched leaf of the active submap (backend extra for tests)."""
+    def export_leaves(self, with_color=False):
+        """(indices int32[n,3], counts f32[n][, colours f32[n,3]]) of every touched leaf of the active submap (backend extra for tests)."""
         n = C.c_int64()
-        self._call("export_leaves", None, None, 0, C.byref(n))
+        self._call("export_leaves", None, None, None, 0, C.byref(n))
         idx = np.zeros((n.value, 3), np.int32)
         cnt = np.zeros(n.value, np.float32)
-        self._call("export_leaves", _vp(idx), _vp(cnt), n.value, C.byref(n))
-        return idx, cnt
+        rgb = np.zeros((n.value, 3), np.float32)
+        self._call("export_leaves", _vp(idx), _vp(cnt), _vp(rgb), n.value, C.byref(n))
+        return (idx, cnt, rgb) if with_color else (idx, cnt)
+
+    def random_init_octo(self, pts, seed=0):
+        """mapping_common.py:67-73 (demo helper): `pts` random leaves of the active submap receive a random hit count in 0..9."""
+        rng = np.random.default_rng(seed)
+        ijk = np.stack([rng.integers(0, self.N, pts), rng.integers(0, self.N, pts), rng.integers(0, self.Nz, pts)], 1)
+        ijk -= np.array([self.N // 2, self.N // 2, self.Nz // 2])
+        xyz = np.repeat(ijk, rng.integers(0, 10, pts), axis=0).astype(np.float32) * np.float32(self.voxel_scale_)
+        sid = self.active_submap_id[None]
+        self.recast_pcl_to_map(self.submaps_base_R_np[sid], self.submaps_base_T_np[sid], xyz, None)
 
     def fuse_submaps(self, submaps):
         t = time.time()

@@ -13,7 +13,7 @@ def _pair(**kw):
     from oracle import OracleOctomap
     from taichislam_amd.mapping import Octomap
     cfg = dict(CFG, **kw)
-    return Octomap(**cfg), OracleOctomap(**cfg)
+    return Octomap(**cfg), OracleOctomap(**{k: v for k, v in cfg.items() if k != "max_disp_particles"})
 
 
 def _leaves_equal(g, o):
@@ -78,3 +78,62 @@ def test_octomap_submaps_and_fusion(hip_lib):
     _leaves_equal(gg, og)
     gg.reset()
     assert gg.export_leaves()[0].shape[0] == 0
+
+
+def _coloured_leaves_equal(g, o, what):
+    gi, gc, gr = g.export_leaves(with_color=True)
+    oi, oc, orgb = o.export_leaves(with_color=True)
+    a = sorted_rows(np.concatenate([gi.astype(np.float64), gc[:, None], gr], 1))
+    b = sorted_rows(np.concatenate([oi.astype(np.float64), oc[:, None], orgb], 1))
+    assert a.shape == b.shape and a.shape[0] > 100 and np.array_equal(a, b), what
+    assert np.any(gr > 0)
+
+
+@pytest.mark.parametrize("same_proj", [True, False])
+def test_octomap_colour(hip_lib, same_proj):
+    """Leaf colours (taichi_octomap.py:120-124, BGR -> RGB / 255): the pixel / point with the largest index colours a leaf, later
+    frames overwrite, exports carry the colour (:100-101) and the fusion takes the colour of the largest source leaf (:189)."""
+    K, frames = small_stream(3)
+    Kc = K.copy(); Kc[0] *= 0.9; Kc[4] *= 0.9; Kc[2] += 3.0
+    g, o = _pair(texture_enabled=True, color_same_proj=same_proj, max_disp_particles=200000)
+    g.set_dep_camera_intrinsic(K); g.set_color_camera_intrinsic(Kc); o.set_intrinsics(K, Kc)
+    rng = np.random.default_rng(5)
+    for R, T, d in frames:
+        tex = rng.integers(0, 256, size=(d.shape[0], d.shape[1], 3)).astype(np.uint8)
+        g.recast_depth_to_map(R, T, d, tex)
+        o.integrate_depth(R, T, d, tex)
+    _coloured_leaves_equal(g, o, "depth + texture")
+    pts = rng.uniform(-3, 3, size=(20000, 3)).astype(np.float32)
+    pts[:4000] = pts[4000:8000]                                               # several points per leaf: the last one wins
+    rgb = rng.integers(0, 256, size=(20000, 3)).astype(np.uint8)
+    g.recast_pcl_to_map(frames[0][0], frames[0][1], pts, rgb)
+    o.integrate_points(frames[0][0], frames[0][1], pts, rgb)
+    _coloured_leaves_equal(g, o, "points + rgb")
+    gx, gcol = g.get_occupy_voxels(0)
+    ox, ocol, on = o.occupied_voxels(0, with_color=True)
+    assert gx.shape[0] == on > 0
+    assert np.array_equal(sorted_rows(np.concatenate([gx, gcol], 1)), sorted_rows(np.concatenate([ox, ocol], 1)))
+
+
+def test_octomap_coloured_fusion(hip_lib):
+    from oracle import OracleOctomap
+    from taichislam_amd.mapping import Octomap
+    K, frames = small_stream(4)
+    cfg = dict(CFG, texture_enabled=True, min_occupy_thres=0)
+    gs, os_ = Octomap(**cfg), OracleOctomap(**cfg)
+    gg, og = Octomap(**dict(cfg, is_global_map=True)), OracleOctomap(**dict(cfg, is_global_map=True))
+    gs.set_dep_camera_intrinsic(K); gs.set_color_camera_intrinsic(K); os_.set_intrinsics(K)
+    rng = np.random.default_rng(9)
+    for s in range(2):
+        Rb, Tb = syn.camera_pose(s * 2)
+        for m in (gs, gg):
+            m.set_base_pose_submap(s, Rb, Tb)
+        for m in (os_, og):
+            m.set_base_pose_submap(s, Rb, Tb)
+        gs.active_submap_id[None] = s; os_.set_active_submap(s)
+        for R, T, d in frames[s * 2:s * 2 + 2]:
+            tex = rng.integers(0, 256, size=(d.shape[0], d.shape[1], 3)).astype(np.uint8)
+            gs.recast_depth_to_map(R, T, d, tex); os_.integrate_depth(R, T, d, tex)
+    gs.active_submap_id[None] = 2; os_.set_active_submap(2)
+    gg.fuse_submaps(gs); og.fuse_submaps(os_)
+    _coloured_leaves_equal(gg, og, "fused colours")
