@@ -131,13 +131,13 @@ int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters)
     int iters = 0;
     if (nused > 0) {
         const int grid = nused < 8192 ? nused : 8192;
-        hipLaunchKernelGGL(k_esdf_init, dim3(grid), dim3(256), 0, m->stream, m->M, s, nused, m->esdf, gamma, max_dist);
+        hipLaunchKernelGGL(k_esdf_init, dim3(grid), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, gamma, max_dist);
         for (;;) {
-            TSL_HIP(hipMemsetAsync(m->esdf_flag, 0, sizeof(int), m->stream));
-            for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(k_esdf_relax, dim3(grid), dim3(256), 0, m->stream, m->M, s, nused, m->esdf, gamma, m->P.vs, 24, m->esdf_flag);
+            TSL_HIP(hipMemsetAsync(m->esdf_flag, 0, sizeof(int), ms(m)));
+            for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(k_esdf_relax, dim3(grid), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, gamma, m->P.vs, 24, m->esdf_flag);
             iters += 2;
-            TSL_HIP(hipMemcpyAsync(m->h_ints, m->esdf_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-            TSL_HIP(hipStreamSynchronize(m->stream));
+            TSL_HIP(hipMemcpyAsync(m->h_ints, m->esdf_flag, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
+            TSL_HIP(hipStreamSynchronize(ms(m)));
             if (m->h_ints[0] == 0 || iters > 4096) break;
         }
     }
@@ -156,11 +156,11 @@ int tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t
     rc = grow(&m->xbuf, &m->xbuf_bytes, need); if (rc) return rc;
     int16_t* didx = (int16_t*)m->xbuf; float* dval = (float*)((char*)m->xbuf + (((size_t)cap * 6 + 15) / 16) * 16);
     int* counter = m->num_particles + 2;
-    TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));
+    TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), ms(m)));
     const int s = m->cfg.is_global_map ? 0 : m->active;
-    if (nused > 0) hipLaunchKernelGGL(k_esdf_export, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, m->stream, m->M, s, nused, m->esdf, m->esdf_gamma, didx, dval, (long long)cap, counter);
-    TSL_HIP(hipMemcpyAsync(m->h_ints, counter, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    if (nused > 0) hipLaunchKernelGGL(k_esdf_export, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, didx, dval, (long long)cap, counter);
+    TSL_HIP(hipMemcpyAsync(m->h_ints, counter, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     const int c = m->h_ints[0];
     *n = c;
     const size_t k = (size_t)(c < cap ? c : cap);

@@ -121,8 +121,8 @@ static int upload_poses(tsl_tsdf* g, const tsl_tsdf* sub)
         for (int a = 0; a < 9; ++a) tab[(size_t)s * 12 + a] = g->baseRf[(size_t)s * 9 + a];
         for (int a = 0; a < 3; ++a) tab[(size_t)s * 12 + 9 + a] = g->baseTf[(size_t)s * 3 + a];
     }
-    TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, g->stream));
-    TSL_HIP(hipStreamSynchronize(g->stream));
+    TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, ms(g)));
+    TSL_HIP(hipStreamSynchronize(ms(g)));
     return TSL_OK;
 }
 
@@ -153,14 +153,14 @@ int tsl_tsdf_fuse_submaps(tsl_tsdf* g, tsl_tsdf* sub)
     int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
     if (nsrc > 0) {
         PoseTab pt = { g->pose_dev };
-        hipLaunchKernelGGL(k_fuse_splat<false>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, pt, g->P.vs, nsrc,
+        hipLaunchKernelGGL(k_fuse_splat<false>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
                            (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose, cacc);
         int ndst = 0; if ((rc = used_bricks(g, &ndst))) return rc;
-        if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, g->stream, g->M, ndst,
+        if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, ms(g), g->M, ndst,
                                          (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, cacc);
     }
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(g->stream));
+    TSL_HIP(hipStreamSynchronize(ms(g)));
     int e = 0;
     TSL_HIP(hipMemcpy(&e, g->M.err, sizeof(int), hipMemcpyDeviceToHost));
     if (e) { (void)hipMemset(g->M.err, 0, sizeof(int)); set_error("fuse_submaps: global brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
@@ -177,11 +177,11 @@ int tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* g, tsl_tsdf* sub, void* acc_dev, void
     int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
     if (nsrc > 0) {
         PoseTab pt = { g->pose_dev };
-        hipLaunchKernelGGL(k_fuse_splat<true>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, pt, g->P.vs, nsrc,
+        hipLaunchKernelGGL(k_fuse_splat<true>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
                            (unsigned long long*)acc_dev, (int*)cnt_occ_dev, g->npose, (unsigned long long*)nullptr);
     }
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(g->stream));
+    TSL_HIP(hipStreamSynchronize(ms(g)));
     return TSL_OK;
 }
 
@@ -192,9 +192,9 @@ int tsl_tsdf_fuse_finalize_dev(tsl_tsdf* g, const void* acc_dev, const void* cnt
     TSL_HIP(hipSetDevice(g->device));
     int rc = tsl_tsdf_reset(g); if (rc) return rc;
     const long long nvox = (long long)g->N * g->N * g->Nz;
-    hipLaunchKernelGGL(k_fuse_finalize_dense, dim3(8192), dim3(256), 0, g->stream, g->M, (const long long*)acc_dev, (const int*)cnt_occ_dev, nvox);
+    hipLaunchKernelGGL(k_fuse_finalize_dense, dim3(8192), dim3(256), 0, ms(g), g->M, (const long long*)acc_dev, (const int*)cnt_occ_dev, nvox);
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(g->stream));
+    TSL_HIP(hipStreamSynchronize(ms(g)));
     int e = 0;
     TSL_HIP(hipMemcpy(&e, g->M.err, sizeof(int), hipMemcpyDeviceToHost));
     if (e) { (void)hipMemset(g->M.err, 0, sizeof(int)); set_error("fuse_finalize: global brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }

@@ -278,9 +278,11 @@ __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-inse
 // (dense_tsdf.py:230-249; crowded voxels by the whole wave) and hands the ray to the other lanes; ray id = position of the
 // sensor voxel in the frame's list.
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+__global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 {
-    const FrameParams& P = *Pp;
+    if ((int)blockIdx.y >= B.n) return;
+    const FrameDev& F = B.f[blockIdx.y];
+    const FrameParams& P = *B.p[blockIdx.y];
     __shared__ int s_key[SEG_LH];
     __shared__ int s_cnt[SEG_LH];
     TSL_T0();
@@ -440,8 +442,10 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, FrameDev F, const Fr
 // k_integrate_bricks starts the long ones first and its tail is made of short ones.
 // part = { first segment, segments | parts of the brick << 16, brick, active rank }
 __device__ __forceinline__ int part_class(int per, int psegs) { return per * 8 >= psegs * 5 ? 0 : (per * 4 >= psegs ? 1 : 2); }
-__global__ void __launch_bounds__(256) k_plan(MapDev M, FrameDev F, int psegs)
+__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs)
 {
+    if ((int)blockIdx.y >= B.n) return;
+    const FrameDev& F = B.f[blockIdx.y];
     const int listed = F.counters[1];
     const int nact = min(listed, F.max_frame_bricks);
     if ((int)blockIdx.x * 256 >= nact && blockIdx.x) return;
@@ -469,8 +473,10 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, FrameDev F, int psegs)
 }
 
 // K4c: counting sort by brick (LDS hash of the bricks seen in each 4096-segment tile, one global reservation per (tile, brick))
-__global__ void __launch_bounds__(256) k_scatter(FrameDev F)
+__global__ void __launch_bounds__(256) k_scatter(BatchDev B)
 {
+    if ((int)blockIdx.y >= B.n) return;
+    const FrameDev& F = B.f[blockIdx.y];
     __shared__ int s_key[LH_SIZE];
     __shared__ int s_cnt[LH_SIZE];
     __shared__ int s_base[LH_SIZE];
@@ -706,19 +712,18 @@ int check_variant2(tsl_tsdf* m)
     return TSL_OK;
 }
 
-int launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st)
+int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st)
 {
-    FrameParams& P = m->P;
-    FrameDev& F = S.F;
+    const FrameParams& P = hp[0];
     if (P.variant != 2) return TSL_OK;
     const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
     prof_begin(m, TSL_K_SEGMENTS, st);
-    if (P.group) hipLaunchKernelGGL(k_segments<true>, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
-    else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks), dim3(256), 0, st, m->M, F, (const FrameParams*)S.Pd);
+    if (P.group) hipLaunchKernelGGL(k_segments<true>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
+    else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((F.max_frame_bricks + 255) / 256), dim3(256), 0, st, m->M, F, m->wg == 1024 ? 4096 : (m->wg == 512 ? 2048 : 1024));
-    hipLaunchKernelGGL(k_scatter, dim3(256), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->wg == 1024 ? 4096 : (m->wg == 512 ? 2048 : 1024));
+    hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;
 }
@@ -730,24 +735,24 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
     if (P.variant == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
         if (m->wg == 1024) {       // 4 segments per thread, bricks up to 4096 segments in one workgroup, no length sort
-            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-            else hipLaunchKernelGGL((k_integrate_bricks<false, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
+            else hipLaunchKernelGGL((k_integrate_bricks<false, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
         } else if (m->wg == 512) {
-            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-            else hipLaunchKernelGGL((k_integrate_bricks<false, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
+            else hipLaunchKernelGGL((k_integrate_bricks<false, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
         } else {
-            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-            else hipLaunchKernelGGL((k_integrate_bricks<false, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
+            else hipLaunchKernelGGL((k_integrate_bricks<false, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
         }
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
         prof_begin(m, TSL_K_INTEGRATE);
-        if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
-        else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream, m->M, F, (const FrameParams*)S.Pd);
+        if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
+        else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
         prof_end(m);
         prof_begin(m, TSL_K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream, m->M, F, (const int*)nullptr, (const int*)nullptr);
+        hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const int*)nullptr, (const int*)nullptr);
         prof_end(m);
     }
     TSL_HIP(hipGetLastError());

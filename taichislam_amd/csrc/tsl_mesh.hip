@@ -154,14 +154,14 @@ int tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tr
     }
     if (!m->mesh_count) { if ((rc = dev_alloc(m, (void**)&m->mesh_count, sizeof(int) * 4, 0))) return rc; }
     int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;
-    TSL_HIP(hipMemsetAsync(m->mesh_count, 0, sizeof(int), m->stream));                          // :182
+    TSL_HIP(hipMemsetAsync(m->mesh_count, 0, sizeof(int), ms(m)));                          // :182
     prof_begin(m, TSL_K_MESH);
-    if (nused > 0) hipLaunchKernelGGL(k_marching_cubes, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, m->stream, m->M, nused, step,
+    if (nused > 0) hipLaunchKernelGGL(k_marching_cubes, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, ms(m), m->M, nused, step,
                                       surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);
     prof_end(m);
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipMemcpyAsync(m->h_ints, m->mesh_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->mesh_count, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     *n_tri = m->h_ints[0];
     return TSL_OK;
 }
@@ -170,7 +170,7 @@ int tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int6
 {
     TSL_REQUIRE(m, "mesh_read: null handle"); TSL_REQUIRE(n_vertices >= 0 && n_vertices <= 3 * m->mesh_cap, "mesh_read: more vertices than the mesh buffers hold");
     TSL_HIP(hipSetDevice(m->device));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     if (n_vertices == 0) return TSL_OK;
     if (verts) TSL_HIP(hipMemcpy(verts, m->mesh_v, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost));
     if (normals) TSL_HIP(hipMemcpy(normals, m->mesh_n, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost));

@@ -65,10 +65,10 @@ int tsl_tsdf_query_points(tsl_tsdf* m, int mode, int param, const float* xyz, in
     int rc = grow(&m->xbuf, &m->xbuf_bytes, (size_t)n * 13 + 64); if (rc) return rc;
     float* dx = (float*)m->xbuf; uint8_t* dout = (uint8_t*)m->xbuf + (size_t)n * 12;
     TSL_HIP(hipMemcpy(dx, xyz, (size_t)n * 12, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_query_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->cfg.is_global_map ? 0 : m->active, m->P.vs, m->surf_thres, mode, param,
+    hipLaunchKernelGGL(k_query_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ms(m), m->M, m->cfg.is_global_map ? 0 : m->active, m->P.vs, m->surf_thres, mode, param,
                        (const float*)dx, (long long)n, dout);
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     TSL_HIP(hipMemcpy(out, dout, (size_t)n, hipMemcpyDeviceToHost));
     return TSL_OK;
 }
@@ -83,10 +83,10 @@ int tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, floa
     float* dpos = (float*)m->xbuf; float* ddir = dpos + c * 3; float* dend = ddir + c * 3; float* dlen = dend + c * 3; uint8_t* dhit = (uint8_t*)(dlen + c);
     TSL_HIP(hipMemcpy(dpos, pos, c * 12, hipMemcpyHostToDevice));
     TSL_HIP(hipMemcpy(ddir, dir, c * 12, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_query_raycast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->cfg.is_global_map ? 0 : m->active, m->P.vs, (float)m->cfg.voxel_scale,
+    hipLaunchKernelGGL(k_query_raycast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ms(m), m->M, m->cfg.is_global_map ? 0 : m->active, m->P.vs, (float)m->cfg.voxel_scale,
                        m->surf_thres, max_dist, (const float*)dpos, (const float*)ddir, (long long)n, dhit, dend, dlen);
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     TSL_HIP(hipMemcpy(hit, dhit, c, hipMemcpyDeviceToHost));
     TSL_HIP(hipMemcpy(end_xyz, dend, c * 12, hipMemcpyDeviceToHost));
     TSL_HIP(hipMemcpy(len, dlen, c * 4, hipMemcpyDeviceToHost));

@@ -59,13 +59,19 @@ template <> struct KeyOps<uint64_t> {
 template <typename K> __device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first);
 
 template <typename K>
-__global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __restrict__ Pp, FrameDev F, K* __restrict__ keys)
+__global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
 {
-    const FrameParams& P = *Pp;
+    const int fq = blockIdx.y;                      // frame of the batch
+    if (fq >= B.n) return;
+    const FrameDev& F = B.f[fq];
+    const FrameParams& P = *B.p[fq];
+    if (P.points) return;
+    K* __restrict__ keys = reinterpret_cast<K*>(F.keys);
     const uint16_t* __restrict__ depth = static_cast<const uint16_t*>(P.input);
     // a workgroup visits a 16x16 tile of the sampled pixels: the voxels it opens are listed together (block_reserve), so
     // neighbouring rays -- which cross the same bricks -- are walked and binned by the same workgroup later on
     const int tiles_x = (P.ww + 15) >> 4;
+    if ((int)blockIdx.x >= tiles_x * ((P.hh + 15) >> 4)) return;      // the grid covers the largest image of the batch
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int jj = ty * 16 + ((int)threadIdx.x >> 4), ii = tx * 16 + ((int)threadIdx.x & 15);
     const int p = jj * P.ww + ii;                                                    // pixel id = raster order
@@ -105,9 +111,14 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(const FrameParams* __res
 
 // recast_pcl_to_map_kernel  dense_tsdf.py:167-186 (z := range, gate on the range)
 template <typename K>
-__global__ void __launch_bounds__(256) k_voxelize_points(const FrameParams* __restrict__ Pp, FrameDev F, K* __restrict__ keys)
+__global__ void __launch_bounds__(256) k_voxelize_points(BatchDev B)
 {
-    const FrameParams& P = *Pp;
+    const int fq = blockIdx.y;                      // frame of the batch
+    if (fq >= B.n) return;
+    const FrameDev& F = B.f[fq];
+    const FrameParams& P = *B.p[fq];
+    if (!P.points || (int)blockIdx.x * 256 >= P.total) return;
+    K* __restrict__ keys = reinterpret_cast<K*>(F.keys);
     const float* __restrict__ xyz = static_cast<const float*>(P.input);
     const int n = P.total;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -199,8 +210,10 @@ __device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* firs
     return (int)h;
 }
 
-__global__ void __launch_bounds__(256) k_group_scan(FrameDev F)
+__global__ void __launch_bounds__(256) k_group_scan(BatchDev B)
 {
+    if ((int)blockIdx.y >= B.n) return;
+    const FrameDev& F = B.f[blockIdx.y];
     // list position of every group: groups only have to be contiguous, not ordered, so a block-aggregated reservation
     // of `count` entries replaces a prefix scan
     __shared__ int s_wave[4];
@@ -222,10 +235,12 @@ __global__ void __launch_bounds__(256) k_group_scan(FrameDev F)
     if (i < nact) F.hoff[sl] = off;
 }
 
-__global__ void __launch_bounds__(256) k_group_fill(const FrameParams* __restrict__ Pp, FrameDev F)
+__global__ void __launch_bounds__(256) k_group_fill(BatchDev B)
 {
+    if ((int)blockIdx.y >= B.n) return;
+    const FrameDev& F = B.f[blockIdx.y];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= Pp->total) return;
+    if (p >= B.p[blockIdx.y]->total) return;
     const int sl = F.slot_of_pix[p];
     if (sl < 0) return;
     F.plist[F.hoff[sl] + atomicAdd(&F.hfill[sl], 1)] = (uint32_t)p;
@@ -500,7 +515,7 @@ int grow(void** p, size_t* have, size_t need)
 int dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill)
 {
     TSL_HIP(hipMalloc(p, bytes));
-    TSL_HIP(hipMemsetAsync(*p, fill, bytes, m->stream));
+    TSL_HIP(hipMemsetAsync(*p, fill, bytes, m->stream_));
     m->bytes += (int64_t)bytes;
     return TSL_OK;
 }
@@ -512,14 +527,14 @@ void prof_begin(tsl_tsdf* m, int kid, hipStream_t st)
     ProfSlot s; s.kid = kid;
     if (m->prof_free.size() >= 2) { s.a = m->prof_free.back(); m->prof_free.pop_back(); s.b = m->prof_free.back(); m->prof_free.pop_back(); }
     else if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
-    (void)hipEventRecord(s.a, st ? st : m->stream);
+    (void)hipEventRecord(s.a, st ? st : m->stream_);
     m->prof.push_back(s);
     m->prof_open = true;
 }
 void prof_end(tsl_tsdf* m, hipStream_t st)
 {
     if (!m->prof_open) return;
-    (void)hipEventRecord(m->prof.back().b, st ? st : m->stream);
+    (void)hipEventRecord(m->prof.back().b, st ? st : m->stream_);
     m->prof_open = false;
 }
 
@@ -550,47 +565,130 @@ static PoseF pose_of(const tsl_tsdf* m, int s)
 }
 
 // per-frame prologue of a working set: publish the frame's parameters, clear stats | nrays | counters (256 bytes)
-__global__ void k_set_params(FrameParams P, FrameParams* dst, int* header) { if (threadIdx.x == 0) *dst = P; header[threadIdx.x] = 0; }
-
-// phase A of one frame on stream `sa`: depth -> rays -> brick-sorted segments.  Every argument is constant for a given
-// (image shape, options); the per-frame values live in *S.Pd.
-template <typename K>
-static int enqueue_phase_a(tsl_tsdf* m, FSet& S, int total, bool points, hipStream_t sa)
+__global__ void k_set_params(ParamPack PP, BatchDev B)
 {
-    FrameDev& F = S.F;
+    if (threadIdx.x == 0) *const_cast<FrameParams*>(B.p[blockIdx.x]) = PP.p[blockIdx.x];
+    reinterpret_cast<int*>(B.f[blockIdx.x].stats)[threadIdx.x] = 0;          // stats | nrays | counters: the set's 256-byte header
+}
+
+// phase A of a batch of n frames on stream `sa`: depth -> rays -> brick-sorted segments, every kernel once with grid.y = frame.
+// The radix-sort grouping and the global-atomics variants only exist per frame (batches of one).
+template <typename K>
+static int enqueue_phase_a(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, hipStream_t sa)
+{
+    const int n = B.n;
+    int total = 0, tiles = 0, any_points = 0, any_depth = 0;
+    for (int q = 0; q < n; ++q) {
+        total = hp[q].total > total ? hp[q].total : total;
+        const int t = ((hp[q].ww + 15) / 16) * ((hp[q].hh + 15) / 16);
+        if (hp[q].points) any_points = 1; else { any_depth = 1; tiles = t > tiles ? t : tiles; }
+    }
     if (total <= 0) return TSL_OK;
-    K* keys = reinterpret_cast<K*>(F.keys);
-    K* keys_s = reinterpret_cast<K*>(F.keys_s);
+    const FrameParams& P0 = hp[0];
     const int blocks = (total + 255) / 256;
     prof_begin(m, TSL_K_VOXELIZE, sa);
-    if (points) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
-    else hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(((m->P.ww + 15) / 16) * ((m->P.hh + 15) / 16)), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, keys);
+    if (any_points) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks, n), dim3(256), 0, sa, B);
+    if (any_depth) hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(tiles, n), dim3(256), 0, sa, B);
     prof_end(m, sa);
-    if (m->P.group) {
+    if (P0.group) {
         prof_begin(m, TSL_K_SORT, sa);
-        hipLaunchKernelGGL(k_group_scan, dim3(blocks), dim3(256), 0, sa, F);
-        hipLaunchKernelGGL(k_group_fill, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
+        hipLaunchKernelGGL(k_group_scan, dim3(blocks, n), dim3(256), 0, sa, B);
+        hipLaunchKernelGGL(k_group_fill, dim3(blocks, n), dim3(256), 0, sa, B);
         prof_end(m, sa);
-        if (m->P.variant != 2) {      // variant 2 builds the rays inside k_segments
+        if (P0.variant != 2) {      // variant 2 builds the rays inside k_segments
             prof_begin(m, TSL_K_RAYS, sa);
-            hipLaunchKernelGGL(k_build_rays_hash<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F);
-            hipLaunchKernelGGL(k_build_rays_big<K>, dim3(64), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, m->M);
+            hipLaunchKernelGGL(k_build_rays_hash<K>, dim3(blocks), dim3(256), 0, sa, B.p[0], B.f[0]);
+            hipLaunchKernelGGL(k_build_rays_big<K>, dim3(64), dim3(256), 0, sa, B.p[0], B.f[0], m->M);
             prof_end(m, sa);
         }
     } else {
+        const FrameDev& F = B.f[0];
         prof_begin(m, TSL_K_SORT, sa);
         size_t tb = m->sort_temp_bytes;
-        TSL_HIP(rocprim::radix_sort_pairs(S.sort_temp, tb, keys, keys_s, F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * m->P.pcl_bits + 1), sa));
+        TSL_HIP(rocprim::radix_sort_pairs(m->fset[m->cur * TSL_NB].sort_temp, tb, reinterpret_cast<K*>(F.keys), reinterpret_cast<K*>(F.keys_s), F.vals, F.vals_s, (size_t)total, 0u, (unsigned)(3 * P0.pcl_bits + 1), sa));
         prof_end(m, sa);
         prof_begin(m, TSL_K_RAYS, sa);
-        hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, (const FrameParams*)S.Pd, F, (const K*)keys_s);
+        hipLaunchKernelGGL(k_build_rays<K>, dim3(blocks), dim3(256), 0, sa, B.p[0], F, (const K*)reinterpret_cast<K*>(F.keys_s));
         prof_end(m, sa);
     }
-    return launch_segments(m, S, total, sa);
+    return launch_segments(m, B, hp, total, sa);
 }
 
+// Issue the queued frames: phase A of the whole batch on the batch's stream (it depends on the images, the poses and the map
+// GEOMETRY only -- its one access to the map is first-touch brick allocation and the occupancy byte -- so it runs beside phase
+// B of the previous batch), then phase B frame by frame on the main stream.
 template <typename K>
-static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
+static int launch_batch_t(tsl_tsdf* m)
+{
+    const int n = m->npend;
+    if (n == 0) return TSL_OK;
+    m->npend = 0;                                   // nothing below re-enters through ms()
+    const int bi = m->cur;
+    BatchHost& H = m->batch[bi];
+    const bool serial = m->overlap == 0;
+    hipStream_t sa = serial ? m->stream_ : H.st;
+    if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
+    BatchDev B; ParamPack PP;
+    for (int q = 0; q < n; ++q) { FSet& S = m->fset[bi * TSL_NB + q]; B.f[q] = S.F; B.p[q] = S.Pd; PP.p[q] = m->pend[q]; }
+    for (int q = n; q < TSL_NB; ++q) { B.f[q] = B.f[0]; B.p[q] = B.p[0]; PP.p[q] = PP.p[0]; }
+    B.n = n;
+    hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, B);
+    if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
+    if (!serial) {
+        TSL_HIP(hipEventRecord(H.a_done, sa));
+        TSL_HIP(hipStreamWaitEvent(m->stream_, H.a_done, 0));
+    }
+    // ---- phase B: apply to the map, in frame order on the main stream ----
+    for (int q = 0; q < n; ++q) {
+        FSet& S = m->fset[bi * TSL_NB + q];
+        m->P = m->pend[q];
+        if (m->P.total > 0 && (m->phases & 2)) { int rc = launch_apply(m, S, m->P.total); if (rc) return rc; }
+    }
+    if (!serial) { TSL_HIP(hipEventRecord(H.b_done, m->stream_)); H.b_pending = true; }
+    m->cur = (bi + 1) % TSL_NBATCH;
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+int flush_pending(tsl_tsdf* m)
+{
+    if (m->npend == 0) return TSL_OK;
+    const FrameParams keep = m->P;                  // the launch helpers read the frame being issued from m->P
+    const int rc = m->pcl_bits <= 10 ? launch_batch_t<uint32_t>(m) : launch_batch_t<uint64_t>(m);
+    m->P = keep;
+    if (rc && !m->deferred_rc) m->deferred_rc = rc;
+    return rc;
+}
+hipStream_t ms(tsl_tsdf* m) { (void)flush_pending(m); return m->stream_; }
+
+static int batch_cap(const tsl_tsdf* m)
+{ return (m->overlap > 0 && m->variant == 2 && m->P.group) ? (m->overlap < TSL_NB ? m->overlap : TSL_NB) : 1; }
+// working set the next queued frame will use; issues the queued frames first when the new one cannot join them
+static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
+{
+    const int slot = map_slot(m, m->active);
+    if (m->npend && (m->npend >= batch_cap(m) || m->pend_points != points || m->pend[0].slot != slot)) { int rc = flush_pending(m); if (rc) return rc; }
+    *set_index = m->cur * TSL_NB + m->npend;
+    return TSL_OK;
+}
+// host buffers are copied into the staging area of the frame's working set on the stream that will run its phase A
+static int stage_host(tsl_tsdf* m, int si, const void* in, size_t in_bytes, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev)
+{
+    FSet& S = m->fset[si];
+    hipStream_t sc = m->overlap == 0 ? m->stream_ : m->batch[si / TSL_NB].st;
+    int rc = grow(&S.stage_in, &S.stage_in_bytes, in_bytes + 16); if (rc) return rc;
+    if (in_bytes) TSL_HIP(hipMemcpyAsync(S.stage_in, in, in_bytes, hipMemcpyHostToDevice, sc));
+    *in_dev = S.stage_in; *tex_dev = nullptr;
+    if (tex && tex_bytes) {
+        rc = grow(&S.stage_tex, &S.stage_tex_bytes, tex_bytes); if (rc) return rc;
+        TSL_HIP(hipMemcpyAsync(S.stage_tex, tex, tex_bytes, hipMemcpyHostToDevice, sc));
+        *tex_dev = S.stage_tex;
+    }
+    TSL_HIP(hipStreamSynchronize(sc));             // the caller may reuse its host buffers after return
+    return TSL_OK;
+}
+
+// queue one frame (m->P holds its parameters); the batch is issued when it is full or when anything else needs the map
+static int queue_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
 {
     FrameParams& P = m->P;
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
@@ -598,34 +696,23 @@ static int run_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, in
     if (P.variant == 2) { int rc = check_variant2(m); if (rc) return rc; }
     P.input = xyz_dev ? xyz_dev : depth_dev; P.total = total; P.points = xyz_dev ? 1 : 0;
     TSL_REQUIRE(!P.tex || P.variant == 2, "texture integration needs the brick-binned path (variant 2)");
-    // ---- phase A: depth -> rays -> brick-sorted segments, into working set `si` on its own stream.  It depends on the
-    //      image, the pose and the map GEOMETRY only, so several frames are in flight; the only map access is first-touch
-    //      brick allocation and the occupancy byte (atomic claims, safe next to phase B of older frames). ----
-    const int si = m->overlap ? (int)(m->frame_no % m->overlap) : 0;      // m->overlap = number of phase-A sets in flight
-    FSet& S = m->fset[si];
-    hipStream_t sa = m->overlap ? S.st : m->stream;
-    if (m->overlap && S.b_pending) TSL_HIP(hipStreamWaitEvent(sa, S.b_done, 0));      // phase B of frame f-NSETS still reads this set
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sa, P, S.Pd, reinterpret_cast<int*>(S.header));
-    m->last_set = si; m->frame_no++;
-    if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, S, total, xyz_dev != nullptr, sa); if (rc) return rc; }
-    if (m->overlap) {
-        TSL_HIP(hipEventRecord(S.a_done, sa));
-        TSL_HIP(hipStreamWaitEvent(m->stream, S.a_done, 0));
-    }
-    // ---- phase B: apply to the map, in frame order on the main stream ----
-    if (total > 0 && (m->phases & 2)) { int rc = launch_apply(m, S, total); if (rc) return rc; }
-    if (m->overlap) { TSL_HIP(hipEventRecord(S.b_done, m->stream)); S.b_pending = true; }
-    TSL_HIP(hipGetLastError());
+    const int cap = batch_cap(m);
+    { int si = 0; int rc = reserve_slot(m, P.points, &si); if (rc) return rc; }
+    m->pend_points = P.points;
+    m->pend[m->npend] = P;
+    m->last_set = m->cur * TSL_NB + m->npend;
+    m->npend++;
+    if (m->npend >= cap) return flush_pending(m);
     return TSL_OK;
 }
 
-static int sort_temp_size(tsl_tsdf* m, size_t* bytes)
+static int sort_temp_size(tsl_tsdf* m, size_t* bytes)   /* called from create: raw stream */
 {
     size_t a = 0, b = 0;
     TSL_HIP(rocprim::radix_sort_pairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                      (size_t)m->F.max_points, 0u, 32u, m->stream));
+                                      (size_t)m->F.max_points, 0u, 32u, m->stream_));
     TSL_HIP(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                      (size_t)m->F.max_points, 0u, 64u, m->stream));
+                                      (size_t)m->F.max_points, 0u, 64u, m->stream_));
     *bytes = a > b ? a : b;
     return TSL_OK;
 }
@@ -682,9 +769,11 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     TSL_HIP(hipSetDevice(device));
     tsl_tsdf* m = new tsl_tsdf();
     m->cfg = *cfg; m->device = device; m->bytes = 0;
-    TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    m->frame_no = 0; m->overlap = TSL_NSETS; m->last_set = 0;   // phase-A sets in flight (3 is marginally better without per-kernel events, 4 with them)
-    for (auto& S : m->fset) { S.st = nullptr; S.a_done = nullptr; S.b_done = nullptr; S.b_pending = false; S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; }
+    TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
+    m->overlap = TSL_NB; m->last_set = 0;
+    for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; }
+    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.b_pending = false; }
+    m->cur = 0; m->npend = 0; m->pend_points = 0; m->deferred_rc = 0;
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
     m->Nz = (int)std::ceil(cfg->map_size_z / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:25
@@ -811,10 +900,12 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&G.part_tab, sizeof(int4) * 3 * (size_t)G.part_cap))) return rc;
         if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
-        TSL_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
-        TSL_HIP(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
-        TSL_HIP(hipEventCreateWithFlags(&S.b_done, hipEventDisableTiming));
-        S.b_pending = false;
+        if (si % TSL_NB == 0) {
+            BatchHost& H = m->batch[si / TSL_NB];
+            TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking));
+            TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
+            TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
+        }
     }
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
@@ -830,15 +921,15 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&m->pose_dev, sizeof(float) * 12 * (size_t)m->npose, 0))) return rc;
     {   // enable the fast exact division only if the device proves it equal to IEEE division for this voxel size
         unsigned long long* bad = reinterpret_cast<unsigned long long*>(m->num_particles + 2);
-        TSL_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), m->stream));
-        hipLaunchKernelGGL(k_verify_div, dim3(8192), dim3(256), 0, m->stream, P.vs, P.rvs, bad);
+        TSL_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), m->stream_));
+        hipLaunchKernelGGL(k_verify_div, dim3(8192), dim3(256), 0, m->stream_, P.vs, P.rvs, bad);
         unsigned long long nbad = 1;
-        TSL_HIP(hipMemcpyAsync(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost, m->stream));
-        TSL_HIP(hipStreamSynchronize(m->stream));
-        TSL_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), m->stream));
+        TSL_HIP(hipMemcpyAsync(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost, m->stream_));
+        TSL_HIP(hipStreamSynchronize(m->stream_));
+        TSL_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), m->stream_));
         P.fastdiv = nbad == 0 ? 1 : 0;
     }
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream_));
     *out = m;
     return TSL_OK;
 }
@@ -847,15 +938,16 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
 {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream);
-    for (auto& S : m->fset) if (S.st) (void)hipStreamSynchronize(S.st);
-    (void)hipStreamSynchronize(m->stream);
+    (void)hipStreamSynchronize(m->stream_);
+    for (auto& H : m->batch) if (H.st) (void)hipStreamSynchronize(H.st);
+    (void)hipStreamSynchronize(m->stream_);
     (void)hipDeviceSynchronize();
     for (auto& S : m->fset) {
-        if (S.st) { (void)hipStreamDestroy(S.st); }
+
         for (void* p : S.owned) if (p) (void)hipFree(p);
-        if (S.a_done) (void)hipEventDestroy(S.a_done);
-        if (S.b_done) (void)hipEventDestroy(S.b_done);
+        if (S.stage_in) (void)hipFree(S.stage_in);
+        if (S.stage_tex) (void)hipFree(S.stage_tex);
+
     }
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket,
                      m->stage_in, m->stage_tex, m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
@@ -865,7 +957,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (m->h_ints) (void)hipHostFree(m->h_ints);
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& e : m->prof_free) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(m->stream);
+    (void)hipStreamDestroy(m->stream_);
     delete m;
 }
 
@@ -877,13 +969,22 @@ int tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* bxy, 
     if (bxy) *bxy = m->N / blk; if (bz) *bz = m->Nz / blk;                                   // dense_tsdf.py:27-28
     return TSL_OK;
 }
-int tsl_tsdf_sync(tsl_tsdf* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); for (auto& S : m->fset) if (S.st) TSL_HIP(hipStreamSynchronize(S.st)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
+int tsl_tsdf_sync(tsl_tsdf* m)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
+    int rc = flush_pending(m);
+    for (auto& H : m->batch) if (H.st) TSL_HIP(hipStreamSynchronize(H.st));
+    TSL_HIP(hipStreamSynchronize(m->stream_));
+    if (!rc && m->deferred_rc) { rc = m->deferred_rc; }
+    m->deferred_rc = 0;
+    return rc;
+}
 int tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* b) { TSL_REQUIRE(m && b, "null"); *b = m->bytes; return TSL_OK; }
 
 static int read_int(tsl_tsdf* m, const int* dev, int* out)
 {
-    TSL_HIP(hipMemcpyAsync(m->h_ints, dev, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->h_ints, dev, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     *out = m->h_ints[0];
     return TSL_OK;
 }
@@ -892,7 +993,7 @@ static int check_dev_err(tsl_tsdf* m)
     int e = 0; int rc = read_int(m, m->M.err, &e); if (rc) return rc;
     if (e) {
         set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : "") + ((e & 4) ? " ray segments" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : ""));
-        (void)hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream);
+        (void)hipMemsetAsync(m->M.err, 0, sizeof(int), ms(m));
         return TSL_ERR_CAPACITY;
     }
     return TSL_OK;
@@ -919,8 +1020,8 @@ int tsl_tsdf_reset(tsl_tsdf* m)
     TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
     int rc = tsl_tsdf_sync(m); if (rc) return rc;
     int used = 0; rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
-    if (used > 0) hipLaunchKernelGGL(k_reset_bricks, dim3(used < 4096 ? used : 4096), dim3(256), 0, m->stream, m->M, used);
-    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, m->stream));
+    if (used > 0) hipLaunchKernelGGL(k_reset_bricks, dim3(used < 4096 ? used : 4096), dim3(256), 0, ms(m), m->M, used);
+    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, ms(m)));
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -948,8 +1049,8 @@ int tsl_tsdf_set_active_submap(tsl_tsdf* m, int32_t sid)
 int tsl_tsdf_set_colormap(tsl_tsdf* m, const float* rgb)
 {
     TSL_REQUIRE(m && rgb, "null"); TSL_HIP(hipSetDevice(m->device));
-    TSL_HIP(hipMemcpyAsync(m->colormap, rgb, sizeof(float) * 3 * 1024, hipMemcpyHostToDevice, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->colormap, rgb, sizeof(float) * 3 * 1024, hipMemcpyHostToDevice, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     return TSL_OK;
 }
 
@@ -968,7 +1069,7 @@ int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[
     P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0; P.tex_input = (const uint8_t*)tex_dev;
     TSL_REQUIRE(!P.tex || (th > 0 && tw > 0 && (!P.same_proj || (th >= h && tw >= w))), "integrate_depth: texture smaller than the depth image");
     m->h_stats->p_used = (int64_t)P.hh * P.ww;
-    return m->pcl_bits <= 10 ? run_frame<uint32_t>(m, depth_dev, nullptr, 0) : run_frame<uint64_t>(m, depth_dev, nullptr, 0);
+    return queue_frame(m, depth_dev, nullptr, 0);
 }
 
 int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
@@ -976,20 +1077,11 @@ int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], 
 {
     TSL_REQUIRE(m && depth, "integrate_depth: null argument"); TSL_REQUIRE(h > 0 && w > 0, "integrate_depth: bad image size");
     TSL_HIP(hipSetDevice(m->device));
-    const size_t nb = (size_t)h * w * sizeof(uint16_t);
-    int rc = grow(&m->stage_in, &m->stage_in_bytes, nb); if (rc) return rc;
-    { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }      // host-buffer path: the single staging buffer must be free again
-    hipStream_t sa = m->stream;
-    TSL_HIP(hipMemcpyAsync(m->stage_in, depth, nb, hipMemcpyHostToDevice, sa));
-    void* tdev = nullptr;
-    if (tex && m->cfg.texture_enabled && th > 0 && tw > 0) {
-        const size_t tb = (size_t)th * tw * 3;
-        rc = grow(&m->stage_tex, &m->stage_tex_bytes, tb); if (rc) return rc;
-        TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, tb, hipMemcpyHostToDevice, sa));
-        tdev = m->stage_tex;
-    }
-    TSL_HIP(hipStreamSynchronize(sa));             // the caller may reuse its host buffers after return
-    return tsl_tsdf_integrate_depth_dev(m, R, T, m->stage_in, h, w, tdev, th, tw);
+    int si = 0; int rc = reserve_slot(m, 0, &si); if (rc) return rc;
+    const bool use_tex = tex && m->cfg.texture_enabled && th > 0 && tw > 0;
+    void *ddev = nullptr, *tdev = nullptr;
+    rc = stage_host(m, si, depth, (size_t)h * w * sizeof(uint16_t), use_tex ? tex : nullptr, use_tex ? (size_t)th * tw * 3 : 0, &ddev, &tdev); if (rc) return rc;
+    return tsl_tsdf_integrate_depth_dev(m, R, T, ddev, h, w, tdev, th, tw);
 }
 
 int tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3], const void* xyz_dev, const void* rgb_dev, int64_t n)
@@ -999,26 +1091,18 @@ int tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T
     fill_frame_params(m, R, T);
     m->P.tex = (m->cfg.texture_enabled && rgb_dev) ? 1 : 0; m->P.tex_input = (const uint8_t*)rgb_dev;
     m->h_stats->p_used = n;
-    return m->pcl_bits <= 10 ? run_frame<uint32_t>(m, nullptr, xyz_dev, n) : run_frame<uint64_t>(m, nullptr, xyz_dev, n);
+    return queue_frame(m, nullptr, xyz_dev, n);
 }
 
 int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n)
 {
     TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz), "integrate_points: bad input");
     TSL_HIP(hipSetDevice(m->device));
-    const size_t nb = (size_t)n * 3 * sizeof(float);
-    int rc = grow(&m->stage_in, &m->stage_in_bytes, nb + 16); if (rc) return rc;
-    { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }
-    hipStream_t sa = m->stream;
-    if (n) TSL_HIP(hipMemcpyAsync(m->stage_in, xyz, nb, hipMemcpyHostToDevice, sa));
-    void* cdev = nullptr;
-    if (rgb && m->cfg.texture_enabled && n) {
-        rc = grow(&m->stage_tex, &m->stage_tex_bytes, (size_t)n * 3); if (rc) return rc;
-        TSL_HIP(hipMemcpyAsync(m->stage_tex, rgb, (size_t)n * 3, hipMemcpyHostToDevice, sa));
-        cdev = m->stage_tex;
-    }
-    TSL_HIP(hipStreamSynchronize(sa));
-    return tsl_tsdf_integrate_points_dev(m, R, T, m->stage_in, cdev, n);
+    int si = 0; int rc = reserve_slot(m, 1, &si); if (rc) return rc;
+    const bool use_tex = rgb && m->cfg.texture_enabled && n;
+    void *xdev = nullptr, *cdev = nullptr;
+    rc = stage_host(m, si, xyz, (size_t)n * 3 * sizeof(float), use_tex ? rgb : nullptr, use_tex ? (size_t)n * 3 : 0, &xdev, &cdev); if (rc) return rc;
+    return tsl_tsdf_integrate_points_dev(m, R, T, xdev, cdev, n);
 }
 
 int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
@@ -1027,8 +1111,8 @@ int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
     const int64_t used = m->h_stats->p_used;
     tsl_frame_stats tmp;
     { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }
-    TSL_HIP(hipMemcpyAsync(m->h_ints, m->fset[m->last_set].F.stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->fset[m->last_set].F.stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     std::memcpy(&tmp, m->h_ints, sizeof(tmp));
     tmp.p_used = used;
     *out = tmp;
@@ -1039,11 +1123,11 @@ int tsl_tsdf_count_active(tsl_tsdf* m, int64_t* n)
 {
     TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device));
     long long* tmp = reinterpret_cast<long long*>(m->num_particles + 2);      // 8-byte scratch word
-    TSL_HIP(hipMemsetAsync(tmp, 0, sizeof(long long), m->stream));
-    hipLaunchKernelGGL(k_count_active, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, m->stream, m->M, map_slot(m, m->active), tmp);
+    TSL_HIP(hipMemsetAsync(tmp, 0, sizeof(long long), ms(m)));
+    hipLaunchKernelGGL(k_count_active, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, ms(m), m->M, map_slot(m, m->active), tmp);
     long long v = 0;
-    TSL_HIP(hipMemcpyAsync(&v, tmp, sizeof(long long), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(&v, tmp, sizeof(long long), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     *n = v;
     return TSL_OK;
 }
@@ -1056,8 +1140,8 @@ static int export_common(tsl_tsdf* m, int mode, int16_t* idx, uint16_t* t, uint1
     int rc = grow(&m->xbuf, &m->xbuf_bytes, total); if (rc) return rc;
     char* base = (char*)m->xbuf;
     int* counter = m->num_particles + 2;
-    TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));
-    hipLaunchKernelGGL(k_export_sparse, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, m->stream, m->M, map_slot(m, m->active), mode,
+    TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), ms(m)));
+    hipLaunchKernelGGL(k_export_sparse, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, ms(m), m->M, map_slot(m, m->active), mode,
                        (int16_t*)(base + o_idx), (uint16_t*)(base + o_t), (uint16_t*)(base + o_w), (int8_t*)(base + o_occ),
                        (col && m->M.col) ? (uint16_t*)(base + o_col) : (uint16_t*)nullptr, (long long)cap, counter);
     int cnt = 0; rc = read_int(m, counter, &cnt); if (rc) return rc;
@@ -1093,10 +1177,10 @@ int tsl_tsdf_import_sparse(tsl_tsdf* m, int sid, const int16_t* idx, const uint1
     if (occ) TSL_HIP(hipMemcpy(base + o_occ, occ, c, hipMemcpyHostToDevice));
     const bool hc = col && m->M.col;
     if (hc) TSL_HIP(hipMemcpy(base + o_col, col, c * 6, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_import_sparse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, map_slot(m, sid),
+    hipLaunchKernelGGL(k_import_sparse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ms(m), m->M, map_slot(m, sid),
                        (const int16_t*)(base + o_idx), (const uint16_t*)(base + o_t), (const uint16_t*)(base + o_w),
                        occ ? (const int8_t*)(base + o_occ) : (const int8_t*)nullptr, hc ? (const uint16_t*)(base + o_col) : (const uint16_t*)nullptr, (long long)n);
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     return check_dev_err(m);
 }
 
@@ -1105,9 +1189,9 @@ static int export_particles(tsl_tsdf* m, tsl_tsdf* dst, int mode, int keep, int 
     TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
     if (!dst) dst = m;
     TSL_REQUIRE(dst->device == m->device, "export: destination map lives on another device");
-    if (!keep) TSL_HIP(hipMemsetAsync(dst->num_particles, 0, sizeof(int), m->stream));          // :342-343 / :372-373
+    if (!keep) TSL_HIP(hipMemsetAsync(dst->num_particles, 0, sizeof(int), ms(m)));          // :342-343 / :372-373
     const PoseF B = pose_of(m, m->active);
-    hipLaunchKernelGGL(k_export_particles, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, m->stream, m->M, map_slot(m, m->active), mode, B,
+    hipLaunchKernelGGL(k_export_particles, dim3(m->nb3 < 4096 ? m->nb3 : 4096), dim3(256), 0, ms(m), m->M, map_slot(m, m->active), mode, B,
                        m->cfg.is_global_map, m->P.vs, m->surf_thres, m->disp_floor, m->disp_ceiling, slice_index, dz, m->colormap,
                        dst->exp_xyz, dst->exp_rgb, dst->exp_val, (long long)dst->max_disp, dst->num_particles);
     int cnt = 0; int rc = read_int(m, dst->num_particles, &cnt); if (rc) return rc;
@@ -1125,7 +1209,7 @@ int tsl_tsdf_slice_voxels(tsl_tsdf* m, float z, float dz, int clear_last, int32_
 int tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64_t n)
 {
     TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "read_exports: n out of range"); TSL_HIP(hipSetDevice(m->device));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     if (n == 0) return TSL_OK;
     if (xyz) TSL_HIP(hipMemcpy(xyz, m->exp_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
     if (rgb) TSL_HIP(hipMemcpy(rgb, m->exp_rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
@@ -1137,8 +1221,8 @@ int tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n)
 {
     TSL_REQUIRE(m, "null"); TSL_HIP(hipSetDevice(m->device));
     m->h_ints[8] = n;
-    TSL_HIP(hipMemcpyAsync(m->num_particles, &m->h_ints[8], sizeof(int), hipMemcpyHostToDevice, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->num_particles, &m->h_ints[8], sizeof(int), hipMemcpyHostToDevice, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     return TSL_OK;
 }
 
@@ -1152,7 +1236,7 @@ int tsl_tsdf_prof_enable(tsl_tsdf* m, int on)
 int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launches)
 {
     TSL_REQUIRE(m, "null"); TSL_REQUIRE(kid >= 0 && kid < TSL_K_COUNT, "bad kernel id"); TSL_HIP(hipSetDevice(m->device));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
     for (auto& s : m->prof) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { m->prof_ms[s.kid] += ms; m->prof_n[s.kid] += 1; }
@@ -1187,7 +1271,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
-    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NSETS ? TSL_NSETS : value); for (auto& S : m->fset) S.b_pending = false; return TSL_OK; }
+    if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NB ? TSL_NB : value); for (auto& H : m->batch) H.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
 }

@@ -121,21 +121,32 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 
 struct ProfSlot { hipEvent_t a, b; int kid; };
 
-#define TSL_NSETS 4
+// Frames are queued and processed TSL_NB at a time: phase A of a whole batch runs as one sequence of launches (grid.y = frame)
+// on the batch's stream while phase B of the previous batch runs on the main stream; two batches are in flight.
+#define TSL_NB 4
+#define TSL_NBATCH 2
+#define TSL_NSETS (TSL_NB * TSL_NBATCH)
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
-    hipStream_t st; hipEvent_t a_done, b_done; bool b_pending;
+    void* stage_in; size_t stage_in_bytes; void* stage_tex; size_t stage_tex_bytes;      // staging of host-pointer inputs of the frame queued into this set
     FrameParams* Pd;                       // this frame's parameters in device memory (written by the frame's prologue kernel)
     std::vector<void*> owned;
 };
+// kernel argument of the batched phase-A kernels: the working sets and (device) parameter blocks of the frames of one batch
+struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
+struct ParamPack { FrameParams p[TSL_NB]; };
+struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; };
 
 }  // namespace tsl
 
 struct tsl_tsdf {
     tsl_tsdf_cfg cfg;
     int device;
-    hipStream_t stream;                  // phase B + everything else
-    tsl::FSet fset[TSL_NSETS]; int64_t frame_no; int overlap; int last_set;      // phase-A sets / streams, round robin
+    hipStream_t stream_;                 // phase B + everything else; entry points take it through tsl::ms(), which first issues queued frames
+    tsl::FSet fset[TSL_NSETS]; tsl::BatchHost batch[TSL_NBATCH];
+    int overlap;                         // frames per batch (0 = one frame at a time on the main stream)
+    int cur, npend, pend_points; tsl::FrameParams pend[TSL_NB]; int deferred_rc;      // frames queued for batch `cur`
+    int last_set;
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;
     tsl::MapDev M;
@@ -172,11 +183,13 @@ struct tsl_tsdf {
 
 namespace tsl {
 int  grow(void** p, size_t* have, size_t need);
+hipStream_t ms(tsl_tsdf* m);                                                 // main stream, after issuing the queued frames
+int  flush_pending(tsl_tsdf* m);
 void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr);
 void prof_end(tsl_tsdf* m, hipStream_t st = nullptr);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  check_variant2(tsl_tsdf* m);
-int  launch_segments(tsl_tsdf* m, FSet& S, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
+int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B: apply to the map
 }

@@ -133,6 +133,28 @@ def test_points_input(hip_lib):
     assert_export_equal(g.export_submap(), o.export_sparse(), "points")
 
 
+@pytest.mark.parametrize("overlap", [0, 1, 2, 3, 4])
+def test_queued_batches_bit_exact(hip_lib, overlap):
+    """Frames are queued and issued in batches (phase A of a batch is one sequence of launches with grid.y = frame); nothing is
+    read back between the frames here, the stream mixes image sizes and a point cloud, and its length is not a multiple of the
+    batch size."""
+    from oracle import BATCHED
+    K, frames = small_stream(7)
+    g, o = make_pair(SMALL, K)
+    g.set_option("overlap", overlap)
+    rng = np.random.default_rng(overlap)
+    d = rng.normal(size=(4000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = (d * rng.uniform(0.5, 4.0, size=(4000, 1))).astype(np.float32)
+    for f, (R, T, dep) in enumerate(frames):
+        if f == 2:
+            dep = dep[:90, :120].copy()                                   # a smaller image inside a batch
+        if f == 4:
+            g.recast_pcl_to_map(R, T, pts, np.array([])); o.integrate_points(R, T, pts, None, mode=BATCHED)
+            continue
+        g.recast_depth_to_map(R, T, dep, np.array([], dtype=int)); o.integrate_depth(R, T, dep, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"queued batches, overlap {overlap}")
+
+
 @pytest.mark.parametrize("group", [0, 1])
 def test_pixel_grouping_paths(hip_lib, group):
     """Pixels of one sensor voxel are summed in raster order with per-add f16 rounding (dense_tsdf.py:230-234) whether the
