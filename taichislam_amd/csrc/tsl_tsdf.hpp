@@ -134,8 +134,21 @@ struct FSet {
 };
 // kernel argument of the batched phase-A kernels: the working sets and (device) parameter blocks of the frames of one batch
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
-struct ParamPack { FrameParams p[TSL_NB]; };
-struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; };
+struct ParamPack { FrameParams p[TSL_NB]; int* ctr; };
+// union of the bricks of a batch and its work items (batched phase B); one per batch in flight
+struct UnionDev {
+    int* utab;        // [nb3] brick -> union index, TSL_EMPTY between batches
+    int* ub;          // [ucap] union index -> brick
+    int* ucnt;        // [ucap][TSL_NB] segments of the brick in frame q (zero between batches)
+    int* uoff;        // [ucap][TSL_NB] first of them in the frame's sorted segment array
+    int* uflag;       // [ucap] bit 0: heavy (more than BSEGS segments in some frame); zero between batches
+    int* uslab;       // [ucap] heavy bricks: slab group (slabs hs*TSL_NB + frame of the shared phase-B scratch)
+    int* uparts;      // [ucap] heavy bricks: parts over all frames
+    int4* items;      // [4][icap] work items: class 0 parts of heavy bricks, 1..3 light bricks
+    int* ctr;         // [8] union bricks | heavy bricks | items per class; cleared by the batch prologue
+    int ucap, icap, hcap;
+};
+struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; UnionDev U; std::vector<void*> owned; };
 
 }  // namespace tsl
 
@@ -177,7 +190,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg;
+    int variant, split, phases, wg, batch_b, bgrid;
     int64_t bytes;
 };
 
@@ -192,4 +205,6 @@ int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B: apply to the map
+int  launch_union(tsl_tsdf* m, const BatchDev& B, const UnionDev& U, hipStream_t st);      // end of phase A: union of the batch's bricks, work items
+int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const UnionDev& U, bool tex);  // batched phase B
 }
