@@ -705,309 +705,6 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
 
-// =====================================================================================================
-// batched phase B: one launch applies up to TSL_NB consecutive frames
-// =====================================================================================================
-// The bricks of the frames of a batch are merged into one list ("union bricks").  A brick that never exceeds BSEGS segments in
-// any frame of the batch is a LIGHT item: one workgroup loads its voxels once, walks the frames in order (accumulate in LDS,
-// apply to the registers) and stores them once.  A brick that does in some frame is HEAVY: every (frame, <= BSEGS segments)
-// piece is a part that adds its sums to the HBM slab of (brick, frame); the last part of the brick to arrive -- over all frames
-// -- applies the slabs in frame order.  Either way a voxel sees the frames in order, so the result equals frame-by-frame
-// processing bit for bit, while the launch has four times the work to balance over the chip.
-#define BSEGS 1024
-#define F_ACC(B, hs, q) ((B).f[0].acc + ((size_t)(hs) * TSL_NB + (q)) * (TSL_BRK3 * 2))
-
-// union of the active bricks of the batch's frames; also restores the "zero between uses" state of the per-frame histograms
-__global__ void __launch_bounds__(256) k_union(MapDev M, BatchDev B, UnionDev U)
-{
-    const int q = blockIdx.y;
-    if (q >= B.n) return;
-    const FrameDev& F = B.f[q];
-    const int listed = F.counters[1];
-    const int nact = min(listed, F.max_frame_bricks);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nact) return;
-    const int b = F.act_b[i];
-    const int v = F.bhist[b], off = F.boffset[b];
-    F.bhist[b] = 0; F.bcursor[b] = 0;
-    const int u = claim_index_1(&U.utab[b], &U.ctr[0], U.ucap);
-    if (u < 0) { atomicOr(M.err, 2); return; }
-    U.ub[u] = b;                                              // idempotent
-    U.ucnt[u * TSL_NB + q] = v; U.uoff[u * TSL_NB + q] = off;
-#ifdef TSL_ALL_HEAVY
-    atomicOr(&U.uflag[u], 1);
-#else
-    if (v > BSEGS) atomicOr(&U.uflag[u], 1);
-#endif
-}
-
-// work items: class 0 = parts of heavy bricks {u, frame, part, parts of that frame}; classes 1..3 = light bricks by total
-// number of segments {u, -1, 0, 0}
-__global__ void __launch_bounds__(256) k_union_items(MapDev M, UnionDev U, int n)
-{
-    const int nu = min(U.ctr[0], U.ucap);
-    if ((int)blockIdx.x * 256 >= nu && blockIdx.x) return;
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    int cnt[TSL_NB], tot = 0, tp = 0, heavy = 0;
-    for (int q = 0; q < TSL_NB; ++q) cnt[q] = 0;
-    if (u < nu) {
-        heavy = U.uflag[u] & 1;
-        for (int q = 0; q < n; ++q) { cnt[q] = U.ucnt[u * TSL_NB + q]; tot += cnt[q]; tp += (cnt[q] + BSEGS - 1) / BSEGS; }
-    }
-    const int cls = u < nu ? (heavy ? 0 : (tot >= 1536 ? 1 : (tot >= 384 ? 2 : 3))) : -1;
-    const int hs = block_reserve_n(&U.ctr[1], heavy);
-    int p0 = 0;
-    for (int c = 0; c < 4; ++c) { const int r = block_reserve_n(&U.ctr[2 + c], cls == c ? (c == 0 ? tp : 1) : 0); if (cls == c) p0 = r; }
-    if (u >= nu) return;
-    if (heavy) {
-        if (hs >= U.hcap || p0 + tp > U.icap) { atomicOr(M.err, 2); return; }
-        U.uslab[u] = hs; U.uparts[u] = tp;
-        for (int q = 0; q < n; ++q) {
-            const int np = (cnt[q] + BSEGS - 1) / BSEGS;
-            for (int k = 0; k < np; ++k) U.items[p0++] = make_int4(u, q, k, np);
-        }
-    } else {
-        if (p0 >= U.icap) { atomicOr(M.err, 2); return; }
-        U.items[(size_t)cls * U.icap + p0] = make_int4(u, -1, 0, 0);
-    }
-}
-
-template <bool TEX>
-__global__ void __launch_bounds__(256) k_integrate_batch(MapDev M, BatchDev B, UnionDev U)
-{
-    __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB, all zero between uses
-    __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
-    __shared__ unsigned long long s_keys[BSEGS];
-    __shared__ int s_bin[64];
-    __shared__ int s_p, s_last;
-    constexpr int NT = 256, RPT = TSL_BRK3 / NT, SPT = BSEGS / NT;
-    const int n = B.n;
-    const int c0 = min(U.ctr[2], U.icap), c1 = min(U.ctr[3], U.icap), c2 = min(U.ctr[4], U.icap), c3 = min(U.ctr[5], U.icap);
-    const int nitems = (*M.err & 2) ? 0 : c0 + c1 + c2 + c3;    // nothing is integrated when the batch overflows its scratch
-    const int slot = B.p[0]->slot;
-    long long uniq[TSL_NB];
-#pragma unroll
-    for (int q = 0; q < TSL_NB; ++q) uniq[q] = 0;
-    {
-        ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
-        for (int i = threadIdx.x; i < TSL_BRK3; i += NT) z[i] = make_ulonglong2(0ull, 0ull);
-        if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
-    }
-    __syncthreads();
-    // accumulate `nseg` sorted segments of frame q (from `pos`) into the LDS sums
-    auto accumulate = [&](int q, int pos, int nseg) {
-        const FrameDev& F = B.f[q];
-        const FrameParams& P = *B.p[q];
-        unsigned long long kk[SPT]; int rr[SPT];
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) { const int i = s * NT + threadIdx.x; if (i < nseg) kk[s] = F.seg_sorted[pos + i]; }
-        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
-        __syncthreads();
-        // counting sort by step count (descending): the lanes of a wave walk segments of (almost) equal length
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) { const int i = s * NT + threadIdx.x; rr[s] = -1; if (i < nseg) rr[s] = atomicAdd(&s_bin[63 - (int)(kk[s] & 63ull)], 1); }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int c = s_bin[threadIdx.x];
-            int inc = c;
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }
-            s_bin[threadIdx.x] = inc - c;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) if (rr[s] >= 0) s_keys[s_bin[63 - (int)(kk[s] & 63ull)] + rr[s]] = kk[s];
-        __syncthreads();
-        uint4 recs[SPT]; uint32_t wids[SPT];
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) {                              // all ray records of this thread in flight at once
-            const int i = s * NT + threadIdx.x;
-            if (i < nseg) {
-                kk[s] = s_keys[i];
-                const int r = (int)((kk[s] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
-                recs[s] = F.rayA[r];
-                wids[s] = TEX ? F.rayFirst[r] + 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) {
-            const int i = s * NT + threadIdx.x;
-            if (i >= nseg) continue;
-            const unsigned long long key = kk[s];
-            const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
-            const RayRegs R = make_ray(recs[s], 0, P);
-            const uint32_t wid = wids[s];
-            int off = (int)(threadIdx.x & 63u) % cnt;                // staggered start: see k_integrate_bricks
-            for (int t = 0; t < cnt; ++t) {
-                const int j = j0 + off;
-                if (++off == cnt) off = 0;
-                float x[3]; int xi[3];
-                step_voxel(R, P, j, x, xi);
-                const int l = acc_swz((((xi[0] + M.hN) & 15) << 8) | (((xi[1] + M.hN) & 15) << 4) | ((xi[2] + M.hNz) & 15));
-                const long long qn = step_term(R, x);
-                atomicAdd(&s_acc[l * 2], (unsigned long long)qn);
-                atomicAdd(&s_acc[l * 2 + 1], (unsigned long long)R.qden);
-                if (TEX) atomicMax(&s_win[l], wid);
-            }
-        }
-        __syncthreads();
-    };
-
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-        // order of issue: the long light bricks, the parts of heavy bricks, then the shorter light bricks
-        int4 item;
-        if (it < c1) item = U.items[(size_t)U.icap + it];
-        else if (it < c1 + c0) item = U.items[it - c1];
-        else if (it < c1 + c0 + c2) item = U.items[2 * (size_t)U.icap + it - c1 - c0];
-        else item = U.items[3 * (size_t)U.icap + it - c1 - c0 - c2];
-        const int u = item.x;
-        const int brick = U.ub[u];
-        if (threadIdx.x == 0) s_p = pool_claim<false>(M, slot, brick);     // allocate the brick on its first touch ever
-        __syncthreads();
-        const int p = s_p;
-        uint32_t* tw = M.tw + (size_t)(p < 0 ? 0 : p) * TSL_BRK3;
-        int8_t* obs = M.obs + (size_t)(p < 0 ? 0 : p) * TSL_BRK3;
-#ifdef TSL_DEBUG_BATCH
-        if (threadIdx.x == 0) { long long* d = B.f[0].dbg + 64 + (size_t)it * 8; d[0] = u; d[1] = item.y; d[2] = item.z; d[3] = item.w; d[4] = brick; d[5] = U.ucnt[u * TSL_NB]; d[6] = U.ucnt[u * TSL_NB + 1]; d[7] = U.ucnt[u * TSL_NB + 2]; }
-        if (threadIdx.x == 0 && it == 0) { long long* d = B.f[0].dbg; d[0] = U.ctr[0]; d[1] = U.ctr[1]; d[2] = c0; d[3] = c1; d[4] = c2; d[5] = c3; d[6] = n; }
-#endif
-        if (item.y < 0) {
-            // ---- light brick: voxels in registers, frames in order ----
-            uint32_t old[RPT]; unsigned dirty = 0u, fresh = 0u;
-            if (p >= 0) {
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) old[r] = tw[r * NT + threadIdx.x];
-            }
-            for (int q = 0; q < n; ++q) {
-                const int cnt = U.ucnt[u * TSL_NB + q];
-                if (cnt == 0) continue;                                   // uniform
-                accumulate(q, U.uoff[u * TSL_NB + q], cnt);
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    const int l = r * NT + threadIdx.x, ls = acc_swz(l);
-                    const unsigned long long qd = s_acc[ls * 2 + 1];
-                    if (qd != 0ull) {
-                        const unsigned long long qn = s_acc[ls * 2];
-                        s_acc[ls * 2] = 0ull; s_acc[ls * 2 + 1] = 0ull;
-                        if (p >= 0) {
-                            if ((old[r] >> 16) == 0u) fresh |= 1u << r;   // W == 0 <=> never integrated; imported voxels already carry observed = 1
-                            old[r] = apply_update(old[r], (long long)qn, (long long)qd);
-                            dirty |= 1u << r;
-                            if (TEX) { reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = B.f[q].colpix[s_win[ls] - 1u]; }
-                            ++uniq[q];
-                        }
-                        if (TEX) s_win[ls] = 0u;
-                    }
-                }
-                __syncthreads();
-            }
-            if (p >= 0) {
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    const int l = r * NT + threadIdx.x;
-                    if (dirty & (1u << r)) tw[l] = old[r];
-                    if (fresh & (1u << r)) obs[l] = 1;
-                }
-            }
-            __syncthreads();                           // every wave has read the brick's frame counts
-            if (threadIdx.x < TSL_NB) { U.ucnt[u * TSL_NB + threadIdx.x] = 0; }
-            if (threadIdx.x == 0) { U.utab[brick] = TSL_EMPTY; U.uflag[u] = 0; }
-        } else {
-            // ---- part of a heavy brick: sums of (brick, frame) are merged in an HBM slab ----
-            const int q = item.y, k = item.z, np = item.w;
-            const int cnt = U.ucnt[u * TSL_NB + q];
-            const int per = (cnt + np - 1) / np;
-            const int pos = k * per, nseg = min(cnt, pos + per) - pos;
-            accumulate(q, U.uoff[u * TSL_NB + q] + pos, nseg);
-            const int hs = U.uslab[u];
-            unsigned long long* acc = F_ACC(B, hs, q);
-            uint32_t* accw = TEX ? B.f[0].accw + ((size_t)hs * TSL_NB + q) * TSL_BRK3 : nullptr;
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const int l = r * NT + threadIdx.x, ls = acc_swz(l);
-                const unsigned long long qd = s_acc[ls * 2 + 1];
-                if (qd != 0ull) {
-                    if (p >= 0) {
-                        __hip_atomic_fetch_add(acc + l * 2, s_acc[ls * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(acc + l * 2 + 1, qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (TEX) atomicMax(accw + l, s_win[ls]);
-                    }
-                    s_acc[ls * 2] = 0ull; s_acc[ls * 2 + 1] = 0ull;
-                    if (TEX) s_win[ls] = 0u;
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int tk = __hip_atomic_fetch_add(&B.f[0].ticket[hs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef TSL_DEBUG_BATCH
-                { long long* d = B.f[0].dbg + 64 + (size_t)it * 8; d[5] = nseg; d[6] = tk; d[7] = hs; }
-#endif
-                s_last = (tk == U.uparts[u] - 1) ? 1 : 0;
-                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); B.f[0].ticket[hs] = 0; }
-            }
-            __syncthreads();
-            if (s_last) {
-                // the last part of the brick (over all frames): apply the slabs in frame order and leave them zeroed
-                uint32_t old[RPT]; unsigned dirty = 0u, fresh = 0u;
-                if (p >= 0) {
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) old[r] = tw[r * NT + threadIdx.x];
-                }
-                for (int f = 0; f < n; ++f) {
-                    if (U.ucnt[u * TSL_NB + f] == 0 || p < 0) continue;
-                    unsigned long long* sl = F_ACC(B, hs, f);
-                    uint32_t* slw = TEX ? B.f[0].accw + ((size_t)hs * TSL_NB + f) * TSL_BRK3 : nullptr;
-                    unsigned long long qn[RPT], qd[RPT];
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {       // device-coherent loads, all in flight before the first use
-                        const int l = r * NT + threadIdx.x;
-                        qn[r] = __hip_atomic_load(&sl[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        qd[r] = __hip_atomic_load(&sl[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        const int l = r * NT + threadIdx.x;
-                        if (qd[r] != 0ull) {
-                            if ((old[r] >> 16) == 0u) fresh |= 1u << r;
-                            old[r] = apply_update(old[r], (long long)qn[r], (long long)qd[r]);
-                            dirty |= 1u << r;
-                            reinterpret_cast<ulonglong2*>(sl)[l] = make_ulonglong2(0ull, 0ull);
-                            if (TEX) {
-                                const uint32_t wsel = __hip_atomic_load(slw + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = B.f[f].colpix[wsel - 1u];
-                                slw[l] = 0u;
-                            }
-                            ++uniq[f];
-                        }
-                    }
-#ifdef TSL_DEBUG_BATCH
-                    { int c = 0; for (int r = 0; r < RPT; ++r) c += qd[r] != 0ull; c = (int)wave_sum_ll(c); if (lane_id() == 0) atomic_add_i64(reinterpret_cast<int64_t*>(B.f[0].dbg) + 32768 + (size_t)u * 8 + f, c); }
-#endif
-                }
-                if (p >= 0) {
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        const int l = r * NT + threadIdx.x;
-                        if (dirty & (1u << r)) tw[l] = old[r];
-                        if (fresh & (1u << r)) obs[l] = 1;
-                    }
-                }
-                __syncthreads();                       // every wave has read the brick's frame counts
-                if (threadIdx.x < TSL_NB) { U.ucnt[u * TSL_NB + threadIdx.x] = 0; }
-                if (threadIdx.x == 0) { U.utab[brick] = TSL_EMPTY; U.uflag[u] = 0; }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < TSL_NB; ++q) {
-        const long long s = wave_sum_ll(uniq[q]);
-        if (lane_id() == 0 && s && q < n) atomic_add_i64(&B.f[q].stats->unique, s);
-    }
-}
-
 int check_variant2(tsl_tsdf* m)
 {
     TSL_REQUIRE(m->F.max_frame_bricks <= 4096 && m->P.max_steps_f < (float)(1 << SEG_J_BITS) && m->F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
@@ -1027,25 +724,6 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     prof_begin(m, TSL_K_BIN, st);
     hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->wg == 1024 ? 4096 : (m->wg == 512 ? 2048 : 1024));
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
-    prof_end(m, st);
-    return TSL_OK;
-}
-
-// batched phase B on the main stream (the union of the batch's bricks was built at the end of phase A)
-int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const UnionDev& U, bool tex)
-{
-    prof_begin(m, TSL_K_INTEGRATE);
-    if (tex) hipLaunchKernelGGL(k_integrate_batch<true>, dim3(m->bgrid), dim3(256), 0, m->stream_, m->M, B, U);
-    else hipLaunchKernelGGL(k_integrate_batch<false>, dim3(m->bgrid), dim3(256), 0, m->stream_, m->M, B, U);
-    prof_end(m);
-    TSL_HIP(hipGetLastError());
-    return TSL_OK;
-}
-int launch_union(tsl_tsdf* m, const BatchDev& B, const UnionDev& U, hipStream_t st)
-{
-    prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_union, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, U);
-    hipLaunchKernelGGL(k_union_items, dim3((U.ucap + 255) / 256), dim3(256), 0, st, m->M, U, B.n);
     prof_end(m, st);
     return TSL_OK;
 }

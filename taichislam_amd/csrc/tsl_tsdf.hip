@@ -520,11 +520,12 @@ int dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill)
     return TSL_OK;
 }
 
-void prof_begin(tsl_tsdf* m, int kid, hipStream_t st)
+void prof_begin(tsl_tsdf* m, int kid, hipStream_t st, int count)
 {
+    if (m->prof_group) return;                     // inside a bracket that covers several launches
     m->prof_open = false;
     if (!m->prof_on || !((m->prof_mask >> kid) & 1)) return;
-    ProfSlot s; s.kid = kid;
+    ProfSlot s; s.kid = kid; s.count = count;
     if (m->prof_free.size() >= 2) { s.a = m->prof_free.back(); m->prof_free.pop_back(); s.b = m->prof_free.back(); m->prof_free.pop_back(); }
     else if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
     (void)hipEventRecord(s.a, st ? st : m->stream_);
@@ -533,7 +534,7 @@ void prof_begin(tsl_tsdf* m, int kid, hipStream_t st)
 }
 void prof_end(tsl_tsdf* m, hipStream_t st)
 {
-    if (!m->prof_open) return;
+    if (m->prof_group || !m->prof_open) return;
     (void)hipEventRecord(m->prof.back().b, st ? st : m->stream_);
     m->prof_open = false;
 }
@@ -569,7 +570,6 @@ __global__ void k_set_params(ParamPack PP, BatchDev B)
 {
     if (threadIdx.x == 0) *const_cast<FrameParams*>(B.p[blockIdx.x]) = PP.p[blockIdx.x];
     reinterpret_cast<int*>(B.f[blockIdx.x].stats)[threadIdx.x] = 0;          // stats | nrays | counters: the set's 256-byte header
-    if (blockIdx.x == 0 && threadIdx.x < 8 && PP.ctr) PP.ctr[threadIdx.x] = 0;  // counters of the batch's brick union
 }
 
 // phase A of a batch of n frames on stream `sa`: depth -> rays -> brick-sorted segments, every kernel once with grid.y = frame.
@@ -633,25 +633,25 @@ static int launch_batch_t(tsl_tsdf* m)
     for (int q = 0; q < n; ++q) { FSet& S = m->fset[bi * TSL_NB + q]; B.f[q] = S.F; B.p[q] = S.Pd; PP.p[q] = m->pend[q]; }
     for (int q = n; q < TSL_NB; ++q) { B.f[q] = B.f[0]; B.p[q] = B.p[0]; PP.p[q] = PP.p[0]; }
     B.n = n;
-    const bool batch_b = !serial && m->pend[0].variant == 2 && m->pend[0].group && m->wg == 256 && m->batch_b;
-    PP.ctr = H.U.ctr;
     hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, B);
-    if (m->phases & 1) {
-        int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc;
-        if (batch_b) { rc = launch_union(m, B, H.U, sa); if (rc) return rc; }
-    }
+    if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
     if (!serial) {
         TSL_HIP(hipEventRecord(H.a_done, sa));
         TSL_HIP(hipStreamWaitEvent(m->stream_, H.a_done, 0));
     }
     // ---- phase B: apply to the map, in frame order on the main stream ----
-    if (batch_b) {
-        bool tex = false; for (int q = 0; q < n; ++q) tex = tex || m->pend[q].tex;
-        if (m->phases & 2) { int rc = launch_apply_batch(m, B, H.U, tex); if (rc) return rc; }
-    } else for (int q = 0; q < n; ++q) {
-        FSet& S = m->fset[bi * TSL_NB + q];
-        m->P = m->pend[q];
-        if (m->P.total > 0 && (m->phases & 2)) { int rc = launch_apply(m, S, m->P.total); if (rc) return rc; }
+    {   // one pair of timing events around the batch's integrate launches (they run back to back on this stream)
+        int nb = 0; for (int q = 0; q < n; ++q) nb += m->pend[q].total > 0;
+        const bool group = m->pend[0].variant == 2 && nb > 0 && (m->phases & 2);
+        if (group) { prof_begin(m, TSL_K_INTEGRATE, nullptr, nb); m->prof_group = true; }
+        int rc = TSL_OK;
+        for (int q = 0; q < n && !rc; ++q) {
+            FSet& S = m->fset[bi * TSL_NB + q];
+            m->P = m->pend[q];
+            if (m->P.total > 0 && (m->phases & 2)) rc = launch_apply(m, S, m->P.total);
+        }
+        if (group) { m->prof_group = false; prof_end(m); }
+        if (rc) return rc;
     }
     if (!serial) { TSL_HIP(hipEventRecord(H.b_done, m->stream_)); H.b_pending = true; }
     m->cur = (bi + 1) % TSL_NBATCH;
@@ -824,9 +824,9 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256; m->batch_b = 1; m->bgrid = 2048;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256;
     m->active = 0; m->variant = 2; m->split = 2;
-    m->prof_on = false; m->prof_open = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
+    m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0; m->stage_in = nullptr; m->stage_in_bytes = 0; m->stage_tex = nullptr; m->stage_tex_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr;
@@ -911,18 +911,6 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
         if (si % TSL_NB == 0) {
             BatchHost& H = m->batch[si / TSL_NB];
-            UnionDev& U = H.U; std::memset(&U, 0, sizeof(U));
-            U.ucap = 2 * F.max_frame_bricks; U.icap = TSL_NB * G.part_cap; U.hcap = F.max_frame_bricks / TSL_NB;
-            auto ownb = [&](void** p, size_t bytes, int fill) -> int { int r = dev_alloc(m, p, bytes, fill); if (!r) H.owned.push_back(*p); return r; };
-            if ((rc = ownb((void**)&U.utab, sizeof(int) * (size_t)m->nb3, 0xff))) return rc;
-            if ((rc = ownb((void**)&U.ub, sizeof(int) * (size_t)U.ucap, 0))) return rc;
-            if ((rc = ownb((void**)&U.ucnt, sizeof(int) * (size_t)U.ucap * TSL_NB, 0))) return rc;
-            if ((rc = ownb((void**)&U.uoff, sizeof(int) * (size_t)U.ucap * TSL_NB, 0))) return rc;
-            if ((rc = ownb((void**)&U.uflag, sizeof(int) * (size_t)U.ucap, 0))) return rc;
-            if ((rc = ownb((void**)&U.uslab, sizeof(int) * (size_t)U.ucap, 0))) return rc;
-            if ((rc = ownb((void**)&U.uparts, sizeof(int) * (size_t)U.ucap, 0))) return rc;
-            if ((rc = ownb((void**)&U.items, sizeof(int4) * 4 * (size_t)U.icap, 0))) return rc;
-            if ((rc = ownb((void**)&U.ctr, sizeof(int) * 8, 0))) return rc;
             TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking));
             TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
             TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
@@ -961,12 +949,6 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream_);
     for (auto& H : m->batch) if (H.st) (void)hipStreamSynchronize(H.st);
-    for (auto& H : m->batch) {
-        for (void* p : H.owned) if (p) (void)hipFree(p);
-        if (H.st) (void)hipStreamDestroy(H.st);
-        if (H.a_done) (void)hipEventDestroy(H.a_done);
-        if (H.b_done) (void)hipEventDestroy(H.b_done);
-    }
     (void)hipStreamSynchronize(m->stream_);
     (void)hipDeviceSynchronize();
     for (auto& S : m->fset) {
@@ -1266,7 +1248,7 @@ int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launche
     TSL_HIP(hipStreamSynchronize(ms(m)));
     for (auto& s : m->prof) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { m->prof_ms[s.kid] += ms; m->prof_n[s.kid] += 1; }
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { m->prof_ms[s.kid] += ms; m->prof_n[s.kid] += s.count; }
         m->prof_free.push_back(s.a); m->prof_free.push_back(s.b);
     }
     m->prof.clear();
@@ -1297,8 +1279,6 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); m->wg = value; return TSL_OK; }
-    if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 1 && value <= 65535, "bgrid out of range"); m->bgrid = value; return TSL_OK; }
-    if (!std::strcmp(name, "batch_b")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->batch_b = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NB ? TSL_NB : value); for (auto& H : m->batch) H.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }

@@ -119,7 +119,7 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 }
 
 
-struct ProfSlot { hipEvent_t a, b; int kid; };
+struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 
 // Frames are queued and processed TSL_NB at a time: phase A of a whole batch runs as one sequence of launches (grid.y = frame)
 // on the batch's stream while phase B of the previous batch runs on the main stream; two batches are in flight.
@@ -134,21 +134,8 @@ struct FSet {
 };
 // kernel argument of the batched phase-A kernels: the working sets and (device) parameter blocks of the frames of one batch
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
-struct ParamPack { FrameParams p[TSL_NB]; int* ctr; };
-// union of the bricks of a batch and its work items (batched phase B); one per batch in flight
-struct UnionDev {
-    int* utab;        // [nb3] brick -> union index, TSL_EMPTY between batches
-    int* ub;          // [ucap] union index -> brick
-    int* ucnt;        // [ucap][TSL_NB] segments of the brick in frame q (zero between batches)
-    int* uoff;        // [ucap][TSL_NB] first of them in the frame's sorted segment array
-    int* uflag;       // [ucap] bit 0: heavy (more than BSEGS segments in some frame); zero between batches
-    int* uslab;       // [ucap] heavy bricks: slab group (slabs hs*TSL_NB + frame of the shared phase-B scratch)
-    int* uparts;      // [ucap] heavy bricks: parts over all frames
-    int4* items;      // [4][icap] work items: class 0 parts of heavy bricks, 1..3 light bricks
-    int* ctr;         // [8] union bricks | heavy bricks | items per class; cleared by the batch prologue
-    int ucap, icap, hcap;
-};
-struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; UnionDev U; std::vector<void*> owned; };
+struct ParamPack { FrameParams p[TSL_NB]; };
+struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; };
 
 }  // namespace tsl
 
@@ -188,9 +175,9 @@ struct tsl_tsdf {
     // esdf
     float* esdf; int* esdf_flag; int64_t esdf_bricks; float esdf_gamma;
     // profiling
-    bool prof_on, prof_open; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
+    bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, batch_b, bgrid;
+    int variant, split, phases, wg;
     int64_t bytes;
 };
 
@@ -198,13 +185,11 @@ namespace tsl {
 int  grow(void** p, size_t* have, size_t need);
 hipStream_t ms(tsl_tsdf* m);                                                 // main stream, after issuing the queued frames
 int  flush_pending(tsl_tsdf* m);
-void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr);
+void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr, int count = 1);
 void prof_end(tsl_tsdf* m, hipStream_t st = nullptr);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B: apply to the map
-int  launch_union(tsl_tsdf* m, const BatchDev& B, const UnionDev& U, hipStream_t st);      // end of phase A: union of the batch's bricks, work items
-int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const UnionDev& U, bool tex);  // batched phase B
 }
