@@ -194,6 +194,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: single 640x480 u16 depth stream (sphere room r=3 m, 1 deg/frame) -> "
                                    "DenseTSDF 512^3 / 2 cm, recast_step 2, max_ray 5 m; one stream+submap per GPU",
                        "frame_stats": stats, "kernels_us": kern,
+                       "kernels_us_note": "integrate: per frame; the other kernels are launched once per batch of up to 4 queued frames",
                        "updates_per_s": stats["steps"] * fps, "merge": merge},
             "roofline": roof,
         }
