@@ -42,8 +42,6 @@ namespace tsl {
 #define SEG_RAY_BITS 24
 #define SEG_SLOT_SHIFT (SEG_CNT_BITS + SEG_J_BITS + SEG_RAY_BITS)
 #define SEG_MAX_CNT 63
-#define SEG_LDS_CAP 4096
-#define SLOT_LDS    4096            // per-block LDS histogram size == max_frame_bricks upper bound for variant 2
 #define SCATTER_TILE 4096
 
 struct RayRegs { float pf0, pf1, pf2, d0, d1, d2, P0, P1, P2, w; long long qden; int n; };

@@ -160,9 +160,6 @@ struct tsl_tsdf {
     void* sort_temp; size_t sort_temp_bytes;
     tsl_frame_stats* h_stats;            // pinned
     int* h_ints;                         // pinned scratch (16 ints)
-    // staging for host-pointer integrate calls
-    void* stage_in; size_t stage_in_bytes;
-    void* stage_tex; size_t stage_tex_bytes;
     // export buffers (export_TSDF_xyz / export_color / export_TSDF, num_TSDF_particles)  dense_tsdf.py:53-60
     float *exp_xyz, *exp_rgb, *exp_val; int* num_particles; int64_t max_disp;
     float* colormap;                     // [1024][3]

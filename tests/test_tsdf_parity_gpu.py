@@ -264,6 +264,29 @@ def test_submap_base_pose_and_switch(hip_lib):
     assert_export_equal(g.export_submap(), o.export_sparse(), "submap 1")
 
 
+def test_queue_keeps_every_frames_own_parameters(hip_lib):
+    """Frames wait in a queue until a batch is full: intrinsics, base pose and active submap are the ones that were current
+    when each frame was queued, and a handle can be dropped with frames still queued."""
+    from oracle import BATCHED
+    K, frames = small_stream(6)
+    K2 = K.copy(); K2[0] *= 1.07; K2[4] *= 0.95; K2[2] -= 2.0
+    cfg = dict(SMALL, max_submap_num=8)
+    g, o = make_pair(cfg, K)
+    for f, (R, T, d) in enumerate(frames):
+        if f == 1:
+            g.set_dep_camera_intrinsic(K2); o.set_intrinsics(K2, K2)
+        if f == 3:
+            assert g.switch_to_next_submap() == 1; o.set_active_submap(1)
+            g.set_base_pose_submap(1, R, T); o.set_base_pose_submap(1, R, T)
+        g.recast_depth_to_map(R, T, d, None); o.integrate_depth(R, T, d, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), "submap 1 after queued parameter changes")
+    g.active_submap_id[None] = 0; o.set_active_submap(0)
+    assert_export_equal(g.export_submap(), o.export_sparse(), "submap 0 after queued parameter changes")
+    g.recast_depth_to_map(*frames[0][:2], frames[0][2], None)
+    g.recast_depth_to_map(*frames[1][:2], frames[1][2], None)
+    del g                                                                  # two frames still queued
+
+
 def test_particle_exports(hip_lib):
     """cvt_TSDF_surface_to_voxels / cvt_TSDF_to_voxels_slice (dense_tsdf.py:339-389) as sorted sets."""
     K, frames = small_stream(3)
