@@ -54,9 +54,16 @@ def _worker(rank, world, port, out):
     sub, _ = _build_submap(rank)
     bases = [syn.camera_pose(0, start_deg=D.stream_start_deg(r)) for r in range(world)]
     g = _global(bases)
-    nbytes = D.allreduce_merge(g, sub)
+    nbytes = D.allreduce_merge(g, sub)                       # brick-sparse exchange (default)
     e = g.export_sparse()
-    np.savez(os.path.join(out, f"rank{rank}.npz"), idx=e["indices"], t=e["TSDF"].view(np.uint16), w=e["W_TSDF"].view(np.uint16), occ=e["occupy"], nbytes=nbytes)
+    g2 = _global(bases)
+    nbytes_dense = D.allreduce_merge(g2, sub, sparse=False)   # dense exchange: same map
+    e2 = g2.export_sparse()
+    for k in ("indices", "TSDF", "W_TSDF", "occupy"):
+        a, b = np.asarray(e[k]), np.asarray(e2[k])
+        assert np.array_equal(a.view(np.uint16) if a.dtype == np.float16 else a, b.view(np.uint16) if b.dtype == np.float16 else b), k
+    np.savez(os.path.join(out, f"rank{rank}.npz"), idx=e["indices"], t=e["TSDF"].view(np.uint16), w=e["W_TSDF"].view(np.uint16), occ=e["occupy"],
+             nbytes=nbytes, nbytes_dense=nbytes_dense)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,7 +99,8 @@ def test_two_rank_merge_equals_single_process(tmp_path):
     ok = ~np.isnan(e["TSDF"].astype(np.float32))
     assert np.array_equal(t[ok], r0["t"][ok]) and np.array_equal(e["W_TSDF"].view(np.uint16), r0["w"]) and np.array_equal(e["occupy"], r0["occ"])
     nvox = g.N * g.N * g.Nz
-    assert int(r0["nbytes"]) == nvox * 20
+    assert int(r0["nbytes_dense"]) == nvox * 20
+    assert 0 < int(r0["nbytes"]) < int(r0["nbytes_dense"]) // 2 and int(r0["nbytes"]) == int(r1["nbytes"])
 
 
 def test_stream_sharding_is_disjoint():
