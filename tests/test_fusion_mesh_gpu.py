@@ -174,3 +174,33 @@ def test_submap_mapping_orchestration(hip_lib):
                           global_opts=dict(map_scale=[10.24, 10.24], voxel_scale=0.04, num_voxel_per_blk_axis=16, max_ray_length=5.0, max_submap_num=16))
     other.input_remote_submap(sent[0])
     assert other.submap_collection.remote_submap_num[None] == 1 and other.global_map.count_active() > 1000
+
+
+def test_brick_sparse_exchange_round_trip_on_device(hip_lib):
+    """The packing / unpacking of the touched bricks around the RCCL all-reduce (taichislam_amd.distributed) on CUDA tensors: with a
+    one-rank nccl group the exchange must leave the accumulators unchanged and move only the touched bricks."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from taichislam_amd import distributed as D
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        N = Nz = 128
+        g = torch.Generator(device="cuda").manual_seed(3)
+        acc = torch.zeros((N * N * Nz, 2), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(N * N * Nz, dtype=torch.int32, device="cuda")
+        vox = torch.randint(0, 40 * 40 * 40, (5000,), generator=g, device="cuda")
+        i, j, k = vox // 1600 + 20, (vox // 40) % 40 + 50, vox % 40 + 70                 # a 40^3 blob: 3x3x4 bricks at most
+        lin = (i * N + j) * Nz + k
+        acc[lin, 0] = torch.randint(-2 ** 40, 2 ** 40, (5000,), generator=g, device="cuda")
+        acc[lin, 1] = torch.randint(1, 2 ** 30, (5000,), generator=g, device="cuda")
+        cnt[lin] = 1
+        a0, c0 = acc.clone(), cnt.clone()
+        nbytes = D._brick_exchange(acc, cnt, N, Nz, None)
+        torch.cuda.synchronize()
+        assert torch.equal(acc, a0) and torch.equal(cnt, c0)
+        nb = int(torch.unique(((i // 16) * 8 + j // 16) * 8 + k // 16).numel())
+        assert nbytes == 8 * 8 * 8 + nb * 4096 * 20
+    finally:
+        dist.destroy_process_group()
