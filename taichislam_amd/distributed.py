@@ -58,7 +58,10 @@ def allreduce_merge(global_map, submaps, group=None, device=None, sparse=True):
     import torch
     import torch.distributed as dist
     acc, cnt = merge_buffers(global_map, device)
-    global_map.fuse_accumulate(submaps, acc, cnt)
+    on_gpu = isinstance(acc, torch.Tensor) and acc.is_cuda
+    if on_gpu:
+        torch.cuda.synchronize(acc.device)          # the accumulators were cleared on torch's stream, the splat runs on the map's
+    global_map.fuse_accumulate(submaps, acc, cnt)     # returns after its stream has drained
     nbytes = 0
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         tacc = acc if isinstance(acc, torch.Tensor) else torch.from_numpy(acc)
@@ -70,5 +73,7 @@ def allreduce_merge(global_map, submaps, group=None, device=None, sparse=True):
             dist.all_reduce(tacc, op=dist.ReduceOp.SUM, group=group)
             dist.all_reduce(tcnt, op=dist.ReduceOp.SUM, group=group)
             nbytes = tacc.numel() * tacc.element_size() + tcnt.numel() * tcnt.element_size()
+    if on_gpu:
+        torch.cuda.synchronize(acc.device)          # the collectives ran on torch's stream
     global_map.fuse_finalize(acc, cnt)
     return int(nbytes)
