@@ -574,13 +574,14 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
         for (int q = 0; q < PSEGS / NT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PSEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = s_keys[i]; }
+        // sorted by length, dealt out in alternating directions: every thread (and wave) gets about the same number of steps
+        for (int q = 0; q < PSEGS / NT; ++q) { const int i = SORT ? q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x) : q * NT + (int)threadIdx.x; if (i < nseg) kk[q] = s_keys[i]; }
         }
         TSL_TICK(F, 1);
         uint4 recs[PSEGS / NT]; uint32_t wids[PSEGS / NT];
 #pragma unroll
         for (int q = 0; q < PSEGS / NT; ++q) {                           // all ray records of this thread in flight at once
-            const int i = q * NT + threadIdx.x;
+            const int i = SORT ? q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x) : q * NT + (int)threadIdx.x;
             if (i < nseg) {
                 const int r = (int)((kk[q] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
                 recs[q] = F.rayA[r];
@@ -589,7 +590,7 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
         }
 #pragma unroll
         for (int q = 0; q < PSEGS / NT; ++q) {
-            const int i = q * NT + threadIdx.x;
+            const int i = SORT ? q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x) : q * NT + (int)threadIdx.x;
             if (i >= nseg) continue;
             const unsigned long long key = kk[q];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
