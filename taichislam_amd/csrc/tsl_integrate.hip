@@ -521,6 +521,7 @@ __device__ __forceinline__ int acc_swz(int l) { return l ^ (((l >> 4) ^ (l >> 8)
 template <bool TEX, int NT, int PSEGS, bool SORT>
 __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
+    constexpr bool EARLY_ROWS = !TEX && NT == 256;             // 16 more live registers per thread: only where they are free
     const FrameParams& P = *Pp;
     __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
@@ -553,6 +554,13 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
         if (SORT && threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         __syncthreads();
+        // the brick's rows of a whole part are requested now and used after the walk
+        uint32_t old[TSL_BRK3 / NT];
+        if (EARLY_ROWS && whole && s_p >= 0) {
+            const uint32_t* twr = M.tw + (size_t)s_p * TSL_BRK3;
+#pragma unroll
+            for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = twr[q * NT + threadIdx.x];
+        }
         if (SORT) {
         // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
         // segments of (almost) equal length instead of idling behind the longest one
@@ -624,9 +632,10 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
         if (p >= 0 && whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
             int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-            uint32_t old[TSL_BRK3 / NT];
+            if (!EARLY_ROWS) {
 #pragma unroll
-            for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = tw[q * NT + threadIdx.x];      // all row loads in flight at once
+                for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = tw[q * NT + threadIdx.x];      // all row loads in flight at once
+            }
 #pragma unroll
             for (int q = 0; q < TSL_BRK3 / NT; ++q) {
                 const int l = q * NT + threadIdx.x, ls = acc_swz(l);
