@@ -103,6 +103,9 @@ int  tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3]
                                const float* xyz, const uint8_t* rgb, int64_t n);
 int  tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3],
                                    const void* xyz_dev, const void* rgb_dev, int64_t n);
+/* The integrate calls only QUEUE the frame (host buffers are copied before they return; device buffers must stay unchanged until
+ * the next call that returns data, or tsl_tsdf_sync).  Queued frames are issued four at a time, or as soon as any other call needs
+ * the map, so results never depend on the queueing; frames still queued when a handle is destroyed are dropped. */
 /* counters of the most recent integrate call (synchronises) */
 int  tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out);
 
