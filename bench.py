@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--split", type=int, default=None)
     ap.add_argument("--overlap", type=int, default=None)
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="backend option for A/B runs (tsl_tsdf_set_option)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merge", action="store_true", help="also run the config-5 global-map merge (default when --gpus > 1)")
     args = ap.parse_args()
@@ -95,6 +96,9 @@ def main():
         m.set_option("split", args.split)
     if args.overlap is not None:
         m.set_option("overlap", args.overlap)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        m.set_option(k, int(v))
 
     def step(f):
         R, T = poses[f]
