@@ -103,6 +103,13 @@ int  tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3]
                                const float* xyz, const uint8_t* rgb, int64_t n);
 int  tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3],
                                    const void* xyz_dev, const void* rgb_dev, int64_t n);
+/* Stream that will read the device buffers of the next integrate_*_dev call (points: 0 depth image, 1 point cloud).  Producers on
+ * another stream order themselves before it (event + hipStreamWaitEvent); the reference's recast_* calls are synchronous
+ * (dense_tsdf.py:157-165), so the Python shim does this for torch tensors. */
+int  tsl_tsdf_input_stream(tsl_tsdf* m, int points, void** hip_stream);
+/* frames queued by integrate_* calls and not yet issued to the device: a device buffer handed to integrate_*_dev is read by kernels
+ * that are only enqueued once this has dropped back to 0 (or any synchronising call was made) */
+int  tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n);
 /* The integrate calls only QUEUE the frame (host buffers are copied before they return; device buffers must stay unchanged until
  * the next call that returns data, or tsl_tsdf_sync).  Queued frames are issued four at a time, or as soon as any other call needs
  * the map, so results never depend on the queueing; frames still queued when a handle is destroyed are dropped. */
@@ -159,7 +166,8 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; two batches in flight)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
-     "wg"       threads per workgroup of the brick integrate kernel: 256 (default, 1024 segments per part), 512, 1024
+     "wg"       threads per workgroup of the brick integrate kernel: 256 (1024 segments per part), 512 (2048), 1024 (r01 kernel only)
+     "kern"     1 (default) = round-2 brick kernel (two steps per iteration, split accumulator planes), 0 = round-1 kernel
      "fastdiv"  0 = force IEEE division
      "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);

@@ -9,6 +9,7 @@ _LIB = None
 
 FAITHFUL = 0
 BATCHED = 1
+IDEAL = 2        # FAITHFUL sequence with the map state in float64 (measurement aid, see tsl_oracle.h)
 
 
 class TsdfCfg(C.Structure):

@@ -105,6 +105,7 @@ typedef struct {
     int64_t cnum[BRK3][3];             /* fusion: sum of w*colour per channel (texture)  */
     uint32_t win[BRK3];                /* per-frame colour winner (ray order + 1)      */
     int     touched;                   /* in the frame touched list                    */
+    double (*ideal)[2];                /* ORA_IDEAL only: {TSDF, W} kept in float64 (lazily allocated) */
 } brick_t;
 
 typedef struct { brick_t** tab; } submap_t;
@@ -185,7 +186,7 @@ static void free_submap(ora_tsdf* m, submap_t* s)
 {
     if (!s->tab) return;
     size_t nb = (size_t)m->nbx * m->nbx * m->nbz;
-    for (size_t b = 0; b < nb; ++b) free(s->tab[b]);
+    for (size_t b = 0; b < nb; ++b) { if (s->tab[b]) free(s->tab[b]->ideal); free(s->tab[b]); }
     free(s->tab); s->tab = NULL;
 }
 
@@ -410,6 +411,15 @@ static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats*
                 float wn = F(W0) + w; if (WMAX < wn) wn = WMAX;
                 b->w[l] = H(wn);                                                       /* :267 */
                 if (tex) for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];             /* :268-269 */
+            } else if (mode == ORA_IDEAL) {
+                /* the same sequence of updates as FAITHFUL with the map state kept in float64: no f16 rounding of TSDF / W
+                 * between updates (what the reference computes up to its storage format).  Measurement aid for the parity
+                 * statement -- how far FAITHFUL and BATCHED each are from it -- never a target of its own. */
+                if (!b->ideal) b->ideal = (double (*)[2])calloc(BRK3, sizeof(double[2]));
+                const double T0 = b->ideal[l][0], W0 = b->ideal[l][1];
+                b->ideal[l][0] = (T0 * W0 + (double)w * (double)sd) / (W0 + (double)w);
+                b->ideal[l][1] = (W0 + (double)w) > (double)WMAX ? (double)WMAX : (W0 + (double)w);
+                b->tsdf[l] = H((float)b->ideal[l][0]); b->w[l] = H((float)b->ideal[l][1]); b->obs[l] = 1;
             } else if (tex && (uint32_t)cell->first + 1u > b->win[l]) {
                 /* BATCHED colour: of the rays that reach a voxel in this frame, the one whose sensor cell was opened by the
                  * latest pixel wins -- an order-free stand-in for the reference's "last writer" race (:268-269) */

@@ -18,6 +18,8 @@
  *   ORA_BATCHED   identical per-ray / per-step arithmetic, but the per-frame contributions
  *                 (w*sd, w) are summed in exact 2^-24 fixed point per voxel and applied once
  *                 per touched voxel.  Order-free => what the GPU implements bit-for-bit.
+ *   ORA_IDEAL     FAITHFUL's update sequence with TSDF / W kept in float64 between updates (f16 only on export): the
+ *                 yardstick for "how far is each of the two from what the reference's formula means".
  */
 #ifndef TSL_ORACLE_H
 #define TSL_ORACLE_H
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-enum { ORA_FAITHFUL = 0, ORA_BATCHED = 1 };
+enum { ORA_FAITHFUL = 0, ORA_BATCHED = 1, ORA_IDEAL = 2 };
 
 typedef struct {
     double map_size_xy, map_size_z;   /* DenseTSDF(map_scale=[xy,z])          dense_tsdf.py:13 */

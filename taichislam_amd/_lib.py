@@ -70,6 +70,8 @@ SIGNATURES = {
     "tsl_tsdf_integrate_depth_dev": (C.c_int, [vp, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     "tsl_tsdf_integrate_points": (C.c_int, [vp, dp, dp, vp, vp, i64]),
     "tsl_tsdf_integrate_points_dev": (C.c_int, [vp, dp, dp, vp, vp, i64]),
+    "tsl_tsdf_input_stream": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "tsl_tsdf_queued_frames": (C.c_int, [vp, pi32]),
     "tsl_tsdf_last_frame_stats": (C.c_int, [vp, C.POINTER(FrameStats)]),
     "tsl_tsdf_count_active": (C.c_int, [vp, pi64]),
     "tsl_tsdf_export_sparse": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, pi64]),
@@ -122,7 +124,8 @@ def lib():
     """Load (building first if the sources are newer and hipcc exists) the HIP library.  Raises if unavailable."""
     global _LIB
     if _LIB is None:
-        path = _build.build_library()
+        # TSL_LIB: developer aid, an alternative build of the same library (e.g. a -DTSL_TIMING build for tools/timing_probe*.py)
+        path = os.environ.get("TSL_LIB") or _build.build_library()
         if not os.path.exists(path):
             raise TslError("libtaichislam_hip.so is missing; run `python -m taichislam_amd.build`")
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -191,9 +191,10 @@ __device__ __forceinline__ int claim_index_1(int* entry, int* counter, int cap)
             int old = atomicCAS(entry, TSL_EMPTY, TSL_LOCKED);
             if (old == TSL_EMPTY) {
                 int idx = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (idx >= cap) idx = TSL_FULL;
-                __hip_atomic_store(entry, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return idx;
+                // out of capacity: the entry goes back to EMPTY (a later reset / larger pool can allocate it) and the caller
+                // reports the failure; TSL_FULL is only ever a return value, never a table entry
+                __hip_atomic_store(entry, idx >= cap ? TSL_EMPTY : idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return idx >= cap ? TSL_FULL : idx;
             }
             v = old;
         } else {

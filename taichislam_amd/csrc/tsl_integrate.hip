@@ -103,7 +103,7 @@ __device__ __forceinline__ int frame_slot_slow(const MapDev& M, const FrameDev& 
         const int p = pool_claim<COOP>(M, s, b);
         if (p >= 0) { F.touched[sl] = p; F.touched_b[sl] = b; }      // idempotent: every claimer writes the same values
         else return -1;
-    } else atomicOr(M.err, 2);
+    } else frame_fail(M, F, 2);
     return sl;
 }
 __device__ __forceinline__ int frame_slot(const MapDev& M, const FrameDev& F, int s, int b)
@@ -116,6 +116,14 @@ __device__ __forceinline__ int frame_slot(const MapDev& M, const FrameDev& F, in
 __device__ __forceinline__ uint32_t apply_update(uint32_t old, long long qnum, long long qden)
 {
     const float num = from_fix(qnum), den = from_fix(qden);
+    const h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
+    const h16 Tn = f2h((h2f(hmul(T0, W0)) + num) / (h2f(W0) + den));
+    float wn = h2f(W0) + den; if (TSL_WMAX < wn) wn = TSL_WMAX;
+    return (uint32_t)Tn | ((uint32_t)f2h(wn) << 16);
+}
+// the same with the sums already converted (from_fix / from_fix32)
+__device__ __forceinline__ uint32_t apply_update_f(uint32_t old, float num, float den)
+{
     const h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
     const h16 Tn = f2h((h2f(hmul(T0, W0)) + num) / (h2f(W0) + den));
     float wn = h2f(W0) + den; if (TSL_WMAX < wn) wn = TSL_WMAX;
@@ -388,14 +396,14 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
                         if (nslot < spl) myseg[nslot++] = en;
                         else {      // more brick crossings than private slots: append behind the per-ray slots
                             const long long pos = (long long)nrays * SEG_RAY_SLOTS + __hip_atomic_fetch_add(&F.counters[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (pos < F.seg_cap) F.seg[pos] = en; else { stored = false; atomicOr(M.err, 4); }
+                            if (pos < F.seg_cap) F.seg[pos] = en; else { stored = false; frame_fail(M, F, 4); }
                         }
                         if (stored) {
                             const int hs = lh_slot<SEG_LH_LOG2>(s_key, b);
                             if (hs >= 0) atomicAdd(&s_cnt[hs], 1);
                             else if (__hip_atomic_fetch_add(&F.bhist[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // hash full (incoherent rays)
                                 const int q = __hip_atomic_fetch_add(&F.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (q < F.max_frame_bricks) F.act_b[q] = b; else atomicOr(M.err, 2);
+                                if (q < F.max_frame_bricks) F.act_b[q] = b; else frame_fail(M, F, 2);
                             }
                         }
                     }
@@ -420,7 +428,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
         const int b = c ? s_key[i] : 0;
         const bool first = c && __hip_atomic_fetch_add(&F.bhist[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
         const int q = wave_reserve(&F.counters[1], first);      // the first block to count a brick this frame lists it as active
-        if (first) { if (q < F.max_frame_bricks) F.act_b[q] = b; else atomicOr(M.err, 2); }
+        if (first) { if (q < F.max_frame_bricks) F.act_b[q] = b; else frame_fail(M, F, 2); }
     }
     TSL_TICK(F, 6);
 #ifdef TSL_TIMING
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 // integrate parts (a brick with more than PART_SEGS segments is integrated by several workgroups).  Neither has to be in
 // any particular order, so block-aggregated reservations replace a prefix scan.  Parts go to three tables by length, so
 // k_integrate_bricks starts the long ones first and its tail is made of short ones.
-// part = { first segment, segments | parts of the brick << 16, brick, active rank }
+// part = { first segment, segments | parts of the brick << 16, pool index of the brick (claimed here, on its first touch ever), active rank }
 __device__ __forceinline__ int part_class(int per, int psegs) { return per * 8 >= psegs * 5 ? 0 : (per * 4 >= psegs ? 1 : 2); }
 __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs)
 {
@@ -462,12 +470,13 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs)
         F.boffset[b] = off;
         const int per = np ? (v + np - 1) / np : 0;
         int4* tab = F.part_tab + (size_t)cls * F.part_cap;
+        const int pool = np ? pool_claim<false>(M, B.p[blockIdx.y]->slot, b) : -1;      // < 0: pool exhausted (reported through M.err), the parts are skipped
         for (int k = 0; k < np; ++k) {
             const int pos = k * per, n = min(v, pos + per) - pos;
-            if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, n | (np << 16), b, i); else atomicOr(M.err, 2);
+            if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, n | (np << 16), pool, i); else frame_fail(M, F, 2);
         }
     }
-    if (i == 0) { F.stats->bricks = listed; if (listed > F.max_frame_bricks) atomicOr(M.err, 2); }
+    if (i == 0) { F.stats->bricks = listed; if (listed > F.max_frame_bricks) frame_fail(M, F, 2); }
 }
 
 // K4c: counting sort by brick (LDS hash of the bricks seen in each 4096-segment tile, one global reservation per (tile, brick))
@@ -512,24 +521,70 @@ __global__ void __launch_bounds__(256) k_scatter(BatchDev B)
     }
 }
 
-// K4d: LDS accumulation per brick, in-place finalise
-// LDS position of a voxel's sums: an entry is 16 bytes = 4 of the 64 banks, so the z digit alone picks the banks.  Rays that
-// cross a brick side by side hit voxels that differ in x or y at equal z -- XOR-ing those digits into the z digit spreads
-// them over the banks.
-__device__ __forceinline__ int acc_swz(int l) { return l ^ (((l >> 4) ^ (l >> 8)) & 15); }
+// =====================================================================================================
+// k_integrate_bricks2 (round 2): the same parts, the same exact sums, reshaped for the way the SIMDs issue.
+//   * the ray step is branch-free (the division form is a template parameter, the square root takes max(s2, 2^-96) --
+//     below that the fixed-point term rounds to zero either way -- and the 64-bit conversion is decided once per pair
+//     of steps for the whole wave), and two steps are evaluated per iteration: two independent dependency chains per
+//     wave where the r01 kernel had one, at the same two waves per SIMD;
+//   * {num} and {den} are separate 32 KiB planes (an 8-byte entry spans two of the 64 banks instead of four) with a
+//     5-bit XOR swizzle of the x / y digits into the bank bits;
+//   * the flush computes all 16 voxels of a thread without branches (stores are predicated), and converts the sums
+//     through the 32-bit path when every sum of the wave fits.
+// =====================================================================================================
+__device__ __forceinline__ int acc_swz5(int l) { return l ^ (((l >> 8) ^ (l >> 5)) & 31); }
+struct StepK { float vs, rvs, T0, T1, T2; int hN, hNz; };
 
-template <bool TEX, int NT, int PSEGS, bool SORT>
-__global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+template <bool FASTDIV>
+__device__ __forceinline__ void step_eval(const RayRegs& R, const StepK& K, int j, int* slot, float* qf)
 {
-    constexpr bool EARLY_ROWS = !TEX && NT == 256;             // 16 more live registers per thread: only where they are free
+    const float jf = (float)j;
+    const float x0 = (R.d0 * jf) * K.vs + K.T0, x1 = (R.d1 * jf) * K.vs + K.T1, x2 = (R.d2 * jf) * K.vs + K.T2;      // dense_tsdf.py:253
+    const int i0 = rnd_i(div_vs(x0, K.vs, K.rvs, FASTDIV ? 1 : 0)), i1 = rnd_i(div_vs(x1, K.vs, K.rvs, FASTDIV ? 1 : 0)), i2 = rnd_i(div_vs(x2, K.vs, K.rvs, FASTDIV ? 1 : 0));   // :254
+    *slot = acc_swz5((((i0 + K.hN) & 15) << 8) | (((i1 + K.hN) & 15) << 4) | ((i2 + K.hNz) & 15));
+    const float v0 = R.P0 - x0, v1 = R.P1 - x1, v2 = R.P2 - x2;                                                      // :258
+    const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
+    // s2 < 2^-96: dist < 2^-48 and w <= 2^16, so |w * sd| * 2^24 < 2^-8 rounds to 0 whatever the root is
+    const float dist = sqrt_rn_norm(fmaxf(s2, 1.2621774483536189e-29f));                                             // :259
+    const float dot = (v0 * R.pf0 + v1 * R.pf1) + v2 * R.pf2;
+    const float sd = dot == 0.0f ? 0.0f : copysignf(dist, dot);                                                      // :260  dist * sign(dot)
+    *qf = rintf((R.w * sd) * TSL_FIX_SCALE);                                                                         // integer-valued (to_fix)
+}
+
+// sums -> f32, exactly rounded once: through one v_cvt_f32_i32 when the value fits 32 bits
+__device__ __forceinline__ bool fits_i32(long long q) { return q == (long long)(int)q; }
+__device__ __forceinline__ float from_fix32(long long q) { return (float)(int)q * (float)TSL_FIX_INV; }
+
+#define FLUSH_CHUNK 8
+template <int N>
+__device__ __forceinline__ void apply_chunk(const uint32_t* old, const long long* qn, const long long* qd, uint32_t* nv, bool all_small)
+{
+    if (all_small) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) nv[q] = apply_update_f(old[q], from_fix32(qn[q]), from_fix32(qd[q]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) nv[q] = apply_update_f(old[q], from_fix(qn[q]), from_fix(qd[q]));
+    }
+}
+
+template <bool TEX, bool FASTDIV, int NT, int WPS = NT / 128>
+__global__ void __launch_bounds__(NT, TEX ? 1 : WPS) k_integrate_bricks2(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+{
+    // NT threads integrate a part of up to 4 * NT segments (4 per thread).  256: two workgroups = 8 waves per CU; 512: a brick with up
+    // to 2048 segments stays whole (no merge through HBM), two workgroups = 16 waves per CU when the kernel fits 128 registers.
+    constexpr int PSEGS = 4 * NT, SPT = 4, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
+    static_assert(VPT % CH == 0 && PSEGS * 8 <= TSL_BRK3 * 8, "brick kernel geometry");
     const FrameParams& P = *Pp;
-    __shared__ unsigned long long s_acc[TSL_BRK3 * 2];          // {num, den} per voxel: 64 KiB
+    __shared__ unsigned long long s_num[TSL_BRK3];              // 32 KiB
+    __shared__ unsigned long long s_den[TSL_BRK3];              // 32 KiB; before the walk its head is the scratch of the length sort
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
-    __shared__ unsigned long long s_keys[SORT ? PSEGS : 1];
     __shared__ int s_bin[64];
     __shared__ int s_p, s_last;
+    unsigned long long* const s_keys = s_den;
     const int nA = min(F.counters[8], F.part_cap), nB = min(F.counters[9], F.part_cap), nC = min(F.counters[10], F.part_cap);
-    const int nparts = (*M.err & 2) ? 0 : nA + nB + nC;          // nothing is integrated when the frame overflows its scratch
+    const int nparts = (F.counters[11] != 0) ? 0 : nA + nB + nC;          // nothing is integrated when the frame overflowed its scratch
+    const StepK K = { P.vs, P.rvs, P.T[0], P.T[1], P.T[2], M.hN, M.hNz };
     long long uniq = 0;
     TSL_T0();
     {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
@@ -538,34 +593,30 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
     }
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
         TSL_TICK(F, 0);
-        // order of issue: long parts, then the short ones (they retire within a few microseconds and free their slots for the
-        // medium parts, which still finish under the tail of the long ones)
         const int4 pt = part < nA ? F.part_tab[part] : (part < nA + nC ? F.part_tab[2 * (size_t)F.part_cap + part - nA] : F.part_tab[F.part_cap + part - nA - nC]);
         const int pos = pt.x, nseg = pt.y & 0xffff, np = pt.y >> 16, rk = pt.w;
         const bool whole = np == 1;
-        unsigned long long kk[PSEGS / NT]; int rr[PSEGS / NT];
+        unsigned long long kk[SPT]; int rr[SPT];
 #pragma unroll
-        for (int q = 0; q < PSEGS / NT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
-        if (threadIdx.x == 0) s_p = pool_claim<false>(M, P.slot, pt.z);       // allocate the brick on its first touch ever
+        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
+        if (threadIdx.x == 0) s_p = pt.z;
         {
-            ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
-            for (int i = threadIdx.x; i < TSL_BRK3; i += NT) z[i] = make_ulonglong2(0ull, 0ull);
+            ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num);
+            for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) zn[i] = make_ulonglong2(0ull, 0ull);
         }
-        if (SORT && threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         __syncthreads();
-        // the brick's rows of a whole part are requested now and used after the walk
-        uint32_t old[TSL_BRK3 / NT];
-        if (EARLY_ROWS && whole && s_p >= 0) {
+        uint32_t old[VPT];                                                // the rows of a whole brick are requested now, used after the walk
+        if (!TEX && whole && s_p >= 0) {
             const uint32_t* twr = M.tw + (size_t)s_p * TSL_BRK3;
 #pragma unroll
-            for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = twr[q * NT + threadIdx.x];
+            for (int q = 0; q < VPT; ++q) old[q] = twr[q * NT + threadIdx.x];
         }
-        if (SORT) {
-        // counting sort of the part's segments by step count (descending) in LDS: the lanes of a wave then walk
-        // segments of (almost) equal length instead of idling behind the longest one
+        // counting sort of the part's segments by step count (descending) in LDS, then dealt out in alternating directions:
+        // the lanes of a wave walk segments of (almost) equal length and every thread gets about the same number of steps
 #pragma unroll
-        for (int q = 0; q < PSEGS / NT; ++q) {
+        for (int q = 0; q < SPT; ++q) {
             const int i = q * NT + threadIdx.x;
             rr[q] = -1;
             if (i < nseg) rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1);
@@ -579,50 +630,53 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PSEGS / NT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
+        for (int q = 0; q < SPT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
         __syncthreads();
+        uint4 recs[SPT]; uint32_t wids[SPT];
 #pragma unroll
-        // sorted by length, dealt out in alternating directions: every thread (and wave) gets about the same number of steps
-        for (int q = 0; q < PSEGS / NT; ++q) { const int i = SORT ? q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x) : q * NT + (int)threadIdx.x; if (i < nseg) kk[q] = s_keys[i]; }
-        }
-        TSL_TICK(F, 1);
-        uint4 recs[PSEGS / NT]; uint32_t wids[PSEGS / NT];
-#pragma unroll
-        for (int q = 0; q < PSEGS / NT; ++q) {                           // all ray records of this thread in flight at once
-            const int i = SORT ? q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x) : q * NT + (int)threadIdx.x;
+        for (int q = 0; q < SPT; ++q) {                                   // dealt keys, then all ray records of this thread in flight at once
+            const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
             if (i < nseg) {
+                kk[q] = s_keys[i];
                 const int r = (int)((kk[q] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
                 recs[q] = F.rayA[r];
                 wids[q] = TEX ? F.rayFirst[r] + 1u : 0u;
             }
         }
+        __syncthreads();                                                  // every thread holds its keys: the sort scratch becomes the {den} plane
+        {
+            ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
+            for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) zd[i] = make_ulonglong2(0ull, 0ull);
+        }
+        __syncthreads();
+        TSL_TICK(F, 1);
 #pragma unroll
-        for (int q = 0; q < PSEGS / NT; ++q) {
-            const int i = SORT ? q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x) : q * NT + (int)threadIdx.x;
+        for (int q = 0; q < SPT; ++q) {
+            const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
             if (i >= nseg) continue;
             const unsigned long long key = kk[q];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
             const RayRegs R = make_ray(recs[q], 0, P);
             const uint32_t wid = wids[q];
             // lanes start at different offsets inside their (equally long) segments: rays that enter a brick together -- all
-            // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration (64-way LDS conflicts)
-            int off = (int)(threadIdx.x & 63u) % cnt;
-            for (int t = 0; t < cnt; ++t) {
-                const int j = j0 + off;
-                if (++off == cnt) off = 0;
-                float x[3]; int xi[3];
-                step_voxel(R, P, j, x, xi);
-                const int l = acc_swz((((xi[0] + M.hN) & 15) << 8) | (((xi[1] + M.hN) & 15) << 4) | ((xi[2] + M.hNz) & 15));
-                const long long qn = step_term(R, x);
-#if defined(TSL_EXP) && TSL_EXP == 1
-                s_acc[l * 2] = (unsigned long long)qn; s_acc[l * 2 + 1] = (unsigned long long)R.qden;
-#elif defined(TSL_EXP) && TSL_EXP == 2
-                { const int l2 = (l & ~63) | (threadIdx.x & 63); atomicAdd(&s_acc[l2 * 2], (unsigned long long)qn); atomicAdd(&s_acc[l2 * 2 + 1], (unsigned long long)R.qden); }
-#else
-                atomicAdd(&s_acc[l * 2], (unsigned long long)qn);
-                atomicAdd(&s_acc[l * 2 + 1], (unsigned long long)R.qden);
-#endif
-                if (TEX) atomicMax(&s_win[l], wid);                                            // dense_tsdf.py:268-269, order-free winner
+            // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration
+            int off = ((int)(threadIdx.x & 63u) * cnt) >> 6;
+            for (int t = 0; t < cnt; t += 2) {
+                const int ja = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
+                const int jb = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
+                int la, lb; float qa, qb;
+                step_eval<FASTDIV>(R, K, ja, &la, &qa);
+                step_eval<FASTDIV>(R, K, jb, &lb, &qb);
+                long long na = (long long)(int)qa, nb = (long long)(int)qb;
+                if (__builtin_expect(__any(!(fabsf(qa) < 2147483648.0f) || !(fabsf(qb) < 2147483648.0f)), 0)) { na = __float2ll_rn(qa); nb = __float2ll_rn(qb); }
+                atomicAdd(&s_num[la], (unsigned long long)na);
+                atomicAdd(&s_den[la], (unsigned long long)R.qden);
+                if (TEX) atomicMax(&s_win[la], wid);                                           // dense_tsdf.py:268-269, order-free winner
+                // the second step of an odd segment's last pair adds zeros to a voxel of the brick (no effect, no branch)
+                const bool vb = t + 1 < cnt;
+                atomicAdd(&s_num[lb], (unsigned long long)(vb ? nb : 0ll));
+                atomicAdd(&s_den[lb], (unsigned long long)(vb ? R.qden : 0ll));
+                if (TEX) atomicMax(&s_win[lb], vb ? wid : 0u);
             }
         }
         TSL_TICK(F, 2);
@@ -632,19 +686,25 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
         if (p >= 0 && whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
             int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-            if (!EARLY_ROWS) {
+            if (TEX) {
 #pragma unroll
-                for (int q = 0; q < TSL_BRK3 / NT; ++q) old[q] = tw[q * NT + threadIdx.x];      // all row loads in flight at once
+                for (int q = 0; q < VPT; ++q) old[q] = tw[q * NT + threadIdx.x];
             }
 #pragma unroll
-            for (int q = 0; q < TSL_BRK3 / NT; ++q) {
-                const int l = q * NT + threadIdx.x, ls = acc_swz(l);
-                const unsigned long long qd = s_acc[ls * 2 + 1];
-                if (qd != 0ull) {
-                    tw[l] = apply_update(old[q], (long long)s_acc[ls * 2], (long long)qd);
-                    if ((old[q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
-                    if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[ls] - 1u];
-                    ++uniq;
+            for (int h = 0; h < VPT; h += CH) {                  // FLUSH_CHUNK voxels at a time, no branch between them
+                long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) { const int ls = acc_swz5((h + q) * NT + threadIdx.x); qn[q] = (long long)s_num[ls]; qd[q] = (long long)s_den[ls]; small = small && fits_i32(qn[q]) && fits_i32(qd[q]); }
+                apply_chunk<CH>(old + h, qn, qd, nv, __all(small));
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int l = (h + q) * NT + threadIdx.x;
+                    if (qd[q] != 0) {
+                        tw[l] = nv[q];
+                        if ((old[h + q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
+                        if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[acc_swz5(l)] - 1u];
+                        ++uniq;
+                    }
                 }
             }
         } else if (p >= 0) {
@@ -652,12 +712,12 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
             // to arrive (arrival ticket, agent-scope release/acquire) applies them and leaves the slab zeroed.
             unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
 #pragma unroll
-            for (int q = 0; q < TSL_BRK3 / NT; ++q) {
-                const int l = q * NT + threadIdx.x, ls = acc_swz(l);
-                const unsigned long long qd = s_acc[ls * 2 + 1];
-                if (qd != 0ull) {
-                    __hip_atomic_fetch_add(acc + l * 2, s_acc[ls * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + l * 2 + 1, qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < VPT; ++q) {
+                const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
+                const unsigned long long d = s_den[ls];
+                if (d != 0ull) {
+                    __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
                 }
             }
@@ -675,30 +735,36 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
                 ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
                 uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
                 int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-                // the sums were produced by L2 atomics of other CUs: read them at L2 as well -- every load of this thread is
-                // issued before the first one is used (they are device-coherent loads, a couple of microseconds each)
-                unsigned long long qn[TSL_BRK3 / NT], qd[TSL_BRK3 / NT]; uint32_t old[TSL_BRK3 / NT];
+                // the sums were produced by L2 atomics of other CUs: read them at L2 as well, every load of this thread issued
+                // before the first one is used
 #pragma unroll
-                for (int q = 0; q < TSL_BRK3 / NT; ++q) {
-                    const int l = q * NT + threadIdx.x;
-                    qn[q] = __hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    qd[q] = __hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    old[q] = tw[l];
-                }
+                for (int h = 0; h < VPT; h += CH) {
+                    long long qn[CH], qd[CH]; uint32_t oldv[CH], nv[CH]; bool small = true;
 #pragma unroll
-                for (int q = 0; q < TSL_BRK3 / NT; ++q) {
-                    const int l = q * NT + threadIdx.x;
-                    if (qd[q] != 0ull) {
-                        tw[l] = apply_update(old[q], (long long)qn[q], (long long)qd[q]);
-                        if ((old[q] >> 16) == 0u) obs[l] = 1;
-                        acc2[l] = make_ulonglong2(0ull, 0ull);
-                        if (TEX) {
-                            uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
-                            const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[wsel - 1u];
-                            *wv = 0u;
+                    for (int q = 0; q < CH; ++q) {
+                        const int l = (h + q) * NT + threadIdx.x;
+                        qn[q] = (long long)__hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        qd[q] = (long long)__hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        oldv[q] = tw[l];
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) small = small && fits_i32(qn[q]) && fits_i32(qd[q]);
+                    apply_chunk<CH>(oldv, qn, qd, nv, __all(small));
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int l = (h + q) * NT + threadIdx.x;
+                        if (qd[q] != 0) {
+                            tw[l] = nv[q];
+                            if ((oldv[q] >> 16) == 0u) obs[l] = 1;
+                            acc2[l] = make_ulonglong2(0ull, 0ull);
+                            if (TEX) {
+                                uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
+                                const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[wsel - 1u];
+                                *wv = 0u;
+                            }
+                            ++uniq;
                         }
-                        ++uniq;
                     }
                 }
             }
@@ -709,6 +775,261 @@ __global__ void __launch_bounds__(NT, (NT == 1024 && !TEX) ? 8 : 1) k_integrate_
 #endif
         __syncthreads();
     }
+    uniq = wave_sum_ll(uniq);
+    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
+}
+
+
+// =====================================================================================================
+// k_integrate_bricks3: the same part arithmetic as k_integrate_bricks2, as a persistent, software-pipelined kernel.
+// What bounded v2 was not the walk but the dependent device-memory round trips around it (part entry -> segment keys -> ray
+// records before, rows / stores after: 1-2 us each at 8 waves per CU) and the two dispatch rounds of ~670 parts on 512 slots.
+// Here 2 workgroups per CU stay resident and take parts in serpentine order over the cost-ordered part list (long, medium,
+// short: the workgroup with the longest part of a tier gets the shortest of the next).  While a part is walked, the entry and the
+// keys of the workgroup's next part are in flight; after the walk the next part's keys are length-sorted in their own 8 KiB of LDS
+// and its ray records requested, and only then the current part is flushed -- every load has a phase of useful work to hide behind.
+// =====================================================================================================
+__device__ __forceinline__ int4 part_entry(const FrameDev& F, int rank, int nA, int nB)
+{
+    return rank < nA ? F.part_tab[rank] : (rank < nA + nB ? F.part_tab[F.part_cap + rank - nA] : F.part_tab[2 * (size_t)F.part_cap + rank - nA - nB]);
+}
+// rank of the t-th part of workgroup w of G in serpentine order
+__device__ __forceinline__ int serp_rank(int t, int w, int G) { return t * G + ((t & 1) ? G - 1 - w : w); }
+
+template <bool TEX, bool FASTDIV, int NT>
+__global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_bricks3(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+{
+    // NT threads walk a part in chunks of CSEGS = 4 * NT segments (4 per thread); a part may hold several chunks (k_plan's psegs), so
+    // a brick with up to psegs segments is integrated by one workgroup and never merged through HBM.  NT = 256: two workgroups per CU;
+    // NT = 512: one (8 waves on one brick: half the walk latency per brick, half as many bricks in flight).
+    constexpr int CSEGS = 4 * NT, SPT = 4, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
+    const FrameParams& P = *Pp;
+    __shared__ unsigned long long s_num[TSL_BRK3];              // 32 KiB
+    __shared__ unsigned long long s_den[TSL_BRK3];              // 32 KiB
+    __shared__ unsigned long long s_keys[CSEGS];                // 8 / 16 KiB: length sort of the NEXT chunk's keys while the planes hold the current sums
+    __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
+    __shared__ int s_bin[64];
+    __shared__ int s_last;
+    const int nA = min(F.counters[8], F.part_cap), nB = min(F.counters[9], F.part_cap), nC = min(F.counters[10], F.part_cap);
+    const int nparts = (F.counters[11] != 0) ? 0 : nA + nB + nC;          // nothing is integrated when the frame overflowed its scratch
+    const int G = gridDim.x, w = blockIdx.x;
+    const StepK K = { P.vs, P.rvs, P.T[0], P.T[1], P.T[2], M.hN, M.hNz };
+    long long uniq = 0;
+    TSL_T0();
+    {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
+        const int nact = min(F.counters[1], F.max_frame_bricks);
+        for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
+    }
+    int t = 0, c = 0;                                          // t-th part of this workgroup, chunk c of it
+    if (serp_rank(0, w, G) >= nparts) return;
+    int4 ptc = part_entry(F, serp_rank(0, w, G), nA, nB);
+    int4 ptn = make_int4(0, 0, -1, 0);
+    if (serp_rank(1, w, G) < nparts) ptn = part_entry(F, serp_rank(1, w, G), nA, nB);
+
+    unsigned long long kk[SPT]; uint4 recs[SPT]; uint32_t wids[SPT];
+    // length-sort `nseg` keys (this thread holds k[q] = key q*NT+tid) through s_keys / s_bin, deal them out in alternating directions
+    // and request the ray records of the dealt keys.  Counting sort by step count, descending: the lanes of a wave walk segments of
+    // (almost) equal length and every thread gets about the same number of steps.  Contains 3 barriers; s_bin must be zero on entry.
+#define TSL_SORT_DEAL(KIN, NSEG)                                                                                        \
+    {                                                                                                                   \
+        int rr[SPT];                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < SPT; ++q) {                                                               \
+            const int i = q * NT + (int)threadIdx.x; rr[q] = -1;                                                        \
+            if (i < (NSEG)) rr[q] = atomicAdd(&s_bin[63 - (int)(KIN[q] & 63ull)], 1);                                   \
+        }                                                                                                               \
+        __syncthreads();                                                                                                \
+        if (threadIdx.x < 64) {                                                                                         \
+            const int cb = s_bin[threadIdx.x]; int inc = cb;                                                            \
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }  \
+            s_bin[threadIdx.x] = inc - cb;                                                                              \
+        }                                                                                                               \
+        __syncthreads();                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < SPT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(KIN[q] & 63ull)] + rr[q]] = KIN[q]; \
+        __syncthreads();                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < SPT; ++q) {                                                               \
+            const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);                            \
+            if (i < (NSEG)) {                                                                                           \
+                kk[q] = s_keys[i];                                                                                      \
+                const int r = (int)((kk[q] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));               \
+                recs[q] = F.rayA[r];                                                                                    \
+                wids[q] = TEX ? F.rayFirst[r] + 1u : 0u;                                                                \
+            }                                                                                                           \
+        }                                                                                                               \
+        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;              /* ordered against the next use by the barriers in between */ \
+    }
+
+    {   // prologue: the first chunk's keys, planes cleared, sort, ray records
+        unsigned long long k0[SPT];
+        const int nseg0 = min(ptc.y & 0xffff, CSEGS);
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; k0[q] = i < nseg0 ? F.seg_sorted[ptc.x + i] : 0ull; }
+        ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
+        for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) { zn[i] = make_ulonglong2(0ull, 0ull); zd[i] = make_ulonglong2(0ull, 0ull); }
+        if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
+        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+        __syncthreads();
+        TSL_SORT_DEAL(k0, nseg0)
+    }
+    uint32_t old[VPT];
+    for (;;) {
+        TSL_TICK(F, 0);
+        const int nseg_part = ptc.y & 0xffff, np = ptc.y >> 16, p = ptc.z, rk = ptc.w;
+        const int nseg = min(CSEGS, nseg_part - c * CSEGS);
+        const bool last = (c + 1) * CSEGS >= nseg_part;               // last chunk of the part: flush after the walk
+        const bool whole = np == 1;
+        // the next unit of work: the next chunk of this part, or the first chunk of the workgroup's next part
+        const bool has_next = !last || serp_rank(t + 1, w, G) < nparts;
+        const int4 ptx = last ? ptn : ptc;
+        const int cx = last ? 0 : c + 1;
+        // requests that ride under the walk: the entry of the part after next, the next chunk's keys, this brick's rows
+        int4 ptn2 = make_int4(0, 0, -1, 0);
+        if (last && serp_rank(t + 2, w, G) < nparts) ptn2 = part_entry(F, serp_rank(t + 2, w, G), nA, nB);
+        unsigned long long kn[SPT];
+        const int nsegn = has_next ? min(CSEGS, (ptx.y & 0xffff) - cx * CSEGS) : 0;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; kn[q] = i < nsegn ? F.seg_sorted[ptx.x + cx * CSEGS + i] : 0ull; }
+        if (!TEX && c == 0 && whole && p >= 0) {
+            const uint32_t* twr = M.tw + (size_t)p * TSL_BRK3;
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) old[q] = twr[q * NT + threadIdx.x];
+        }
+        TSL_TICK(F, 1);
+        // ---- walk ----
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
+            if (i >= nseg) continue;
+            const unsigned long long key = kk[q];
+            const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
+            const RayRegs R = make_ray(recs[q], 0, P);
+            const uint32_t wid = wids[q];
+            // lanes start at different offsets inside their (equally long) segments: rays that enter a brick together -- all
+            // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration
+            int off = ((int)(threadIdx.x & 63u) * cnt) >> 6;
+            for (int s = 0; s < cnt; s += 2) {
+                const int ja = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
+                const int jb = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
+                int la, lb; float qa, qb;
+                step_eval<FASTDIV>(R, K, ja, &la, &qa);
+                step_eval<FASTDIV>(R, K, jb, &lb, &qb);
+                long long na = (long long)(int)qa, nb = (long long)(int)qb;
+                if (__builtin_expect(__any(!(fabsf(qa) < 2147483648.0f) || !(fabsf(qb) < 2147483648.0f)), 0)) { na = __float2ll_rn(qa); nb = __float2ll_rn(qb); }
+                atomicAdd(&s_num[la], (unsigned long long)na);
+                atomicAdd(&s_den[la], (unsigned long long)R.qden);
+                if (TEX) atomicMax(&s_win[la], wid);                                           // dense_tsdf.py:268-269, order-free winner
+                // the second step of an odd segment's last pair adds zeros to a voxel of the brick (no effect, no branch)
+                const bool vb = s + 1 < cnt;
+                atomicAdd(&s_num[lb], (unsigned long long)(vb ? nb : 0ll));
+                atomicAdd(&s_den[lb], (unsigned long long)(vb ? R.qden : 0ll));
+                if (TEX) atomicMax(&s_win[lb], vb ? wid : 0u);
+            }
+        }
+        TSL_TICK(F, 2);
+        __syncthreads();
+        TSL_TICK(F, 3);
+        // ---- the next chunk's keys are here: sort them and request its ray records, then flush under that latency ----
+        if (has_next) TSL_SORT_DEAL(kn, nsegn)
+        if (!last) { ++c; continue; }
+        if (p >= 0 && whole) {
+            uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+            int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+            if (TEX) {
+#pragma unroll
+                for (int q = 0; q < VPT; ++q) old[q] = tw[q * NT + threadIdx.x];
+            }
+#pragma unroll
+            for (int h = 0; h < VPT; h += CH) {                  // CH voxels at a time, no branch between them
+                long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) { const int ls = acc_swz5((h + q) * NT + threadIdx.x); qn[q] = (long long)s_num[ls]; qd[q] = (long long)s_den[ls]; small = small && fits_i32(qn[q]) && fits_i32(qd[q]); }
+                apply_chunk<CH>(old + h, qn, qd, nv, __all(small));
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int l = (h + q) * NT + threadIdx.x;
+                    if (qd[q] != 0) {
+                        tw[l] = nv[q];
+                        if ((old[h + q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
+                        if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[acc_swz5(l)] - 1u];
+                        ++uniq;
+                    }
+                }
+            }
+        } else if (p >= 0) {
+            // brick split over `np` workgroups: add the partial sums into the brick's HBM scratch slab; the last workgroup
+            // to arrive (arrival ticket, agent-scope release/acquire) applies them and leaves the slab zeroed.
+            unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
+                const unsigned long long d = s_den[ls];
+                if (d != 0ull) {
+                    __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int tk = __hip_atomic_fetch_add(&F.ticket[rk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (tk == np - 1) ? 1 : 0;
+                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); F.ticket[rk] = 0; }
+            }
+            __syncthreads();
+            if (s_last) {
+                ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
+                uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+                int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+                // the sums were produced by L2 atomics of other CUs: read them at L2 as well, CH voxels in flight per thread
+#pragma unroll
+                for (int h = 0; h < VPT; h += CH) {
+                    long long qn[CH], qd[CH]; uint32_t oldv[CH], nv[CH]; bool small = true;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int l = (h + q) * NT + threadIdx.x;
+                        qn[q] = (long long)__hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        qd[q] = (long long)__hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        oldv[q] = tw[l];
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) small = small && fits_i32(qn[q]) && fits_i32(qd[q]);
+                    apply_chunk<CH>(oldv, qn, qd, nv, __all(small));
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int l = (h + q) * NT + threadIdx.x;
+                        if (qd[q] != 0) {
+                            tw[l] = nv[q];
+                            if ((oldv[q] >> 16) == 0u) obs[l] = 1;
+                            acc2[l] = make_ulonglong2(0ull, 0ull);
+                            if (TEX) {
+                                uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
+                                const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[wsel - 1u];
+                                *wv = 0u;
+                            }
+                            ++uniq;
+                        }
+                    }
+                }
+            }
+        }
+        TSL_TICK(F, 4);
+#ifdef TSL_TIMING
+        if (lane_id() == 0 && _wv < 16384) { F.dbg[_wv * 16 + 10] = nseg_part; F.dbg[_wv * 16 + 11] = whole; F.dbg[_wv * 16 + 12] = t; }
+#endif
+        if (!has_next) break;
+        __syncthreads();                                                  // every thread has read the sums of the finished part
+        {
+            ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
+            for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) { zn[i] = make_ulonglong2(0ull, 0ull); zd[i] = make_ulonglong2(0ull, 0ull); }
+            if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
+        }
+        __syncthreads();
+        ++t; c = 0; ptc = ptn; ptn = ptn2;
+    }
+#undef TSL_SORT_DEAL
     uniq = wave_sum_ll(uniq);
     if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
@@ -730,7 +1051,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->wg == 1024 ? 4096 : (m->wg == 512 ? 2048 : 1024));
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->kern == 2 ? m->chunks * (m->wg == 512 ? 2048 : 1024) : 1024);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;
@@ -740,18 +1061,25 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
 {
     FrameParams& P = m->P;
     FrameDev& F = S.F;
-    if (P.variant == 2) {
+    if (P.variant == 2 && m->kern == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
-        if (m->wg == 1024) {       // 4 segments per thread, bricks up to 4096 segments in one workgroup, no length sort
-            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-            else hipLaunchKernelGGL((k_integrate_bricks<false, 1024, 4096, false>), dim3(1024), dim3(1024), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-        } else if (m->wg == 512) {
-            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-            else hipLaunchKernelGGL((k_integrate_bricks<false, 512, 2048, false>), dim3(1024), dim3(512), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-        } else {
-            if (P.tex) hipLaunchKernelGGL((k_integrate_bricks<true, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-            else hipLaunchKernelGGL((k_integrate_bricks<false, 256, 1024, true>), dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-        }
+        const FrameParams* Pd = (const FrameParams*)S.Pd;
+        // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
+#define TSL_LAUNCH_IB3(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_bricks3<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, F, Pd); \
+                                      else hipLaunchKernelGGL((k_integrate_bricks3<TEXV, FD, 256>), dim3((TEXV ? 1 : 2) * m->ncu), dim3(256), 0, m->stream_, m->M, F, Pd); } while (0)
+        if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB3(true, true); else TSL_LAUNCH_IB3(true, false); }
+        else { if (P.fastdiv) TSL_LAUNCH_IB3(false, true); else TSL_LAUNCH_IB3(false, false); }
+#undef TSL_LAUNCH_IB3
+        prof_end(m);
+    } else if (P.variant == 2) {
+        prof_begin(m, TSL_K_INTEGRATE);
+        const FrameParams* Pd = (const FrameParams*)S.Pd;
+#define TSL_LAUNCH_IB2(TEXV, FD, NTV) hipLaunchKernelGGL((k_integrate_bricks2<TEXV, FD, NTV>), dim3(1024), dim3(NTV), 0, m->stream_, m->M, F, Pd)
+#define TSL_LAUNCH_IB2_NT(TEXV, FD) TSL_LAUNCH_IB2(TEXV, FD, 256)
+        if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB2_NT(true, true); else TSL_LAUNCH_IB2_NT(true, false); }
+        else { if (P.fastdiv) TSL_LAUNCH_IB2_NT(false, true); else TSL_LAUNCH_IB2_NT(false, false); }
+#undef TSL_LAUNCH_IB2_NT
+#undef TSL_LAUNCH_IB2
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);

@@ -696,12 +696,76 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t in_bytes, cons
     return TSL_OK;
 }
 
+// frame scratch: shared part + TSL_NSETS per-frame working sets, allocated on the first integrate call
+static int ensure_frame_scratch(tsl_tsdf* m)
+{
+    if (m->scratch_ready) return TSL_OK;
+    const tsl_tsdf_cfg* cfg = &m->cfg;
+    FrameDev& F = m->F;
+    int rc;
+    const size_t np = (size_t)F.max_points;
+    if ((rc = dev_alloc(m, (void**)&F.slot_tab, sizeof(int) * (size_t)m->nb3, 0xff))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.touched, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.ticket, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&F.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc; }
+    for (int si = 0; si < TSL_NSETS; ++si) {
+        FSet& S = m->fset[si];
+        S.F = F;
+        FrameDev& G = S.F;
+        auto own = [&](void** p, size_t bytes) -> int { int r = dev_alloc(m, p, bytes, 0); if (!r) S.owned.push_back(*p); return r; };
+        if ((rc = own((void**)&G.keys, 8 * np))) return rc;
+        if ((rc = own((void**)&G.keys_s, 8 * np))) return rc;
+        if ((rc = own((void**)&G.vals, 4 * np))) return rc;
+        if ((rc = own((void**)&G.vals_s, 4 * np))) return rc;
+        if ((rc = own((void**)&G.pix, 8 * np))) return rc;
+        if ((rc = own((void**)&G.rayA, 16 * np))) return rc;
+        if ((rc = own((void**)&G.rayN, 4 * np))) return rc;
+        if ((rc = own((void**)&G.rayFirst, 4 * np))) return rc;
+        {   // sensor-voxel hash table (>= 4 entries per possible point) and the group lists
+            int lg = 10; while ((1ll << lg) < 4 * (long long)np) ++lg;
+            G.hlog2 = lg; G.hwide = m->pcl_bits > 10;
+            const size_t hs = (size_t)1 << lg;
+            if ((rc = dev_alloc(m, &G.hkey, 8 * hs, 0xff))) return rc; S.owned.push_back(G.hkey);
+            if ((rc = own((void**)&G.hcnt, 4 * hs))) return rc;
+            if ((rc = own((void**)&G.hoff, 4 * hs))) return rc;
+            if ((rc = own((void**)&G.hfill, 4 * hs))) return rc;
+            if ((rc = own((void**)&G.slot_of_pix, 4 * np))) return rc;
+            if ((rc = own((void**)&G.act, 4 * np))) return rc;
+            if ((rc = own((void**)&G.plist, 4 * np))) return rc;
+            if ((rc = own((void**)&G.big, 4 * (np / GROUP_SMALL + 16)))) return rc;
+        }
+        if (cfg->texture_enabled) { if ((rc = own((void**)&G.colpix, 8 * np))) return rc; }
+        S.header_bytes = 256;
+        if ((rc = own(&S.header, S.header_bytes))) return rc;
+        G.stats = reinterpret_cast<tsl_frame_stats*>(S.header);
+        G.nrays = reinterpret_cast<int*>((char*)S.header + 80);
+        G.counters = reinterpret_cast<int*>((char*)S.header + 96);
+        if ((rc = own((void**)&G.seg, 8 * (size_t)F.seg_cap))) return rc;
+        if ((rc = own((void**)&G.seg_sorted, 8 * (size_t)F.seg_cap))) return rc;
+        if ((rc = own((void**)&G.bhist, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.bcursor, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.boffset, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
+        G.part_cap = F.seg_cap / 256 + F.max_frame_bricks + 8;
+        if ((rc = own((void**)&G.part_tab, sizeof(int4) * 3 * (size_t)G.part_cap))) return rc;
+        if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
+        if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
+    }
+    TSL_HIP(hipStreamSynchronize(m->stream_));                  // the fills ran on the main stream; phase A uses the batch streams
+    m->scratch_ready = true;
+    return TSL_OK;
+}
+
 // queue one frame (m->P holds its parameters); the batch is issued when it is full or when anything else needs the map
 static int queue_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, int64_t npts)
 {
     FrameParams& P = m->P;
     const int total = xyz_dev ? (int)npts : P.hh * P.ww;
     TSL_REQUIRE(total <= m->F.max_points, "integrate: more pixels/points than max_points");
+    { int rc = ensure_frame_scratch(m); if (rc) return rc; }
     if (P.variant == 2) { int rc = check_variant2(m); if (rc) return rc; }
     P.input = xyz_dev ? xyz_dev : depth_dev; P.total = total; P.points = xyz_dev ? 1 : 0;
     TSL_REQUIRE(!P.tex || P.variant == 2, "texture integration needs the brick-binned path (variant 2)");
@@ -768,15 +832,8 @@ int tsl_device_count(int* n)
     return TSL_OK;
 }
 
-int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
+static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
 {
-    TSL_REQUIRE(cfg && out, "tsl_tsdf_create: null argument");
-    TSL_REQUIRE(cfg->voxel_scale > 0 && cfg->num_voxel_per_blk_axis >= 1 && cfg->recast_step >= 1, "tsl_tsdf_create: bad config");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available"); return TSL_ERR_NO_DEVICE; }
-    TSL_REQUIRE(device >= 0 && device < ndev, "tsl_tsdf_create: bad device index");
-    TSL_HIP(hipSetDevice(device));
-    tsl_tsdf* m = new tsl_tsdf();
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
     m->overlap = TSL_NB; m->last_set = 0;
@@ -824,7 +881,8 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256; m->kern = 2; m->chunks = 2;
+    { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
@@ -835,7 +893,9 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
     M.N = m->N; M.Nz = m->Nz; M.nbx = m->nbx; M.nbz = m->nbz; M.nb3 = m->nb3; M.nsub = m->nsub; M.hN = m->N / 2; M.hNz = m->Nz / 2;
-    int64_t want = cfg->max_bricks > 0 ? cfg->max_bricks : 32768;
+    // default pool: one full 512^3 volume of bricks (0.8 GB) per handle, four of them when the handle holds several submaps
+    // (SubmapMapping's default collection of up to 1024 submaps shares the pool); max_bricks overrides
+    int64_t want = cfg->max_bricks > 0 ? cfg->max_bricks : 32768 * (int64_t)(m->nsub > 4 ? 4 : (m->nsub > 1 ? m->nsub : 1));
     const int64_t all = (int64_t)m->nsub * m->nb3;
     if (want > all) want = all;
     M.max_bricks = (int)want;
@@ -849,7 +909,8 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
     if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
     M.err = M.pool_top + 1;
 
-    // ---- frame scratch: shared part + TSL_NSETS per-frame working sets ----
+    // ---- frame scratch sizes (the buffers themselves are allocated by the first integrate call: a global map that only
+    //      receives fusions or imports never pays for them) ----
     FrameDev& F = m->F; std::memset(&F, 0, sizeof(F));
     F.max_points = cfg->max_points > 0 ? cfg->max_points : 640 * 480;
     F.max_frame_bricks = cfg->max_frame_bricks > 0 ? cfg->max_frame_bricks : 4096;
@@ -858,63 +919,12 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         const int64_t cap = (int64_t)F.max_points * 32;
         F.seg_cap = (int)(cap > (1ll << 30) ? (1ll << 30) : cap);
     }
-    const size_t np = (size_t)F.max_points;
     if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.slot_tab, sizeof(int) * (size_t)m->nb3, 0xff))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.touched, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.ticket, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
-    if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&F.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc; }
-    for (int si = 0; si < TSL_NSETS; ++si) {
-        FSet& S = m->fset[si];
-        S.F = F;
-        FrameDev& G = S.F;
-        auto own = [&](void** p, size_t bytes) -> int { int r = dev_alloc(m, p, bytes, 0); if (!r) S.owned.push_back(*p); return r; };
-        if ((rc = own((void**)&G.keys, 8 * np))) return rc;
-        if ((rc = own((void**)&G.keys_s, 8 * np))) return rc;
-        if ((rc = own((void**)&G.vals, 4 * np))) return rc;
-        if ((rc = own((void**)&G.vals_s, 4 * np))) return rc;
-        if ((rc = own((void**)&G.pix, 8 * np))) return rc;
-        if ((rc = own((void**)&G.rayA, 16 * np))) return rc;
-        if ((rc = own((void**)&G.rayN, 4 * np))) return rc;
-        if ((rc = own((void**)&G.rayFirst, 4 * np))) return rc;
-        {   // sensor-voxel hash table (>= 4 entries per possible point) and the group lists
-            int lg = 10; while ((1ll << lg) < 4 * (long long)np) ++lg;
-            G.hlog2 = lg; G.hwide = m->pcl_bits > 10;
-            const size_t hs = (size_t)1 << lg;
-            if ((rc = dev_alloc(m, &G.hkey, 8 * hs, 0xff))) return rc; S.owned.push_back(G.hkey);
-            if ((rc = own((void**)&G.hcnt, 4 * hs))) return rc;
-            if ((rc = own((void**)&G.hoff, 4 * hs))) return rc;
-            if ((rc = own((void**)&G.hfill, 4 * hs))) return rc;
-            if ((rc = own((void**)&G.slot_of_pix, 4 * np))) return rc;
-            if ((rc = own((void**)&G.act, 4 * np))) return rc;
-            if ((rc = own((void**)&G.plist, 4 * np))) return rc;
-            if ((rc = own((void**)&G.big, 4 * (np / GROUP_SMALL + 16)))) return rc;
-        }
-        if (cfg->texture_enabled) { if ((rc = own((void**)&G.colpix, 8 * np))) return rc; }
-        S.header_bytes = 256;
-        if ((rc = own(&S.header, S.header_bytes))) return rc;
-        G.stats = reinterpret_cast<tsl_frame_stats*>(S.header);
-        G.nrays = reinterpret_cast<int*>((char*)S.header + 80);
-        G.counters = reinterpret_cast<int*>((char*)S.header + 96);
-        if ((rc = own((void**)&G.seg, 8 * (size_t)F.seg_cap))) return rc;
-        if ((rc = own((void**)&G.seg_sorted, 8 * (size_t)F.seg_cap))) return rc;
-        if ((rc = own((void**)&G.bhist, sizeof(int) * (size_t)m->nb3))) return rc;
-        if ((rc = own((void**)&G.bcursor, sizeof(int) * (size_t)m->nb3))) return rc;
-        if ((rc = own((void**)&G.boffset, sizeof(int) * (size_t)m->nb3))) return rc;
-        if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
-        G.part_cap = F.seg_cap / 256 + F.max_frame_bricks + 8;
-        if ((rc = own((void**)&G.part_tab, sizeof(int4) * 3 * (size_t)G.part_cap))) return rc;
-        if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
-        if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
-        if (si % TSL_NB == 0) {
-            BatchHost& H = m->batch[si / TSL_NB];
-            TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking));
-            TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
-            TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
-        }
+    for (int bi = 0; bi < TSL_NBATCH; ++bi) {
+        BatchHost& H = m->batch[bi];
+        TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking));
+        TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
     }
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
@@ -939,6 +949,20 @@ int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
         P.fastdiv = nbad == 0 ? 1 : 0;
     }
     TSL_HIP(hipStreamSynchronize(m->stream_));
+    return TSL_OK;
+}
+
+int tsl_tsdf_create(const tsl_tsdf_cfg* cfg, int device, tsl_tsdf** out)
+{
+    TSL_REQUIRE(cfg && out, "tsl_tsdf_create: null argument");
+    TSL_REQUIRE(cfg->voxel_scale > 0 && cfg->num_voxel_per_blk_axis >= 1 && cfg->recast_step >= 1, "tsl_tsdf_create: bad config");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available"); return TSL_ERR_NO_DEVICE; }
+    TSL_REQUIRE(device >= 0 && device < ndev, "tsl_tsdf_create: bad device index");
+    TSL_HIP(hipSetDevice(device));
+    tsl_tsdf* m = new tsl_tsdf();          // value-initialised: every pointer starts null, so a partly built handle can be destroyed
+    const int rc = init_handle(m, cfg, device);
+    if (rc) { const std::string keep = g_err; tsl_tsdf_destroy(m); g_err = keep; return rc; }
     *out = m;
     return TSL_OK;
 }
@@ -947,10 +971,15 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
 {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream_);
+    if (m->stream_) (void)hipStreamSynchronize(m->stream_);
     for (auto& H : m->batch) if (H.st) (void)hipStreamSynchronize(H.st);
-    (void)hipStreamSynchronize(m->stream_);
+    if (m->stream_) (void)hipStreamSynchronize(m->stream_);
     (void)hipDeviceSynchronize();
+    for (auto& H : m->batch) {
+        if (H.st) (void)hipStreamDestroy(H.st);
+        if (H.a_done) (void)hipEventDestroy(H.a_done);
+        if (H.b_done) (void)hipEventDestroy(H.b_done);
+    }
     for (auto& S : m->fset) {
 
         for (void* p : S.owned) if (p) (void)hipFree(p);
@@ -966,7 +995,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (m->h_ints) (void)hipHostFree(m->h_ints);
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& e : m->prof_free) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(m->stream_);
+    if (m->stream_) (void)hipStreamDestroy(m->stream_);
     delete m;
 }
 
@@ -978,15 +1007,29 @@ int tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* bxy, 
     if (bxy) *bxy = m->N / blk; if (bz) *bz = m->Nz / blk;                                   // dense_tsdf.py:27-28
     return TSL_OK;
 }
+// The device reports exhausted capacity through one sticky word (bit 0 brick pool, 1 frame bricks / parts, 2 ray segments,
+// 3 sensor voxel too crowded).  Every call that synchronises reads it, turns it into TSL_ERR_CAPACITY once and clears it: a frame or
+// a brick that was dropped is never dropped silently.
+static int take_dev_err(tsl_tsdf* m)
+{
+    TSL_HIP(hipMemcpyAsync(&m->h_ints[24], m->M.err, sizeof(int), hipMemcpyDeviceToHost, m->stream_));
+    TSL_HIP(hipStreamSynchronize(m->stream_));
+    const int e = m->h_ints[24];
+    if (!e) return TSL_OK;
+    set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : "") +
+              ((e & 4) ? " ray segments" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : "") + "; the affected frames / bricks were not integrated");
+    TSL_HIP(hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream_));
+    return TSL_ERR_CAPACITY;
+}
 int tsl_tsdf_sync(tsl_tsdf* m)
 {
     TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
     int rc = flush_pending(m);
     for (auto& H : m->batch) if (H.st) TSL_HIP(hipStreamSynchronize(H.st));
-    TSL_HIP(hipStreamSynchronize(m->stream_));
+    const int ec = take_dev_err(m);                // synchronises the main stream
     if (!rc && m->deferred_rc) { rc = m->deferred_rc; }
     m->deferred_rc = 0;
-    return rc;
+    return rc ? rc : ec;
 }
 int tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* b) { TSL_REQUIRE(m && b, "null"); *b = m->bytes; return TSL_OK; }
 
@@ -997,16 +1040,7 @@ static int read_int(tsl_tsdf* m, const int* dev, int* out)
     *out = m->h_ints[0];
     return TSL_OK;
 }
-static int check_dev_err(tsl_tsdf* m)
-{
-    int e = 0; int rc = read_int(m, m->M.err, &e); if (rc) return rc;
-    if (e) {
-        set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : "") + ((e & 4) ? " ray segments" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : ""));
-        (void)hipMemsetAsync(m->M.err, 0, sizeof(int), ms(m));
-        return TSL_ERR_CAPACITY;
-    }
-    return TSL_OK;
-}
+static int check_dev_err(tsl_tsdf* m) { (void)ms(m); return take_dev_err(m); }
 int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
 {
     TSL_REQUIRE(m && name && value, "null");
@@ -1027,12 +1061,13 @@ int tsl_tsdf_bricks_in_use(tsl_tsdf* m, int32_t* n)
 int tsl_tsdf_reset(tsl_tsdf* m)
 {
     TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
-    int rc = tsl_tsdf_sync(m); if (rc) return rc;
-    int used = 0; rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
+    const int pending = tsl_tsdf_sync(m);          // a capacity error of the discarded contents is still reported, after the reset
+    if (pending && pending != TSL_ERR_CAPACITY) return pending;
+    int used = 0; int rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
     if (used > 0) hipLaunchKernelGGL(k_reset_bricks, dim3(used < 4096 ? used : 4096), dim3(256), 0, ms(m), m->M, used);
-    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, ms(m)));
+    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int), ms(m)));
     TSL_HIP(hipGetLastError());
-    return TSL_OK;
+    return pending;
 }
 
 int tsl_tsdf_set_intrinsics(tsl_tsdf* m, const double Kd[9], const double Kc[9])
@@ -1114,18 +1149,33 @@ int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
     return tsl_tsdf_integrate_points_dev(m, R, T, xdev, cdev, n);
 }
 
+/* HIP stream that will read the input of the NEXT integrate_*_dev call (phase A of the batch the frame joins).  A caller that
+ * produces its device buffers on its own stream orders that stream before this one (event record + hipStreamWaitEvent), and a
+ * caching allocator is told that this stream uses the buffer (torch: tensor.record_stream) -- see mapping/dense_tsdf.py. */
+int tsl_tsdf_input_stream(tsl_tsdf* m, int points, void** hip_stream)
+{
+    TSL_REQUIRE(m && hip_stream, "input_stream: null argument"); TSL_HIP(hipSetDevice(m->device));
+    int si = 0; int rc = reserve_slot(m, points ? 1 : 0, &si); if (rc) return rc;
+    *hip_stream = (void*)(m->overlap == 0 ? m->stream_ : m->batch[si / TSL_NB].st);
+    return TSL_OK;
+}
+
+/* frames queued but not yet issued to the device (0 right after a batch went out) */
+int tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); *n = m->npend; return TSL_OK; }
+
 int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
 {
     TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
     const int64_t used = m->h_stats->p_used;
     tsl_frame_stats tmp;
+    if (!m->scratch_ready) { std::memset(out, 0, sizeof(*out)); return TSL_OK; }      // nothing was ever integrated
     { int rc2 = tsl_tsdf_sync(m); if (rc2) return rc2; }
     TSL_HIP(hipMemcpyAsync(m->h_ints, m->fset[m->last_set].F.stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, ms(m)));
     TSL_HIP(hipStreamSynchronize(ms(m)));
     std::memcpy(&tmp, m->h_ints, sizeof(tmp));
     tmp.p_used = used;
     *out = tmp;
-    return check_dev_err(m);
+    return TSL_OK;
 }
 
 int tsl_tsdf_count_active(tsl_tsdf* m, int64_t* n)
@@ -1263,6 +1313,7 @@ int tsl_tsdf_debug_counters(tsl_tsdf* m, int64_t* out, int reset)
 {
     TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
     int rc = tsl_tsdf_sync(m); if (rc) return rc;
+    TSL_REQUIRE(m->scratch_ready, "debug_counters: nothing integrated yet");
     TSL_HIP(hipMemcpy(out, m->F.dbg, sizeof(long long) * 16384 * 16, hipMemcpyDeviceToHost));
     if (reset) TSL_HIP(hipMemset(m->F.dbg, 0, sizeof(long long) * 16384 * 16));
     return TSL_OK;
@@ -1278,7 +1329,9 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     }
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
-    if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); m->wg = value; return TSL_OK; }
+    if (!std::strcmp(name, "kern")) { TSL_REQUIRE(value == 1 || value == 2, "kern must be 1 or 2"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->kern = value; return TSL_OK; }
+    if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
+    if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NB ? TSL_NB : value); for (auto& H : m->batch) H.b_pending = false; return TSL_OK; }
     if (!std::strcmp(name, "split")) { TSL_REQUIRE(value >= 1 && value <= 64 && (64 % value) == 0, "split must divide 64"); m->split = value; return TSL_OK; }

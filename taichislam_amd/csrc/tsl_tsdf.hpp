@@ -44,7 +44,7 @@ struct FrameDev {
     uint2* colpix;                               // [pixel] f16 colour {r|g<<16, b} of the ray opened by that pixel (texture)
     tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
     int*   nrays;                                // ray count of this frame
-    int*   counters;                             // [0] grouped pixels [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] crowded voxels [8..10] parts per table
+    int*   counters;                             // [0] grouped pixels [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] crowded voxels [8..10] parts per table [11] frame overflow bits
     unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick
     int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment
     int   *act_b;                                // [max_frame_bricks] active bricks of the frame, in the order they were listed
@@ -62,6 +62,11 @@ struct FrameDev {
     int    hwide;                                // sensor-voxel keys are 64 bit
     int    max_points;
 };
+
+// A frame that runs out of its own scratch (bit 1: frame bricks / parts, bit 2: ray segments) is not integrated at all: the flag
+// lives in the frame's header (counters[11], cleared by the frame's prologue), so it cannot leak into other frames, and it is
+// mirrored into the handle's sticky word, which the host reports (TSL_ERR_CAPACITY) from the next call that synchronises.
+__device__ __forceinline__ void frame_fail(const MapDev& M, const FrameDev& F, int bits) { atomicOr(&F.counters[11], bits); atomicOr(M.err, bits); }
 
 // ---- sensor voxel -> ray  (process_point dense_tsdf.py:230-234, process_new_pcl :242-249); citations are to dense_tsdf.py ----
 #define GROUP_SMALL 48        // sensor voxels with more pixels are replayed by a whole wave / workgroup
@@ -147,6 +152,7 @@ struct tsl_tsdf {
     int overlap;                         // frames per batch (0 = one frame at a time on the main stream)
     int cur, npend, pend_points; tsl::FrameParams pend[TSL_NB]; int deferred_rc;      // frames queued for batch `cur`
     int last_set;
+    bool scratch_ready;                  // frame scratch allocated (first integrate call)
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;
     tsl::MapDev M;
@@ -174,7 +180,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg;
+    int variant, split, phases, wg, kern, ncu, chunks;
     int64_t bytes;
 };
 

@@ -58,6 +58,8 @@ class DenseTSDF(BaseMap):
         self.color_same_proj = color_same_proj
         self.clear_last_TSDF_exporting = False
         self.device = device
+        self._ext_streams = {}
+        self._held = []
         self.mem_per_voxel = 2 + 2 + 1 + 1 + (6 if texture_enabled else 0)
 
         cfg = _lib.TsdfCfg(float(map_scale[0]), float(map_scale[1]), float(voxel_scale), int(num_voxel_per_blk_axis),
@@ -150,14 +152,59 @@ class DenseTSDF(BaseMap):
         return v.value
 
     # ---- integration (dense_tsdf.py:157-165) -----------------------------------------------------------------
+    def _adopt_device_inputs(self, points, *tensors):
+        """The reference's recast_* calls are synchronous; here a frame is only queued and its kernels are enqueued later (when
+        its batch of four is full, or when anything else needs the map) on the library's own streams.  For torch tensors the
+        shim therefore (1) makes the stream that will read the frame wait for the work already queued on torch's current
+        stream (the tensor may still be being produced), (2) keeps the tensors referenced until their batch has been issued
+        and (3) then tells torch's caching allocator that this stream reads them (record_stream), so a tensor the caller
+        drops right after the call is not recycled before the queued frame has read it."""
+        import torch
+        s = C.c_void_p()
+        self._call("input_stream", int(points), C.byref(s))
+        dev = tensors[0].device
+        ext = self._ext_streams.get(s.value)
+        if ext is None:
+            ext = self._ext_streams[s.value] = torch.cuda.ExternalStream(s.value, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        if not cur.query():
+            ext.wait_stream(cur)
+        self._held.append((ext, tensors))
+
+    def _release_device_inputs(self, force=False):
+        """Hand the held input tensors over to the allocator once the frames that read them have been issued."""
+        if not self._held:
+            return
+        if not force:
+            n = C.c_int32()
+            self._call("queued_frames", C.byref(n))
+            if n.value:
+                return
+        for ext, tensors in self._held:
+            for x in tensors:
+                x.record_stream(ext)
+        self._held.clear()
+
+    def sync(self):
+        super().sync()
+        self._release_device_inputs(force=True)
+
     def recast_pcl_to_map(self, R, T, xyz_array, rgb_array=None, n=None):
         """recast_pcl_to_map(R, T, xyz_array, rgb_array); the third positional `n` of the stale demo
         (TaichiSLAM_demo.py:52) is tolerated and ignored."""
         r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
         if _is_device_tensor(xyz_array):
-            x = xyz_array.contiguous().float()
-            self._keep = x
-            self._call("integrate_points_dev", r, t, C.c_void_p(x.data_ptr()), None, int(x.shape[0]))
+            import torch
+            x = xyz_array.reshape(-1, 3).contiguous().float()
+            ins, rgb_ptr = [x], None
+            if self.enable_texture and rgb_array is not None and _is_device_tensor(rgb_array) and rgb_array.numel():
+                c = rgb_array.reshape(-1, 3).contiguous().to(torch.uint8)
+                assert c.shape[0] == x.shape[0], "rgb_array must hold one colour per point"
+                ins.append(c)
+                rgb_ptr = C.c_void_p(c.data_ptr())
+            self._adopt_device_inputs(1, *ins)
+            self._call("integrate_points_dev", r, t, C.c_void_p(x.data_ptr()), rgb_ptr, int(x.shape[0]))
+            self._release_device_inputs()
             return
         xyz = np.ascontiguousarray(np.asarray(xyz_array, dtype=np.float32).reshape(-1, 3))
         rgb = None
@@ -168,13 +215,19 @@ class DenseTSDF(BaseMap):
     def recast_depth_to_map(self, R, T, depthmap, texture=None):
         r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
         if _is_device_tensor(depthmap):
-            assert depthmap.dim() == 2 and depthmap.element_size() == 2 and depthmap.is_contiguous(), \
-                "device depth must be a contiguous 16-bit [h,w] tensor (uint16 millimetres)"
-            tex_ptr, th, tw = None, 0, 0
+            import torch
+            assert depthmap.dim() == 2 and depthmap.is_contiguous() and \
+                depthmap.dtype in (torch.int16, getattr(torch, "uint16", torch.int16)), \
+                "device depth must be a contiguous [h,w] uint16 tensor of millimetres (int16 = the same bits)"
+            ins, tex_ptr, th, tw = [depthmap], None, 0, 0
             if self.enable_texture and texture is not None and _is_device_tensor(texture):
+                assert texture.dtype == torch.uint8 and texture.is_contiguous() and texture.dim() == 3 and texture.shape[2] == 3
+                ins.append(texture)
                 tex_ptr, th, tw = C.c_void_p(texture.data_ptr()), int(texture.shape[0]), int(texture.shape[1])
+            self._adopt_device_inputs(0, *ins)
             self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]),
                        int(depthmap.shape[1]), tex_ptr, th, tw)
+            self._release_device_inputs()
             return
         depth = np.ascontiguousarray(np.asarray(depthmap, dtype=np.uint16))
         if depth.ndim != 2:
