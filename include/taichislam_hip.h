@@ -137,13 +137,32 @@ int  tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n);
 
 /* ---- submap fusion  (dense_tsdf.py:272-318) ------------------------------------------------------ */
 int  tsl_tsdf_fuse_submaps(tsl_tsdf* global, tsl_tsdf* submaps);
-/* multi-GPU form: splat this rank's submaps into exact fixed-point accumulators over the dense global grid,
- * all-reduce(sum) them with RCCL (caller side: torch.distributed / ncclAllReduce on the *_dev buffers), then finalise.
- * acc_dev: int64 [N*N*Nz][2] = {sum w*tsdf, sum w} in 2^-24 fixed point; cnt_occ_dev: int32 [N*N*Nz] = contributions * 65536
- * + occupancy sum.  Both must be zero before the first accumulate; integer sums make the result independent of the
- * number of ranks and of the reduction order. */
-int  tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* global, tsl_tsdf* submaps, void* acc_dev, void* cnt_occ_dev);
-int  tsl_tsdf_fuse_finalize_dev(tsl_tsdf* global, const void* acc_dev, const void* cnt_occ_dev);
+/* ---- multi-GPU global-map merge: one submap collection per GPU, one exchange at merge time -------------------------------------
+ * Swarm counterpart of submap_mapping.py:226-253 + utils/communication.py:9-43 (agents ship zlib'd numpy submaps over LCM and every
+ * agent fuses them, dense_tsdf.py:272-318): every rank splats its own submaps into exact 2^-24 fixed-point sums per touched 16^3
+ * brick, the union of touched bricks is all-reduced (RCCL over xGMI) and every rank writes the same global TSDF.  Integer sums: the
+ * result is bit-identical for any number of ranks and equal to one GPU fusing every submap.  The global map's pose table must hold the
+ * base pose of every submap id used by any rank (tsl_tsdf_set_base_pose_submap), as for tsl_tsdf_fuse_submaps. */
+typedef struct tsl_comm tsl_comm;                                  /* an RCCL communicator (RCCL is bound at run time, dlopen) */
+int   tsl_comm_unique_id(char id[128]);                            /* ncclGetUniqueId on one rank; ship the 128 bytes to the others */
+int   tsl_comm_create(const char id[128], int nranks, int rank, int device, tsl_comm** out);   /* ncclCommInitRank (collective) */
+void  tsl_comm_destroy(tsl_comm* c);
+void* tsl_comm_handle(tsl_comm* c);                                /* the ncclComm_t */
+/* one call: splat, all-reduce the touched-brick mask (MAX) and the packed union bricks (SUM) on `rccl_comm` (an ncclComm_t from
+ * tsl_comm_handle or the caller's own; NULL = this rank alone), finalise.  bytes_per_rank (nullable) = payload all-reduced. */
+int   tsl_tsdf_allreduce_merge(tsl_tsdf* global, tsl_tsdf* submaps, void* rccl_comm, int64_t* bytes_per_rank);
+/* the same in steps, for callers that run the two reductions themselves (torch.distributed, MPI); *_dev buffers are the caller's:
+ *   merge_begin  : reset `global`, splat `submaps`, write the touched-brick byte mask (tsl_tsdf_merge_mask_bytes bytes)
+ *   -> all-reduce(MAX) the mask
+ *   merge_union  : ascending list of the union bricks, *nunion of them
+ *   merge_pack   : acc_dev int64 [nunion][4096][2] = {sum w*tsdf, sum w}, cnt_dev int32 [nunion][4096] = contributions * 65536 + occupancy
+ *   -> all-reduce(SUM) both
+ *   merge_finish : write the global map from the sums */
+int   tsl_tsdf_merge_mask_bytes(const tsl_tsdf* global, int64_t* n);
+int   tsl_tsdf_merge_begin(tsl_tsdf* global, tsl_tsdf* submaps, void* mask_dev, int64_t mask_bytes);
+int   tsl_tsdf_merge_union(tsl_tsdf* global, const void* mask_dev, int32_t* nunion);
+int   tsl_tsdf_merge_pack(tsl_tsdf* global, void* acc_dev, void* cnt_dev);
+int   tsl_tsdf_merge_finish(tsl_tsdf* global, const void* acc_dev, const void* cnt_dev);
 
 /* ---- marching cubes  (marching_cube_mesher.py:127-193) ------------------------------------------- */
 /* generate_mesh(step): result stays on the device in the map's mesh buffers (3*max_tri rows each);
@@ -166,8 +185,10 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; two batches in flight)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
-     "wg"       threads per workgroup of the brick integrate kernel: 256 (1024 segments per part), 512 (2048), 1024 (r01 kernel only)
-     "kern"     1 (default) = round-2 brick kernel (two steps per iteration, split accumulator planes), 0 = round-1 kernel
+     "wg"       threads per workgroup of the brick integrate kernel: 256 (default; chunks of 1024 segments, two workgroups per CU) or
+                512 (chunks of 2048, one workgroup per CU)
+     "chunks"   chunks a part may hold (1..8, default 1): a brick with up to chunks x chunk-size segments is integrated by one
+                workgroup and never merged through HBM
      "fastdiv"  0 = force IEEE division
      "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);

@@ -63,6 +63,7 @@ def lib():
         L.ora_tsdf_integrate_depth.argtypes = [vp, C.c_int, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                                C.POINTER(FrameStats)]
         L.ora_tsdf_integrate_points.argtypes = [vp, C.c_int, dp, dp, vp, vp, i64, C.POINTER(FrameStats)]
+        L.ora_tsdf_integrate_depth_mt.argtypes = [vp, dp, dp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FrameStats)]
         L.ora_tsdf_count_active.restype = i64
         L.ora_tsdf_count_active.argtypes = [vp]
         L.ora_tsdf_export_sparse.restype = i64
@@ -173,6 +174,16 @@ class OracleTSDF:
             texture = None
         self.L.ora_tsdf_integrate_depth(self.h, mode, r, t, _p(depth), depth.shape[0], depth.shape[1],
                                         _p(texture), th, tw, C.byref(st))
+        return st.as_dict()
+
+    def integrate_depth_mt(self, R, T, depth, nthreads):
+        """All-core port of the BATCHED semantics (tsl_oracle.c: brick-binned, OpenMP); bit-identical to integrate_depth(mode=BATCHED)."""
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        _, r = _d(R, 9)
+        _, t = _d(T, 3)
+        st = FrameStats()
+        rc = self.L.ora_tsdf_integrate_depth_mt(self.h, r, t, _p(depth), depth.shape[0], depth.shape[1], int(nthreads), C.byref(st))
+        assert rc == 0
         return st.as_dict()
 
     def integrate_points(self, R, T, xyz, rgb=None, mode=BATCHED):

@@ -494,6 +494,147 @@ int ora_tsdf_integrate_depth(ora_tsdf* m, int mode, const double R[9], const dou
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* All-core CPU baseline ("port", bench.py cpu_baseline_allcore): BATCHED semantics -- the same    */
+/* exact sums, bit-identical map (tests/test_oracle_kat.py) -- computed the way the GPU path is    */
+/* organised, because ray-parallel atomics scale negatively (every ray starts in the same voxels): */
+/* rays are cut into per-brick segments in parallel, segments are counting-sorted by brick, and    */
+/* bricks are integrated in parallel (no two threads touch one brick).  NOT a restatement of the   */
+/* reference's loop structure; FAITHFUL on one thread stays the restatement.                       */
+/* ------------------------------------------------------------------------------------------ */
+#ifdef _OPENMP
+#include <omp.h>
+typedef struct { float pf[3], dir[3], P[3], w; int64_t qden; int n; } mt_ray;
+typedef struct { uint32_t brick; uint32_t ray; uint16_t j0, cnt; } mt_seg;
+typedef struct { mt_seg* a; size_t n, cap; } mt_vec;
+static void mt_push(mt_vec* v, mt_seg s)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 4096; v->a = (mt_seg*)realloc(v->a, sizeof(mt_seg) * v->cap); }
+    v->a[v->n++] = s;
+}
+static inline int mt_step_voxel(const ora_tsdf* m, const mt_ray* r, int j, float x[3], int xi[3])
+{
+    const float jf = (float)j;
+    for (int a = 0; a < 3; ++a) { x[a] = (r->dir[a] * jf) * m->vs + m->inT[a]; xi[a] = rnd_i(x[a] / m->vs); }   /* dense_tsdf.py:253-254 */
+    return in_volume(m, xi[0], xi[1], xi[2]);
+}
+int ora_tsdf_integrate_depth_mt(ora_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w, int nthreads, ora_frame_stats* st_out)
+{
+    if (m->cfg.texture_enabled) return -1;
+    ora_frame_stats st; memset(&st, 0, sizeof(st));
+    set_pose(m, R, T);
+    const int step = m->cfg.recast_step;
+    const int hh = (int)((float)h / (float)step), ww = (int)((float)w / (float)step);
+    pcl_grid g; pcl_init(&g, (int64_t)hh * ww);
+    for (int jj = 0; jj < hh; ++jj) for (int ii = 0; ii < ww; ++ii) {                        /* phase A: serial, raster order (as integrate_depth) */
+        int j = jj * step, i = ii * step;
+        st.p_used++;
+        uint16_t d = depth[(size_t)j * w + i];
+        if (d == 0 || (float)d > m->thr_max || (float)d < m->thr_min) continue;
+        float dep = (float)d / 1000.0f;
+        float pt[3] = { ((float)i - m->cx) * dep / m->fx, ((float)j - m->cy) * dep / m->fy, dep }, pm[3];
+        for (int a = 0; a < 3; ++a) pm[a] = (m->inR[a * 3] * pt[0] + m->inR[a * 3 + 1] * pt[1]) + m->inR[a * 3 + 2] * pt[2];
+        if (process_point(m, &g, pm, dep, NULL, jj * ww + ii)) st.p_valid++; else st.p_oob++;
+    }
+    const int s = map_slot(m, m->active);
+    const float vs = m->vs;
+    mt_ray* rays = (mt_ray*)malloc(sizeof(mt_ray) * (size_t)(g.n > 0 ? g.n : 1));
+    int nrays = 0;
+    for (int c = 0; c < g.n; ++c) {                                                          /* rays: process_new_pcl :242-249, serial (cheap) */
+        pcl_cell* cell = &g.cells[c];
+        st.v_pcl++;
+        f16 cc = H((float)cell->cnt), p[3];
+        for (int a = 0; a < 3; ++a) p[a] = hdiv(cell->sum[a], cc);
+        f16 len = hsqrt(hadd(hadd(hmul(p[0], p[0]), hmul(p[1], p[1])), hmul(p[2], p[2])));
+        f16 zbar = hdiv(cell->z, cc), zz = hmul(zbar, zbar);
+        float lenf = F(len), zzf = F(zz);
+        if (!(lenf > 0.0f) || !isfinite(lenf) || !(zzf > 0.0f) || !isfinite(zzf)) { st.v_skipped++; continue; }
+        mt_ray* r = &rays[nrays++];
+        for (int a = 0; a < 3; ++a) { r->pf[a] = F(p[a]); r->dir[a] = F(hdiv(p[a], len)); r->P[a] = r->pf[a] + m->inT[a]; }
+        int oi = rnd_i(r->P[0] / vs), oj = rnd_i(r->P[1] / vs), ok = rnd_i(r->P[2] / vs);
+        if (in_volume(m, oi, oj, ok)) { int l; brick_t* b = get_brick(m, s, oi, oj, ok, 1, &l); b->occ[l] = 1; }
+        float nf = lenf / vs + m->internal_f; if (m->max_steps_f < nf) nf = m->max_steps_f;
+        r->n = (int)nf;
+        r->w = 1.0f / zzf; if (r->w > W_CLAMP) r->w = W_CLAMP;
+        r->qden = to_fix(r->w);
+    }
+    if (nthreads < 1) nthreads = 1;
+    mt_vec* tv = (mt_vec*)calloc((size_t)nthreads, sizeof(mt_vec));
+    int64_t n_oob = 0, n_ok = 0;
+    const size_t nb3 = (size_t)m->nbx * m->nbx * m->nbz;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64) reduction(+ : n_oob, n_ok)
+    for (int q = 0; q < nrays; ++q) {                                                        /* cut every ray into runs of steps inside one brick */
+        const mt_ray* r = &rays[q];
+        mt_vec* v = &tv[omp_get_thread_num()];
+        long cur = -1; int j0 = 0, cnt = 0;
+        for (int j = 1; j <= r->n; ++j) {
+            float x[3]; int xi[3];
+            long b = -1;
+            if (mt_step_voxel(m, r, j, x, xi)) {
+                int ui = xi[0] + m->N / 2, uj = xi[1] + m->N / 2, uk = xi[2] + m->Nz / 2;
+                b = (long)(((size_t)(ui >> 4) * m->nbx + (size_t)(uj >> 4)) * m->nbz + (size_t)(uk >> 4));
+                n_ok++;
+            } else n_oob++;
+            if (b != cur) {
+                if (cur >= 0) mt_push(v, (mt_seg){ (uint32_t)cur, (uint32_t)q, (uint16_t)j0, (uint16_t)cnt });
+                cur = b; j0 = j; cnt = 0;
+            }
+            cnt++;
+        }
+        if (cur >= 0) mt_push(v, (mt_seg){ (uint32_t)cur, (uint32_t)q, (uint16_t)j0, (uint16_t)cnt });
+    }
+    st.steps = n_ok; st.steps_oob = n_oob;
+    size_t nseg = 0; for (int t = 0; t < nthreads; ++t) nseg += tv[t].n;
+    uint32_t* hist = (uint32_t*)calloc(nb3 + 1, sizeof(uint32_t));
+    for (int t = 0; t < nthreads; ++t) for (size_t i = 0; i < tv[t].n; ++i) hist[tv[t].a[i].brick + 1]++;
+    uint32_t* act = (uint32_t*)malloc(sizeof(uint32_t) * (nb3 > 0 ? nb3 : 1)); size_t nact = 0;
+    for (size_t b = 0; b < nb3; ++b) { if (hist[b + 1]) act[nact++] = (uint32_t)b; hist[b + 1] += hist[b]; }
+    mt_seg* sorted = (mt_seg*)malloc(sizeof(mt_seg) * (nseg > 0 ? nseg : 1));
+    uint32_t* cursor = (uint32_t*)malloc(sizeof(uint32_t) * (nb3 + 1)); memcpy(cursor, hist, sizeof(uint32_t) * (nb3 + 1));
+    for (int t = 0; t < nthreads; ++t) for (size_t i = 0; i < tv[t].n; ++i) sorted[cursor[tv[t].a[i].brick]++] = tv[t].a[i];
+    submap_t* sm = &m->sub[s];
+    if (!sm->tab) sm->tab = (brick_t**)calloc(nb3, sizeof(brick_t*));
+    for (size_t i = 0; i < nact; ++i) if (!sm->tab[act[i]]) sm->tab[act[i]] = (brick_t*)calloc(1, sizeof(brick_t));    /* allocation stays serial */
+    int64_t uniq = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1) reduction(+ : uniq)
+    for (size_t i = 0; i < nact; ++i) {                                                      /* one thread per brick: plain adds, then the frame's update */
+        brick_t* b = sm->tab[act[i]];
+        for (uint32_t q = hist[act[i]]; q < hist[act[i] + 1]; ++q) {
+            const mt_seg sg = sorted[q]; const mt_ray* r = &rays[sg.ray];
+            for (int j = sg.j0; j < sg.j0 + sg.cnt; ++j) {
+                float x[3]; int xi[3];
+                mt_step_voxel(m, r, j, x, xi);
+                const int l = (((xi[0] + m->N / 2) & 15) * 16 + ((xi[1] + m->N / 2) & 15)) * 16 + ((xi[2] + m->Nz / 2) & 15);
+                float v[3] = { r->P[0] - x[0], r->P[1] - x[1], r->P[2] - x[2] };                 /* :258-260 */
+                float dist = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+                float dot = (v[0] * r->pf[0] + v[1] * r->pf[1]) + v[2] * r->pf[2];
+                b->num[l] += to_fix(r->w * (dist * (float)sgn_f(dot)));
+                b->den[l] += r->qden;
+            }
+        }
+        for (int l = 0; l < BRK3; ++l) {
+            if (b->den[l] == 0) continue;
+            uniq++;
+            float num = from_fix(b->num[l]), den = from_fix(b->den[l]);
+            f16 T0 = b->tsdf[l], W0 = b->w[l];
+            b->tsdf[l] = H((F(hmul(T0, W0)) + num) / (F(W0) + den));
+            float wn = F(W0) + den; if (WMAX < wn) wn = WMAX;
+            b->w[l] = H(wn); b->obs[l] = 1;
+            b->num[l] = 0; b->den[l] = 0;
+        }
+    }
+    st.unique = uniq; st.bricks = (int64_t)nact;
+    for (int t = 0; t < nthreads; ++t) free(tv[t].a);
+    free(tv); free(hist); free(act); free(sorted); free(cursor); free(rays);
+    pcl_free(&g);
+    if (st_out) *st_out = st;
+    return 0;
+}
+#else
+int ora_tsdf_integrate_depth_mt(ora_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w, int nthreads, ora_frame_stats* st_out)
+{ (void)nthreads; return ora_tsdf_integrate_depth(m, ORA_BATCHED, R, T, depth, h, w, NULL, 0, 0, st_out); }
+#endif
+
 /* recast_pcl_to_map  dense_tsdf.py:157-160,167-186 */
 int ora_tsdf_integrate_points(ora_tsdf* m, int mode, const double R[9], const double T[3],
                               const float* xyz, const uint8_t* rgb, int64_t n, ora_frame_stats* st_out)

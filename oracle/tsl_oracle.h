@@ -72,6 +72,9 @@ void      ora_tsdf_reset(ora_tsdf* m);
 int ora_tsdf_integrate_depth(ora_tsdf* m, int mode, const double R[9], const double T[3],
                              const uint16_t* depth, int h, int w,
                              const uint8_t* tex, int th, int tw, ora_frame_stats* st);
+/* all-core "port" of the BATCHED semantics (brick-binned like the GPU path; bit-identical map), for bench.py's cpu_baseline_allcore */
+int ora_tsdf_integrate_depth_mt(ora_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
+                                int nthreads, ora_frame_stats* st);
 int ora_tsdf_integrate_points(ora_tsdf* m, int mode, const double R[9], const double T[3],
                               const float* xyz, const uint8_t* rgb, int64_t n, ora_frame_stats* st);
 

@@ -83,8 +83,16 @@ SIGNATURES = {
     "tsl_tsdf_num_particles": (C.c_int, [vp, pi32]),
     "tsl_tsdf_set_num_particles": (C.c_int, [vp, i32]),
     "tsl_tsdf_fuse_submaps": (C.c_int, [vp, vp]),
-    "tsl_tsdf_fuse_accumulate_dev": (C.c_int, [vp, vp, vp, vp]),
-    "tsl_tsdf_fuse_finalize_dev": (C.c_int, [vp, vp, vp]),
+    "tsl_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "tsl_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "tsl_comm_destroy": (None, [vp]),
+    "tsl_comm_handle": (vp, [vp]),
+    "tsl_tsdf_allreduce_merge": (C.c_int, [vp, vp, vp, pi64]),
+    "tsl_tsdf_merge_mask_bytes": (C.c_int, [vp, pi64]),
+    "tsl_tsdf_merge_begin": (C.c_int, [vp, vp, vp, i64]),
+    "tsl_tsdf_merge_union": (C.c_int, [vp, vp, pi32]),
+    "tsl_tsdf_merge_pack": (C.c_int, [vp, vp, vp]),
+    "tsl_tsdf_merge_finish": (C.c_int, [vp, vp, vp]),
     "tsl_mesh_generate": (C.c_int, [vp, C.c_int, f32, i64, pi32]),
     "tsl_mesh_read": (C.c_int, [vp, vp, vp, vp, i64]),
     "tsl_tsdf_query_points": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp]),

@@ -269,4 +269,16 @@ __device__ __forceinline__ int pool_claim(const MapDev& M, int s, int b)
     return v;
 }
 
+// one voxel of a (reset) global map from the fusion's sums: {sum w*t, sum w} in 2^-24 fixed point, c = contributions * 65536 + occupancy sum
+// (fuse_with_interploation dense_tsdf.py:272-280 applied once per voxel; used by tsl_fuse.hip and tsl_merge.hip)
+__device__ __forceinline__ void fuse_write_voxel(const MapDev& G, size_t v, long long qn, long long qd, int c)
+{
+    const int occ_sum = (int)(int16_t)(c & 0xffff);
+    const float num = from_fix(qn), den = from_fix(qd);
+    G.tw[v] = (uint32_t)f2h(num / den) | ((uint32_t)f2h(den) << 16);          // empty global map: T0 = W0 = 0  (:275,:278)
+    G.obs[v] = 1;
+    G.occ[v] = (int8_t)occ_sum;                                                // i8 wrap as in the reference (:280, Q7)
+}
+
+
 }  // namespace tsl

@@ -13,7 +13,6 @@ namespace tsl {
 
 struct PoseTab { const float* p; };     // [npose][12]: R row-major, T
 
-template <bool DENSE>
 __global__ void __launch_bounds__(256) k_fuse_splat(MapDev S, MapDev G, PoseTab poses, float vs, int nused,
                                                     unsigned long long* acc, int* cnt, int npose, unsigned long long* cacc)
 {
@@ -44,18 +43,14 @@ __global__ void __launch_bounds__(256) k_fuse_splat(MapDev S, MapDev G, PoseTab 
                 const float wt = ((1.0f - fabsf((float)ci - f[0])) * (1.0f - fabsf((float)cj - f[1]))) * (1.0f - fabsf((float)ck - f[2]));   // :303
                 const float w_tsdf = wsrc * wt;                                                  // :307
                 if (!in_volume(G, ci, cj, ck)) continue;
-                size_t dst;
-                if (DENSE) dst = ((size_t)(ci + G.hN) * G.N + (size_t)(cj + G.hN)) * G.Nz + (size_t)(ck + G.hNz);
-                else {
-                    int gl; const int gb = brick_of(G, ci, cj, ck, &gl);
-                    const int gp = pool_claim<false>(G, 0, gb);
-                    if (gp < 0) continue;
-                    dst = (size_t)gp * TSL_BRK3 + gl;
-                }
+                int gl; const int gb = brick_of(G, ci, cj, ck, &gl);
+                const int gp = pool_claim<false>(G, 0, gb);
+                if (gp < 0) continue;
+                const size_t dst = (size_t)gp * TSL_BRK3 + gl;
                 __hip_atomic_fetch_add(acc + dst * 2, (unsigned long long)to_fix(w_tsdf * tsdf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :275 numerator
                 __hip_atomic_fetch_add(acc + dst * 2 + 1, (unsigned long long)to_fix(w_tsdf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // :274
                 __hip_atomic_fetch_add(cnt + dst, (1 << 16) + occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                 // :279-280
-                if (!DENSE && cacc) {                                                            // :277 colour, exact weighted sums per channel
+                if (cacc) {                                                            // :277 colour, exact weighted sums per channel
                     const uint2 cs = reinterpret_cast<const uint2*>(S.col)[v];
                     const float cf[3] = { h2f((h16)(cs.x & 0xffffu)), h2f((h16)(cs.x >> 16)), h2f((h16)(cs.y & 0xffffu)) };
                     for (int a = 0; a < 3; ++a)
@@ -66,15 +61,6 @@ __global__ void __launch_bounds__(256) k_fuse_splat(MapDev S, MapDev G, PoseTab 
     }
 }
 
-__device__ __forceinline__ void fuse_write(const MapDev& G, size_t v, long long qn, long long qd, int c)
-{
-    const int occ_sum = (int)(int16_t)(c & 0xffff);
-    const float num = from_fix(qn), den = from_fix(qd);
-    G.tw[v] = (uint32_t)f2h(num / den) | ((uint32_t)f2h(den) << 16);          // empty global map: T0 = W0 = 0  (:275,:278)
-    G.obs[v] = 1;
-    G.occ[v] = (int8_t)occ_sum;                                                // i8 wrap as in the reference (:280, Q7)
-}
-
 // finalise from the per-brick scratch of the global map
 __global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsigned long long* acc, int* cnt, unsigned long long* cacc)
 {
@@ -83,7 +69,7 @@ __global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsi
             const size_t v = (size_t)p * TSL_BRK3 + l;
             const int c = cnt[v];
             if (c == 0) continue;
-            fuse_write(G, v, (long long)acc[v * 2], (long long)acc[v * 2 + 1], c);
+            fuse_write_voxel(G, v, (long long)acc[v * 2], (long long)acc[v * 2 + 1], c);
             if (cacc) {
                 const float den = from_fix((long long)acc[v * 2 + 1]);
                 h16 cc[3];
@@ -92,20 +78,6 @@ __global__ void __launch_bounds__(256) k_fuse_finalize(MapDev G, int nused, unsi
             }
             acc[v * 2] = 0ull; acc[v * 2 + 1] = 0ull; cnt[v] = 0;
         }
-}
-
-// finalise from dense (all-reduced) arrays over the whole global grid
-__global__ void __launch_bounds__(256) k_fuse_finalize_dense(MapDev G, const long long* pair, const int* cnt, long long nvox)
-{
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nvox; q += (long long)gridDim.x * 256) {
-        const int c = cnt[q];
-        if (c == 0) continue;
-        const int uk = (int)(q % G.Nz), uj = (int)((q / G.Nz) % G.N), ui = (int)(q / ((long long)G.Nz * G.N));
-        int gl; const int gb = brick_of(G, ui - G.hN, uj - G.hN, uk - G.hNz, &gl);
-        const int gp = pool_claim<false>(G, 0, gb);
-        if (gp < 0) continue;
-        fuse_write(G, (size_t)gp * TSL_BRK3 + gl, pair[q * 2], pair[q * 2 + 1], c);
-    }
 }
 
 static int upload_poses(tsl_tsdf* g, const tsl_tsdf* sub)
@@ -128,6 +100,31 @@ static int upload_poses(tsl_tsdf* g, const tsl_tsdf* sub)
 
 static int used_bricks(tsl_tsdf* m, int* n) { return tsl_tsdf_bricks_in_use(m, n); }
 
+// reset `g` and splat every submap of `sub` into g's per-brick accumulators (allocated on first use); *ndst = bricks of g touched
+int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst)
+{
+    int rc = tsl_tsdf_sync(sub); if (rc) return rc;
+    rc = tsl_tsdf_reset(g); if (rc && rc != TSL_ERR_CAPACITY) return rc;                  // :313 (a capacity error of the discarded contents does not matter here)
+    if (!g->fuse_acc) {
+        const size_t nv = (size_t)g->M.max_bricks * TSL_BRK3;
+        if ((rc = dev_alloc(g, &g->fuse_acc, nv * 16, 0))) return rc;
+        if ((rc = dev_alloc(g, &g->fuse_cnt, nv * 4, 0))) return rc;
+        if (g->M.col) { if ((rc = dev_alloc(g, &g->fuse_cacc, nv * 24, 0))) return rc; }
+    }
+    unsigned long long* cacc = (g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
+    if ((rc = upload_poses(g, sub))) return rc;
+    int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
+    *ndst = 0;
+    if (nsrc > 0) {
+        PoseTab pt = { g->pose_dev };
+        hipLaunchKernelGGL(k_fuse_splat, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
+                           (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose, cacc);
+        if ((rc = used_bricks(g, ndst))) return rc;
+    }
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+
 }  // namespace tsl
 
 using namespace tsl;
@@ -140,65 +137,13 @@ int tsl_tsdf_fuse_submaps(tsl_tsdf* g, tsl_tsdf* sub)
     TSL_REQUIRE(g->cfg.is_global_map, "fuse_submaps: destination must be a global map (is_global_map=True)");
     TSL_REQUIRE(g->device == sub->device, "fuse_submaps: maps live on different devices");
     TSL_HIP(hipSetDevice(g->device));
-    int rc = tsl_tsdf_sync(sub); if (rc) return rc;
-    if ((rc = tsl_tsdf_reset(g))) return rc;                                                // :313
-    if (!g->fuse_acc) {
-        const size_t nv = (size_t)g->M.max_bricks * TSL_BRK3;
-        if ((rc = dev_alloc(g, &g->fuse_acc, nv * 16, 0))) return rc;
-        if ((rc = dev_alloc(g, &g->fuse_cnt, nv * 4, 0))) return rc;
-        if (g->M.col) { if ((rc = dev_alloc(g, &g->fuse_cacc, nv * 24, 0))) return rc; }
-    }
+    int ndst = 0;
+    int rc = fuse_splat_into_global(g, sub, &ndst); if (rc) return rc;
     unsigned long long* cacc = (g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
-    if ((rc = upload_poses(g, sub))) return rc;
-    int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
-    if (nsrc > 0) {
-        PoseTab pt = { g->pose_dev };
-        hipLaunchKernelGGL(k_fuse_splat<false>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
-                           (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose, cacc);
-        int ndst = 0; if ((rc = used_bricks(g, &ndst))) return rc;
-        if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, ms(g), g->M, ndst,
-                                         (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, cacc);
-    }
+    if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, ms(g), g->M, ndst,
+                                     (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, cacc);
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(ms(g)));
-    int e = 0;
-    TSL_HIP(hipMemcpy(&e, g->M.err, sizeof(int), hipMemcpyDeviceToHost));
-    if (e) { (void)hipMemset(g->M.err, 0, sizeof(int)); set_error("fuse_submaps: global brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
-    return TSL_OK;
-}
-
-int tsl_tsdf_fuse_accumulate_dev(tsl_tsdf* g, tsl_tsdf* sub, void* acc_dev, void* cnt_occ_dev)
-{
-    TSL_REQUIRE(g && sub && acc_dev && cnt_occ_dev, "fuse_accumulate: null argument");
-    TSL_REQUIRE(g->cfg.is_global_map && g->device == sub->device, "fuse_accumulate: bad destination");
-    TSL_HIP(hipSetDevice(g->device));
-    int rc = tsl_tsdf_sync(sub); if (rc) return rc;
-    if ((rc = upload_poses(g, sub))) return rc;
-    int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
-    if (nsrc > 0) {
-        PoseTab pt = { g->pose_dev };
-        hipLaunchKernelGGL(k_fuse_splat<true>, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
-                           (unsigned long long*)acc_dev, (int*)cnt_occ_dev, g->npose, (unsigned long long*)nullptr);
-    }
-    TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(ms(g)));
-    return TSL_OK;
-}
-
-int tsl_tsdf_fuse_finalize_dev(tsl_tsdf* g, const void* acc_dev, const void* cnt_occ_dev)
-{
-    TSL_REQUIRE(g && acc_dev && cnt_occ_dev, "fuse_finalize: null argument");
-    TSL_REQUIRE(g->cfg.is_global_map, "fuse_finalize: destination must be a global map");
-    TSL_HIP(hipSetDevice(g->device));
-    int rc = tsl_tsdf_reset(g); if (rc) return rc;
-    const long long nvox = (long long)g->N * g->N * g->Nz;
-    hipLaunchKernelGGL(k_fuse_finalize_dense, dim3(8192), dim3(256), 0, ms(g), g->M, (const long long*)acc_dev, (const int*)cnt_occ_dev, nvox);
-    TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(ms(g)));
-    int e = 0;
-    TSL_HIP(hipMemcpy(&e, g->M.err, sizeof(int), hipMemcpyDeviceToHost));
-    if (e) { (void)hipMemset(g->M.err, 0, sizeof(int)); set_error("fuse_finalize: global brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
-    return TSL_OK;
+    return tsl_tsdf_sync(g);                                    // reports an exhausted brick pool of the global map (TSL_ERR_CAPACITY)
 }
 
 }  // extern "C"

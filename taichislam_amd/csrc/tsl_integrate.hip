@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256) k_scatter(BatchDev B)
 }
 
 // =====================================================================================================
-// k_integrate_bricks2 (round 2): the same parts, the same exact sums, reshaped for the way the SIMDs issue.
+// Brick kernel, round 2 -- building blocks: the same parts and the same exact sums as round 1, reshaped for the way the SIMDs issue.
 //   * the ray step is branch-free (the division form is a template parameter, the square root takes max(s2, 2^-96) --
 //     below that the fixed-point term rounds to zero either way -- and the 64-bit conversion is decided once per pair
 //     of steps for the whole wave), and two steps are evaluated per iteration: two independent dependency chains per
@@ -568,220 +568,8 @@ __device__ __forceinline__ void apply_chunk(const uint32_t* old, const long long
     }
 }
 
-template <bool TEX, bool FASTDIV, int NT, int WPS = NT / 128>
-__global__ void __launch_bounds__(NT, TEX ? 1 : WPS) k_integrate_bricks2(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
-{
-    // NT threads integrate a part of up to 4 * NT segments (4 per thread).  256: two workgroups = 8 waves per CU; 512: a brick with up
-    // to 2048 segments stays whole (no merge through HBM), two workgroups = 16 waves per CU when the kernel fits 128 registers.
-    constexpr int PSEGS = 4 * NT, SPT = 4, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
-    static_assert(VPT % CH == 0 && PSEGS * 8 <= TSL_BRK3 * 8, "brick kernel geometry");
-    const FrameParams& P = *Pp;
-    __shared__ unsigned long long s_num[TSL_BRK3];              // 32 KiB
-    __shared__ unsigned long long s_den[TSL_BRK3];              // 32 KiB; before the walk its head is the scratch of the length sort
-    __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
-    __shared__ int s_bin[64];
-    __shared__ int s_p, s_last;
-    unsigned long long* const s_keys = s_den;
-    const int nA = min(F.counters[8], F.part_cap), nB = min(F.counters[9], F.part_cap), nC = min(F.counters[10], F.part_cap);
-    const int nparts = (F.counters[11] != 0) ? 0 : nA + nB + nC;          // nothing is integrated when the frame overflowed its scratch
-    const StepK K = { P.vs, P.rvs, P.T[0], P.T[1], P.T[2], M.hN, M.hNz };
-    long long uniq = 0;
-    TSL_T0();
-    {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
-        const int nact = min(F.counters[1], F.max_frame_bricks);
-        for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
-    }
-    for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
-        TSL_TICK(F, 0);
-        const int4 pt = part < nA ? F.part_tab[part] : (part < nA + nC ? F.part_tab[2 * (size_t)F.part_cap + part - nA] : F.part_tab[F.part_cap + part - nA - nC]);
-        const int pos = pt.x, nseg = pt.y & 0xffff, np = pt.y >> 16, rk = pt.w;
-        const bool whole = np == 1;
-        unsigned long long kk[SPT]; int rr[SPT];
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; if (i < nseg) kk[q] = F.seg_sorted[pos + i]; }     // in flight while LDS is cleared
-        if (threadIdx.x == 0) s_p = pt.z;
-        {
-            ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num);
-            for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) zn[i] = make_ulonglong2(0ull, 0ull);
-        }
-        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
-        if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
-        __syncthreads();
-        uint32_t old[VPT];                                                // the rows of a whole brick are requested now, used after the walk
-        if (!TEX && whole && s_p >= 0) {
-            const uint32_t* twr = M.tw + (size_t)s_p * TSL_BRK3;
-#pragma unroll
-            for (int q = 0; q < VPT; ++q) old[q] = twr[q * NT + threadIdx.x];
-        }
-        // counting sort of the part's segments by step count (descending) in LDS, then dealt out in alternating directions:
-        // the lanes of a wave walk segments of (almost) equal length and every thread gets about the same number of steps
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) {
-            const int i = q * NT + threadIdx.x;
-            rr[q] = -1;
-            if (i < nseg) rr[q] = atomicAdd(&s_bin[63 - (int)(kk[q] & 63ull)], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int c = s_bin[threadIdx.x];
-            int inc = c;
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }
-            s_bin[threadIdx.x] = inc - c;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) if (rr[q] >= 0) s_keys[s_bin[63 - (int)(kk[q] & 63ull)] + rr[q]] = kk[q];
-        __syncthreads();
-        uint4 recs[SPT]; uint32_t wids[SPT];
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) {                                   // dealt keys, then all ray records of this thread in flight at once
-            const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
-            if (i < nseg) {
-                kk[q] = s_keys[i];
-                const int r = (int)((kk[q] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
-                recs[q] = F.rayA[r];
-                wids[q] = TEX ? F.rayFirst[r] + 1u : 0u;
-            }
-        }
-        __syncthreads();                                                  // every thread holds its keys: the sort scratch becomes the {den} plane
-        {
-            ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
-            for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) zd[i] = make_ulonglong2(0ull, 0ull);
-        }
-        __syncthreads();
-        TSL_TICK(F, 1);
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) {
-            const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
-            if (i >= nseg) continue;
-            const unsigned long long key = kk[q];
-            const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
-            const RayRegs R = make_ray(recs[q], 0, P);
-            const uint32_t wid = wids[q];
-            // lanes start at different offsets inside their (equally long) segments: rays that enter a brick together -- all
-            // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration
-            int off = ((int)(threadIdx.x & 63u) * cnt) >> 6;
-            for (int t = 0; t < cnt; t += 2) {
-                const int ja = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
-                const int jb = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
-                int la, lb; float qa, qb;
-                step_eval<FASTDIV>(R, K, ja, &la, &qa);
-                step_eval<FASTDIV>(R, K, jb, &lb, &qb);
-                long long na = (long long)(int)qa, nb = (long long)(int)qb;
-                if (__builtin_expect(__any(!(fabsf(qa) < 2147483648.0f) || !(fabsf(qb) < 2147483648.0f)), 0)) { na = __float2ll_rn(qa); nb = __float2ll_rn(qb); }
-                atomicAdd(&s_num[la], (unsigned long long)na);
-                atomicAdd(&s_den[la], (unsigned long long)R.qden);
-                if (TEX) atomicMax(&s_win[la], wid);                                           // dense_tsdf.py:268-269, order-free winner
-                // the second step of an odd segment's last pair adds zeros to a voxel of the brick (no effect, no branch)
-                const bool vb = t + 1 < cnt;
-                atomicAdd(&s_num[lb], (unsigned long long)(vb ? nb : 0ll));
-                atomicAdd(&s_den[lb], (unsigned long long)(vb ? R.qden : 0ll));
-                if (TEX) atomicMax(&s_win[lb], vb ? wid : 0u);
-            }
-        }
-        TSL_TICK(F, 2);
-        __syncthreads();
-        TSL_TICK(F, 3);
-        const int p = s_p;
-        if (p >= 0 && whole) {
-            uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
-            int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-            if (TEX) {
-#pragma unroll
-                for (int q = 0; q < VPT; ++q) old[q] = tw[q * NT + threadIdx.x];
-            }
-#pragma unroll
-            for (int h = 0; h < VPT; h += CH) {                  // FLUSH_CHUNK voxels at a time, no branch between them
-                long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true;
-#pragma unroll
-                for (int q = 0; q < CH; ++q) { const int ls = acc_swz5((h + q) * NT + threadIdx.x); qn[q] = (long long)s_num[ls]; qd[q] = (long long)s_den[ls]; small = small && fits_i32(qn[q]) && fits_i32(qd[q]); }
-                apply_chunk<CH>(old + h, qn, qd, nv, __all(small));
-#pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const int l = (h + q) * NT + threadIdx.x;
-                    if (qd[q] != 0) {
-                        tw[l] = nv[q];
-                        if ((old[h + q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
-                        if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[acc_swz5(l)] - 1u];
-                        ++uniq;
-                    }
-                }
-            }
-        } else if (p >= 0) {
-            // brick split over `np` workgroups: add the partial sums into the brick's HBM scratch slab; the last workgroup
-            // to arrive (arrival ticket, agent-scope release/acquire) applies them and leaves the slab zeroed.
-            unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
-#pragma unroll
-            for (int q = 0; q < VPT; ++q) {
-                const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
-                const unsigned long long d = s_den[ls];
-                if (d != 0ull) {
-                    __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int tk = __hip_atomic_fetch_add(&F.ticket[rk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = (tk == np - 1) ? 1 : 0;
-                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); F.ticket[rk] = 0; }
-            }
-            __syncthreads();
-            if (s_last) {
-                ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
-                uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
-                int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-                // the sums were produced by L2 atomics of other CUs: read them at L2 as well, every load of this thread issued
-                // before the first one is used
-#pragma unroll
-                for (int h = 0; h < VPT; h += CH) {
-                    long long qn[CH], qd[CH]; uint32_t oldv[CH], nv[CH]; bool small = true;
-#pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int l = (h + q) * NT + threadIdx.x;
-                        qn[q] = (long long)__hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        qd[q] = (long long)__hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        oldv[q] = tw[l];
-                    }
-#pragma unroll
-                    for (int q = 0; q < CH; ++q) small = small && fits_i32(qn[q]) && fits_i32(qd[q]);
-                    apply_chunk<CH>(oldv, qn, qd, nv, __all(small));
-#pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int l = (h + q) * NT + threadIdx.x;
-                        if (qd[q] != 0) {
-                            tw[l] = nv[q];
-                            if ((oldv[q] >> 16) == 0u) obs[l] = 1;
-                            acc2[l] = make_ulonglong2(0ull, 0ull);
-                            if (TEX) {
-                                uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
-                                const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[wsel - 1u];
-                                *wv = 0u;
-                            }
-                            ++uniq;
-                        }
-                    }
-                }
-            }
-        }
-        TSL_TICK(F, 4);
-#ifdef TSL_TIMING
-        if (lane_id() == 0 && _wv < 16384) { F.dbg[_wv * 16 + 10] = nseg; F.dbg[_wv * 16 + 11] = whole; F.dbg[_wv * 16 + 12] = part; }
-#endif
-        __syncthreads();
-    }
-    uniq = wave_sum_ll(uniq);
-    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
-}
-
-
 // =====================================================================================================
-// k_integrate_bricks3: the same part arithmetic as k_integrate_bricks2, as a persistent, software-pipelined kernel.
+// k_integrate_bricks: the same part arithmetic as k_integrate_bricks2, as a persistent, software-pipelined kernel.
 // What bounded v2 was not the walk but the dependent device-memory round trips around it (part entry -> segment keys -> ray
 // records before, rows / stores after: 1-2 us each at 8 waves per CU) and the two dispatch rounds of ~670 parts on 512 slots.
 // Here 2 workgroups per CU stay resident and take parts in serpentine order over the cost-ordered part list (long, medium,
@@ -797,7 +585,7 @@ __device__ __forceinline__ int4 part_entry(const FrameDev& F, int rank, int nA, 
 __device__ __forceinline__ int serp_rank(int t, int w, int G) { return t * G + ((t & 1) ? G - 1 - w : w); }
 
 template <bool TEX, bool FASTDIV, int NT>
-__global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_bricks3(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+__global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
 {
     // NT threads walk a part in chunks of CSEGS = 4 * NT segments (4 per thread); a part may hold several chunks (k_plan's psegs), so
     // a brick with up to psegs segments is integrated by one workgroup and never merged through HBM.  NT = 256: two workgroups per CU;
@@ -874,6 +662,10 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
     for (;;) {
         TSL_TICK(F, 0);
         const int nseg_part = ptc.y & 0xffff, np = ptc.y >> 16, p = ptc.z, rk = ptc.w;
+#ifdef TSL_TIMING
+        long long* const _rec = F.dbg + 131072 + (size_t)blockIdx.x * 64 + (size_t)(t < 8 ? t : 7) * 8;
+        if (threadIdx.x == 0 && c == 0) { _rec[0] = wall_clock64(); _rec[1] = nseg_part; _rec[2] = np; }
+#endif
         const int nseg = min(CSEGS, nseg_part - c * CSEGS);
         const bool last = (c + 1) * CSEGS >= nseg_part;               // last chunk of the part: flush after the walk
         const bool whole = np == 1;
@@ -899,6 +691,9 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
         for (int q = 0; q < SPT; ++q) {
             const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
             if (i >= nseg) continue;
+#ifdef TSL_EXP_NOWALK
+            if (nseg >= 0) continue;
+#endif
             const unsigned long long key = kk[q];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
             const RayRegs R = make_ray(recs[q], 0, P);
@@ -927,6 +722,9 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
         TSL_TICK(F, 2);
         __syncthreads();
         TSL_TICK(F, 3);
+#ifdef TSL_TIMING
+        if (threadIdx.x == 0 && last) _rec[3] = wall_clock64();
+#endif
         // ---- the next chunk's keys are here: sort them and request its ray records, then flush under that latency ----
         if (has_next) TSL_SORT_DEAL(kn, nsegn)
         if (!last) { ++c; continue; }
@@ -961,7 +759,11 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
 #pragma unroll
             for (int q = 0; q < VPT; ++q) {
                 const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
+#ifdef TSL_EXP_NOSPLITFLUSH
+                const unsigned long long d = 0ull;
+#else
                 const unsigned long long d = s_den[ls];
+#endif
                 if (d != 0ull) {
                     __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1017,6 +819,7 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
         }
         TSL_TICK(F, 4);
 #ifdef TSL_TIMING
+        if (threadIdx.x == 0) _rec[4] = wall_clock64();
         if (lane_id() == 0 && _wv < 16384) { F.dbg[_wv * 16 + 10] = nseg_part; F.dbg[_wv * 16 + 11] = whole; F.dbg[_wv * 16 + 12] = t; }
 #endif
         if (!has_next) break;
@@ -1051,7 +854,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->kern == 2 ? m->chunks * (m->wg == 512 ? 2048 : 1024) : 1024);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024));
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;
@@ -1061,25 +864,15 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
 {
     FrameParams& P = m->P;
     FrameDev& F = S.F;
-    if (P.variant == 2 && m->kern == 2) {
+    if (P.variant == 2) {
         prof_begin(m, TSL_K_INTEGRATE);
         const FrameParams* Pd = (const FrameParams*)S.Pd;
         // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
-#define TSL_LAUNCH_IB3(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_bricks3<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, F, Pd); \
-                                      else hipLaunchKernelGGL((k_integrate_bricks3<TEXV, FD, 256>), dim3((TEXV ? 1 : 2) * m->ncu), dim3(256), 0, m->stream_, m->M, F, Pd); } while (0)
+#define TSL_LAUNCH_IB3(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_bricks<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, F, Pd); \
+                                      else hipLaunchKernelGGL((k_integrate_bricks<TEXV, FD, 256>), dim3((TEXV ? 1 : 2) * m->ncu), dim3(256), 0, m->stream_, m->M, F, Pd); } while (0)
         if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB3(true, true); else TSL_LAUNCH_IB3(true, false); }
         else { if (P.fastdiv) TSL_LAUNCH_IB3(false, true); else TSL_LAUNCH_IB3(false, false); }
 #undef TSL_LAUNCH_IB3
-        prof_end(m);
-    } else if (P.variant == 2) {
-        prof_begin(m, TSL_K_INTEGRATE);
-        const FrameParams* Pd = (const FrameParams*)S.Pd;
-#define TSL_LAUNCH_IB2(TEXV, FD, NTV) hipLaunchKernelGGL((k_integrate_bricks2<TEXV, FD, NTV>), dim3(1024), dim3(NTV), 0, m->stream_, m->M, F, Pd)
-#define TSL_LAUNCH_IB2_NT(TEXV, FD) TSL_LAUNCH_IB2(TEXV, FD, 256)
-        if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB2_NT(true, true); else TSL_LAUNCH_IB2_NT(true, false); }
-        else { if (P.fastdiv) TSL_LAUNCH_IB2_NT(false, true); else TSL_LAUNCH_IB2_NT(false, false); }
-#undef TSL_LAUNCH_IB2_NT
-#undef TSL_LAUNCH_IB2
         prof_end(m);
     } else {
         const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);

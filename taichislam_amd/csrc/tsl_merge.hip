@@ -1,0 +1,242 @@
+// tsl_merge.hip -- multi-GPU global-map merge: one submap collection per GPU, ONE exchange at merge time.
+// Replaces, for the swarm case, taichi_slam/mapping/submap_mapping.py:226-253 + taichi_slam/utils/communication.py:9-43 (submaps
+// shipped between agents as zlib'd numpy dicts over LCM, then fused by every agent, dense_tsdf.py:272-318) with an all-reduce of the
+// fusion's exact integer sums over RCCL / xGMI.
+//
+// Every rank splats its own submaps into the per-brick accumulators of its (reset) global map -- the same kernel as the single-GPU
+// fusion (tsl_fuse.hip): {sum w*t, sum w} in 2^-24 fixed point (int64) + contribution | occupancy counts (int32) per voxel of every
+// 16^3 brick it touches.  Only bricks travel:
+//     1. a byte mask over the brick grid (nb^3 bytes: 32 KiB for 512^3) is all-reduced (MAX)  -> the union of touched bricks,
+//     2. the union bricks are packed in ascending brick order (identical on every rank; bricks a rank did not touch are zeros),
+//     3. the packed int64 / int32 planes are all-reduced (SUM),
+//     4. every rank writes the same global TSDF from the sums.
+// Integer sums make the merged map independent of the number of ranks and of the reduction order: bit-identical to one GPU fusing
+// every submap (tests/test_merge_gpu.py).  RCCL is bound at run time (dlopen): the library has no link-time dependency on it, a caller
+// that has its own collective (torch.distributed, MPI) uses the step functions and runs the two reductions itself.
+#include "tsl_tsdf.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace tsl {
+
+struct PoseTab { const float* p; };
+int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst);          // tsl_fuse.hip
+
+// ---- kernels ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_merge_mask(MapDev G, int nused, uint8_t* mask)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < nused) mask[G.owner[p]] = 1;                       // global map: one submap slot, owner = brick id
+}
+
+// ascending list of the bricks whose mask byte is set: one workgroup, block-wide prefix sums over the brick grid (deterministic order)
+__global__ void __launch_bounds__(1024) k_merge_union(const uint8_t* mask, int nb3, int* list, int* count)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb3; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const bool on = b < nb3 && mask[b] != 0;
+        const unsigned long long m = __ballot(on);
+        const int wid = threadIdx.x >> 6;
+        if (lane_id() == 0) s_w[wid] = popc64(m);
+        __syncthreads();
+        int off = s_base + rank_below(m);
+        for (int q = 0; q < wid; ++q) off += s_w[q];
+        if (on) list[off] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) { int tot = 0; for (int q = 0; q < 16; ++q) tot += s_w[q]; s_base += tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = s_base;
+}
+
+// packed planes of the union bricks (this rank's sums, zeros for bricks it did not touch); the local accumulators go back to zero
+__global__ void __launch_bounds__(256) k_merge_pack(MapDev G, const int* list, int nunion, unsigned long long* acc, int* cnt,
+                                                    ulonglong2* pacc, int* pcnt)
+{
+    for (int u = blockIdx.x; u < nunion; u += gridDim.x) {
+        const int p = pool_lookup_ro(G, 0, list[u]);
+        ulonglong2* a = reinterpret_cast<ulonglong2*>(acc) + (size_t)(p < 0 ? 0 : p) * TSL_BRK3;
+        int* c = cnt + (size_t)(p < 0 ? 0 : p) * TSL_BRK3;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const size_t o = (size_t)u * TSL_BRK3 + l;
+            if (p >= 0) { pacc[o] = a[l]; pcnt[o] = c[l]; a[l] = make_ulonglong2(0ull, 0ull); c[l] = 0; }
+            else { pacc[o] = make_ulonglong2(0ull, 0ull); pcnt[o] = 0; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_merge_finish(MapDev G, const int* list, int nunion, const ulonglong2* pacc, const int* pcnt)
+{
+    __shared__ int s_p;
+    for (int u = blockIdx.x; u < nunion; u += gridDim.x) {
+        if (threadIdx.x == 0) s_p = pool_claim<false>(G, 0, list[u]);       // bricks only other ranks touched are allocated now
+        __syncthreads();
+        const int p = s_p;
+        if (p >= 0)
+            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+                const size_t o = (size_t)u * TSL_BRK3 + l;
+                const int c = pcnt[o];
+                if (c != 0) fuse_write_voxel(G, (size_t)p * TSL_BRK3 + l, (long long)pacc[o].x, (long long)pacc[o].y, c);
+            }
+        __syncthreads();
+    }
+}
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.h) return TSL_OK;
+    // a process that already carries an RCCL (torch ships one) keeps using that copy; otherwise ROCm's
+    const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }
+    for (const char* n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+    if (!h) { set_error(std::string("RCCL not found: ") + (dlerror() ? dlerror() : "")); return TSL_ERR_HIP; }
+    Rccl r; r.h = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) { set_error("RCCL: missing symbols"); return TSL_ERR_HIP; }
+    g_rccl = r;
+    return TSL_OK;
+}
+#define TSL_NCCL(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { \
+    tsl::set_error(std::string(#expr) + ": " + tsl::g_rccl.GetErrorString(_r)); return TSL_ERR_HIP; } } while (0)
+
+static int merge_state(tsl_tsdf* g)            // per-handle exchange scratch: mask, union list, counter
+{
+    if (g->mrg_mask) return TSL_OK;
+    int rc;
+    if ((rc = dev_alloc(g, (void**)&g->mrg_mask, (size_t)g->nb3, 0))) return rc;
+    if ((rc = dev_alloc(g, (void**)&g->mrg_list, sizeof(int) * (size_t)(g->nb3 + 4), 0))) return rc;
+    g->mrg_count = g->mrg_list + g->nb3;
+    return TSL_OK;
+}
+
+}  // namespace tsl
+
+struct tsl_comm { ncclComm_t comm; int nranks, rank, device; };
+
+using namespace tsl;
+
+extern "C" {
+
+// ---- step API -------------------------------------------------------------------------------------------------------------------------
+int tsl_tsdf_merge_begin(tsl_tsdf* g, tsl_tsdf* sub, void* mask_dev, int64_t mask_bytes)
+{
+    TSL_REQUIRE(g && sub && mask_dev, "merge_begin: null argument");
+    TSL_REQUIRE(g->cfg.is_global_map && g->device == sub->device, "merge_begin: destination must be a global map on the submaps' device");
+    TSL_REQUIRE(mask_bytes >= g->nb3, "merge_begin: the mask needs one byte per 16^3 brick of the global grid (tsl_tsdf_merge_mask_bytes)");
+    TSL_HIP(hipSetDevice(g->device));
+    int rc = merge_state(g); if (rc) return rc;
+    int ndst = 0;
+    if ((rc = fuse_splat_into_global(g, sub, &ndst))) return rc;
+    TSL_HIP(hipMemsetAsync(mask_dev, 0, (size_t)mask_bytes, ms(g)));
+    if (ndst > 0) hipLaunchKernelGGL(k_merge_mask, dim3((ndst + 255) / 256), dim3(256), 0, ms(g), g->M, ndst, (uint8_t*)mask_dev);
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(ms(g)));
+    g->mrg_nunion = -1;
+    return TSL_OK;
+}
+
+int tsl_tsdf_merge_mask_bytes(const tsl_tsdf* g, int64_t* n) { TSL_REQUIRE(g && n, "null"); *n = g->nb3; return TSL_OK; }
+
+int tsl_tsdf_merge_union(tsl_tsdf* g, const void* mask_dev, int32_t* nunion)
+{
+    TSL_REQUIRE(g && mask_dev && nunion, "merge_union: null argument"); TSL_REQUIRE(g->mrg_mask, "merge_union: call merge_begin first");
+    TSL_HIP(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_merge_union, dim3(1), dim3(1024), 0, ms(g), (const uint8_t*)mask_dev, g->nb3, g->mrg_list, g->mrg_count);
+    TSL_HIP(hipMemcpyAsync(&g->h_ints[25], g->mrg_count, sizeof(int), hipMemcpyDeviceToHost, ms(g)));
+    TSL_HIP(hipStreamSynchronize(ms(g)));
+    g->mrg_nunion = g->h_ints[25];
+    *nunion = g->mrg_nunion;
+    return TSL_OK;
+}
+
+int tsl_tsdf_merge_pack(tsl_tsdf* g, void* acc_dev, void* cnt_dev)
+{
+    TSL_REQUIRE(g && g->mrg_nunion >= 0, "merge_pack: call merge_union first");
+    TSL_REQUIRE(g->mrg_nunion == 0 || (acc_dev && cnt_dev), "merge_pack: null buffers");
+    TSL_HIP(hipSetDevice(g->device));
+    const int n = g->mrg_nunion;
+    if (n > 0) hipLaunchKernelGGL(k_merge_pack, dim3(n < 4096 ? n : 4096), dim3(256), 0, ms(g), g->M, g->mrg_list, n,
+                                  (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, (ulonglong2*)acc_dev, (int*)cnt_dev);
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(ms(g)));
+    return TSL_OK;
+}
+
+int tsl_tsdf_merge_finish(tsl_tsdf* g, const void* acc_dev, const void* cnt_dev)
+{
+    TSL_REQUIRE(g && g->mrg_nunion >= 0, "merge_finish: call merge_union / merge_pack first");
+    TSL_HIP(hipSetDevice(g->device));
+    const int n = g->mrg_nunion;
+    if (n > 0) hipLaunchKernelGGL(k_merge_finish, dim3(n < 4096 ? n : 4096), dim3(256), 0, ms(g), g->M, g->mrg_list, n, (const ulonglong2*)acc_dev, (const int*)cnt_dev);
+    TSL_HIP(hipGetLastError());
+    g->mrg_nunion = -1;
+    return tsl_tsdf_sync(g);                        // reports an exhausted brick pool of the global map
+}
+
+// ---- communicator + one-call form ---------------------------------------------------------------------------------------------------------
+int tsl_comm_unique_id(char id[128])
+{
+    TSL_REQUIRE(id, "comm_unique_id: null"); int rc = rccl_load(); if (rc) return rc;
+    ncclUniqueId u; TSL_NCCL(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, u.internal, 128);
+    return TSL_OK;
+}
+int tsl_comm_create(const char id[128], int nranks, int rank, int device, tsl_comm** out)
+{
+    TSL_REQUIRE(id && out && nranks >= 1 && rank >= 0 && rank < nranks, "comm_create: bad argument"); int rc = rccl_load(); if (rc) return rc;
+    TSL_HIP(hipSetDevice(device));
+    ncclUniqueId u; std::memcpy(u.internal, id, 128);
+    ncclComm_t c = nullptr;
+    TSL_NCCL(g_rccl.CommInitRank(&c, nranks, u, rank));
+    *out = new tsl_comm{ c, nranks, rank, device };
+    return TSL_OK;
+}
+void tsl_comm_destroy(tsl_comm* c) { if (!c) return; if (g_rccl.CommDestroy && c->comm) (void)g_rccl.CommDestroy(c->comm); delete c; }
+void* tsl_comm_handle(tsl_comm* c) { return c ? (void*)c->comm : nullptr; }
+
+int tsl_tsdf_allreduce_merge(tsl_tsdf* g, tsl_tsdf* sub, void* rccl_comm, int64_t* bytes_per_rank)
+{
+    TSL_REQUIRE(g && sub, "allreduce_merge: null handle");
+    TSL_HIP(hipSetDevice(g->device));
+    int rc = merge_state(g); if (rc) return rc;
+    if (rccl_comm) { rc = rccl_load(); if (rc) return rc; }
+    ncclComm_t comm = (ncclComm_t)rccl_comm;
+    if ((rc = tsl_tsdf_merge_begin(g, sub, g->mrg_mask, g->nb3))) return rc;
+    hipStream_t st = ms(g);
+    int64_t bytes = 0;
+    if (comm) { TSL_NCCL(g_rccl.AllReduce(g->mrg_mask, g->mrg_mask, (size_t)g->nb3, ncclUint8, ncclMax, comm, st)); bytes += g->nb3; }
+    int32_t n = 0;
+    if ((rc = tsl_tsdf_merge_union(g, g->mrg_mask, &n))) return rc;
+    const size_t nv = (size_t)n * TSL_BRK3;
+    if ((rc = grow(&g->mrg_pacc, &g->mrg_pacc_bytes, nv * 16 + 16))) return rc;
+    if ((rc = grow(&g->mrg_pcnt, &g->mrg_pcnt_bytes, nv * 4 + 16))) return rc;
+    if ((rc = tsl_tsdf_merge_pack(g, g->mrg_pacc, g->mrg_pcnt))) return rc;
+    if (comm && n > 0) {
+        TSL_NCCL(g_rccl.AllReduce(g->mrg_pacc, g->mrg_pacc, nv * 2, ncclInt64, ncclSum, comm, st));
+        TSL_NCCL(g_rccl.AllReduce(g->mrg_pcnt, g->mrg_pcnt, nv, ncclInt32, ncclSum, comm, st));
+        bytes += (int64_t)nv * 20;
+    }
+    if (bytes_per_rank) *bytes_per_rank = bytes;
+    return tsl_tsdf_merge_finish(g, g->mrg_pacc, g->mrg_pcnt);
+}
+
+}  // extern "C"

@@ -252,14 +252,38 @@ class DenseTSDF(BaseMap):
         print(f"[DenseTSDF] Fuse submaps {(time.time() - t) * 1000:.1f}ms, active local: "
               f"{submaps.active_submap_id[None]} remote: {submaps.remote_submap_num[None]}")
 
-    def fuse_accumulate(self, submaps, acc, cnt):
-        """Multi-GPU merge, step 1: splat `submaps` into the dense accumulators (torch CUDA tensors: acc int64 [N*N*Nz,2],
-        cnt int32 [N*N*Nz]); see taichislam_amd.distributed.allreduce_merge."""
-        _lib.check(self.L.tsl_tsdf_fuse_accumulate_dev(self.h, submaps.h, C.c_void_p(acc.data_ptr()), C.c_void_p(cnt.data_ptr())))
+    # multi-GPU merge (include/taichislam_hip.h; taichislam_amd.distributed.allreduce_merge drives these)
+    def allreduce_merge(self, submaps, comm=None):
+        """One native call: splat `submaps`, all-reduce over `comm` (taichislam_amd.distributed.Communicator, None = this rank
+        alone), finalise.  Returns the bytes all-reduced."""
+        n = C.c_int64()
+        _lib.check(self.L.tsl_tsdf_allreduce_merge(self.h, submaps.h, comm.handle if comm is not None else None, C.byref(n)))
+        return n.value
 
-    def fuse_finalize(self, acc, cnt):
-        """Multi-GPU merge, step 3: rebuild this global map from the (all-reduced) accumulators."""
-        _lib.check(self.L.tsl_tsdf_fuse_finalize_dev(self.h, C.c_void_p(acc.data_ptr()), C.c_void_p(cnt.data_ptr())))
+    def merge_begin(self, submaps):
+        """Step 1: reset this global map, splat `submaps` into the per-brick sums; returns the touched-brick byte mask (torch CUDA)."""
+        import torch
+        nb = C.c_int64()
+        self._call("merge_mask_bytes", C.byref(nb))
+        mask = torch.zeros(nb.value, dtype=torch.uint8, device=f"cuda:{self.device}")
+        torch.cuda.current_stream(mask.device).synchronize()
+        _lib.check(self.L.tsl_tsdf_merge_begin(self.h, submaps.h, C.c_void_p(mask.data_ptr()), nb.value))
+        return mask
+
+    def merge_pack(self, mask):
+        """Step 2 (after the MAX all-reduce of the mask): packed sums of the union bricks, (int64 [n,4096,2], int32 [n,4096])."""
+        import torch
+        n = C.c_int32()
+        self._call("merge_union", C.c_void_p(mask.data_ptr()), C.byref(n))
+        acc = torch.empty((n.value, 4096, 2), dtype=torch.int64, device=mask.device)
+        cnt = torch.empty((n.value, 4096), dtype=torch.int32, device=mask.device)
+        torch.cuda.current_stream(mask.device).synchronize()
+        self._call("merge_pack", C.c_void_p(acc.data_ptr()) if n.value else None, C.c_void_p(cnt.data_ptr()) if n.value else None)
+        return acc, cnt
+
+    def merge_finish(self, acc, cnt):
+        """Step 3 (after the SUM all-reduce of both): write the global map."""
+        self._call("merge_finish", C.c_void_p(acc.data_ptr()) if len(acc) else None, C.c_void_p(cnt.data_ptr()) if len(cnt) else None)
 
     # ---- visualisation exports (dense_tsdf.py:320-404) --------------------------------------------------------------
     def cvt_occupy_to_voxels(self):

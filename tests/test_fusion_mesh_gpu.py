@@ -121,35 +121,6 @@ def test_fuse_submaps_bit_exact(hip_lib):
     assert np.array_equal(eg2["indices"], eg["indices"]) and np.array_equal(eg2["W_TSDF"], eg["W_TSDF"])
 
 
-def test_fuse_dense_accumulate_matches_direct(hip_lib):
-    """The multi-GPU merge form: splat into dense int64 accumulators, (all-reduce), finalise == direct fusion."""
-    import ctypes as C
-    import torch
-    from taichislam_amd import _lib
-    from taichislam_amd.mapping import DenseTSDF
-    K, frames = small_stream(4)
-    cfg = dict(SMALL, map_scale=[5.12, 5.12], max_submap_num=8)
-    gs, _ = _two_submap_collection(cfg, K, frames)
-    gcfg = dict(cfg, is_global_map=True)
-    direct, dense = DenseTSDF(**gcfg), DenseTSDF(**gcfg)
-    for m in (direct, dense):
-        for sid, f in ((0, 0), (1, 2)):
-            m.set_base_pose_submap(sid, frames[f][0], frames[f][1])
-    direct.fuse_submaps(gs)
-    nvox = dense.N * dense.N * dense.Nz
-    acc = torch.zeros((nvox, 2), dtype=torch.int64, device="cuda")
-    cnt = torch.zeros(nvox, dtype=torch.int32, device="cuda")
-    L = _lib.lib()
-    _lib.check(L.tsl_tsdf_fuse_accumulate_dev(dense.h, gs.h, C.c_void_p(acc.data_ptr()), C.c_void_p(cnt.data_ptr())))
-    # splitting the work in two halves and summing is what the all-reduce does
-    acc2, cnt2 = acc.clone(), cnt.clone()
-    _lib.check(L.tsl_tsdf_fuse_finalize_dev(dense.h, C.c_void_p(acc2.data_ptr()), C.c_void_p(cnt2.data_ptr())))
-    a, b = sort_export(direct.export_submap()), sort_export(dense.export_submap())
-    assert np.array_equal(a["indices"], b["indices"]) and a["indices"].shape[0] > 10000
-    ok = ~np.isnan(a["TSDF"].view(np.float16))
-    assert np.array_equal(a["TSDF"][ok], b["TSDF"][ok]) and np.array_equal(a["W_TSDF"], b["W_TSDF"]) and np.array_equal(a["occupy"], b["occupy"])
-
-
 def test_submap_mapping_orchestration(hip_lib):
     """SubmapMapping (submap_mapping.py:126-181): keyframe-stepped submaps, local_to_global fusion, wire format."""
     from taichislam_amd.mapping import DenseTSDF, SubmapMapping
@@ -176,31 +147,3 @@ def test_submap_mapping_orchestration(hip_lib):
     assert other.submap_collection.remote_submap_num[None] == 1 and other.global_map.count_active() > 1000
 
 
-def test_brick_sparse_exchange_round_trip_on_device(hip_lib):
-    """The packing / unpacking of the touched bricks around the RCCL all-reduce (taichislam_amd.distributed) on CUDA tensors: with a
-    one-rank nccl group the exchange must leave the accumulators unchanged and move only the touched bricks."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from taichislam_amd import distributed as D
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        N = Nz = 128
-        g = torch.Generator(device="cuda").manual_seed(3)
-        acc = torch.zeros((N * N * Nz, 2), dtype=torch.int64, device="cuda")
-        cnt = torch.zeros(N * N * Nz, dtype=torch.int32, device="cuda")
-        vox = torch.randint(0, 40 * 40 * 40, (5000,), generator=g, device="cuda")
-        i, j, k = vox // 1600 + 20, (vox // 40) % 40 + 50, vox % 40 + 70                 # a 40^3 blob: 3x3x4 bricks at most
-        lin = (i * N + j) * Nz + k
-        acc[lin, 0] = torch.randint(-2 ** 40, 2 ** 40, (5000,), generator=g, device="cuda")
-        acc[lin, 1] = torch.randint(1, 2 ** 30, (5000,), generator=g, device="cuda")
-        cnt[lin] = 1
-        a0, c0 = acc.clone(), cnt.clone()
-        nbytes = D._brick_exchange(acc, cnt, N, Nz, None)
-        torch.cuda.synchronize()
-        assert torch.equal(acc, a0) and torch.equal(cnt, c0)
-        nb = int(torch.unique(((i // 16) * 8 + j // 16) * 8 + k // 16).numel())
-        assert nbytes == 8 * 8 * 8 + nb * 4096 * 20
-    finally:
-        dist.destroy_process_group()

@@ -1,0 +1,148 @@
+"""GPU tests of the multi-GPU global-map merge (csrc/tsl_merge.hip, taichislam_amd.distributed) on real DenseTSDF handles.
+
+Reference role: taichi_slam/mapping/submap_mapping.py:157-160,226-253 + dense_tsdf.py:272-318 (every agent fuses every agent's
+submaps).  Claim under test: the merged map is bit-identical to ONE process fusing all submaps -- for one rank, for two ranks
+simulated inside one process, for the library's own RCCL communicator, and for two real processes sharing this GPU over gloo
+(RCCL refuses two ranks on one device; the driver's 8-GPU run exercises the nccl path through bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from taichislam_amd.utils import synthetic as syn
+from util import SMALL, sort_export
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(SMALL, map_scale=[5.12, 5.12], max_submap_num=8)
+H, W, FRAMES_PER_RANK = 120, 160, 2
+
+
+def _rank_stream(rank):
+    from taichislam_amd import distributed as D
+    K = syn.scaled_intrinsics(H, W)
+    out = []
+    for f in range(FRAMES_PER_RANK):
+        R, T = syn.camera_pose(f, start_deg=D.stream_start_deg(rank) * 0.5)      # 22.5 degrees apart: heavily overlapping submaps
+        out.append((R, T, syn.sphere_room_depth(R, T, H, W, K=K)))
+    return K, out
+
+
+def _rank_submaps(rank, device=0):
+    """Rank r integrates its stream into submap id r of its own collection (base pose = its first camera pose)."""
+    from taichislam_amd.mapping import DenseTSDF
+    K, fr = _rank_stream(rank)
+    sub = DenseTSDF(**CFG, device=device)
+    sub.set_dep_camera_intrinsic(K)
+    sub.active_submap_id[None] = rank
+    sub.set_base_pose_submap(rank, fr[0][0], fr[0][1])
+    for R, T, d in fr:
+        sub.recast_depth_to_map(R, T, d, None)
+    sub.active_submap_id[None] = rank + 1                 # closed, as create_new_submap would
+    return sub
+
+
+def _global(world, device=0):
+    from taichislam_amd.mapping import DenseTSDF
+    g = DenseTSDF(**dict(CFG, is_global_map=True), device=device)
+    for r in range(world):
+        _, fr = _rank_stream(r)
+        g.set_base_pose_submap(r, fr[0][0], fr[0][1])
+    return g
+
+
+def _single_process_reference(world):
+    """One collection holding every rank's submap, fused directly (dense_tsdf.py:312-318)."""
+    from taichislam_amd.mapping import DenseTSDF
+    both = DenseTSDF(**CFG)
+    for r in range(world):
+        K, fr = _rank_stream(r)
+        both.set_dep_camera_intrinsic(K)
+        both.active_submap_id[None] = r
+        both.set_base_pose_submap(r, fr[0][0], fr[0][1])
+        for R, T, d in fr:
+            both.recast_depth_to_map(R, T, d, None)
+    both.active_submap_id[None] = world
+    g = _global(world)
+    g.fuse_submaps(both)
+    return sort_export(g.export_submap())
+
+
+def _assert_same(a, b, what):
+    assert a["indices"].shape == b["indices"].shape and np.array_equal(a["indices"], b["indices"]), f"{what}: voxel sets differ"
+    ok = ~np.isnan(a["TSDF"].view(np.float16))
+    assert np.array_equal(a["TSDF"][ok], b["TSDF"][ok]) and np.array_equal(a["W_TSDF"], b["W_TSDF"]) and np.array_equal(a["occupy"], b["occupy"]), what
+
+
+def test_one_rank_merge_equals_fuse_submaps(hip_lib):
+    from taichislam_amd import distributed as D
+    ref = _single_process_reference(1)
+    assert ref["indices"].shape[0] > 50000
+    sub = _rank_submaps(0)
+    g = _global(1)
+    assert g.allreduce_merge(sub, None) == 0                       # native one-call form, no communicator: nothing travels
+    _assert_same(sort_export(g.export_submap()), ref, "native, one rank")
+    g2 = _global(1)
+    assert D.allreduce_merge(g2, sub) == 0                          # step protocol, no process group
+    _assert_same(sort_export(g2.export_submap()), ref, "steps, one rank")
+    g2.allreduce_merge(sub, None)                                   # merging again rebuilds the same map (accumulators were left at zero)
+    _assert_same(sort_export(g2.export_submap()), ref, "second merge")
+
+
+def test_two_ranks_simulated_in_one_process(hip_lib):
+    """The step protocol with the two reductions done by hand (torch.maximum / add): exactly what the all-reduces compute."""
+    import torch
+    ref = _single_process_reference(2)
+    subs = [_rank_submaps(r) for r in range(2)]
+    gs = [_global(2) for _ in range(2)]
+    masks = [g.merge_begin(s) for g, s in zip(gs, subs)]
+    assert not torch.equal(masks[0], masks[1])                      # the ranks touch different brick sets
+    m = torch.maximum(masks[0], masks[1])
+    packs = [g.merge_pack(m) for g in gs]
+    assert packs[0][0].shape == packs[1][0].shape and packs[0][0].shape[0] == int(m.sum())
+    acc, cnt = packs[0][0] + packs[1][0], packs[0][1] + packs[1][1]
+    torch.cuda.synchronize()
+    for g in gs:
+        g.merge_finish(acc, cnt)
+        _assert_same(sort_export(g.export_submap()), ref, "two simulated ranks")
+
+
+def test_native_rccl_communicator_world_1(hip_lib):
+    """tsl_comm_* + tsl_tsdf_allreduce_merge on a one-rank RCCL communicator created by the library itself."""
+    from taichislam_amd import distributed as D
+    ref = _single_process_reference(1)
+    comm = D.Communicator(D.Communicator.unique_id(), 1, 0, device=0)
+    sub, g = _rank_submaps(0), _global(1)
+    nbytes = D.allreduce_merge(g, sub, comm=comm)
+    assert nbytes > 32 * 32 * 32 // 64 and nbytes % 20 in (0, (g.N // 16) ** 2 * (g.Nz // 16) % 20)
+    _assert_same(sort_export(g.export_submap()), ref, "RCCL world 1")
+    comm.close()
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from taichislam_amd import distributed as D
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sub, g = _rank_submaps(rank), _global(world)
+    nbytes = D.allreduce_merge(g, sub)                              # CUDA tensors through gloo: real HIP handles, real 2-rank reductions
+    e = sort_export(g.export_submap())
+    np.savez(os.path.join(out, f"rank{rank}.npz"), indices=e["indices"], TSDF=e["TSDF"], W_TSDF=e["W_TSDF"], occupy=e["occupy"], nbytes=nbytes)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_over_gloo(hip_lib, tmp_path):
+    import torch.multiprocessing as mp
+    ref = _single_process_reference(2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    _assert_same(dict(r0), ref, "rank 0 vs single process")
+    _assert_same(dict(r1), ref, "rank 1 vs single process")
+    nvox_dense = (512 // 4) ** 3 * 20
+    assert int(r0["nbytes"]) == int(r1["nbytes"]) and 0 < int(r0["nbytes"]) < nvox_dense // 2

@@ -43,13 +43,16 @@ def test_kernel_variants_agree(hip_lib, variant, split):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"variant {variant} split {split}")
 
 
-@pytest.mark.parametrize("kern", [1, 2])
-def test_integrate_kernel_generations(hip_lib, kern):
+@pytest.mark.parametrize("wg,chunks", [(256, 1), (256, 2), (256, 8), (512, 1), (512, 3)])
+def test_integrate_workgroup_and_part_sizes(hip_lib, wg, chunks):
+    """The brick kernel's geometry (threads per workgroup, chunks per part: which bricks are split over workgroups and merged through
+    HBM) must not show in the result."""
     K, frames = small_stream(2)
     g, o = make_pair(SMALL, K)
-    g.set_option("kern", kern)
+    g.set_option("wg", wg)
+    g.set_option("chunks", chunks)
     _run_both(g, o, frames)
-    assert_export_equal(g.export_submap(), o.export_sparse(), f"brick kernel {kern}")
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} chunks {chunks}")
 
 
 @pytest.mark.parametrize("which", [0, 1])

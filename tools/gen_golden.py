@@ -54,5 +54,40 @@ def main():
     print("wrote tests/golden/tsdf_small.npz:", e["TSDF"].shape[0], "voxels,", ntri, "triangles,", li.shape[0], "octomap leaves")
 
 
+C2 = dict(map_scale=[10.24, 10.24], voxel_scale=0.02, num_voxel_per_blk_axis=16, max_ray_length=5.0, min_ray_length=0.3,
+          internal_voxels=10, recast_step=2)
+C2_FRAMES, C2_STRIDE = 2, 64
+
+
+def digest_export(e):
+    """Order-independent digest of a sparse export: SHA-256 of the index / TSDF / W / occupancy arrays sorted by voxel index, the
+    voxel count, and every C2_STRIDE-th voxel in full (so a mismatch can be located)."""
+    import hashlib
+    order = np.argsort(lin(e["indices"]), kind="stable")
+    idx = np.ascontiguousarray(e["indices"][order]); t = np.ascontiguousarray(np.asarray(e["TSDF"]).view(np.uint16)[order])
+    w = np.ascontiguousarray(np.asarray(e["W_TSDF"]).view(np.uint16)[order]); occ = np.ascontiguousarray(e["occupy"][order])
+    sha = lambda a: hashlib.sha256(a.tobytes()).hexdigest()
+    return {"n": np.int64(idx.shape[0]), "sha_idx": sha(idx), "sha_tsdf": sha(t), "sha_w": sha(w), "sha_occ": sha(occ),
+            "s_idx": idx[::C2_STRIDE], "s_tsdf": t[::C2_STRIDE], "s_w": w[::C2_STRIDE], "s_occ": occ[::C2_STRIDE]}
+
+
+def main_c2():
+    """BASELINE configs[1] at full size (640x480 -> 512^3 / 2 cm), two frames, both oracle modes, as digests + a 1/64 sample."""
+    from oracle import FAITHFUL
+    fr = list(syn.sphere_room_stream(C2_FRAMES))
+    out = {}
+    for name, mode in (("batched", BATCHED), ("faithful", FAITHFUL)):
+        o = OracleTSDF(**C2)
+        o.set_intrinsics(syn.K_DEPTH)
+        stats = [o.integrate_depth(R, T, d, mode=mode) for R, T, d in fr]
+        for k, v in digest_export(o.export_sparse()).items():
+            out[f"{name}_{k}"] = v
+        out[f"{name}_stats"] = np.array([[s[k] for k in sorted(s)] for s in stats], np.int64)
+    out["stat_keys"] = np.array(sorted(stats[0]))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "tsdf_c2_digest.npz"), **out)
+    print("wrote tests/golden/tsdf_c2_digest.npz:", int(out["batched_n"]), "voxels")
+
+
 if __name__ == "__main__":
     main()
+    main_c2()
