@@ -64,7 +64,7 @@ typedef struct {
 
 /* kernel ids for tsl_tsdf_prof_query */
 enum { TSL_K_VOXELIZE = 0, TSL_K_SORT = 1, TSL_K_RAYS = 2, TSL_K_INTEGRATE = 3, TSL_K_FINALIZE = 4,
-       TSL_K_MESH = 5, TSL_K_SEGMENTS = 6, TSL_K_BIN = 7, TSL_K_COUNT };
+       TSL_K_MESH = 5, TSL_K_SEGMENTS = 6, TSL_K_BIN = 7, TSL_K_ESDF = 8, TSL_K_FUSE = 9, TSL_K_COUNT };
 
 const char* tsl_version(void);
 const char* tsl_last_error(void);
@@ -132,6 +132,11 @@ int  tsl_tsdf_surface_voxels(tsl_tsdf* m, tsl_tsdf* dst /* NULL = m itself */, i
 int  tsl_tsdf_slice_voxels(tsl_tsdf* m, float z, float dz, int clear_last, int32_t* n);
 /* read back export_TSDF_xyz / export_color / export_TSDF (any may be NULL), rows [0, n) */
 int  tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64_t n);
+/* export_TSDF_xyz[row] = v (field 0) / export_color[row] = v (field 1): callers append marker points to the particle list (tests/gen_topo_graph.py:64-65) */
+int  tsl_tsdf_set_export_row(tsl_tsdf* m, int field, int64_t row, const float v[3]);
+/* the first n exported particles as the data block of a sensor_msgs/PointCloud2: interleaved float32 rows x y z [r g b], point_step 12 / 24
+ * (what utils/ros_pcl_transfer.py:96-136 builds from the numpy copies, scripts/taichislam_node.py:420-425) -- interleaved on the device */
+int  tsl_tsdf_pack_pointcloud2(tsl_tsdf* m, int has_rgb, int64_t n, void* out_host);
 int  tsl_tsdf_num_particles(tsl_tsdf* m, int32_t* n);
 int  tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n);
 
@@ -176,8 +181,24 @@ int  tsl_tsdf_query_points(tsl_tsdf* m, int mode, int param, const float* xyz, i
 /* raycast(pos, dir, max_dist) per query: hit flag, last evaluated position, length travelled */
 int  tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, float max_dist, int64_t n, uint8_t* hit, float* end_xyz, float* len);
 
-/* ---- ESDF  (dense_esdf.py:228-333, see DESIGN.md for the definition used) ------------------------ */
-int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters);
+/* ---- ESDF  (dense_esdf.py:228-333 as the definition) -----------------------------------------------------------------
+ * |TSDF| < gamma: ESDF = TSDF; elsewhere the 26-neighbour quasi-Euclidean distance (edge cost |dir| * voxel) to that band along voxels
+ * of the same sign, capped at max_dist.  tsl_esdf_update is INCREMENTAL: the integrate kernels mark the bricks they write, an update
+ * re-initialises and relaxes only those bricks dilated by max_dist (device-side work lists, one host synchronisation at the end) and
+ * yields exactly the map a full recompute yields.  The first update, one after reset / import / fusion or with other parameters, and
+ * every update when option "esdf_full" is set, covers all bricks.  n_relaxed (nullable) = brick relaxations performed. */
+typedef struct {
+    int32_t incremental;         /* 0: all bricks were recomputed */
+    int32_t dirty_bricks;        /* bricks written since the previous update */
+    int32_t region_bricks;       /* bricks re-initialised and relaxed (dirty bricks dilated by max_dist) */
+    int32_t total_bricks;        /* bricks of the handle */
+    int64_t brick_relaxations;   /* LDS relaxations run (a brick is revisited when its surroundings change) */
+    int64_t voxel_pushes;        /* active voxels expanded */
+    int32_t rounds, max_passes;  /* relaxation rounds that had work; most LDS passes one brick relaxation needed */
+    int64_t passes;              /* LDS passes over all brick relaxations */
+} tsl_esdf_stats;
+int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed);
+int  tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out);
 int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);
 
 /* backend knobs for A/B-ing kernel variants: name in
@@ -189,6 +210,8 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
                 512 (chunks of 2048, one workgroup per CU)
      "chunks"   chunks a part may hold (1..8, default 1): a brick with up to chunks x chunk-size segments is integrated by one
                 workgroup and never merged through HBM
+     "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
+     "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)
      "fastdiv"  0 = force IEEE division
      "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);

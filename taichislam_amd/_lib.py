@@ -6,9 +6,9 @@ import os
 from . import build as _build
 
 TSL_OK = 0
-K_VOXELIZE, K_SORT, K_RAYS, K_INTEGRATE, K_FINALIZE, K_MESH, K_SEGMENTS, K_BIN = range(8)
+K_VOXELIZE, K_SORT, K_RAYS, K_INTEGRATE, K_FINALIZE, K_MESH, K_SEGMENTS, K_BIN, K_ESDF, K_FUSE = range(10)
 KERNEL_NAMES = {K_VOXELIZE: "voxelize", K_SORT: "sort", K_RAYS: "build_rays", K_INTEGRATE: "integrate",
-                K_FINALIZE: "finalize", K_MESH: "marching_cubes", K_SEGMENTS: "segments", K_BIN: "bin"}
+                K_FINALIZE: "finalize", K_MESH: "marching_cubes", K_SEGMENTS: "segments", K_BIN: "bin", K_ESDF: "esdf", K_FUSE: "fuse"}
 
 
 class TsdfCfg(C.Structure):
@@ -32,6 +32,14 @@ class OctoCfg(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("p_used", "p_valid", "p_oob", "v_pcl", "v_skipped", "steps",
                                           "steps_oob", "unique", "bricks")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class EsdfStats(C.Structure):
+    _fields_ = [("incremental", C.c_int32), ("dirty_bricks", C.c_int32), ("region_bricks", C.c_int32), ("total_bricks", C.c_int32),
+                ("brick_relaxations", C.c_int64), ("voxel_pushes", C.c_int64), ("rounds", C.c_int32), ("max_passes", C.c_int32), ("passes", C.c_int64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -80,6 +88,8 @@ SIGNATURES = {
     "tsl_tsdf_surface_voxels": (C.c_int, [vp, vp, C.c_int, pi32]),
     "tsl_tsdf_slice_voxels": (C.c_int, [vp, f32, f32, C.c_int, pi32]),
     "tsl_tsdf_read_exports": (C.c_int, [vp, vp, vp, vp, i64]),
+    "tsl_tsdf_set_export_row": (C.c_int, [vp, C.c_int, i64, vp]),
+    "tsl_tsdf_pack_pointcloud2": (C.c_int, [vp, C.c_int, i64, vp]),
     "tsl_tsdf_num_particles": (C.c_int, [vp, pi32]),
     "tsl_tsdf_set_num_particles": (C.c_int, [vp, i32]),
     "tsl_tsdf_fuse_submaps": (C.c_int, [vp, vp]),
@@ -98,6 +108,7 @@ SIGNATURES = {
     "tsl_tsdf_query_points": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp]),
     "tsl_tsdf_query_raycast": (C.c_int, [vp, vp, vp, f32, i64, vp, vp, vp]),
     "tsl_esdf_update": (C.c_int, [vp, f32, f32, pi32]),
+    "tsl_esdf_last_stats": (C.c_int, [vp, C.POINTER(EsdfStats)]),
     "tsl_esdf_export": (C.c_int, [vp, vp, vp, i64, pi64]),
     "tsl_tsdf_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "tsl_tsdf_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),

@@ -236,6 +236,7 @@ struct MapDev {
     int8_t* occ;               // [max_bricks][4096]
     uint16_t* col;             // [max_bricks][4096][4] f16 rgb (+pad) or nullptr
     int* owner;                // [max_bricks] -> s*nb3 + b
+    uint8_t* touch;            // [max_bricks] set by the integrate kernels when they write a brick's TSDF (consumed by the incremental ESDF)
     int* pool_top;             // bricks handed out so far
     int* err;                  // sticky device error flags (bit0: brick pool full, bit1: frame scratch full)
 };

@@ -1,89 +1,239 @@
-// tsl_esdf.hip -- ESDF of the active submap from its TSDF.
+// tsl_esdf.hip -- incremental ESDF of the active submap from its TSDF.
 //
-// The reference's ESDF (taichi_slam/mapping/dense_esdf.py:228-333, reference root) is a legacy module that cannot be
-// constructed at HEAD and whose queue propagation is incomplete; it serves as the DEFINITION only:
-//   * voxels with |TSDF| < gamma are "fixed": ESDF := TSDF                                   (:228-230, :313-317)
-//   * every other observed voxel starts at sign(TSDF)*max_dist                              (:325, :329)
-//   * distances are lowered in magnitude through the 26-neighbourhood, edge cost |dir|*voxel (:282-297), only between
-//     voxels on the same side of the surface (:289, :295).
-// The fixed point of that relaxation is unique, so instead of the reference's two serial queues every brick (16^3 + halo)
-// is staged in LDS and relaxed there for several sweeps per launch; launches repeat until no brick changes.
+// The reference's ESDF (taichi_slam/mapping/dense_esdf.py:228-333, reference root) is a legacy module that cannot be constructed at
+// HEAD and whose queue propagation is incomplete; it serves as the DEFINITION:
+//   * voxels with |TSDF| < gamma are "fixed": ESDF := TSDF                                                    (:228-230, :313-317)
+//   * every other observed voxel starts at sign(TSDF) * max_dist                                              (:325, :329)
+//   * magnitudes are lowered through the 26-neighbourhood, edge cost |dir| * voxel (:282-297), only between voxels on the same side
+//     of the surface (:289, :295); the per-frame hook (:400-402) only revisits what the frame changed ("updated_TSDF", raise / lower
+//     queues :100-102, :255-333).
+// The least fixed point of that relaxation is unique, which is what makes an incremental update checkable: it must equal the full
+// recompute bit for bit (tests/test_esdf_gpu.py does so after every frame of a stream).
+//
+// Incremental update.  Every kernel that writes TSDF values marks the brick in MapDev.touch.  An update
+//   1. collects the marked ("dirty") bricks of the active submap,
+//   2. dilates them by ceil(max_dist / 16 voxels) bricks -> region R.  A voxel outside R is farther than max_dist (Chebyshev, hence
+//      in path cost) from every changed voxel, so neither its value nor any path that determines it can involve one: it keeps its
+//      value and serves as a boundary condition,
+//   3. re-initialises R (flags from the current TSDF; band := |TSDF|, the rest := max_dist -- this is what lets values RISE),
+//   4. relaxes R in rounds.  A round stages every brick on its work list in LDS with its one-voxel halo (18^3 values + flags) and runs a
+//      push relaxation driven by per-voxel active bits -- band voxels (first visit) and halo voxels push, a voxel that improves becomes
+//      active -- so the work follows the wavefront instead of sweeping 4096 voxels x 26 neighbours per pass.  A brick whose boundary
+//      layer improved puts the neighbours that see it on the next round's list (device-side, deduplicated).  Rounds are plain launches on
+//      the handle's stream; the host launches a batch sized by max_dist, synchronises ONCE and reads the counters.
+//      (A single persistent kernel with an asynchronous brick queue was tried first: exact, but with no ordering between bricks each was
+//      relaxed ~23 times -- 5.2 ms per update at 512^3.  Rounds keep the wavefront order: ~2-3 relaxations per brick.)
+// The first update, an update after reset() / import / fusion, or one with different parameters is the same procedure with R = all bricks.
 #include "tsl_tsdf.hpp"
 
 namespace tsl {
 
 #define ESDF_T 18
 #define ESDF_T3 (ESDF_T * ESDF_T * ESDF_T)
+#define EF_NODE 1
+#define EF_NEG 2
+#define EF_FIXED 4
 
-__global__ void __launch_bounds__(256) k_esdf_init(MapDev M, int s, int nused, float* esdf, float gamma, float max_dist)
+struct EsdfDev {
+    float* mag;                // [max_bricks][4096] magnitude
+    uint8_t* fl;               // [max_bricks][4096] EF_* of the voxel at the last (re)initialisation
+    uint8_t* region;           // [max_bricks] 1: brick is part of this update's region, 2: relaxed once already
+    int* stamp;                // [max_bricks] last round the brick was put on a work list for (dedupe)
+    int* dirty;                // [max_bricks] dirty list
+    int* work;                 // [3][max_bricks] work lists of rounds k, k+1, k+2 (mod 3)
+    int cap;                   // max_bricks
+    int* ctr;                  // [0] dirty count [1] region count [2..4] work list lengths [5] brick relaxations [6] voxel pushes [7] rounds with work
+};
+
+// 1. dirty bricks of submap s (and, when `all`, every brick of it); touch marks are consumed
+__global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s, int nused, int all)
 {
-    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
-        if (M.owner[p] / M.nb3 != s) continue;
-        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-            const size_t v = (size_t)p * TSL_BRK3 + l;
-            const float t = h2f((h16)(M.tw[v] & 0xffffu));
-            esdf[v] = (M.obs[v] > 0 && fabsf(t) < gamma) ? fabsf(t) : max_dist;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool take = false;
+    if (p < nused) {
+        const bool mine = M.owner[p] / M.nb3 == s;
+        if (mine) { take = all || M.touch[p] != 0; M.touch[p] = 0; }
+        E.region[p] = 0; E.stamp[p] = -1;
+    }
+    const int q = wave_reserve(&E.ctr[0], take);
+    if (take) E.dirty[q] = p;
+}
+
+// 2. region = dirty bricks dilated by r bricks (existing bricks of the submap only)
+__global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s, int r)
+{
+    const int nd = E.ctr[0];
+    const int side = 2 * r + 1, vol = side * side * side;
+    for (int d = blockIdx.x; d < nd; d += gridDim.x) {
+        const int b = M.owner[E.dirty[d]] - s * M.nb3;
+        const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
+        for (int t = threadIdx.x; t < vol; t += 256) {
+            const int i = bi + t / (side * side) - r, j = bj + (t / side) % side - r, k = bk + t % side - r;
+            if (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) continue;
+            const int p = pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+            if (p >= 0) E.region[p] = 1;
         }
     }
 }
 
-// flags: 0 not a node, 1 positive side, 2 negative side, +4 fixed
-__global__ void __launch_bounds__(256) k_esdf_relax(MapDev M, int s, int nused, float* esdf, float gamma, float vs, int sweeps, int* changed)
+// 3. (re)initialise the region's voxels; every brick of the region is on the work list of round 0
+__global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, int nused, float gamma, float max_dist)
 {
-    __shared__ float s_mag[ESDF_T3];
-    __shared__ unsigned char s_flag[ESDF_T3];
-    const float c1 = 1.0f * vs, c2 = sqrtf(2.0f) * vs, c3 = sqrtf(3.0f) * vs;              // dense_esdf.py:286
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
-        const int owner = M.owner[p];
-        if (owner / M.nb3 != s) continue;
-        const int b = owner - s * M.nb3;
+        if (E.region[p] != 1) continue;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            uint8_t f = 0; float mg = max_dist;
+            if (M.obs[v] > 0) {
+                const float t = h2f((h16)(M.tw[v] & 0xffffu));
+                f = EF_NODE | (t < 0.0f ? EF_NEG : 0);
+                if (fabsf(t) < gamma) { f |= EF_FIXED; mg = fabsf(t); }
+            }
+            E.fl[v] = f; E.mag[v] = mg;
+        }
+        if (threadIdx.x == 0) {
+            const int q = __hip_atomic_fetch_add(&E.ctr[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            E.work[q] = p; E.stamp[p] = 0;
+            __hip_atomic_fetch_add(&E.ctr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// 4. one relaxation round: every brick on this round's work list is staged in LDS with its one-voxel halo and relaxed to its local fixed
+//    point; a brick whose boundary layer improved puts the neighbours that see it on the next round's list.  Rounds are separate launches
+//    (the kernel boundary is the only synchronisation: no fences, no spinning); a launch whose list is empty returns at once.
+__global__ void __launch_bounds__(256) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, int round)
+{
+    __shared__ uint32_t s_d[ESDF_T3];              // magnitude bits (non-negative floats order like unsigned integers)
+    __shared__ uint8_t s_f[ESDF_T3];
+    __shared__ uint32_t s_a[(ESDF_T3 + 31) / 32 + 1];   // active bits: the voxel pushes in the next pass (+ one spare word: 64-bit reads)
+    __shared__ int s_nb[27];                       // pool index of the 27 bricks around (and including) this one, -1 = absent
+    __shared__ int s_notify;
+    const int cur = round % 3, nxt = (round + 1) % 3, clr = (round + 2) % 3;
+    const int n = E.ctr[2 + cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) E.ctr[7] = round + 1; }      // list (round+2) was consumed in round-1
+    if (n == 0) return;
+    const float cost[4] = { 0.0f, 1.0f * vs, sqrtf(2.0f) * vs, sqrtf(3.0f) * vs };              // dense_esdf.py:286
+    const int* list = E.work + (size_t)cur * E.cap;
+    int* next = E.work + (size_t)nxt * E.cap;
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int p = list[w];
+        const int b = M.owner[p] - s * M.nb3;
         const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
+        if (threadIdx.x < 27) {
+            const int i = bi + (int)threadIdx.x / 9 - 1, j = bj + ((int)threadIdx.x / 3) % 3 - 1, k = bk + (int)threadIdx.x % 3 - 1;
+            s_nb[threadIdx.x] = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+        }
+        if (threadIdx.x == 0) s_notify = 0;
+        for (int i = threadIdx.x; i < (ESDF_T3 + 31) / 32 + 1; i += 256) s_a[i] = 0u;
+        __syncthreads();
+        const bool first = E.region[p] == 1;                        // first relaxation in this update: the band voxels push too
+        // ---- stage brick + halo ----
         for (int t = threadIdx.x; t < ESDF_T3; t += 256) {
             const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-            const int i = bi * 16 + tx - 1 - M.hN, j = bj * 16 + ty - 1 - M.hN, k = bk * 16 + tz - 1 - M.hNz;
-            unsigned char fl = 0; float mg = 0.0f;
-            if (in_volume(M, i, j, k)) {
-                int l; const int nb = brick_of(M, i, j, k, &l);
-                const int np = nb == b ? p : pool_lookup_ro(M, s, nb);
-                if (np >= 0) {
-                    const size_t v = (size_t)np * TSL_BRK3 + l;
-                    if (M.obs[v] > 0) {
-                        const float tv = h2f((h16)(M.tw[v] & 0xffffu));
-                        fl = (tv < 0.0f ? 2 : 1) | (fabsf(tv) < gamma ? 4 : 0);
-                        mg = esdf[v];
+            const int ox = (tx + 15) >> 4, oy = (ty + 15) >> 4, oz = (tz + 15) >> 4;                 // 0, 1, 2: which neighbour brick
+            const int np = s_nb[(ox * 3 + oy) * 3 + oz];
+            uint8_t f = 0; uint32_t d = 0u;
+            if (np >= 0) {
+                const size_t v = (size_t)np * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+                f = E.fl[v];
+                d = __float_as_uint(E.mag[v]);
+            }
+            const bool halo = ox != 1 || oy != 1 || oz != 1;
+            s_f[t] = f; s_d[t] = d;
+            if ((f & EF_NODE) && (halo || (first && (f & EF_FIXED)))) atomicOr(&s_a[t >> 5], 1u << (t & 31));
+        }
+        __syncthreads();
+        // ---- push relaxation: active voxels offer value + edge cost to their same-side, non-fixed neighbours INSIDE the brick.
+        //      A thread owns 23 consecutive tile entries (their active bits sit in one or two words): it takes its set bits with one
+        //      returning atomic AND, and per active voxel reads the 26 neighbours' flags and values as ONE batch of independent LDS
+        //      loads, then issues non-returning atomic mins + active-bit ORs for the candidates that beat what it read (a min that
+        //      lost a race is a no-op and the extra activation is harmless).  LDS operations of a wave execute in order. ----
+        long long pushes = 0; int passes = 0;
+        const int tb = (int)threadIdx.x * 23;
+        volatile uint32_t* vd = s_d;
+        volatile uint32_t* va = s_a;
+        for (;;) {
+            bool act = false;
+            unsigned long long mine = 0ull;
+            if (tb < ESDF_T3) {
+                const int w0 = tb >> 5, sh = tb & 31;
+                const unsigned long long m23 = ((1ull << 23) - 1ull) << sh;
+                unsigned long long seen = (unsigned long long)va[w0] | ((unsigned long long)va[w0 + 1] << 32);       // s_a has one spare word
+                if (seen & m23) {
+                    unsigned long long got = __hip_atomic_fetch_and(&s_a[w0], ~(uint32_t)m23, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (m23 >> 32) got |= (unsigned long long)__hip_atomic_fetch_and(&s_a[w0 + 1], ~(uint32_t)(m23 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 32;
+                    mine = (got & m23) >> sh;
+                }
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            for (; mine; mine &= mine - 1ull) {
+                const int t = tb + (int)__builtin_ctzll(mine);
+                if (t >= ESDF_T3) break;
+                const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
+                const uint32_t cls = s_f[t] & (EF_NODE | EF_NEG);
+                const float dv = __uint_as_float(vd[t]);
+                ++pushes;
+                uint32_t fn[26], dn[26]; int idx[26];
+#pragma unroll
+                for (int q = 0; q < 26; ++q) {
+                    const int c = q < 13 ? q : q + 1;                                      // 0..26 without the centre
+                    const int dx = c / 9 - 1, dy = (c / 3) % 3 - 1, dz = c % 3 - 1;
+                    const int x = tx + dx, y = ty + dy, z = tz + dz;
+                    const bool ok = x >= 1 && x <= 16 && y >= 1 && y <= 16 && z >= 1 && z <= 16;
+                    idx[q] = ok ? (x * ESDF_T + y) * ESDF_T + z : -1;
+                    const int j = ok ? idx[q] : t;
+                    fn[q] = s_f[j]; dn[q] = vd[j];
+                }
+#pragma unroll
+                for (int q = 0; q < 26; ++q) {
+                    const int c = q < 13 ? q : q + 1;
+                    const int dx = c / 9 - 1, dy = (c / 3) % 3 - 1, dz = c % 3 - 1;
+                    if (idx[q] < 0 || (fn[q] & (EF_NODE | EF_NEG | EF_FIXED)) != cls) continue;          // node, same side, not fixed
+                    const uint32_t cand = __float_as_uint(dv + cost[dx * dx + dy * dy + dz * dz]);
+                    if (cand < dn[q]) {
+                        __hip_atomic_fetch_min(&s_d[idx[q]], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(&s_a[idx[q] >> 5], 1u << (idx[q] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        act = true;
                     }
                 }
             }
-            s_flag[t] = fl; s_mag[t] = mg;
+            ++passes;
+            if (!__syncthreads_or(act)) break;
+        }
+        // ---- write back what changed; a changed voxel of the boundary layer puts the neighbours that hold it in their halo on the
+        //      next round's list ----
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const int x = (l >> 8) + 1, y = ((l >> 4) & 15) + 1, z = (l & 15) + 1;
+            const float nv = __uint_as_float(s_d[(x * ESDF_T + y) * ESDF_T + z]);
+            float* g = &E.mag[(size_t)p * TSL_BRK3 + l];
+            if (nv != *g) {
+                *g = nv;
+                const int lx = x == 1 ? 0 : (x == 16 ? 2 : 1), ly = y == 1 ? 0 : (y == 16 ? 2 : 1), lz = z == 1 ? 0 : (z == 16 ? 2 : 1);
+                if (lx != 1 || ly != 1 || lz != 1) {
+                    int m = 0;
+                    for (int ax = (lx == 0 ? 0 : 1); ax <= (lx == 2 ? 2 : 1); ++ax)
+                        for (int ay = (ly == 0 ? 0 : 1); ay <= (ly == 2 ? 2 : 1); ++ay)
+                            for (int az = (lz == 0 ? 0 : 1); az <= (lz == 2 ? 2 : 1); ++az) m |= 1 << ((ax * 3 + ay) * 3 + az);
+                    atomicOr(&s_notify, m & ~(1 << 13));
+                }
+            }
         }
         __syncthreads();
-        bool any = false;
-        for (int it = 0; it < sweeps; ++it) {
-            bool ch = false;
-            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-                const int t = (((l >> 8) + 1) * ESDF_T + (((l >> 4) & 15) + 1)) * ESDF_T + ((l & 15) + 1);
-                const unsigned char fl = s_flag[t];
-                if (fl == 0 || (fl & 4)) continue;
-                float best = s_mag[t];
-                for (int di = -1; di <= 1; ++di) for (int dj = -1; dj <= 1; ++dj) for (int dk = -1; dk <= 1; ++dk) {
-                    const int m2 = di * di + dj * dj + dk * dk;
-                    if (m2 == 0) continue;
-                    const int n = t + (di * ESDF_T + dj) * ESDF_T + dk;
-                    if ((s_flag[n] & 3) != (fl & 3)) continue;
-                    const float cand = s_mag[n] + (m2 == 1 ? c1 : (m2 == 2 ? c2 : c3));
-                    if (cand < best) best = cand;
-                }
-                if (best < s_mag[t]) { s_mag[t] = best; ch = true; }
+        pushes = wave_sum_ll(pushes);
+        if (lane_id() == 0 && pushes) __hip_atomic_fetch_add(&E.ctr[6], (int)pushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            E.region[p] = 2;
+            for (int m = s_notify, q = 0; m; m >>= 1, ++q) {
+                if (!(m & 1)) continue;
+                const int np = s_nb[q];
+                if (np < 0 || E.region[np] == 0) continue;                                     // absent, or outside this update's region
+                if (__hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round + 1) continue;   // already listed
+                next[__hip_atomic_fetch_add(&E.ctr[2 + nxt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = np;
             }
-            any |= ch;
-            if (!__syncthreads_or(ch)) break;
-        }
-        if (__syncthreads_or(any)) {
-            for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-                const int t = (((l >> 8) + 1) * ESDF_T + (((l >> 4) & 15) + 1)) * ESDF_T + ((l & 15) + 1);
-                esdf[(size_t)p * TSL_BRK3 + l] = s_mag[t];
-            }
-            if (threadIdx.x == 0) *changed = 1;
+            __hip_atomic_fetch_add(&E.ctr[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&E.ctr[8], passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&E.ctr[9], passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -117,35 +267,63 @@ using namespace tsl;
 
 extern "C" {
 
-int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_iters)
+int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed)
 {
     TSL_REQUIRE(m, "esdf_update: null handle"); TSL_REQUIRE(gamma > 0 && max_dist > 0, "esdf_update: gamma and max_dist must be positive");
     TSL_HIP(hipSetDevice(m->device));
     int rc;
+    const int nb = m->M.max_bricks;
     if (!m->esdf) {
-        if ((rc = dev_alloc(m, (void**)&m->esdf, sizeof(float) * (size_t)m->M.max_bricks * TSL_BRK3, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&m->esdf_flag, sizeof(int) * 4, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf, sizeof(float) * (size_t)nb * TSL_BRK3, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_fl, (size_t)nb * TSL_BRK3, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_region, (size_t)nb, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_inq, sizeof(int) * (size_t)nb, 0xff))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_list, sizeof(int) * (size_t)nb, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 12, 0))) return rc;
+        m->esdf_valid = false;
     }
-    int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;
+    int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;          // issues the queued frames first
     const int s = m->cfg.is_global_map ? 0 : m->active;
-    int iters = 0;
+    // a changed voxel influences voxels up to max_dist away: that many voxels = `reach` bricks in every direction
+    int reach = (int)std::ceil((double)max_dist / ((double)m->P.vs * 16.0)); if (reach < 1) reach = 1;
+    const bool full = m->esdf_force_full || !m->esdf_valid || m->esdf_submap != s || m->esdf_gamma != gamma || m->esdf_maxd != max_dist ||
+                      2 * reach + 1 >= m->nbx;              // the dilation would cover the grid anyway
+    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_queue, nb, m->esdf_ctr };
+    tsl_esdf_stats st; std::memset(&st, 0, sizeof(st));
+    st.incremental = full ? 0 : 1; st.total_bricks = nused;
+    hipStream_t q = ms(m);
     if (nused > 0) {
-        const int grid = nused < 8192 ? nused : 8192;
-        hipLaunchKernelGGL(k_esdf_init, dim3(grid), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, gamma, max_dist);
+        TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 12, q));
+        prof_begin(m, TSL_K_ESDF);                                   // one event pair around the update's launches (collect .. last round)
+        m->prof_group = true;
+        hipLaunchKernelGGL(k_esdf_collect, dim3((nused + 255) / 256), dim3(256), 0, q, m->M, E, s, nused, full ? 1 : 0);
+        hipLaunchKernelGGL(k_esdf_dilate, dim3(nused < 4096 ? nused : 4096), dim3(256), 0, q, m->M, E, s, full ? 0 : reach);
+        hipLaunchKernelGGL(k_esdf_init, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, q, m->M, E, nused, gamma, max_dist);
+        // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
+        // few more.  A batch of rounds is launched blind (a round without work returns at once), then ONE synchronisation reads the
+        // counters; only if the last launched round still had work (not seen in practice) another batch follows.
+        int round = 0;
+        const int grid = 4 * m->ncu;
         for (;;) {
-            TSL_HIP(hipMemsetAsync(m->esdf_flag, 0, sizeof(int), ms(m)));
-            for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(k_esdf_relax, dim3(grid), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, gamma, m->P.vs, 24, m->esdf_flag);
-            iters += 2;
-            TSL_HIP(hipMemcpyAsync(m->h_ints, m->esdf_flag, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
-            TSL_HIP(hipStreamSynchronize(ms(m)));
-            if (m->h_ints[0] == 0 || iters > 4096) break;
+            const int batch = 2 * reach + 8;
+            for (int k = 0; k < batch; ++k, ++round) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(256), 0, q, m->M, E, s, m->P.vs, round);
+            if (m->prof_group) { m->prof_group = false; prof_end(m); }
+            TSL_HIP(hipMemcpyAsync(&m->h_ints[16], m->esdf_ctr, sizeof(int) * 12, hipMemcpyDeviceToHost, q));
+            TSL_HIP(hipGetLastError());
+            TSL_HIP(hipStreamSynchronize(q));
+            if (m->h_ints[16 + 2 + round % 3] == 0 || round > 100000) break;
         }
+        st.dirty_bricks = m->h_ints[16]; st.region_bricks = m->h_ints[17]; st.brick_relaxations = m->h_ints[21]; st.voxel_pushes = m->h_ints[22];
+        st.rounds = m->h_ints[23]; st.passes = m->h_ints[24]; st.max_passes = m->h_ints[25];
     }
-    m->esdf_gamma = gamma;
-    if (n_iters) *n_iters = iters;
-    TSL_HIP(hipGetLastError());
+    m->esdf_stats = st;
+    m->esdf_gamma = gamma; m->esdf_maxd = max_dist; m->esdf_submap = s; m->esdf_valid = true;
+    if (n_relaxed) *n_relaxed = (int32_t)st.brick_relaxations;
     return TSL_OK;
 }
+
+int tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out) { TSL_REQUIRE(m && out, "null"); *out = m->esdf_stats; return TSL_OK; }
 
 int tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n)
 {

@@ -117,8 +117,10 @@ int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst)
     *ndst = 0;
     if (nsrc > 0) {
         PoseTab pt = { g->pose_dev };
+        prof_begin(g, TSL_K_FUSE);
         hipLaunchKernelGGL(k_fuse_splat, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
                            (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose, cacc);
+        prof_end(g);
         if ((rc = used_bricks(g, ndst))) return rc;
     }
     TSL_HIP(hipGetLastError());

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256) k_finalize(MapDev M, FrameDev F, const in
     for (int q = blockIdx.x; q < nwork; q += gridDim.x) {
         const int sl = list ? list[q] : q;
         const int p = F.touched[sl];
+        if (threadIdx.x == 0) M.touch[p] = 1;
         ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc + (size_t)sl * (TSL_BRK3 * 2));
         uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
         int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
@@ -728,6 +729,7 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
         // ---- the next chunk's keys are here: sort them and request its ray records, then flush under that latency ----
         if (has_next) TSL_SORT_DEAL(kn, nsegn)
         if (!last) { ++c; continue; }
+        if (p >= 0 && threadIdx.x == 0) M.touch[p] = 1;               // the brick's TSDF changes in this frame (incremental ESDF)
         if (p >= 0 && whole) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
             int8_t* obs = M.obs + (size_t)p * TSL_BRK3;

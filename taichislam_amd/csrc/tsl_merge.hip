@@ -161,9 +161,9 @@ int tsl_tsdf_merge_union(tsl_tsdf* g, const void* mask_dev, int32_t* nunion)
     TSL_REQUIRE(g && mask_dev && nunion, "merge_union: null argument"); TSL_REQUIRE(g->mrg_mask, "merge_union: call merge_begin first");
     TSL_HIP(hipSetDevice(g->device));
     hipLaunchKernelGGL(k_merge_union, dim3(1), dim3(1024), 0, ms(g), (const uint8_t*)mask_dev, g->nb3, g->mrg_list, g->mrg_count);
-    TSL_HIP(hipMemcpyAsync(&g->h_ints[25], g->mrg_count, sizeof(int), hipMemcpyDeviceToHost, ms(g)));
+    TSL_HIP(hipMemcpyAsync(&g->h_ints[29], g->mrg_count, sizeof(int), hipMemcpyDeviceToHost, ms(g)));
     TSL_HIP(hipStreamSynchronize(ms(g)));
-    g->mrg_nunion = g->h_ints[25];
+    g->mrg_nunion = g->h_ints[29];
     *nunion = g->mrg_nunion;
     return TSL_OK;
 }

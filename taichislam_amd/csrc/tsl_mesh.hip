@@ -134,6 +134,123 @@ __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int
     }
 }
 
+
+// ---- step 1 (every caller of the reference: scripts/taichislam_node.py:338, tests/marching_cube_test.py:21): brick + halo staged in LDS ----
+// A cell needs its 8 corners (voxel .. voxel + 1) and, per emitted vertex, the central differences around the voxel nearest to the
+// vertex (corner .. corner + 1, each +- 1): everything a brick's cells read lies in [-1, 17]^3 around the brick.  That 19^3 tile
+// (f16 TSDF bits + observed bits, 14.3 KiB) is gathered ONCE per brick through the 27 surrounding brick-table entries; the corner
+// reads (8 per voxel) and the normal reads (6 per vertex, up to 90 per voxel) then come from LDS instead of one table lookup +
+// one scattered 4-byte load each.  Emission is unchanged: wave-level inclusive scan of the triangle counts, one atomic per wave.
+#define MC_T 19
+#define MC_T3 (MC_T * MC_T * MC_T)
+__device__ __forceinline__ int mc_tile(int x, int y, int z) { return (x * MC_T + y) * MC_T + z; }      // tile coords = brick coords + 1
+
+__global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused, float thres, float vs, long long max_tri,
+                                                            float* __restrict__ verts, float* __restrict__ normals, float* __restrict__ colors, int* counter)
+{
+    __shared__ unsigned long long s_tri[256];
+    __shared__ float s_val[8][256];
+    __shared__ uint16_t s_t[MC_T3];                    // TSDF f16 bits (0 where nothing is stored: reading an inactive cell yields 0, A7)
+    __shared__ uint32_t s_o[(MC_T3 + 31) / 32];        // TSDF_observed > 0
+    __shared__ int s_nb[27];
+    s_tri[threadIdx.x] = MC_TRI_PACKED[threadIdx.x];
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        const int owner = M.owner[p];
+        const int s = owner / M.nb3, b = owner - s * M.nb3;
+        const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
+        __syncthreads();                                                     // the previous brick's tile is no longer read
+        if (threadIdx.x < 27) {
+            const int i = bi + (int)threadIdx.x / 9 - 1, j = bj + ((int)threadIdx.x / 3) % 3 - 1, k = bk + (int)threadIdx.x % 3 - 1;
+            s_nb[threadIdx.x] = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+        }
+        for (int i = threadIdx.x; i < (MC_T3 + 31) / 32; i += 256) s_o[i] = 0u;
+        __syncthreads();
+        for (int t = threadIdx.x; t < MC_T3; t += 256) {
+            const int tz = t % MC_T, ty = (t / MC_T) % MC_T, tx = t / (MC_T * MC_T);
+            const int np = s_nb[(((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4)];
+            uint16_t tv = 0;
+            if (np >= 0 && in_volume(M, bi * 16 + tx - 1 - M.hN, bj * 16 + ty - 1 - M.hN, bk * 16 + tz - 1 - M.hNz)) {
+                const size_t v = (size_t)np * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+                tv = (uint16_t)(M.tw[v] & 0xffffu);
+                if (M.obs[v] > 0) atomicOr(&s_o[t >> 5], 1u << (t & 31));
+            }
+            s_t[t] = tv;
+        }
+        __syncthreads();
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
+            const int l = l0 + threadIdx.x;
+            const int lx = l >> 8, ly = (l >> 4) & 15, lz = l & 15;
+            const int i = bi * 16 + lx - M.hN, j = bj * 16 + ly - M.hN, k = bk * 16 + lz - M.hNz;
+            const int t0 = mc_tile(lx + 1, ly + 1, lz + 1);
+            int ntri = 0, cube = 0;
+            unsigned long long tri = ~0ull;
+            if (((s_o[t0 >> 5] >> (t0 & 31)) & 1u) && h2f(s_t[t0]) < thres) {                    // :184
+                bool bad = false;
+                for (int q = 0; q < 8; ++q) {                                                     // :133-138
+                    int d[3]; corner_off(q, d);
+                    const int t = mc_tile(lx + 1 + d[0], ly + 1 + d[1], lz + 1 + d[2]);
+                    const float val = h2f(s_t[t]);
+                    s_val[q][threadIdx.x] = val;
+                    if (!((s_o[t >> 5] >> (t & 31)) & 1u)) bad = true;
+                    if (val < 0.0f) cube |= 1 << q;                                               // :141-144
+                }
+                if (!bad) {
+                    tri = s_tri[cube];
+                    for (int t = 0; t < 5; ++t) if (((tri >> (12 * t)) & 0xfull) != 0xfull) ++ntri;   // :173-177
+                }
+            }
+            int inc = ntri;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane_id() >= d) inc += o; }
+            const int wave_total = __shfl(inc, 63);
+            int base = 0;
+            if (wave_total) {
+                if (lane_id() == 63) base = __hip_atomic_fetch_add(counter, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = __shfl(base, 63);
+            }
+            long long idx = (long long)base + inc - ntri;
+            for (int t = 0; t < 5 && ntri; ++t) {
+                if (((tri >> (12 * t)) & 0xfull) == 0xfull) continue;
+                if (idx < max_tri) {                                                              // Q10: clamp by the returned index
+                    for (int q = 0; q < 3; ++q) {
+                        const int e = (int)((tri >> (4 * (3 * t + q))) & 0xfull);
+                        int ca, cb; edge_corners(e, &ca, &cb);
+                        int da[3], db[3]; corner_off(ca, da); corner_off(cb, db);
+                        const float v0 = s_val[ca][threadIdx.x], v1 = s_val[cb][threadIdx.x];
+                        const float p0[3] = { (float)(i + da[0]), (float)(j + da[1]), (float)(k + da[2]) };
+                        const float p1[3] = { (float)(i + db[0]), (float)(j + db[1]), (float)(k + db[2]) };
+                        float pv[3], mu = 0.0f;
+                        if (fabsf(0.0f - v0) < MC_EPS) { pv[0] = p0[0]; pv[1] = p0[1]; pv[2] = p0[2]; }            // vertexInterp :44-60
+                        else if (fabsf(0.0f - v1) < MC_EPS) { pv[0] = p1[0]; pv[1] = p1[1]; pv[2] = p1[2]; }
+                        else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
+                        if (colors) {                                                            // vertexInterp_color :62-82 (Q13); colours stay in HBM
+                            const uint2 ca2 = rd_col(M, s, i + da[0], j + da[1], k + da[2]);
+                            const uint2 cb2 = rd_col(M, s, i + db[0], j + db[1], k + db[2]);
+                            const h16 c0[3] = { (h16)(ca2.x & 0xffffu), (h16)(ca2.x >> 16), (h16)(ca2.y & 0xffffu) };
+                            const h16 c1[3] = { (h16)(cb2.x & 0xffffu), (h16)(cb2.x >> 16), (h16)(cb2.y & 0xffffu) };
+                            float vc[3] = { h2f(c0[0]), h2f(c0[1]), h2f(c0[2]) };
+                            if (h2f(c0[0]) == 0.0f) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c1[a]); }
+                            else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])); }
+                            const size_t oc = ((size_t)idx * 3 + q) * 3;
+                            for (int a = 0; a < 3; ++a) colors[oc + a] = vc[a];
+                        }
+                        // generate_normal :84-93 around the voxel nearest to the vertex: it is one of the edge's two corners
+                        const int q0 = (int)rnd_f(pv[0]) - i + lx + 1, q1 = (int)rnd_f(pv[1]) - j + ly + 1, q2 = (int)rnd_f(pv[2]) - k + lz + 1;
+                        const h16 n0 = hsub(s_t[mc_tile(q0 + 1, q1, q2)], s_t[mc_tile(q0 - 1, q1, q2)]);
+                        const h16 n1 = hsub(s_t[mc_tile(q0, q1 + 1, q2)], s_t[mc_tile(q0, q1 - 1, q2)]);
+                        const h16 n2 = hsub(s_t[mc_tile(q0, q1, q2 + 1)], s_t[mc_tile(q0, q1, q2 - 1)]);
+                        const h16 nrm = hsqrt(hadd(hadd(hmul(n0, n0), hmul(n1, n1)), hmul(n2, n2)));
+                        const h16 inv = f2h(1.0f / h2f(nrm));
+                        const size_t o = ((size_t)idx * 3 + q) * 3;
+                        verts[o] = pv[0] * vs; verts[o + 1] = pv[1] * vs; verts[o + 2] = pv[2] * vs;                  // :41-42,:97-99
+                        normals[o] = h2f(hmul(inv, n0)); normals[o + 1] = h2f(hmul(inv, n1)); normals[o + 2] = h2f(hmul(inv, n2));   // :100-102
+                    }
+                }
+                ++idx;
+            }
+        }
+    }
+}
+
 }  // namespace tsl
 
 using namespace tsl;
@@ -156,8 +273,12 @@ int tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tr
     int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;
     TSL_HIP(hipMemsetAsync(m->mesh_count, 0, sizeof(int), ms(m)));                          // :182
     prof_begin(m, TSL_K_MESH);
-    if (nused > 0) hipLaunchKernelGGL(k_marching_cubes, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, ms(m), m->M, nused, step,
-                                      surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);
+    if (nused > 0 && step == 1 && !m->mesh_gather)
+        hipLaunchKernelGGL(k_marching_cubes_lds, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, ms(m), m->M, nused,
+                           surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);
+    else if (nused > 0)             // coarser meshes (step > 1) reach beyond the brick's halo: every value through the brick table
+        hipLaunchKernelGGL(k_marching_cubes, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, ms(m), m->M, nused, step,
+                           surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);
     prof_end(m);
     TSL_HIP(hipGetLastError());
     TSL_HIP(hipMemcpyAsync(m->h_ints, m->mesh_count, sizeof(int), hipMemcpyDeviceToHost, ms(m)));

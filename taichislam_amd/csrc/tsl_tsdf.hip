@@ -450,6 +450,15 @@ __global__ void __launch_bounds__(256) k_export_particles(MapDev M, int s, int m
     }
 }
 
+// PointCloud2 data block: interleaved float32 rows [x y z] or [x y z r g b]  (taichi_slam/utils/ros_pcl_transfer.py:96-136, scripts/taichislam_node.py:420-425)
+__global__ void __launch_bounds__(256) k_pack_pointcloud2(const float* __restrict__ xyz, const float* __restrict__ rgb, float* __restrict__ out, long long n, int stride)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n * stride) return;
+    const long long row = q / stride; const int c = (int)(q - row * stride);
+    out[q] = c < 3 ? xyz[row * 3 + c] : rgb[row * 3 + c - 3];
+}
+
 // reset(): hand every brick back (dense_tsdf.py:309-310 deactivates the whole tree)
 __global__ void __launch_bounds__(256) k_reset_bricks(MapDev M, int nused)
 {
@@ -888,7 +897,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_flag = nullptr; m->esdf_bricks = 0; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
@@ -906,6 +915,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     if ((rc = dev_alloc(m, (void**)&M.occ, (size_t)want * TSL_BRK3, 0))) return rc;
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&M.col, sizeof(uint16_t) * 4 * (size_t)want * TSL_BRK3, 0))) return rc; }
     if ((rc = dev_alloc(m, (void**)&M.owner, sizeof(int) * (size_t)want, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.touch, (size_t)want, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
     M.err = M.pool_top + 1;
 
@@ -989,7 +999,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     }
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
-                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_flag, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
                      m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
@@ -1013,9 +1023,9 @@ int tsl_tsdf_get_dims(const tsl_tsdf* m, int32_t* N, int32_t* Nz, int32_t* bxy, 
 // a brick that was dropped is never dropped silently.
 static int take_dev_err(tsl_tsdf* m)
 {
-    TSL_HIP(hipMemcpyAsync(&m->h_ints[24], m->M.err, sizeof(int), hipMemcpyDeviceToHost, m->stream_));
+    TSL_HIP(hipMemcpyAsync(&m->h_ints[28], m->M.err, sizeof(int), hipMemcpyDeviceToHost, m->stream_));
     TSL_HIP(hipStreamSynchronize(m->stream_));
-    const int e = m->h_ints[24];
+    const int e = m->h_ints[28];
     if (!e) return TSL_OK;
     set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : "") +
               ((e & 4) ? " ray segments" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : "") + "; the affected frames / bricks were not integrated");
@@ -1065,6 +1075,7 @@ int tsl_tsdf_reset(tsl_tsdf* m)
     const int pending = tsl_tsdf_sync(m);          // a capacity error of the discarded contents is still reported, after the reset
     if (pending && pending != TSL_ERR_CAPACITY) return pending;
     int used = 0; int rc = tsl_tsdf_bricks_in_use(m, &used); if (rc) return rc;
+    m->esdf_valid = false;
     if (used > 0) hipLaunchKernelGGL(k_reset_bricks, dim3(used < 4096 ? used : 4096), dim3(256), 0, ms(m), m->M, used);
     TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int), ms(m)));
     TSL_HIP(hipGetLastError());
@@ -1227,6 +1238,7 @@ int tsl_tsdf_import_sparse(tsl_tsdf* m, int sid, const int16_t* idx, const uint1
     TSL_REQUIRE(idx && t && w, "import_sparse: null arrays");
     TSL_REQUIRE(sid >= 0 && (m->cfg.is_global_map || sid < m->nsub), "import_sparse: submap id out of range");
     TSL_HIP(hipSetDevice(m->device));
+    m->esdf_valid = false;
     const size_t c = (size_t)n;
     const size_t o_idx = 0, o_t = o_idx + c * 6, o_w = o_t + c * 2, o_occ = o_w + c * 2, o_col = ((o_occ + c + 15) / 16) * 16, total = o_col + c * 6 + 64;
     int rc = grow(&m->xbuf, &m->xbuf_bytes, total); if (rc) return rc;
@@ -1276,6 +1288,28 @@ int tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64
     if (val) TSL_HIP(hipMemcpy(val, m->exp_val, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     return TSL_OK;
 }
+int tsl_tsdf_set_export_row(tsl_tsdf* m, int field, int64_t row, const float v[3])
+{
+    TSL_REQUIRE(m && v && (field == 0 || field == 1), "set_export_row: bad argument"); TSL_REQUIRE(row >= 0 && row < m->max_disp, "set_export_row: row out of range");
+    TSL_HIP(hipSetDevice(m->device));
+    TSL_HIP(hipMemcpyAsync((field ? m->exp_rgb : m->exp_xyz) + 3 * row, v, sizeof(float) * 3, hipMemcpyHostToDevice, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
+    return TSL_OK;
+}
+
+int tsl_tsdf_pack_pointcloud2(tsl_tsdf* m, int has_rgb, int64_t n, void* out_host)
+{
+    TSL_REQUIRE(m && (n == 0 || out_host), "pack_pointcloud2: null argument"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "pack_pointcloud2: n out of range");
+    TSL_HIP(hipSetDevice(m->device));
+    if (n == 0) return TSL_OK;
+    const int stride = has_rgb ? 6 : 3;
+    int rc = grow(&m->xbuf, &m->xbuf_bytes, sizeof(float) * (size_t)stride * (size_t)n); if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_pointcloud2, dim3((unsigned)(((long long)n * stride + 255) / 256)), dim3(256), 0, ms(m), m->exp_xyz, m->exp_rgb, (float*)m->xbuf, (long long)n, stride);
+    TSL_HIP(hipMemcpyAsync(out_host, m->xbuf, sizeof(float) * (size_t)stride * (size_t)n, hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
+    return TSL_OK;
+}
+
 int tsl_tsdf_num_particles(tsl_tsdf* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device)); int v = 0; int rc = read_int(m, m->num_particles, &v); *n = v; return rc; }
 int tsl_tsdf_set_num_particles(tsl_tsdf* m, int32_t n)
 {
@@ -1330,6 +1364,8 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     }
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
+    if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }
+    if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)

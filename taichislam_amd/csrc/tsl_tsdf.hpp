@@ -173,12 +173,13 @@ struct tsl_tsdf {
     // sparse export staging
     void* xbuf; size_t xbuf_bytes;
     // mesh buffers (mesh_vertices / mesh_normals / mesh_colors, num_facelets)  marching_cube_mesher.py:16-22
-    float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap;
+    float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap; int mesh_gather;      // mesh_gather: option, 1 = global-gather kernel also for step 1 (A/B)
     void *fuse_acc, *fuse_cnt, *fuse_cacc;           // global-map fusion scratch ({num,den} int64 pairs, count|occupancy)
     uint8_t* mrg_mask; int *mrg_list, *mrg_count; int mrg_nunion;      // multi-GPU merge: touched-brick mask, union list (tsl_merge.hip)
     void *mrg_pacc, *mrg_pcnt; size_t mrg_pacc_bytes, mrg_pcnt_bytes;  // packed union bricks of the one-call form
     // esdf
-    float* esdf; int* esdf_flag; int64_t esdf_bricks; float esdf_gamma;
+    float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq; int esdf_qcap;      // tsl_esdf.hip
+    bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];

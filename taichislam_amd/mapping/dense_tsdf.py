@@ -59,7 +59,7 @@ class DenseTSDF(BaseMap):
         self.clear_last_TSDF_exporting = False
         self.device = device
         self._ext_streams = {}
-        self._held = []
+        self._held, self._inflight = [], []
         self.mem_per_voxel = 2 + 2 + 1 + 1 + (6 if texture_enabled else 0)
 
         cfg = _lib.TsdfCfg(float(map_scale[0]), float(map_scale[1]), float(voxel_scale), int(num_voxel_per_blk_axis),
@@ -82,8 +82,10 @@ class DenseTSDF(BaseMap):
         self.num_export_particles = ScalarField(lambda: 0, None, "num_export_particles")
         self.num_export_ESDF_particles = ScalarField(lambda: 0, None, "num_export_ESDF_particles")
         md = self.max_disp_particles
-        self.export_TSDF_xyz = DeviceArrayField(self, lambda n: self._read_exports(n)[0], md, 3, "export_TSDF_xyz")
-        self.export_color = DeviceArrayField(self, lambda n: self._read_exports(n)[1], md, 3, "export_color")
+        self.export_TSDF_xyz = DeviceArrayField(self, lambda n: self._read_exports(n)[0], md, 3, "export_TSDF_xyz",
+                                                writer=lambda row, v: self._call("set_export_row", 0, row, _vp(np.ascontiguousarray(v[:3], np.float32))))
+        self.export_color = DeviceArrayField(self, lambda n: self._read_exports(n)[1], md, 3, "export_color",
+                                             writer=lambda row, v: self._call("set_export_row", 1, row, _vp(np.ascontiguousarray(v[:3], np.float32))))
         self.export_TSDF = DeviceArrayField(self, lambda n: self._read_exports(n)[2], md, 1, "export_TSDF")
         self.export_x = self.export_TSDF_xyz
         self.TSDF = MapFieldRef(self, "TSDF")
@@ -156,9 +158,9 @@ class DenseTSDF(BaseMap):
         """The reference's recast_* calls are synchronous; here a frame is only queued and its kernels are enqueued later (when
         its batch of four is full, or when anything else needs the map) on the library's own streams.  For torch tensors the
         shim therefore (1) makes the stream that will read the frame wait for the work already queued on torch's current
-        stream (the tensor may still be being produced), (2) keeps the tensors referenced until their batch has been issued
-        and (3) then tells torch's caching allocator that this stream reads them (record_stream), so a tensor the caller
-        drops right after the call is not recycled before the queued frame has read it."""
+        stream (the tensor may still be being produced) and (2) keeps the tensors referenced until the kernels that read them
+        have run (an event recorded behind the batch on the reading stream), so a tensor the caller drops right after the
+        call is not recycled by torch's caching allocator under a queued frame."""
         import torch
         s = C.c_void_p()
         self._call("input_stream", int(points), C.byref(s))
@@ -172,22 +174,37 @@ class DenseTSDF(BaseMap):
         self._held.append((ext, tensors))
 
     def _release_device_inputs(self, force=False):
-        """Hand the held input tensors over to the allocator once the frames that read them have been issued."""
-        if not self._held:
+        """Drop the references to input tensors whose frames have been read."""
+        if force:
+            self._held.clear(); self._inflight.clear()
             return
-        if not force:
+        if self._held:
             n = C.c_int32()
             self._call("queued_frames", C.byref(n))
-            if n.value:
-                return
-        for ext, tensors in self._held:
-            for x in tensors:
-                x.record_stream(ext)
-        self._held.clear()
+            if n.value == 0:                                   # the batch went out: an event behind it on every stream that reads it
+                import torch
+                done = {}
+                for ext, tensors in self._held:
+                    if id(ext) not in done:
+                        done[id(ext)] = torch.cuda.Event()
+                        done[id(ext)].record(ext)
+                    self._inflight.append((done[id(ext)], tensors))
+                self._held.clear()
+        while self._inflight and self._inflight[0][0].query():
+            self._inflight.pop(0)
 
     def sync(self):
         super().sync()
         self._release_device_inputs(force=True)
+
+    def __del__(self):
+        try:
+            if self.h is not None and (self._held or self._inflight):
+                super().sync()                                  # nothing may still read the tensors when they are released
+            self._held.clear(); self._inflight.clear()
+        except Exception:
+            pass
+        super().__del__()
 
     def recast_pcl_to_map(self, R, T, xyz_array, rgb_array=None, n=None):
         """recast_pcl_to_map(R, T, xyz_array, rgb_array); the third positional `n` of the stale demo
@@ -302,6 +319,18 @@ class DenseTSDF(BaseMap):
     def cvt_TSDF_to_voxels_slice(self, z, dz=0.5, clear_last=True):
         n = C.c_int32()
         self._call("slice_voxels", float(z), float(dz), int(bool(clear_last)), C.byref(n))
+
+    def pointcloud2(self, n=None, has_rgb=None):
+        """The first `n` exported particles (default: all of the last cvt_* call) as a sensor_msgs/PointCloud2 payload -- what
+        scripts/taichislam_node.py:420-425 + utils/ros_pcl_transfer.py:96-136 assemble from numpy copies -- interleaved on the device.
+        See taichislam_amd.utils.ros_adapters for the message fields."""
+        from ..utils import ros_adapters
+        n = self.num_TSDF_particles[None] if n is None else int(n)
+        n = max(0, min(n, self.max_disp_particles))
+        has_rgb = self.enable_texture if has_rgb is None else bool(has_rgb)
+        data = np.empty((n, 6 if has_rgb else 3), np.float32)
+        self._call("pack_pointcloud2", int(has_rgb), n, _vp(data))
+        return ros_adapters.pointcloud2_payload(data, has_rgb)
 
     def get_voxels_TSDF_surface(self):
         self.cvt_TSDF_surface_to_voxels()
@@ -420,12 +449,19 @@ class DenseTSDF(BaseMap):
 
     # ---- ESDF (definition from the legacy dense_esdf.py:228-333) -----------------------------------
     def update_esdf(self, gamma=None, max_dist=None):
-        """Recompute the ESDF of the active submap; returns the number of relaxation launches."""
+        """Bring the ESDF of the active submap up to date with its TSDF -- incrementally: only the bricks integrated into since
+        the previous call (dilated by max_dist) are recomputed, with the result of a full recompute.  Returns the number of brick
+        relaxations; `esdf_stats()` has the breakdown.  The reference's hook ran after every frame (dense_esdf.py:400-402)."""
         it = C.c_int32()
         g = self.voxel_scale if gamma is None else gamma                 # dense_esdf.py:40 gamma = voxel_scale
         md = self.max_ray_length if max_dist is None else max_dist       # dense_esdf.py:265 sign * max_ray_length
         _lib.check(self.L.tsl_esdf_update(self.h, float(g), float(md), C.byref(it)))
         return it.value
+
+    def esdf_stats(self):
+        st = _lib.EsdfStats()
+        _lib.check(self.L.tsl_esdf_last_stats(self.h, C.byref(st)))
+        return st.as_dict()
 
     def export_esdf(self):
         """(indices int16[n,3], esdf f32[n]) for every observed voxel of the active submap."""

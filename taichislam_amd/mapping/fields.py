@@ -29,8 +29,8 @@ class ScalarField:
 class DeviceArrayField:
     """1-d vector field living in a device export buffer; `.to_numpy()` copies `rows` rows back."""
 
-    def __init__(self, owner, reader, rows, width, name):
-        self._owner, self._reader, self._rows, self._width, self._name = owner, reader, rows, width, name
+    def __init__(self, owner, reader, rows, width, name, writer=None):
+        self._owner, self._reader, self._rows, self._width, self._name, self._writer = owner, reader, rows, width, name, writer
 
     @property
     def shape(self):
@@ -38,6 +38,12 @@ class DeviceArrayField:
 
     def to_numpy(self, n=None):
         return self._reader(self._rows if n is None else int(n))
+
+    def __setitem__(self, row, value):
+        """`field[i] = vector` (tests/gen_topo_graph.py:64-65 appends a marker point to export_TSDF_xyz this way)."""
+        if self._writer is None:
+            raise TypeError(f"{self._name} cannot be written")
+        self._writer(int(row), np.asarray(value, dtype=np.float32).reshape(-1))
 
     def __repr__(self):
         return f"<device field {self._name} {self.shape}>"

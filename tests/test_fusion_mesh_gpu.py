@@ -147,3 +147,56 @@ def test_submap_mapping_orchestration(hip_lib):
     assert other.submap_collection.remote_submap_num[None] == 1 and other.global_map.count_active() > 1000
 
 
+
+
+def test_submap_mapping_global_map_matches_the_oracle(hip_lib):
+    """The package's SubmapMapping (same call trace as the reference's class, tests/test_reference_callers.py) on the HIP shims: three
+    keyframe-stepped submaps; the global map it maintains equals the oracle's fusion of the same submaps bit for bit, and a second
+    agent that ingests the submaps from the wire rebuilds the same closed submaps."""
+    from oracle import BATCHED, OracleTSDF
+    from taichislam_amd.mapping import DenseTSDF, SubmapMapping
+    opts = dict(map_scale=[10.24, 10.24], voxel_scale=0.04, num_voxel_per_blk_axis=16, max_ray_length=5.0, max_submap_num=16)
+    K, frames = small_stream(8)
+    sm = SubmapMapping(DenseTSDF, keyframe_step=3, sub_opts=opts, global_opts=opts)
+    sent = []
+    sm.map_send_handle = sent.append
+    sm.set_dep_camera_intrinsic(K)
+    ext = (np.eye(3), np.zeros(3))
+    oc = OracleTSDF(**opts); oc.set_intrinsics(K)
+    for f, (R, T, d) in enumerate(frames):
+        if f and f % 3 == 0:
+            oc.set_active_submap(oc.get_active_submap() + 1)
+        if f % 3 == 0:
+            oc.set_base_pose_submap(oc.get_active_submap(), R, T)
+        sm.recast_depth_to_map_by_frame(f, True, (R, T), ext, d, np.array([], dtype=int))
+        oc.integrate_depth(R, T, d, mode=BATCHED)
+    assert len(sent) == 2 and sorted(sm.submaps.values()) == [0, 1, 2]
+    sm.local_to_global()
+    og = OracleTSDF(**dict(opts, is_global_map=True))
+    for fid, sid in sm.submaps.items():
+        og.set_base_pose_submap(sid, frames[fid][0], frames[fid][1])
+    og.fuse_submaps(oc, mode=BATCHED)
+    a, b = sort_export(sm.global_map.export_submap()), sort_export(og.export_sparse())
+    assert np.array_equal(a["indices"], b["indices"]) and a["indices"].shape[0] > 50000
+    ok = ~np.isnan(a["TSDF"].view(np.float16))
+    assert np.array_equal(a["TSDF"][ok], b["TSDF"][ok]) and np.array_equal(a["W_TSDF"], b["W_TSDF"]) and np.array_equal(a["occupy"], b["occupy"])
+    # a second agent ingests the two finished submaps from the wire: its collection holds them as remote submaps with the sender's poses
+    other = SubmapMapping(DenseTSDF, keyframe_step=3, sub_opts=opts, global_opts=opts)
+    for buf in sent:
+        other.input_remote_submap(buf)
+    assert other.submap_collection.remote_submap_num[None] == 2 and sorted(other.submaps) == [0, 3]
+    first_two = OracleTSDF(**opts); first_two.set_intrinsics(K)
+    for f, (R, T, d) in enumerate(frames[:6]):
+        if f == 3:
+            first_two.set_active_submap(1)
+        if f % 3 == 0:
+            first_two.set_base_pose_submap(first_two.get_active_submap(), R, T)
+        first_two.integrate_depth(R, T, d, mode=BATCHED)
+    first_two.set_active_submap(2)
+    og2 = OracleTSDF(**dict(opts, is_global_map=True))
+    og2.set_base_pose_submap(0, frames[0][0], frames[0][1]); og2.set_base_pose_submap(1, frames[3][0], frames[3][1])
+    og2.fuse_submaps(first_two, mode=BATCHED)
+    a2, b2 = sort_export(other.global_map.export_submap()), sort_export(og2.export_sparse())
+    assert np.array_equal(a2["indices"], b2["indices"])
+    ok = ~np.isnan(a2["TSDF"].view(np.float16))
+    assert np.array_equal(a2["TSDF"][ok], b2["TSDF"][ok]) and np.array_equal(a2["W_TSDF"], b2["W_TSDF"])

@@ -1,0 +1,240 @@
+"""The reference's own caller on this package's classes.
+
+`taichi_slam/mapping/submap_mapping.py` (the orchestration that drives the hot path in swarm mode) is loaded BY PATH from the reference
+tree, unmodified, into a stand-in `taichi_slam.mapping` package whose `DenseTSDF` / `Octomap` / `BaseMap` are supplied by the test.
+Nothing of the reference is vendored: where the tree is absent (the GPU box) these tests skip.
+
+  * CPU (here): the reference class and `taichislam_amd.mapping.SubmapMapping` are driven through the same scenario on a recording
+    stand-in for the map classes; the two call traces into the map classes, the wire buffers and the bookkeeping must be identical.
+    That is what makes the package's own class a faithful substitute where the reference file cannot be loaded.
+  * GPU (a box that has both a GPU and the reference tree): the reference class runs on the real HIP-backed shims and its global
+    map must equal the CPU oracle's fusion of the same submaps bit for bit."""
+import importlib.util
+import io
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/taichi_slam/mapping/submap_mapping.py"
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present on this machine")
+
+
+def load_reference_submap_mapping(DenseTSDF, Octomap, BaseMap):
+    """Import the reference file with `taichi_slam.mapping.{mapping_common,dense_tsdf,taichi_octomap}` resolved to the given classes."""
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "taichi_slam" or k.startswith("taichi_slam.")}
+    try:
+        pkg = types.ModuleType("taichi_slam"); pkg.__path__ = []
+        sub = types.ModuleType("taichi_slam.mapping"); sub.__path__ = []; sub.__package__ = "taichi_slam.mapping"
+        mods = {"taichi_slam": pkg, "taichi_slam.mapping": sub}
+        for name, attr, cls in (("mapping_common", "BaseMap", BaseMap), ("dense_tsdf", "DenseTSDF", DenseTSDF), ("taichi_octomap", "Octomap", Octomap)):
+            m = types.ModuleType(f"taichi_slam.mapping.{name}")
+            setattr(m, attr, cls)
+            mods[m.__name__] = m
+        sys.modules.update(mods)
+        spec = importlib.util.spec_from_file_location("taichi_slam.mapping.submap_mapping", REF)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        return mod.SubmapMapping
+    finally:
+        for k in [k for k in sys.modules if k == "taichi_slam" or k.startswith("taichi_slam.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+# ---- recording stand-in for the map classes ------------------------------------------------------------------------------------------
+def _digest(x):
+    if isinstance(x, np.ndarray):
+        return ("nd", x.shape, str(x.dtype), round(float(np.asarray(x, dtype=np.float64).sum()), 9))
+    if isinstance(x, (list, tuple)):
+        return tuple(_digest(v) for v in x)
+    if isinstance(x, dict):
+        return tuple(sorted((k, _digest(v)) for k, v in x.items()))
+    if isinstance(x, _Field):
+        return ("field", x.name, x.owner.tag)
+    if isinstance(x, RecMap):
+        return ("map", x.tag)
+    return x
+
+
+class _Field:
+    def __init__(self, owner, name):
+        self.owner, self.name, self.v = owner, name, 0
+
+    def __getitem__(self, k):
+        return self.v
+
+    def __setitem__(self, k, v):
+        self.v = v
+
+
+class RecBase:
+    pass
+
+
+class RecMap(RecBase):
+    """Every call the orchestration makes into a map class is appended to the shared TRACE as (map tag, method, digested arguments)."""
+    TRACE = None
+    COUNT = 0
+
+    def __init__(self, **kw):
+        RecMap.COUNT += 1
+        self.tag = ("global" if kw.get("is_global_map") else "collection") + f"#{RecMap.COUNT % 2}"
+        self.kw = kw
+        self.enable_texture = kw.get("texture_enabled", False)
+        self.max_disp_particles = kw.get("max_disp_particles", 0)
+        self.max_submap_num = kw.get("max_submap_num", 0)
+        self.active, self.remote = 0, 0
+        for f in ("export_color", "export_TSDF_xyz", "num_TSDF_particles", "export_x", "num_export_particles"):
+            setattr(self, f, _Field(self, f))
+        RecMap.TRACE.append((self.tag, "__init__", _digest(kw)))
+
+    def _rec(self, name, *a):
+        RecMap.TRACE.append((self.tag, name, _digest(a)))
+
+    def __setattr__(self, k, v):
+        if k == "clear_last_TSDF_exporting":
+            self._rec("set clear_last_TSDF_exporting", v)
+        object.__setattr__(self, k, v)
+
+    def get_active_submap_id(self):
+        return self.active
+
+    def switch_to_next_submap(self):
+        self.active += 1
+        self._rec("switch_to_next_submap")
+        return self.active
+
+    def export_submap(self):
+        self._rec("export_submap")
+        n = 5 + self.active
+        return {"indices": np.arange(3 * n, dtype=np.int16).reshape(n, 3), "TSDF": np.linspace(0, 1, n).astype(np.float16),
+                "W_TSDF": np.ones(n, np.float16), "color": np.array([]), "occupy": np.zeros(n, np.int8), "map_scale": [10.0, 10.0],
+                "voxel_scale": 0.05, "texture_enabled": False, "num_voxel_per_blk_axis": 10}
+
+    def input_remote_submap(self, submap):
+        self.remote += 1
+        self._rec("input_remote_submap", {k: v for k, v in submap.items()})
+        return self.max_submap_num - self.remote
+
+    def __getattr__(self, name):                      # every other method: record and return None
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a: self._rec(name, *a)
+
+
+class RecTSDF(RecMap):
+    pass
+
+
+class RecOcto(RecMap):
+    pass
+
+
+def _scenario(SM, tsdf_cls, octo_cls, kind):
+    """Drive one SubmapMapping class; returns (trace, sent map buffers decoded, sent trajectories decoded, bookkeeping)."""
+    RecMap.TRACE, RecMap.COUNT = [], 0
+    sent_maps, sent_traj = [], []
+    dec = lambda b: np.load(io.BytesIO(zlib.decompress(b)), allow_pickle=True).item()
+    cls = tsdf_cls if kind == "tsdf" else octo_cls
+    sm = SM(cls, keyframe_step=3, sub_opts={"voxel_scale": 0.04, "max_submap_num": 16}, global_opts={"map_scale": [20, 20]})
+    sm.map_send_handle = lambda b: sent_maps.append(_digest(dec(b)))
+    sm.traj_send_handle = lambda b: sent_traj.append(_digest(dec(b)))
+    if hasattr(sm, "autosave_path"):
+        sm.autosave_path = None
+    else:                                             # the reference saves to a hard-coded path (submap_mapping.py:144-145): record instead
+        sm.saveMap = lambda filename: RecMap.TRACE.append(("saveMap", filename))
+    K = np.arange(9.0)
+    sm.set_dep_camera_intrinsic(K); sm.set_color_camera_intrinsic(K + 1)
+    ext = (np.eye(3), np.array([0.1, 0.0, 0.05]))
+    rng = np.random.default_rng(5)
+    for f in range(11):
+        a = 0.1 * f
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        T = np.array([0.2 * f, 0.1, 0.0])
+        if f == 6:                                    # the pose graph moves two frames, one of which started a submap
+            sm.set_frame_poses({3: (R @ R, T + 1.0), 4: (R, T - 0.5)})
+        if f % 4 == 3:
+            sm.recast_pcl_to_map_by_frame(f, f % 2 == 1, (R, T), ext, rng.standard_normal((7, 3)).astype(np.float32), np.array([]))
+        else:
+            sm.recast_depth_to_map_by_frame(f, True, (R, T), ext, np.full((4, 6), 1000 + f, np.uint16), np.array([], dtype=int))
+        if f == 8:
+            sm.set_exporting_local(); sm.cvt_TSDF_surface_to_voxels() if kind == "tsdf" else sm.cvt_occupy_to_voxels(0)
+            sm.set_exporting_global(); sm.cvt_TSDF_surface_to_voxels() if kind == "tsdf" else sm.cvt_occupy_to_voxels(1)
+            if kind == "tsdf":
+                sm.cvt_TSDF_to_voxels_slice(0.5)
+    remote = {"indices": np.ones((4, 3), np.int16), "TSDF": np.ones(4, np.float16), "W_TSDF": np.ones(4, np.float16), "color": np.array([]),
+              "occupy": np.zeros(4, np.int8), "frame_id": 1000, "pose": (np.eye(3), np.array([1.0, 2.0, 3.0]))}
+    f = io.BytesIO(); np.save(f, remote)
+    sm.input_remote_submap(zlib.compress(f.getbuffer(), 1))
+    f = io.BytesIO(); np.save(f, {1000: (np.eye(3), np.zeros(3)), 6: (np.eye(3), np.ones(3))})
+    sm.input_remote_traj(zlib.compress(f.getbuffer(), 1))
+    book = {"submaps": dict(sm.submaps), "frame_count": sm.frame_count, "last_frame_id": sm.last_frame_id,
+            "active_submap_frame_id": sm.active_submap_frame_id, "pgo": _digest({k: tuple(v) for k, v in sm.pgo_poses.items()}),
+            "ego": _digest({k: tuple(v) for k, v in sm.ego_motion_poses.items()}), "exporting_global": sm.exporting_global}
+    trace = [t for t in RecMap.TRACE if t[0] != "saveMap"]          # the reference's unconditional autosave is the documented difference
+    return trace, sent_maps, sent_traj, book
+
+
+@needs_ref
+@pytest.mark.parametrize("kind", ["tsdf", "octo"])
+def test_package_submap_mapping_makes_the_same_calls_as_the_reference(kind):
+    from taichislam_amd.mapping import submap_mapping as mine
+    Ref = load_reference_submap_mapping(RecTSDF, RecOcto, RecBase)
+    # the package class picks its defaults by `issubclass(submap_type, Octomap)`: give it the recording classes under its own names
+    old = (mine.DenseTSDF, mine.Octomap)
+    mine.DenseTSDF, mine.Octomap = RecTSDF, RecOcto
+    try:
+        a = _scenario(Ref, RecTSDF, RecOcto, kind)
+        b = _scenario(mine.SubmapMapping, RecTSDF, RecOcto, kind)
+    finally:
+        mine.DenseTSDF, mine.Octomap = old
+    assert len(a[0]) > 40
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert x == y, f"call {i}: reference {x} != package {y}"
+    assert len(a[0]) == len(b[0])
+    assert a[1] == b[1] and len(a[1]) == 3, "submaps put on the wire differ"
+    assert a[2] == b[2] and len(a[2]) == 1, "trajectories put on the wire differ"
+    assert a[3] == b[3]
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_reference_submap_mapping_runs_unmodified_on_the_hip_shims(hip_lib, tmp_path):
+    """Three keyframe-stepped submaps + one remote submap through the reference's own class on the HIP-backed DenseTSDF; the global map
+    it builds must equal the oracle's fusion of the same submaps bit for bit."""
+    from oracle import BATCHED, OracleTSDF
+    from taichislam_amd import mapping as M
+    from util import small_stream, sort_export
+    Ref = load_reference_submap_mapping(M.DenseTSDF, M.Octomap, M.BaseMap)
+    opts = dict(map_scale=[10.24, 10.24], voxel_scale=0.04, num_voxel_per_blk_axis=16, max_ray_length=5.0, max_submap_num=16)
+    K, frames = small_stream(8)
+    sm = Ref(M.DenseTSDF, keyframe_step=3, sub_opts=opts, global_opts=opts)
+    sent = []
+    sm.map_send_handle = sent.append
+    sm.traj_send_handle = lambda b: None
+    sm.saveMap = lambda filename: sm.global_map.saveMap(str(tmp_path / "autosave.npy"))     # only the hard-coded path is patched (:144-145)
+    sm.set_dep_camera_intrinsic(K)
+    ext = (np.eye(3), np.zeros(3))
+    oc = OracleTSDF(**opts); oc.set_intrinsics(K)
+    for f, (R, T, d) in enumerate(frames):
+        if f and f % 3 == 0:
+            oc.set_active_submap(oc.get_active_submap() + 1)
+        if f % 3 == 0:
+            oc.set_base_pose_submap(oc.get_active_submap(), R, T)
+        sm.recast_depth_to_map_by_frame(f, True, (R, T), ext, d, np.array([], dtype=int))
+        oc.integrate_depth(R, T, d, mode=BATCHED)
+    assert len(sent) == 2 and sorted(sm.submaps.values()) == [0, 1, 2]
+    sm.local_to_global()
+    og = OracleTSDF(**dict(opts, is_global_map=True))
+    for fid, sid in sm.submaps.items():
+        og.set_base_pose_submap(sid, frames[fid][0], frames[fid][1])
+    og.fuse_submaps(oc, mode=BATCHED)
+    a, b = sort_export(sm.global_map.export_submap()), sort_export(og.export_sparse())
+    assert np.array_equal(a["indices"], b["indices"]) and a["indices"].shape[0] > 50000
+    ok = ~np.isnan(a["TSDF"].view(np.float16))
+    assert np.array_equal(a["TSDF"][ok], b["TSDF"][ok]) and np.array_equal(a["W_TSDF"], b["W_TSDF"]) and np.array_equal(a["occupy"], b["occupy"])

@@ -418,3 +418,23 @@ def test_capacity_errors_are_reported_and_do_not_stick(hip_lib):
     only_b = DenseTSDF(**SMALL); only_b.set_dep_camera_intrinsic(K)
     only_b.recast_depth_to_map(Rb, Tb, db, None)
     assert_export_equal(g.export_submap(), only_b.export_submap(), "after reset")
+
+
+def test_pointcloud2_payload_and_export_row_writes(hip_lib):
+    """next-4 glue: the PointCloud2 data block interleaved on the device equals what the reference's node assembles from numpy copies
+    (utils/ros_pcl_transfer.py:96-136, scripts/taichislam_node.py:420-425); `export_TSDF_xyz[i] = p` (tests/gen_topo_graph.py:64) works."""
+    K, frames = small_stream(2)
+    g, _ = make_pair(SMALL, K)
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+    g.cvt_TSDF_surface_to_voxels()
+    n = g.num_TSDF_particles[None]
+    assert n > 100
+    xyz, rgb = g.export_TSDF_xyz.to_numpy()[:n], g.export_color.to_numpy()[:n]
+    for has_rgb in (False, True):
+        msg = g.pointcloud2(has_rgb=has_rgb)
+        want = np.concatenate((xyz, rgb.astype(float)), axis=1) if has_rgb else xyz          # pub_to_ros :420-425
+        assert msg["data"] == want.astype(np.float32).tobytes() and msg["width"] == n and msg["point_step"] == (24 if has_rgb else 12)
+        assert [f["name"] for f in msg["fields"]] == list("xyzrgb" if has_rgb else "xyz") and msg["row_step"] == msg["point_step"] * n
+    g.export_TSDF_xyz[n] = np.array([1.5, -2.5, 0.25])
+    assert np.array_equal(g.export_TSDF_xyz.to_numpy(n + 1)[n], np.array([1.5, -2.5, 0.25], np.float32))
