@@ -33,6 +33,7 @@ namespace tsl {
 #define EF_NODE 1
 #define EF_NEG 2
 #define EF_FIXED 4
+#define ESDF_SWEEPS 1
 
 struct EsdfDev {
     float* mag;                // [max_bricks][4096] magnitude
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, int nuse
 // 4. one relaxation round: every brick on this round's work list is staged in LDS with its one-voxel halo and relaxed to its local fixed
 //    point; a brick whose boundary layer improved puts the neighbours that see it on the next round's list.  Rounds are separate launches
 //    (the kernel boundary is the only synchronisation: no fences, no spinning); a launch whose list is empty returns at once.
-__global__ void __launch_bounds__(256) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, int round)
+__global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, int round)
 {
     __shared__ uint32_t s_d[ESDF_T3];              // magnitude bits (non-negative floats order like unsigned integers)
     __shared__ uint8_t s_f[ESDF_T3];
@@ -128,94 +129,122 @@ __global__ void __launch_bounds__(256) k_esdf_round(MapDev M, EsdfDev E, int s, 
         for (int i = threadIdx.x; i < (ESDF_T3 + 31) / 32 + 1; i += 256) s_a[i] = 0u;
         __syncthreads();
         const bool first = E.region[p] == 1;                        // first relaxation in this update: the band voxels push too
-        // ---- stage brick + halo ----
-        for (int t = threadIdx.x; t < ESDF_T3; t += 256) {
-            const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-            const int ox = (tx + 15) >> 4, oy = (ty + 15) >> 4, oz = (tz + 15) >> 4;                 // 0, 1, 2: which neighbour brick
-            const int np = s_nb[(ox * 3 + oy) * 3 + oz];
-            uint8_t f = 0; uint32_t d = 0u;
-            if (np >= 0) {
-                const size_t v = (size_t)np * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
-                f = E.fl[v];
-                d = __float_as_uint(E.mag[v]);
+        // ---- stage brick + halo: a thread's 23 entries are requested in two batches of independent loads ----
+#pragma unroll 1
+        for (int q0 = 0; q0 < 24; q0 += 12) {
+            int np[12]; uint8_t f[12]; uint32_t d[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int t = (q0 + q) * 256 + (int)threadIdx.x;
+                np[q] = -1;
+                if (t < ESDF_T3) {
+                    const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
+                    np[q] = s_nb[(((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4)];             // 0, 1, 2 per axis: which neighbour brick
+                }
             }
-            const bool halo = ox != 1 || oy != 1 || oz != 1;
-            s_f[t] = f; s_d[t] = d;
-            if ((f & EF_NODE) && (halo || (first && (f & EF_FIXED)))) atomicOr(&s_a[t >> 5], 1u << (t & 31));
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int t = (q0 + q) * 256 + (int)threadIdx.x;
+                f[q] = 0; d[q] = 0u;
+                if (np[q] >= 0) {
+                    const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
+                    const size_t v = (size_t)np[q] * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+                    f[q] = E.fl[v]; d[q] = __float_as_uint(E.mag[v]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int t = (q0 + q) * 256 + (int)threadIdx.x;
+                if (t >= ESDF_T3) continue;
+                const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
+                const bool halo = tx == 0 || tx == 17 || ty == 0 || ty == 17 || tz == 0 || tz == 17;
+                s_f[t] = f[q]; s_d[t] = d[q];
+                if ((f[q] & EF_NODE) && (halo || (first && (f[q] & EF_FIXED)))) atomicOr(&s_a[t >> 5], 1u << (t & 31));
+            }
         }
         __syncthreads();
         // ---- push relaxation: active voxels offer value + edge cost to their same-side, non-fixed neighbours INSIDE the brick.
-        //      A thread owns 23 consecutive tile entries (their active bits sit in one or two words): it takes its set bits with one
-        //      returning atomic AND, and per active voxel reads the 26 neighbours' flags and values as ONE batch of independent LDS
-        //      loads, then issues non-returning atomic mins + active-bit ORs for the candidates that beat what it read (a min that
-        //      lost a race is a no-op and the extra activation is harmless).  LDS operations of a wave execute in order. ----
+        //      Entry t belongs to thread t mod 256 (a front -- a sheet of neighbouring voxels -- spreads over all threads).  Per pass a
+        //      thread reads the active words of its 23 entries as one batch; an active entry is cleared with a non-returning atomic AND,
+        //      then its value and the 26 neighbours' flags and values are read as ONE batch of independent LDS loads, and non-returning
+        //      atomic mins + active-bit ORs go out for the candidates that beat what was read (a min that lost a race is a no-op and the
+        //      extra activation is harmless).  LDS operations of a wave execute in order: the value read follows the clear, the OR
+        //      follows the min. ----
         long long pushes = 0; int passes = 0;
-        const int tb = (int)threadIdx.x * 23;
         volatile uint32_t* vd = s_d;
         volatile uint32_t* va = s_a;
         for (;;) {
             bool act = false;
-            unsigned long long mine = 0ull;
-            if (tb < ESDF_T3) {
-                const int w0 = tb >> 5, sh = tb & 31;
-                const unsigned long long m23 = ((1ull << 23) - 1ull) << sh;
-                unsigned long long seen = (unsigned long long)va[w0] | ((unsigned long long)va[w0 + 1] << 32);       // s_a has one spare word
-                if (seen & m23) {
-                    unsigned long long got = __hip_atomic_fetch_and(&s_a[w0], ~(uint32_t)m23, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (m23 >> 32) got |= (unsigned long long)__hip_atomic_fetch_and(&s_a[w0 + 1], ~(uint32_t)(m23 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 32;
-                    mine = (got & m23) >> sh;
-                }
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            for (; mine; mine &= mine - 1ull) {
-                const int t = tb + (int)__builtin_ctzll(mine);
-                if (t >= ESDF_T3) break;
+            constexpr int PER = (ESDF_T3 + 255) / 256;
+            // several scan + push sweeps per barrier: LDS atomics are visible to the other waves at once, the barrier is only needed to
+            // agree that nothing is active any more, so the front may advance a few voxels between two barriers
+#pragma unroll 1
+            for (int sweep = 0; sweep < ESDF_SWEEPS; ++sweep) {
+            uint32_t mine = 0u;                                    // bit q: my q-th entry is active
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; if (t < ESDF_T3) mine |= ((va[t >> 5] >> (t & 31)) & 1u) << q; }
+#pragma unroll 1
+            for (; mine; mine &= mine - 1u) {
+                const int t = (int)__builtin_ctz(mine) * 256 + (int)threadIdx.x;
+                __hip_atomic_fetch_and(&s_a[t >> 5], ~(1u << (t & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
                 const uint32_t cls = s_f[t] & (EF_NODE | EF_NEG);
                 const float dv = __uint_as_float(vd[t]);
                 ++pushes;
-                uint32_t fn[26], dn[26]; int idx[26];
+                uint32_t fn[26], dn[26], okm = 0u;
 #pragma unroll
-                for (int q = 0; q < 26; ++q) {
-                    const int c = q < 13 ? q : q + 1;                                      // 0..26 without the centre
+                for (int c = 0; c < 27; ++c) {
+                    if (c == 13) continue;
+                    const int qq = c < 13 ? c : c - 1;
                     const int dx = c / 9 - 1, dy = (c / 3) % 3 - 1, dz = c % 3 - 1;
                     const int x = tx + dx, y = ty + dy, z = tz + dz;
                     const bool ok = x >= 1 && x <= 16 && y >= 1 && y <= 16 && z >= 1 && z <= 16;
-                    idx[q] = ok ? (x * ESDF_T + y) * ESDF_T + z : -1;
-                    const int j = ok ? idx[q] : t;
-                    fn[q] = s_f[j]; dn[q] = vd[j];
+                    okm |= (ok ? 1u : 0u) << qq;
+                    const int j = ok ? t + (dx * ESDF_T + dy) * ESDF_T + dz : t;
+                    fn[qq] = s_f[j]; dn[qq] = vd[j];
                 }
 #pragma unroll
-                for (int q = 0; q < 26; ++q) {
-                    const int c = q < 13 ? q : q + 1;
+                for (int c = 0; c < 27; ++c) {
+                    if (c == 13) continue;
+                    const int qq = c < 13 ? c : c - 1;
                     const int dx = c / 9 - 1, dy = (c / 3) % 3 - 1, dz = c % 3 - 1;
-                    if (idx[q] < 0 || (fn[q] & (EF_NODE | EF_NEG | EF_FIXED)) != cls) continue;          // node, same side, not fixed
+                    if (!((okm >> qq) & 1u) || (fn[qq] & (EF_NODE | EF_NEG | EF_FIXED)) != cls) continue;          // node, same side, not fixed
                     const uint32_t cand = __float_as_uint(dv + cost[dx * dx + dy * dy + dz * dz]);
-                    if (cand < dn[q]) {
-                        __hip_atomic_fetch_min(&s_d[idx[q]], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_or(&s_a[idx[q] >> 5], 1u << (idx[q] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cand < dn[qq]) {
+                        const int j = t + (dx * ESDF_T + dy) * ESDF_T + dz;
+                        __hip_atomic_fetch_min(&s_d[j], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(&s_a[j >> 5], 1u << (j & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         act = true;
                     }
                 }
             }
+            }
             ++passes;
             if (!__syncthreads_or(act)) break;
         }
-        // ---- write back what changed; a changed voxel of the boundary layer puts the neighbours that hold it in their halo on the
-        //      next round's list ----
-        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-            const int x = (l >> 8) + 1, y = ((l >> 4) & 15) + 1, z = (l & 15) + 1;
-            const float nv = __uint_as_float(s_d[(x * ESDF_T + y) * ESDF_T + z]);
-            float* g = &E.mag[(size_t)p * TSL_BRK3 + l];
-            if (nv != *g) {
-                *g = nv;
-                const int lx = x == 1 ? 0 : (x == 16 ? 2 : 1), ly = y == 1 ? 0 : (y == 16 ? 2 : 1), lz = z == 1 ? 0 : (z == 16 ? 2 : 1);
-                if (lx != 1 || ly != 1 || lz != 1) {
-                    int m = 0;
-                    for (int ax = (lx == 0 ? 0 : 1); ax <= (lx == 2 ? 2 : 1); ++ax)
-                        for (int ay = (ly == 0 ? 0 : 1); ay <= (ly == 2 ? 2 : 1); ++ay)
-                            for (int az = (lz == 0 ? 0 : 1); az <= (lz == 2 ? 2 : 1); ++az) m |= 1 << ((ax * 3 + ay) * 3 + az);
-                    atomicOr(&s_notify, m & ~(1 << 13));
+        // ---- write back what changed (16 voxels per thread, their old values requested as one batch); a changed voxel of the boundary
+        //      layer puts the neighbours that hold it in their halo on the next round's list ----
+        {
+            float old[TSL_BRK3 / 256];
+            float* gm = E.mag + (size_t)p * TSL_BRK3;
+#pragma unroll
+            for (int q = 0; q < TSL_BRK3 / 256; ++q) old[q] = gm[q * 256 + threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < TSL_BRK3 / 256; ++q) {
+                const int l = q * 256 + threadIdx.x;
+                const int x = (l >> 8) + 1, y = ((l >> 4) & 15) + 1, z = (l & 15) + 1;
+                const float nv = __uint_as_float(s_d[(x * ESDF_T + y) * ESDF_T + z]);
+                if (nv != old[q]) {
+                    gm[l] = nv;
+                    const int lx = x == 1 ? 0 : (x == 16 ? 2 : 1), ly = y == 1 ? 0 : (y == 16 ? 2 : 1), lz = z == 1 ? 0 : (z == 16 ? 2 : 1);
+                    if (lx != 1 || ly != 1 || lz != 1) {
+                        int m = 0;
+                        for (int ax = (lx == 0 ? 0 : 1); ax <= (lx == 2 ? 2 : 1); ++ax)
+                            for (int ay = (ly == 0 ? 0 : 1); ay <= (ly == 2 ? 2 : 1); ++ay)
+                                for (int az = (lz == 0 ? 0 : 1); az <= (lz == 2 ? 2 : 1); ++az) m |= 1 << ((ax * 3 + ay) * 3 + az);
+                        atomicOr(&s_notify, m & ~(1 << 13));
+                    }
                 }
             }
         }
