@@ -103,10 +103,11 @@ int  tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3]
                                const float* xyz, const uint8_t* rgb, int64_t n);
 int  tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3],
                                    const void* xyz_dev, const void* rgb_dev, int64_t n);
-/* Stream that will read the device buffers of the next integrate_*_dev call (points: 0 depth image, 1 point cloud).  Producers on
- * another stream order themselves before it (event + hipStreamWaitEvent); the reference's recast_* calls are synchronous
- * (dense_tsdf.py:157-165), so the Python shim does this for torch tensors. */
-int  tsl_tsdf_input_stream(tsl_tsdf* m, int points, void** hip_stream);
+/* Stream that will read the device buffers of the next integrate_*_dev call (points: 0 depth image, 1 point cloud).  With `ordered`,
+ * that stream is first made to wait for everything queued so far on `producer` (the hipStream_t the caller fills its buffers on; NULL =
+ * the default stream): the reference's recast_* calls are synchronous (dense_tsdf.py:157-165), so the Python shim does this for torch
+ * tensors with torch's current stream. */
+int  tsl_tsdf_input_stream(tsl_tsdf* m, int points, int ordered, void* producer, void** hip_stream);
 /* frames queued by integrate_* calls and not yet issued to the device: a device buffer handed to integrate_*_dev is read by kernels
  * that are only enqueued once this has dropped back to 0 (or any synchronising call was made) */
 int  tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n);

@@ -78,7 +78,7 @@ SIGNATURES = {
     "tsl_tsdf_integrate_depth_dev": (C.c_int, [vp, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     "tsl_tsdf_integrate_points": (C.c_int, [vp, dp, dp, vp, vp, i64]),
     "tsl_tsdf_integrate_points_dev": (C.c_int, [vp, dp, dp, vp, vp, i64]),
-    "tsl_tsdf_input_stream": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "tsl_tsdf_input_stream": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "tsl_tsdf_queued_frames": (C.c_int, [vp, pi32]),
     "tsl_tsdf_last_frame_stats": (C.c_int, [vp, C.POINTER(FrameStats)]),
     "tsl_tsdf_count_active": (C.c_int, [vp, pi64]),

@@ -1006,6 +1006,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     if (m->h_ints) (void)hipHostFree(m->h_ints);
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& e : m->prof_free) (void)hipEventDestroy(e);
+    for (auto& e : m->in_ev) if (e) (void)hipEventDestroy(e);
     if (m->stream_) (void)hipStreamDestroy(m->stream_);
     delete m;
 }
@@ -1162,13 +1163,21 @@ int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
 }
 
 /* HIP stream that will read the input of the NEXT integrate_*_dev call (phase A of the batch the frame joins).  A caller that
- * produces its device buffers on its own stream orders that stream before this one (event record + hipStreamWaitEvent), and a
- * caching allocator is told that this stream uses the buffer (torch: tensor.record_stream) -- see mapping/dense_tsdf.py. */
-int tsl_tsdf_input_stream(tsl_tsdf* m, int points, void** hip_stream)
+ * produces its device buffers on its own stream passes that stream as `producer`: the reading stream is made to wait for what the
+ * producer has queued so far (one event record + one stream wait, events are cached).  producer = NULL: the legacy default stream;
+ * `ordered` = 0 skips the ordering (the caller guarantees the buffers are complete). */
+int tsl_tsdf_input_stream(tsl_tsdf* m, int points, int ordered, void* producer, void** hip_stream)
 {
     TSL_REQUIRE(m && hip_stream, "input_stream: null argument"); TSL_HIP(hipSetDevice(m->device));
     int si = 0; int rc = reserve_slot(m, points ? 1 : 0, &si); if (rc) return rc;
-    *hip_stream = (void*)(m->overlap == 0 ? m->stream_ : m->batch[si / TSL_NB].st);
+    hipStream_t consumer = m->overlap == 0 ? m->stream_ : m->batch[si / TSL_NB].st;
+    *hip_stream = (void*)consumer;
+    if (ordered && (hipStream_t)producer != consumer) {
+        if (!m->in_ev[0]) for (auto& e : m->in_ev) TSL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipEvent_t e = m->in_ev[m->in_ev_next]; m->in_ev_next = (m->in_ev_next + 1) % 8;
+        TSL_HIP(hipEventRecord(e, (hipStream_t)producer));
+        TSL_HIP(hipStreamWaitEvent(consumer, e, 0));
+    }
     return TSL_OK;
 }
 

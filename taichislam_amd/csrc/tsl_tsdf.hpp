@@ -152,6 +152,7 @@ struct tsl_tsdf {
     int overlap;                         // frames per batch (0 = one frame at a time on the main stream)
     int cur, npend, pend_points; tsl::FrameParams pend[TSL_NB]; int deferred_rc;      // frames queued for batch `cur`
     int last_set;
+    hipEvent_t in_ev[8]; int in_ev_next;  // cached events ordering callers' producer streams before the input-reading stream (tsl_tsdf_input_stream)
     bool scratch_ready;                  // frame scratch allocated (first integrate call)
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;

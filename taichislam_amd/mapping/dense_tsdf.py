@@ -157,20 +157,18 @@ class DenseTSDF(BaseMap):
     def _adopt_device_inputs(self, points, *tensors):
         """The reference's recast_* calls are synchronous; here a frame is only queued and its kernels are enqueued later (when
         its batch of four is full, or when anything else needs the map) on the library's own streams.  For torch tensors the
-        shim therefore (1) makes the stream that will read the frame wait for the work already queued on torch's current
-        stream (the tensor may still be being produced) and (2) keeps the tensors referenced until the kernels that read them
+        shim therefore (1) has the stream that will read the frame wait for the work already queued on torch's current
+        stream (the tensor may still be being produced; tsl_tsdf_input_stream) and (2) keeps the tensors referenced until the kernels that read them
         have run (an event recorded behind the batch on the reading stream), so a tensor the caller drops right after the
         call is not recycled by torch's caching allocator under a queued frame."""
         import torch
         s = C.c_void_p()
-        self._call("input_stream", int(points), C.byref(s))
-        dev = tensors[0].device
+        cur = torch.cuda.current_stream(tensors[0].device)
+        # ordering is done by the library (cached events): asking torch whether its stream is idle costs ~100 us when the GPU is busy
+        self._call("input_stream", int(points), 1, C.c_void_p(cur.cuda_stream), C.byref(s))
         ext = self._ext_streams.get(s.value)
         if ext is None:
-            ext = self._ext_streams[s.value] = torch.cuda.ExternalStream(s.value, device=dev)
-        cur = torch.cuda.current_stream(dev)
-        if not cur.query():
-            ext.wait_stream(cur)
+            ext = self._ext_streams[s.value] = torch.cuda.ExternalStream(s.value, device=tensors[0].device)
         self._held.append((ext, tensors))
 
     def _release_device_inputs(self, force=False):
