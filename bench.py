@@ -12,6 +12,7 @@ the timed region the ranks merge their submaps into one global map with ONE exch
 Rank 0 prints exactly one JSON line.  The other BASELINE configs (1: marching cubes on a 128^3 sphere, 3: Octomap 1024^3 / 5 cm,
 4: TSDF + incremental ESDF per frame + mesh every 10th frame) print their own line with --config; they are single-GPU."""
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -180,12 +181,16 @@ def main():
         m.sync()
 
     barrier()
+    # Python's cyclic collector is paused for the timed region (as timeit does): a full collection of this process (torch, numpy, the
+    # frame lists) takes ~35 ms, two thirds of a 300-frame run, and would land in it at random
+    gc.collect(); gc.disable()
     t0 = time.perf_counter()
     for f in range(args.warmup, nframes):
         step(f)
     m.sync()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     dt_rank = dt
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")

@@ -111,6 +111,12 @@ int  tsl_tsdf_input_stream(tsl_tsdf* m, int points, int ordered, void* producer,
 /* frames queued by integrate_* calls and not yet issued to the device: a device buffer handed to integrate_*_dev is read by kernels
  * that are only enqueued once this has dropped back to 0 (or any synchronising call was made) */
 int  tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n);
+/* Lifetime of device input buffers without synchronising: *queued_total = frames handed to integrate_* since the handle was created
+ * (the frame of the latest call has index queued_total - 1), *consumed = how many of them the device has certainly finished reading.
+ * The buffers of frame i may be reused or freed once consumed > i.  Host-side bookkeeping only (no device query, never blocks): the
+ * library never queues more than eight batches (32 frames) ahead of the device -- the integrate call that would exceed that waits for
+ * the oldest batch -- and that wait, like every synchronising call, advances the count. */
+int  tsl_tsdf_frames_consumed(tsl_tsdf* m, int64_t* queued_total, int64_t* consumed);
 /* The integrate calls only QUEUE the frame (host buffers are copied before they return; device buffers must stay unchanged until
  * the next call that returns data, or tsl_tsdf_sync).  Queued frames are issued four at a time, or as soon as any other call needs
  * the map, so results never depend on the queueing; frames still queued when a handle is destroyed are dropped. */

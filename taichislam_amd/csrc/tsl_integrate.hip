@@ -443,38 +443,81 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
     }
 }
 
-// K4b: lay out the frame's active bricks (listed by k_segments): a range of the sorted segment array per brick and its
-// integrate parts (a brick with more than PART_SEGS segments is integrated by several workgroups).  Neither has to be in
-// any particular order, so block-aggregated reservations replace a prefix scan.  Parts go to three tables by length, so
-// k_integrate_bricks starts the long ones first and its tail is made of short ones.
-// part = { first segment, segments | parts of the brick << 16, pool index of the brick (claimed here, on its first touch ever), active rank }
-__device__ __forceinline__ int part_class(int per, int psegs) { return per * 8 >= psegs * 5 ? 0 : (per * 4 >= psegs ? 1 : 2); }
-__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs)
+// K4b: lay out the frame's active bricks (listed by k_segments) -- a range of the sorted segment array per brick -- and the batch's
+// integrate work list.  A brick whose segments of ALL frames of the batch together number at most `unit_max` becomes one UNIT: one
+// workgroup walks its frames in order and keeps the voxels in registers in between (one read and one write of the brick per batch,
+// no ordering traffic).  A heavier brick is walked in PARTS of at most `psegs` segments of one frame; every part adds its sums into the
+// (frame, brick)'s slot of the batch's merge slab, and the workgroup that arrives last at the brick -- over all its frames -- applies
+// the frames in order.  Items are binned into PLAN_NCLS classes by the segments they walk (long first).
+// Nothing has to be in any particular order inside a class, so block-aggregated reservations replace a prefix scan.
+// unit = { brick id, segments of the batch | frames with segments << 28, pool index (claimed here, on the brick's first touch ever), - }
+// part = { first segment, segments | parts of the (frame, brick) << 16 | frames of the batch with segments << 28, pool index,
+//          slab slot of the (frame, brick) = the brick's first slot + frame }
+#define PART_NP_BITS 12
+#define PLAN_NCLS 4
+#define HDR_FAIL 11            // header words (FrameDev.counters): frame overflow bits
+#define HDR_CLAIM 12           //   batch (first frame's header): next rank to claim
+#define HDR_SLAB 13            //   batch: merge-slab slots handed out
+#define HDR_PARTS 16           //   [16..19] parts per class
+#define HDR_UNITS 20           //   batch: [20..23] units per class
+__device__ __forceinline__ int plan_class(int w) { return w >= 2560 ? 0 : (w >= 1280 ? 1 : (w >= 512 ? 2 : 3)); }
+__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max, unsigned long long gen)
 {
     if ((int)blockIdx.y >= B.n) return;
-    const FrameDev& F = B.f[blockIdx.y];
+    const int y = blockIdx.y;
+    const FrameDev& F = B.f[y];
     const int listed = F.counters[1];
     const int nact = min(listed, F.max_frame_bricks);
     if ((int)blockIdx.x * 256 >= nact && blockIdx.x) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int v = 0, b = 0, np = 0, cls = 2;
+    int v = 0, b = 0, np = 0, pcls = -1, ucls = -1, tm = 0, wb = 0;
     if (i < nact) {
         b = F.act_b[i];
         v = F.bhist[b];
-        np = (v + psegs - 1) / psegs;
-        cls = np ? part_class((v + np - 1) / np, psegs) : 2;
+        int vmax = 0;
+        for (int q = 0; q < B.n; ++q) { const int vq = B.f[q].bhist[b]; if (vq > 0) tm |= 1 << q; wb += vq; vmax = max(vmax, vq); }
+        if (wb <= unit_max) { if ((tm & -tm) == (1 << y)) ucls = plan_class(wb); }         // the brick's first frame lists the unit
+        else if (v > 0) { np = (v + psegs - 1) / psegs; pcls = plan_class(min(psegs, vmax)); }
     }
     const int off = block_reserve_n(&F.counters[3], v);
-    int p0 = 0;
-    for (int c = 0; c < 3; ++c) { const int q = block_reserve_n(&F.counters[8 + c], cls == c ? np : 0); if (cls == c) p0 = q; }
+    int p0 = 0, u0 = 0;
+    for (int c = 0; c < PLAN_NCLS; ++c) {
+        const int q = block_reserve_n(&F.counters[HDR_PARTS + c], pcls == c ? np : 0); if (pcls == c) p0 = q;
+        const int u = block_reserve_n(&B.f[0].counters[HDR_UNITS + c], ucls == c ? 1 : 0); if (ucls == c) u0 = u;
+    }
     if (i < nact) {
         F.boffset[b] = off;
-        const int per = np ? (v + np - 1) / np : 0;
-        int4* tab = F.part_tab + (size_t)cls * F.part_cap;
-        const int pool = np ? pool_claim<false>(M, B.p[blockIdx.y]->slot, b) : -1;      // < 0: pool exhausted (reported through M.err), the parts are skipped
-        for (int k = 0; k < np; ++k) {
-            const int pos = k * per, n = min(v, pos + per) - pos;
-            if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, n | (np << 16), pool, i); else frame_fail(M, F, 2);
+        F.bnseg[b] = v;
+        const int pool = (np || ucls >= 0) ? pool_claim<false>(M, B.p[y]->slot, b) : -1;      // < 0: pool exhausted (reported through M.err), the item is skipped
+        if (ucls >= 0) {
+            if (u0 < B.f[0].unit_cap) B.f[0].unit_tab[(size_t)ucls * B.f[0].unit_cap + u0] = make_int4(b, (int)((uint32_t)wb | ((uint32_t)tm << 28)), pool, 0);
+            else for (int q = 0; q < B.n; ++q) if ((tm >> q) & 1) frame_fail(M, B.f[q], 2);
+        }
+        if (np && pool >= 0) {
+            // the brick's TSL_NB consecutive slots of the batch's merge slab (one per frame)
+            // (the brick's first frame of the batch claims them, the other frames' threads -- other blocks of this small grid, all resident --
+            //  wait for its tag)
+            unsigned long long cur;
+            if ((tm & -tm) == (1 << y)) {
+                const int mine = __hip_atomic_fetch_add(&B.f[0].counters[HDR_SLAB], TSL_NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur = (gen << 20) | (unsigned long long)min(mine, (1 << 20) - 1);
+                __hip_atomic_store(&M.slab_of[pool], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                int spins = 0;
+                while (((cur = __hip_atomic_load(&M.slab_of[pool], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != gen && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(2);
+                if ((cur >> 20) != gen) cur = (1u << 20) - 1u;                      // cannot happen; fails the capacity check below
+            }
+            const int base = (int)(cur & ((1u << 20) - 1u));
+            if (base + TSL_NB > F.max_frame_bricks || np >= (1 << PART_NP_BITS)) frame_fail(M, F, 2);
+            else {
+                F.npf[base + y] = np;
+                const int per = (v + np - 1) / np;
+                int4* tab = F.part_tab + (size_t)pcls * F.part_cap;
+                for (int k = 0; k < np; ++k) {
+                    const int pos = k * per, n = min(v, pos + per) - pos;
+                    if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, (int)((uint32_t)n | ((uint32_t)np << 16) | ((uint32_t)tm << 28)), pool, base + y); else frame_fail(M, F, 2);
+                }
+            }
         }
     }
     if (i == 0) { F.stats->bricks = listed; if (listed > F.max_frame_bricks) frame_fail(M, F, 2); }
@@ -556,7 +599,7 @@ __device__ __forceinline__ void step_eval(const RayRegs& R, const StepK& K, int 
 __device__ __forceinline__ bool fits_i32(long long q) { return q == (long long)(int)q; }
 __device__ __forceinline__ float from_fix32(long long q) { return (float)(int)q * (float)TSL_FIX_INV; }
 
-#define FLUSH_CHUNK 8
+#define FLUSH_CHUNK 4
 template <int N>
 __device__ __forceinline__ void apply_chunk(const uint32_t* old, const long long* qn, const long long* qd, uint32_t* nv, bool all_small)
 {
@@ -570,56 +613,131 @@ __device__ __forceinline__ void apply_chunk(const uint32_t* old, const long long
 }
 
 // =====================================================================================================
-// k_integrate_bricks: the same part arithmetic as k_integrate_bricks2, as a persistent, software-pipelined kernel.
-// What bounded v2 was not the walk but the dependent device-memory round trips around it (part entry -> segment keys -> ray
-// records before, rows / stores after: 1-2 us each at 8 waves per CU) and the two dispatch rounds of ~670 parts on 512 slots.
-// Here 2 workgroups per CU stay resident and take parts in serpentine order over the cost-ordered part list (long, medium,
-// short: the workgroup with the longest part of a tier gets the shortest of the next).  While a part is walked, the entry and the
-// keys of the workgroup's next part are in flight; after the walk the next part's keys are length-sorted in their own 8 KiB of LDS
-// and its ray records requested, and only then the current part is flushed -- every load has a phase of useful work to hide behind.
+// k_integrate_batch: phase B of a whole batch of frames (up to TSL_NB) as ONE persistent, software-pipelined launch.
+//
+// The work list (k_plan) is class-major: for each of PLAN_NCLS length classes the batch's UNITS, then the PARTS of frame 0, 1, ...
+// The resident workgroups claim items from it in rank order through one counter, two items ahead of the one they walk.
+//   UNIT  a brick whose whole batch fits one workgroup: its frames are walked in order, the brick's voxels stay in registers in
+//         between (each frame's sums are applied to them exactly as a per-frame launch would apply them to memory), the brick is
+//         read once and written once per batch and nothing has to be ordered against other workgroups.
+//   PART  (a slice of) one frame's segments in a heavier brick.  A part's walk depends only on its frame's rays, never on the map, so
+//         the parts of all frames of the batch are walked side by side, in any order; each adds its sums into the (frame, brick)'s slot
+//         of the batch's merge slab in HBM (L2 atomics) and takes an arrival ticket of the brick.  The workgroup that arrives last --
+//         over all parts of all frames -- reads the brick once, applies the frames' sums in frame order exactly as per-frame launches
+//         would, writes it once and leaves the slots zeroed.  Nobody ever waits for another workgroup.
+//
+// Inside a workgroup the pipeline is the one of round 2's per-frame kernel, over "steps" (one chunk of CSEGS segments of one frame of
+// one item): while a step is walked, the keys of the next step -- next chunk, next frame of the unit, or the first step of the next
+// claimed item -- are in flight; after the walk they are length-sorted in their own 8 KiB of LDS and their ray records requested,
+// and only then the finished frame is applied.  The items' descriptions live in a three-slot LDS ring (current, next, being fetched).
+// One launch per batch removes three of four kernel tails (half of the workgroups of a per-frame launch were idle for the second
+// half of it), and with longest-first dynamic claims over a four-frame work list the heavy bricks next to the sensor no longer
+// set the length of every frame.
 // =====================================================================================================
-__device__ __forceinline__ int4 part_entry(const FrameDev& F, int rank, int nA, int nB)
-{
-    return rank < nA ? F.part_tab[rank] : (rank < nA + nB ? F.part_tab[F.part_cap + rank - nA] : F.part_tab[2 * (size_t)F.part_cap + rank - nA - nB]);
-}
-// rank of the t-th part of workgroup w of G in serpentine order
-__device__ __forceinline__ int serp_rank(int t, int w, int G) { return t * G + ((t & 1) ? G - 1 - w : w); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane holds (read from LDS): keep it in an SGPR
+// item record in LDS
+#define IT_UNIT 0       // 1: unit
+#define IT_POOL 1       // pool index of the brick (< 0: skip)
+#define IT_SLAB 2       // parts: slab slot
+#define IT_NP   3       // parts: parts of the (frame, brick)
+#define IT_TMALL 4      // parts: frames of the batch that integrate into the brick
+#define IT_FMASK 5      // frames this item walks
+#define IT_OFF  6       // [6..9] first segment per frame
+#define IT_N    10      // [10..13] segments per frame
+#define IT_WORDS 16
+#define NRANGE (PLAN_NCLS * (TSL_NB + 1))
 
 template <bool TEX, bool FASTDIV, int NT>
-__global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_bricks(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp)
+__global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_batch(MapDev M, BatchDev B)
 {
-    // NT threads walk a part in chunks of CSEGS = 4 * NT segments (4 per thread); a part may hold several chunks (k_plan's psegs), so
-    // a brick with up to psegs segments is integrated by one workgroup and never merged through HBM.  NT = 256: two workgroups per CU;
-    // NT = 512: one (8 waves on one brick: half the walk latency per brick, half as many bricks in flight).
+    // NT threads walk a step of up to CSEGS = 4 * NT segments (4 per thread).  NT = 256: two workgroups per CU; NT = 512: one (8 waves
+    // on one brick: half the walk latency per brick, half as many bricks in flight).
     constexpr int CSEGS = 4 * NT, SPT = 4, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
-    const FrameParams& P = *Pp;
+    static_assert(VPT <= 16, "the written / first-touch masks hold 16 voxels per thread");
     __shared__ unsigned long long s_num[TSL_BRK3];              // 32 KiB
     __shared__ unsigned long long s_den[TSL_BRK3];              // 32 KiB
-    __shared__ unsigned long long s_keys[CSEGS];                // 8 / 16 KiB: length sort of the NEXT chunk's keys while the planes hold the current sums
+    __shared__ unsigned long long s_keys[CSEGS];                // 8 / 16 KiB: length sort of the NEXT step's keys while the planes hold the current sums
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
     __shared__ int s_bin[64];
     __shared__ int s_last;
-    const int nA = min(F.counters[8], F.part_cap), nB = min(F.counters[9], F.part_cap), nC = min(F.counters[10], F.part_cap);
-    const int nparts = (F.counters[11] != 0) ? 0 : nA + nB + nC;          // nothing is integrated when the frame overflowed its scratch
-    const int G = gridDim.x, w = blockIdx.x;
-    const StepK K = { P.vs, P.rvs, P.T[0], P.T[1], P.T[2], M.hN, M.hNz };
-    long long uniq = 0;
-    TSL_T0();
-    {   // restore the "all zero between uses" invariant of this set's per-brick histogram / cursor
-        const int nact = min(F.counters[1], F.max_frame_bricks);
-        for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = F.act_b[i]; F.bhist[b] = 0; F.bcursor[b] = 0; }
+    __shared__ int s_claim[2];
+    __shared__ int s_cum[NRANGE + 1];                           // first rank of every range of the work list (class-major: units, frame 0, 1, ...)
+    __shared__ int s_it[3][IT_WORDS];
+    uint32_t okmask = 0u;
+#pragma unroll
+    for (int q = 0; q < TSL_NB; ++q) if (q < B.n) {
+        const FrameDev& Fq = B.f[q];
+        if (Fq.counters[HDR_FAIL] == 0) okmask |= 1u << q;                 // nothing of a frame that overflowed its scratch is integrated
+        // restore the "all zero between uses" invariant of the set's per-brick histogram / cursor
+        const int nact = min(Fq.counters[1], Fq.max_frame_bricks);
+        for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = Fq.act_b[i]; Fq.bhist[b] = 0; Fq.bcursor[b] = 0; }
     }
-    int t = 0, c = 0;                                          // t-th part of this workgroup, chunk c of it
-    if (serp_rank(0, w, G) >= nparts) return;
-    int4 ptc = part_entry(F, serp_rank(0, w, G), nA, nB);
-    int4 ptn = make_int4(0, 0, -1, 0);
-    if (serp_rank(1, w, G) < nparts) ptn = part_entry(F, serp_rank(1, w, G), nA, nB);
+    if (threadIdx.x == 0) {
+        int acc = 0, k = 0;
+        for (int c = 0; c < PLAN_NCLS; ++c) {
+            s_cum[k++] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap);
+            for (int q = 0; q < TSL_NB; ++q) { s_cum[k++] = acc; if ((okmask >> q) & 1u) acc += min(B.f[q].counters[HDR_PARTS + c], B.f[q].part_cap); }
+        }
+        s_cum[NRANGE] = acc;
+        s_claim[0] = __hip_atomic_fetch_add(&B.f[0].counters[HDR_CLAIM], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int total = uni(s_cum[NRANGE]);
+    int* const claim = &B.f[0].counters[HDR_CLAIM];
+    // rank -> table entry; *kq = -1 for a unit, else the frame of the part
+    auto entry_of = [&](int r, int* kq) -> int4 {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < NRANGE; ++j) k += r >= uni(s_cum[j]) ? 1 : 0;
+        const int local = r - uni(s_cum[k]), cls = k / (TSL_NB + 1), sub = k - cls * (TSL_NB + 1);
+        *kq = sub - 1;
+        if (sub == 0) return B.f[0].unit_tab[(size_t)cls * B.f[0].unit_cap + local];
+        const FrameDev& Fq = B.f[sub - 1];
+        return Fq.part_tab[(size_t)cls * Fq.part_cap + local];
+    };
+    // per-frame segment ranges of a unit (thread q < TSL_NB loads frame q's); parts carry theirs in the entry
+    auto info_of = [&](const int4 e, int kq, int* io, int* in) {
+        *io = 0; *in = 0;
+        const int q = threadIdx.x;
+        if (q < TSL_NB) {
+            if (kq < 0) { if ((((uint32_t)e.y >> 28) & okmask) >> q & 1u) { *io = B.f[q].boffset[e.x]; *in = B.f[q].bnseg[e.x]; } }
+            else if (q == kq) { *io = e.x; *in = e.y & 0xffff; }
+        }
+    };
+    auto commit = [&](int slot, const int4 e, int kq, int io, int in) {
+        int* it = s_it[slot];
+        if (threadIdx.x < TSL_NB) { it[IT_OFF + threadIdx.x] = io; it[IT_N + threadIdx.x] = in; }
+        if (threadIdx.x == 0) {
+            const uint32_t tm = ((uint32_t)e.y >> 28) & okmask;
+            uint32_t fm = kq < 0 ? tm : 1u << kq;
+            int pool = e.z;
+            if (fm == 0u) { fm = 1u; pool = -1; }                  // a unit whose frames all overflowed: nothing to walk, nothing to apply
+            it[IT_UNIT] = kq < 0 ? 1 : 0; it[IT_POOL] = pool; it[IT_SLAB] = e.w; it[IT_NP] = kq < 0 ? 1 : (e.y >> 16) & ((1 << PART_NP_BITS) - 1);
+            it[IT_TMALL] = (int)tm; it[IT_FMASK] = (int)fm;
+        }
+    };
+    const int r0 = uni(s_claim[0]);
+    if (r0 >= total) return;
+    { int kq, io, in; const int4 e = entry_of(r0, &kq); info_of(e, kq, &io, &in); commit(0, e, kq, io, in); }
+    __syncthreads();
+    // steps (chunks of CSEGS segments) of the frames `fm` of the item in ring slot `sl`
+    auto steps_of = [&](int sl, uint32_t fm) -> int {
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) if ((fm >> q) & 1u) n += max(1, (uni(s_it[sl][IT_N + q]) + CSEGS - 1) / CSEGS);
+        return n;
+    };
+    long long uniq = 0;
+    int t = 0, slot = 0, c = 0; (void)t;                       // t-th item of this workgroup (in ring slot `slot`), chunk c of frame f of it
+    int n_known = 0;                                           // items already fetched behind the current one (ring slots slot+1, slot+2)
+    bool exhausted = false;                                    // a claim came back beyond the end of the list
+    int f = __builtin_ctz((uint32_t)uni(s_it[0][IT_FMASK]));
 
     unsigned long long kk[SPT]; uint4 recs[SPT]; uint32_t wids[SPT];
     // length-sort `nseg` keys (this thread holds k[q] = key q*NT+tid) through s_keys / s_bin, deal them out in alternating directions
-    // and request the ray records of the dealt keys.  Counting sort by step count, descending: the lanes of a wave walk segments of
-    // (almost) equal length and every thread gets about the same number of steps.  Contains 3 barriers; s_bin must be zero on entry.
-#define TSL_SORT_DEAL(KIN, NSEG)                                                                                        \
+    // and request the ray records of the dealt keys from frame FD.  Counting sort by step count, descending: the lanes of a wave walk
+    // segments of (almost) equal length and every thread gets about the same number of steps.  Contains 3 barriers; s_bin must be zero on entry.
+#define TSL_SORT_DEAL(KIN, NSEG, FD)                                                                                    \
     {                                                                                                                   \
         int rr[SPT];                                                                                                    \
         _Pragma("unroll") for (int q = 0; q < SPT; ++q) {                                                               \
@@ -640,61 +758,97 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
             if (i < (NSEG)) {                                                                                           \
                 kk[q] = s_keys[i];                                                                                      \
                 const int r = (int)((kk[q] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));               \
-                recs[q] = F.rayA[r];                                                                                    \
-                wids[q] = TEX ? F.rayFirst[r] + 1u : 0u;                                                                \
+                recs[q] = (FD).rayA[r];                                                                                 \
+                wids[q] = TEX ? (FD).rayFirst[r] + 1u : 0u;                                                             \
             }                                                                                                           \
         }                                                                                                               \
         if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;              /* ordered against the next use by the barriers in between */ \
     }
+    // the pipeline is empty (launch start, or the workgroup ran out of fetched items): request the first step of the item in `SL` now
+#define TSL_PRIME(SL, FQ)                                                                                               \
+    {                                                                                                                   \
+        const FrameDev& F0 = B.f[FQ];                                                                                   \
+        const int off0 = uni(s_it[SL][IT_OFF + (FQ)]), nseg0 = min(uni(s_it[SL][IT_N + (FQ)]), CSEGS);                  \
+        unsigned long long k0[SPT];                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; k0[q] = i < nseg0 ? F0.seg_sorted[off0 + i] : 0ull; } \
+        TSL_SORT_DEAL(k0, nseg0, F0)                                                                                    \
+    }
 
-    {   // prologue: the first chunk's keys, planes cleared, sort, ray records
-        unsigned long long k0[SPT];
-        const int nseg0 = min(ptc.y & 0xffff, CSEGS);
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; k0[q] = i < nseg0 ? F.seg_sorted[ptc.x + i] : 0ull; }
+    {   // the sums are zero between items: cleared here once, afterwards by whoever reads them
         ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
         for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) { zn[i] = make_ulonglong2(0ull, 0ull); zd[i] = make_ulonglong2(0ull, 0ull); }
         if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         __syncthreads();
-        TSL_SORT_DEAL(k0, nseg0)
+        TSL_PRIME(0, f)
     }
     uint32_t old[VPT];
+    uint32_t vmask = 0u;                                       // bits 0..15: voxel written by this item, 16..31: its weight was zero when the item began
+    bool have_old = false;
+    int target = 0;                                            // parts: arrivals the brick expects in this batch
     for (;;) {
-        TSL_TICK(F, 0);
-        const int nseg_part = ptc.y & 0xffff, np = ptc.y >> 16, p = ptc.z, rk = ptc.w;
-#ifdef TSL_TIMING
-        long long* const _rec = F.dbg + 131072 + (size_t)blockIdx.x * 64 + (size_t)(t < 8 ? t : 7) * 8;
-        if (threadIdx.x == 0 && c == 0) { _rec[0] = wall_clock64(); _rec[1] = nseg_part; _rec[2] = np; }
-#endif
-        const int nseg = min(CSEGS, nseg_part - c * CSEGS);
-        const bool last = (c + 1) * CSEGS >= nseg_part;               // last chunk of the part: flush after the walk
-        const bool whole = np == 1;
-        // the next unit of work: the next chunk of this part, or the first chunk of the workgroup's next part
-        const bool has_next = !last || serp_rank(t + 1, w, G) < nparts;
-        const int4 ptx = last ? ptn : ptc;
-        const int cx = last ? 0 : c + 1;
-        // requests that ride under the walk: the entry of the part after next, the next chunk's keys, this brick's rows
-        int4 ptn2 = make_int4(0, 0, -1, 0);
-        if (last && serp_rank(t + 2, w, G) < nparts) ptn2 = part_entry(F, serp_rank(t + 2, w, G), nA, nB);
-        unsigned long long kn[SPT];
-        const int nsegn = has_next ? min(CSEGS, (ptx.y & 0xffff) - cx * CSEGS) : 0;
+        const int* const it = s_it[slot];
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;
+        const bool unit = uni(it[IT_UNIT]) != 0;
+        const int p = uni(it[IT_POOL]), rk = uni(it[IT_SLAB]);
+        const uint32_t fmask = (uint32_t)uni(it[IT_FMASK]), tmall = (uint32_t)uni(it[IT_TMALL]);
+        const int n_f = uni(it[IT_N + f]);
+        const FrameDev& F = B.f[f];
+        const FrameParams& P = *B.p[f];
+        const StepK K = { P.vs, P.rvs, P.T[0], P.T[1], P.T[2], M.hN, M.hNz };
+        const uint32_t later = fmask >> (f + 1);
+        const bool first_frame = (fmask & ((1u << f) - 1u)) == 0u, last_frame = later == 0u;
+        const bool first_step = first_frame && c == 0;
+        const int nseg = min(CSEGS, n_f - c * CSEGS);
+        const bool last_chunk = (c + 1) * CSEGS >= n_f;               // last chunk of the frame: apply after the walk
+        const bool last_step = last_chunk && last_frame;
+        // claim the next item late: when at most one more step is known behind this one (two steps of lookahead keep the pipeline
+        // full; an early claim would take an item away from a workgroup that could start it sooner)
+        int known = max(1, (n_f + CSEGS - 1) / CSEGS) - 1 - c + steps_of(slot, later << (f + 1));
+        if (n_known >= 1) known += steps_of(slot1, (uint32_t)uni(s_it[slot1][IT_FMASK]));
+        const bool do_claim = !exhausted && n_known < 2 && known <= 1;
+        if (do_claim && threadIdx.x == 0) s_claim[0] = __hip_atomic_fetch_add(claim, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // parts: arrivals the brick expects in this batch (the parts of all its frames); requested early, used after the walk
+        if (!unit && c == 0 && p >= 0) {
+            target = 0;
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; kn[q] = i < nsegn ? F.seg_sorted[ptx.x + cx * CSEGS + i] : 0ull; }
-        if (!TEX && c == 0 && whole && p >= 0) {
-            const uint32_t* twr = M.tw + (size_t)p * TSL_BRK3;
+            for (int q = 0; q < TSL_NB; ++q) if ((tmall >> q) & 1u) target += F.npf[rk - f + q];
+        }
+#ifdef TSL_TIMING
+        long long* const _rec = F.dbg + 131072 + (size_t)blockIdx.x * 128 + (size_t)(t < 16 ? t : 15) * 8;
+        if (threadIdx.x == 0 && first_step) { _rec[0] = wall_clock64(); _rec[1] = (unit ? 1 : 0) | (uni(it[IT_NP]) << 8) | ((long long)fmask << 32); _rec[2] = 0; _rec[5] = 0; }
+        if (threadIdx.x == 0 && c == 0) _rec[2] += n_f;
+        long long* const _ph = F.dbg + 196608 + (size_t)blockIdx.x * 128 + (size_t)(t < 16 ? t : 15) * 8;
+        if (threadIdx.x == 0 && first_step) { _ph[0] = _ph[1] = _ph[2] = _ph[3] = _ph[4] = 0; }
+        const long long _ta = wall_clock64();
+#endif
+        // the next step: the next chunk of this frame, the first chunk of the unit's next frame, or the first step of the next item
+        const bool has_next = !last_step || n_known >= 1;
+        int fx = f, cx = c + 1, slotx = slot;
+        if (last_chunk) {
+            cx = 0;
+            if (!last_frame) fx = f + 1 + __builtin_ctz(later);
+            else if (has_next) { slotx = slot1; fx = __builtin_ctz((uint32_t)uni(s_it[slotx][IT_FMASK])); }
+        }
+        const FrameDev& Fx = B.f[fx];
+        // requests that ride under the walk: the next step's keys, the unit's voxels
+        unsigned long long kn[SPT];
+        const int offx = uni(s_it[slotx][IT_OFF + fx]) + cx * CSEGS;
+        const int nsegn = has_next ? min(CSEGS, uni(s_it[slotx][IT_N + fx]) - cx * CSEGS) : 0;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) { const int i = q * NT + threadIdx.x; kn[q] = i < nsegn ? Fx.seg_sorted[offx + i] : 0ull; }
+        const uint32_t* const twr = M.tw + (size_t)(p >= 0 ? p : 0) * TSL_BRK3;
+        if (first_step) { have_old = false; vmask = 0u; }
+        if (!TEX && unit && p >= 0 && first_step) {                  // the unit's voxels are requested under its first walk
 #pragma unroll
             for (int q = 0; q < VPT; ++q) old[q] = twr[q * NT + threadIdx.x];
+            have_old = true;
         }
-        TSL_TICK(F, 1);
         // ---- walk ----
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const int i = q * NT + ((q & 1) ? NT - 1 - (int)threadIdx.x : (int)threadIdx.x);
             if (i >= nseg) continue;
-#ifdef TSL_EXP_NOWALK
-            if (nseg >= 0) continue;
-#endif
             const unsigned long long key = kk[q];
             const int cnt = (int)(key & ((1u << SEG_CNT_BITS) - 1)), j0 = (int)((key >> SEG_CNT_BITS) & ((1u << SEG_J_BITS) - 1));
             const RayRegs R = make_ray(recs[q], 0, P);
@@ -720,56 +874,93 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
                 if (TEX) atomicMax(&s_win[lb], vb ? wid : 0u);
             }
         }
-        TSL_TICK(F, 2);
         __syncthreads();
-        TSL_TICK(F, 3);
 #ifdef TSL_TIMING
-        if (threadIdx.x == 0 && last) _rec[3] = wall_clock64();
+        if (threadIdx.x == 0 && last_step) _rec[3] = wall_clock64();
+        const long long _tb = wall_clock64();
 #endif
-        // ---- the next chunk's keys are here: sort them and request its ray records, then flush under that latency ----
-        if (has_next) TSL_SORT_DEAL(kn, nsegn)
-        if (!last) { ++c; continue; }
-        if (p >= 0 && threadIdx.x == 0) M.touch[p] = 1;               // the brick's TSDF changes in this frame (incremental ESDF)
-        if (p >= 0 && whole) {
+        // the claimed item: its table entry now, its per-frame ranges after the sort (both land in the ring at the end of this step)
+        bool fetching = false;
+        int4 ne = make_int4(0, 0, -1, 0); int nkq = 0, nio = 0, nin = 0;
+        if (do_claim) {
+            const int r = uni(s_claim[0]);
+            if (r < total) { fetching = true; ne = entry_of(r, &nkq); } else exhausted = true;
+        }
+        // ---- the next step's keys are here: sort them and request its ray records, then apply under that latency ----
+        if (has_next) TSL_SORT_DEAL(kn, nsegn, Fx)
+        if (fetching) info_of(ne, nkq, &nio, &nin);
+#ifdef TSL_TIMING
+        const long long _tc = wall_clock64();
+        if (threadIdx.x == 0) { _ph[0] += _tb - _ta; _ph[1] += _tc - _tb; _ph[4] += 1; }
+#endif
+        if (!last_chunk) {
+            if (fetching) { commit(n_known == 0 ? slot1 : slot2, ne, nkq, nio, nin); ++n_known; __syncthreads(); }
+            ++c; continue;
+        }
+        if (p >= 0 && threadIdx.x == 0) M.touch[p] = 1;                   // the brick's TSDF changes in this batch (incremental ESDF)
+        if (p >= 0 && unit) {
             uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
-            int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-            if (TEX) {
+            if (!have_old) {
 #pragma unroll
                 for (int q = 0; q < VPT; ++q) old[q] = tw[q * NT + threadIdx.x];
+                have_old = true;
+            }
+            if (first_frame) {
+#pragma unroll
+                for (int q = 0; q < VPT; ++q) vmask |= ((old[q] >> 16) == 0u ? 1u : 0u) << (16 + q);      // W == 0 <=> never integrated
             }
 #pragma unroll
-            for (int h = 0; h < VPT; h += CH) {                  // CH voxels at a time, no branch between them
-                long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true;
+            for (int h = 0; h < VPT; h += CH) {                  // CH voxels at a time, no branch between them; the sums are left zero
+                long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true, anyu = false;
 #pragma unroll
-                for (int q = 0; q < CH; ++q) { const int ls = acc_swz5((h + q) * NT + threadIdx.x); qn[q] = (long long)s_num[ls]; qd[q] = (long long)s_den[ls]; small = small && fits_i32(qn[q]) && fits_i32(qd[q]); }
+                for (int q = 0; q < CH; ++q) {
+                    const int ls = acc_swz5((h + q) * NT + threadIdx.x);
+                    qn[q] = (long long)s_num[ls]; qd[q] = (long long)s_den[ls]; s_num[ls] = 0ull; s_den[ls] = 0ull;
+                    small = small && fits_i32(qn[q]) && fits_i32(qd[q]); anyu = anyu || qd[q] != 0;
+                }
+                if (!__any(anyu)) continue;                      // none of this wave's 64 x CH voxels was touched by the frame
                 apply_chunk<CH>(old + h, qn, qd, nv, __all(small));
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
-                    const int l = (h + q) * NT + threadIdx.x;
-                    if (qd[q] != 0) {
-                        tw[l] = nv[q];
-                        if ((old[h + q] >> 16) == 0u) obs[l] = 1;       // W == 0 <=> never integrated; imported voxels already carry observed = 1
-                        if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[acc_swz5(l)] - 1u];
-                        ++uniq;
+                    const bool upd = qd[q] != 0;
+                    old[h + q] = upd ? nv[q] : old[h + q];
+                    vmask |= (upd ? 1u : 0u) << (h + q);
+                    uniq += upd ? 1 : 0;
+                    if (TEX && upd) {
+                        const int l = (h + q) * NT + threadIdx.x;
+                        reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[s_win[acc_swz5(l)] - 1u];
+                    }
+                }
+            }
+            if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
+            if (last_frame) {                                    // the unit's last frame: the voxels go back to the map
+                int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+#pragma unroll
+                for (int q = 0; q < VPT; ++q) {
+                    const int l = q * NT + threadIdx.x;
+                    if ((vmask >> q) & 1u) {
+                        tw[l] = old[q];
+                        if ((vmask >> (16 + q)) & 1u) obs[l] = 1;       // imported voxels already carry observed = 1
                     }
                 }
             }
         } else if (p >= 0) {
-            // brick split over `np` workgroups: add the partial sums into the brick's HBM scratch slab; the last workgroup
-            // to arrive (arrival ticket, agent-scope release/acquire) applies them and leaves the slab zeroed.
-            unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
+            // part of a heavy brick: add the sums into the (frame, brick)'s slot of the batch's HBM slab; the workgroup that arrives last at
+            // the brick (arrival ticket over the parts of all its frames, agent-scope release/acquire) applies the frames in order.
+            const int base = rk - f;
+            {
+                unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
 #pragma unroll
-            for (int q = 0; q < VPT; ++q) {
-                const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
-#ifdef TSL_EXP_NOSPLITFLUSH
-                const unsigned long long d = 0ull;
-#else
-                const unsigned long long d = s_den[ls];
-#endif
-                if (d != 0ull) {
-                    __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
+                for (int q = 0; q < VPT; ++q) {
+                    const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
+                    const unsigned long long d = s_den[ls];
+                    if (d != 0ull) {
+                        __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
+                    }
+                    s_num[ls] = 0ull; s_den[ls] = 0ull;
+                    if (TEX) s_win[ls] = 0u;
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -777,66 +968,97 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_br
             if (threadIdx.x == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int tk = __hip_atomic_fetch_add(&F.ticket[rk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = (tk == np - 1) ? 1 : 0;
-                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); F.ticket[rk] = 0; }
+                const int tk = __hip_atomic_fetch_add(&F.ticket[base], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (tk == target - 1) ? 1 : 0;
+                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); F.ticket[base] = 0; }
             }
             __syncthreads();
             if (s_last) {
-                ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
                 uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
                 int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-                // the sums were produced by L2 atomics of other CUs: read them at L2 as well, CH voxels in flight per thread
+#ifdef TSL_TIMING
+                if (threadIdx.x == 0) _rec[5] = wall_clock64();
+#endif
+                vmask = 0u;                                      // a part item: the unit registers are free
 #pragma unroll
-                for (int h = 0; h < VPT; h += CH) {
-                    long long qn[CH], qd[CH]; uint32_t oldv[CH], nv[CH]; bool small = true;
+                for (int q = 0; q < VPT; ++q) { old[q] = tw[q * NT + threadIdx.x]; }
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int l = (h + q) * NT + threadIdx.x;
-                        qn[q] = (long long)__hip_atomic_load(&acc[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        qd[q] = (long long)__hip_atomic_load(&acc[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        oldv[q] = tw[l];
-                    }
+                for (int q = 0; q < VPT; ++q) vmask |= ((old[q] >> 16) == 0u ? 1u : 0u) << (16 + q);
+                for (int g = 0; g < TSL_NB; ++g) {
+                    if (!((tmall >> g) & 1u)) continue;
+                    const FrameDev& Fg = B.f[g];
+                    unsigned long long* accg = Fg.acc + (size_t)(base + g) * (TSL_BRK3 * 2);
+                    ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(accg);
+                    long long ug = 0;
+                    // the sums were produced by L2 atomics of other CUs: read them at L2 as well, CH voxels in flight per thread
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) small = small && fits_i32(qn[q]) && fits_i32(qd[q]);
-                    apply_chunk<CH>(oldv, qn, qd, nv, __all(small));
+                    for (int h = 0; h < VPT; h += CH) {
+                        long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true;
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int l = (h + q) * NT + threadIdx.x;
-                        if (qd[q] != 0) {
-                            tw[l] = nv[q];
-                            if ((oldv[q] >> 16) == 0u) obs[l] = 1;
-                            acc2[l] = make_ulonglong2(0ull, 0ull);
-                            if (TEX) {
-                                uint32_t* wv = F.accw + (size_t)rk * TSL_BRK3 + l;
-                                const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = F.colpix[wsel - 1u];
-                                *wv = 0u;
-                            }
-                            ++uniq;
+                        for (int q = 0; q < CH; ++q) {
+                            const int l = (h + q) * NT + threadIdx.x;
+                            qn[q] = (long long)__hip_atomic_load(&accg[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            qd[q] = (long long)__hip_atomic_load(&accg[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) small = small && fits_i32(qn[q]) && fits_i32(qd[q]);
+                        apply_chunk<CH>(old + h, qn, qd, nv, __all(small));
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) {
+                            const int l = (h + q) * NT + threadIdx.x;
+                            if (qd[q] != 0) {
+                                old[h + q] = nv[q];
+                                vmask |= 1u << (h + q);
+                                acc2[l] = make_ulonglong2(0ull, 0ull);
+                                if (TEX) {
+                                    uint32_t* wv = Fg.accw + (size_t)(base + g) * TSL_BRK3 + l;
+                                    const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = Fg.colpix[wsel - 1u];
+                                    *wv = 0u;
+                                }
+                                ++ug;
+                            }
+                        }
+                    }
+                    ug = wave_sum_ll(ug);
+                    if (lane_id() == 0 && ug) atomic_add_i64(&Fg.stats->unique, ug);
+                }
+#pragma unroll
+                for (int q = 0; q < VPT; ++q) {
+                    const int l = q * NT + threadIdx.x;
+                    if ((vmask >> q) & 1u) {
+                        tw[l] = old[q];
+                        if ((vmask >> (16 + q)) & 1u) obs[l] = 1;
                     }
                 }
             }
-        }
-        TSL_TICK(F, 4);
-#ifdef TSL_TIMING
-        if (threadIdx.x == 0) _rec[4] = wall_clock64();
-        if (lane_id() == 0 && _wv < 16384) { F.dbg[_wv * 16 + 10] = nseg_part; F.dbg[_wv * 16 + 11] = whole; F.dbg[_wv * 16 + 12] = t; }
-#endif
-        if (!has_next) break;
-        __syncthreads();                                                  // every thread has read the sums of the finished part
-        {
+        } else {                                                          // brick pool exhausted (reported by k_plan): drop the sums
             ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
             for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) { zn[i] = make_ulonglong2(0ull, 0ull); zd[i] = make_ulonglong2(0ull, 0ull); }
             if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         }
-        __syncthreads();
-        ++t; c = 0; ptc = ptn; ptn = ptn2;
+#ifdef TSL_TIMING
+        const long long _td = wall_clock64();
+#endif
+        {   // this frame's distinct-voxel count
+            const long long u = wave_sum_ll(uniq);
+            if (lane_id() == 0 && u) atomic_add_i64(&F.stats->unique, u);
+            uniq = 0;
+        }
+        if (fetching) { commit(n_known == 0 ? slot1 : slot2, ne, nkq, nio, nin); ++n_known; }
+#ifdef TSL_TIMING
+        if (threadIdx.x == 0 && last_step) _rec[4] = wall_clock64();
+        if (threadIdx.x == 0) { _ph[2] += _td - _tc; _ph[3] += wall_clock64() - _td; }
+#endif
+        if (!has_next && n_known == 0) break;                             // the list is exhausted and nothing is left in the ring
+        __syncthreads();                                                  // the sums are zero again, the ring slot is written
+        c = 0;
+        if (last_frame) { ++t; slot = slot1; --n_known; f = __builtin_ctz((uint32_t)uni(s_it[slot][IT_FMASK])); }
+        else f = fx;
+        if (!has_next) TSL_PRIME(slot, f)                                 // nothing was in flight for this step
     }
+#undef TSL_PRIME
 #undef TSL_SORT_DEAL
-    uniq = wave_sum_ll(uniq);
-    if (lane_id() == 0 && uniq) atomic_add_i64(&F.stats->unique, uniq);
 }
 
 int check_variant2(tsl_tsdf* m)
@@ -856,9 +1078,22 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024));
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024), m->unit_max, (unsigned long long)++m->batch_gen);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
+    return TSL_OK;
+}
+
+// phase B of a batch on the main stream: one launch of the brick kernel (variant 2), or per frame the global-atomics kernels (variants 0/1)
+int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P)
+{
+    // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
+#define TSL_LAUNCH_IB(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, B); \
+                                     else hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3((TEXV ? 1 : 2) * m->ncu), dim3(256), 0, m->stream_, m->M, B); } while (0)
+    if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
+    else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }
+#undef TSL_LAUNCH_IB
+    TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
 
@@ -866,26 +1101,14 @@ int launch_apply(tsl_tsdf* m, FSet& S, int total)
 {
     FrameParams& P = m->P;
     FrameDev& F = S.F;
-    if (P.variant == 2) {
-        prof_begin(m, TSL_K_INTEGRATE);
-        const FrameParams* Pd = (const FrameParams*)S.Pd;
-        // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
-#define TSL_LAUNCH_IB3(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_bricks<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, F, Pd); \
-                                      else hipLaunchKernelGGL((k_integrate_bricks<TEXV, FD, 256>), dim3((TEXV ? 1 : 2) * m->ncu), dim3(256), 0, m->stream_, m->M, F, Pd); } while (0)
-        if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB3(true, true); else TSL_LAUNCH_IB3(true, false); }
-        else { if (P.fastdiv) TSL_LAUNCH_IB3(false, true); else TSL_LAUNCH_IB3(false, false); }
-#undef TSL_LAUNCH_IB3
-        prof_end(m);
-    } else {
-        const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
-        prof_begin(m, TSL_K_INTEGRATE);
-        if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-        else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
-        prof_end(m);
-        prof_begin(m, TSL_K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const int*)nullptr, (const int*)nullptr);
-        prof_end(m);
-    }
+    const int iblocks = (int)(((int64_t)total * P.split + 255) / 256);
+    prof_begin(m, TSL_K_INTEGRATE);
+    if (P.variant == 1) hipLaunchKernelGGL(k_integrate<1>, dim3(iblocks), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
+    else hipLaunchKernelGGL(k_integrate<0>, dim3(iblocks), dim3(256), 0, m->stream_, m->M, F, (const FrameParams*)S.Pd);
+    prof_end(m);
+    prof_begin(m, TSL_K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize, dim3(1024), dim3(256), 0, m->stream_, m->M, F, (const int*)nullptr, (const int*)nullptr);
+    prof_end(m);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }

@@ -637,6 +637,13 @@ static int launch_batch_t(tsl_tsdf* m)
     BatchHost& H = m->batch[bi];
     const bool serial = m->overlap == 0;
     hipStream_t sa = serial ? m->stream_ : H.st;
+    // back-pressure: the host never runs more than TSL_INFLIGHT batches ahead of the device (bounded queues, bounded lifetime of the
+    // callers' input buffers); waiting for the batch issued TSL_INFLIGHT batches ago also tells which frames have been consumed
+    const int ring = (int)(m->batch_seq % TSL_INFLIGHT);
+    if (m->ring_upto[ring] > 0) {
+        TSL_HIP(hipEventSynchronize(m->ring_ev[ring]));
+        if (m->ring_upto[ring] > m->frames_consumed) m->frames_consumed = m->ring_upto[ring];
+    }
     if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
     BatchDev B; ParamPack PP;
     for (int q = 0; q < n; ++q) { FSet& S = m->fset[bi * TSL_NB + q]; B.f[q] = S.F; B.p[q] = S.Pd; PP.p[q] = m->pend[q]; }
@@ -644,25 +651,29 @@ static int launch_batch_t(tsl_tsdf* m)
     B.n = n;
     hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, B);
     if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
+    m->frames_issued += n;
     if (!serial) {
         TSL_HIP(hipEventRecord(H.a_done, sa));
         TSL_HIP(hipStreamWaitEvent(m->stream_, H.a_done, 0));
     }
-    // ---- phase B: apply to the map, in frame order on the main stream ----
-    {   // one pair of timing events around the batch's integrate launches (they run back to back on this stream)
-        int nb = 0; for (int q = 0; q < n; ++q) nb += m->pend[q].total > 0;
-        const bool group = m->pend[0].variant == 2 && nb > 0 && (m->phases & 2);
-        if (group) { prof_begin(m, TSL_K_INTEGRATE, nullptr, nb); m->prof_group = true; }
+    // ---- phase B: apply to the map on the main stream: the brick kernel takes the whole batch in one launch (frame order is kept per
+    //      brick inside it); the global-atomics variants run frame by frame ----
+    if (m->phases & 2) {
         int rc = TSL_OK;
-        for (int q = 0; q < n && !rc; ++q) {
-            FSet& S = m->fset[bi * TSL_NB + q];
-            m->P = m->pend[q];
-            if (m->P.total > 0 && (m->phases & 2)) rc = launch_apply(m, S, m->P.total);
+        if (m->pend[0].variant == 2) {
+            bool any = false; for (int q = 0; q < n; ++q) any = any || m->pend[q].total > 0;
+            if (any) { prof_begin(m, TSL_K_INTEGRATE, nullptr, 1); rc = launch_apply_batch(m, B, m->pend[0]); prof_end(m); }
+        } else {
+            for (int q = 0; q < n && !rc; ++q) {
+                FSet& S = m->fset[bi * TSL_NB + q];
+                m->P = m->pend[q];
+                if (m->P.total > 0) rc = launch_apply(m, S, m->P.total);
+            }
         }
-        if (group) { m->prof_group = false; prof_end(m); }
         if (rc) return rc;
     }
     if (!serial) { TSL_HIP(hipEventRecord(H.b_done, m->stream_)); H.b_pending = true; }
+    TSL_HIP(hipEventRecord(m->ring_ev[ring], m->stream_)); m->ring_upto[ring] = m->frames_issued; m->batch_seq++;
     m->cur = (bi + 1) % TSL_NBATCH;
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -719,12 +730,22 @@ static int ensure_frame_scratch(tsl_tsdf* m)
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.ticket, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&F.npf, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&F.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc; }
     for (int si = 0; si < TSL_NSETS; ++si) {
         FSet& S = m->fset[si];
         S.F = F;
         FrameDev& G = S.F;
         auto own = [&](void** p, size_t bytes) -> int { int r = dev_alloc(m, p, bytes, 0); if (!r) S.owned.push_back(*p); return r; };
+        if (si >= TSL_NB) {         // the second batch in flight merges its split bricks through its own slab (owned by its first set)
+            FrameDev& G0 = m->fset[TSL_NB].F;
+            if (si == TSL_NB) {
+                if ((rc = own((void**)&G.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3))) return rc;
+                if ((rc = own((void**)&G.ticket, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
+                if ((rc = own((void**)&G.npf, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
+                if (cfg->texture_enabled) { if ((rc = own((void**)&G.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3))) return rc; }
+            } else { G.acc = G0.acc; G.ticket = G0.ticket; G.npf = G0.npf; G.accw = G0.accw; }
+        }
         if ((rc = own((void**)&G.keys, 8 * np))) return rc;
         if ((rc = own((void**)&G.keys_s, 8 * np))) return rc;
         if ((rc = own((void**)&G.vals, 4 * np))) return rc;
@@ -757,9 +778,12 @@ static int ensure_frame_scratch(tsl_tsdf* m)
         if ((rc = own((void**)&G.bhist, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.bcursor, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.boffset, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.bnseg, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
         G.part_cap = F.seg_cap / 256 + F.max_frame_bricks + 8;
-        if ((rc = own((void**)&G.part_tab, sizeof(int4) * 3 * (size_t)G.part_cap))) return rc;
+        if ((rc = own((void**)&G.part_tab, sizeof(int4) * 4 * (size_t)G.part_cap))) return rc;
+        G.unit_cap = TSL_NB * F.max_frame_bricks;
+        if (si % TSL_NB == 0) { if ((rc = own((void**)&G.unit_tab, sizeof(int4) * 4 * (size_t)G.unit_cap))) return rc; }
         if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
     }
@@ -848,6 +872,8 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->overlap = TSL_NB; m->last_set = 0;
     for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; }
     for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.b_pending = false; }
+    m->frames_issued = 0; m->frames_consumed = 0; m->batch_seq = 0;
+    for (int k = 0; k < TSL_INFLIGHT; ++k) { m->ring_ev[k] = nullptr; m->ring_upto[k] = 0; }
     m->cur = 0; m->npend = 0; m->pend_points = 0; m->deferred_rc = 0;
     const int blk = cfg->num_voxel_per_blk_axis;
     m->N = (int)std::ceil(cfg->map_size_xy / cfg->voxel_scale / (double)blk) * blk;          // dense_tsdf.py:24
@@ -890,7 +916,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256; m->chunks = 1;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256; m->chunks = 2; m->unit_max = 4096; m->batch_gen = 0;
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -916,6 +942,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&M.col, sizeof(uint16_t) * 4 * (size_t)want * TSL_BRK3, 0))) return rc; }
     if ((rc = dev_alloc(m, (void**)&M.owner, sizeof(int) * (size_t)want, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.touch, (size_t)want, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.slab_of, sizeof(unsigned long long) * (size_t)want, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
     M.err = M.pool_top + 1;
 
@@ -936,6 +963,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
         TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
         TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
     }
+    for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], hipEventDisableTiming));
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 16, hipHostMallocDefault));
     std::memset(m->h_stats, 0, sizeof(tsl_frame_stats));
@@ -997,9 +1025,9 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         if (S.stage_tex) (void)hipFree(S.stage_tex);
 
     }
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket,
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket, m->F.npf,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
-                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->M.touch, m->M.slab_of, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
                      m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
@@ -1007,6 +1035,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     for (auto& s : m->prof) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& e : m->prof_free) (void)hipEventDestroy(e);
     for (auto& e : m->in_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->ring_ev) if (e) (void)hipEventDestroy(e);
     if (m->stream_) (void)hipStreamDestroy(m->stream_);
     delete m;
 }
@@ -1039,6 +1068,7 @@ int tsl_tsdf_sync(tsl_tsdf* m)
     int rc = flush_pending(m);
     for (auto& H : m->batch) if (H.st) TSL_HIP(hipStreamSynchronize(H.st));
     const int ec = take_dev_err(m);                // synchronises the main stream
+    m->frames_consumed = m->frames_issued;         // everything issued has run
     if (!rc && m->deferred_rc) { rc = m->deferred_rc; }
     m->deferred_rc = 0;
     return rc ? rc : ec;
@@ -1183,6 +1213,16 @@ int tsl_tsdf_input_stream(tsl_tsdf* m, int points, int ordered, void* producer, 
 
 /* frames queued but not yet issued to the device (0 right after a batch went out) */
 int tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); *n = m->npend; return TSL_OK; }
+
+/* frames (counted since the handle was created) whose input buffers the device has finished reading: host-side bookkeeping of
+ * the back-pressure ring (launch_batch_t) and of tsl_tsdf_sync, no device query */
+int tsl_tsdf_frames_consumed(tsl_tsdf* m, int64_t* queued_total, int64_t* consumed)
+{
+    TSL_REQUIRE(m, "null");
+    if (queued_total) *queued_total = m->frames_issued + m->npend;
+    if (consumed) *consumed = m->frames_consumed;
+    return TSL_OK;
+}
 
 int tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out)
 {
@@ -1375,6 +1415,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
+    if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)

@@ -44,17 +44,20 @@ struct FrameDev {
     uint2* colpix;                               // [pixel] f16 colour {r|g<<16, b} of the ray opened by that pixel (texture)
     tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
     int*   nrays;                                // ray count of this frame
-    int*   counters;                             // [0] grouped pixels [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] crowded voxels [8..10] parts per table [11] frame overflow bits
+    int*   counters;                             // [0] grouped pixels [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] crowded voxels [11] frame overflow bits
+                                                 // [16..19] parts per class; in the header of a batch's FIRST frame: [12] next rank to claim [13] merge-slab slots [20..23] units per class
     unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick
-    int   *bhist, *bcursor, *boffset;            // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment
+    int   *bhist, *bcursor, *boffset, *bnseg;    // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment, segment count (valid for this frame's bricks)
     int   *act_b;                                // [max_frame_bricks] active bricks of the frame, in the order they were listed
-    int4  *part_tab; int part_cap;               // integrate work list, three tables (long, medium, short parts): {first segment, segments | parts << 16, brick, active rank}
-    // ---- shared by all sets (only touched in phase B, i.e. serially on the main stream) ----
+    int4  *part_tab; int part_cap;               // integrate work list of the frame's heavy bricks, one table per length class (k_plan)
+    int4  *unit_tab; int unit_cap;               // first set of a batch: the batch's units (bricks integrated for all frames by one workgroup), one table per class
+    // ---- shared by the sets of a batch (acc / ticket / accw) or by all sets: only touched in phase B, i.e. serially on the main stream ----
     int*   slot_tab;                             // variants 0/1: [nb3] brick id -> frame scratch slot, EMPTY between frames
     int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
     int*   touched_b;                            // variants 0/1: [max_frame_bricks] -> brick id
-    unsigned long long* acc;                     // [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point (zero between frames)
-    int* ticket;                                 // [max_frame_bricks] arrival tickets of split bricks (zero between frames)
+    unsigned long long* acc;                     // merge slab [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point (zero between launches)
+    int* ticket;                                 // [max_frame_bricks] arrival tickets of the batch's heavy bricks, at the brick's first slot (zero between launches)
+    int* npf;                                    // [max_frame_bricks] parts of the (frame, brick) that owns the slot
     uint32_t* accw;                              // [max_frame_bricks][4096] colour winner (first pixel + 1) of bricks split over workgroups (texture)
     long long* dbg;                              // developer timing counters (TSL_TIMING builds)
     int    seg_cap;
@@ -141,6 +144,7 @@ struct FSet {
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
 struct ParamPack { FrameParams p[TSL_NB]; };
 struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; };
+#define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
 }  // namespace tsl
 
@@ -151,6 +155,8 @@ struct tsl_tsdf {
     tsl::FSet fset[TSL_NSETS]; tsl::BatchHost batch[TSL_NBATCH];
     int overlap;                         // frames per batch (0 = one frame at a time on the main stream)
     int cur, npend, pend_points; tsl::FrameParams pend[TSL_NB]; int deferred_rc;      // frames queued for batch `cur`
+    int64_t frames_issued, frames_consumed;  // frames handed to the device so far / of those, frames whose inputs have been read
+    int64_t batch_seq; hipEvent_t ring_ev[TSL_INFLIGHT]; int64_t ring_upto[TSL_INFLIGHT];      // back-pressure ring: end of phase B of the last TSL_INFLIGHT batches
     int last_set;
     hipEvent_t in_ev[8]; int in_ev_next;  // cached events ordering callers' producer streams before the input-reading stream (tsl_tsdf_input_stream)
     bool scratch_ready;                  // frame scratch allocated (first integrate call)
@@ -184,7 +190,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, ncu, chunks;
+    int variant, split, phases, wg, ncu, chunks, unit_max; uint64_t batch_gen;
     int64_t bytes;
 };
 
@@ -198,5 +204,6 @@ void convert_pose(const double* Rb, const double* Tb, const double* R, const dou
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
-int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B: apply to the map
+int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B, variants 0/1: apply one frame to the map
+int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // phase B, variant 2: apply a batch of frames (one launch)
 }

@@ -58,8 +58,8 @@ class DenseTSDF(BaseMap):
         self.color_same_proj = color_same_proj
         self.clear_last_TSDF_exporting = False
         self.device = device
-        self._ext_streams = {}
-        self._held, self._inflight = [], []
+        self._held, self._pending_inputs = [], None
+        self._c_total, self._c_done, self._c_stream = C.c_int64(), C.c_int64(), C.c_void_p()
         self.mem_per_voxel = 2 + 2 + 1 + 1 + (6 if texture_enabled else 0)
 
         cfg = _lib.TsdfCfg(float(map_scale[0]), float(map_scale[1]), float(voxel_scale), int(num_voxel_per_blk_axis),
@@ -158,38 +158,27 @@ class DenseTSDF(BaseMap):
         """The reference's recast_* calls are synchronous; here a frame is only queued and its kernels are enqueued later (when
         its batch of four is full, or when anything else needs the map) on the library's own streams.  For torch tensors the
         shim therefore (1) has the stream that will read the frame wait for the work already queued on torch's current
-        stream (the tensor may still be being produced; tsl_tsdf_input_stream) and (2) keeps the tensors referenced until the kernels that read them
-        have run (an event recorded behind the batch on the reading stream), so a tensor the caller drops right after the
-        call is not recycled by torch's caching allocator under a queued frame."""
+        stream (the tensor may still be being produced; tsl_tsdf_input_stream) and (2) keeps the tensors referenced until the
+        device has read them (tsl_tsdf_frames_consumed; the library never lets the host run more than eight batches ahead,
+        so at most ~36 frames are held), so a tensor the caller drops right after the call is not recycled by torch's
+        caching allocator under a queued frame.  No torch stream / event queries: they cost ~100 us each while the GPU is busy."""
         import torch
-        s = C.c_void_p()
         cur = torch.cuda.current_stream(tensors[0].device)
-        # ordering is done by the library (cached events): asking torch whether its stream is idle costs ~100 us when the GPU is busy
-        self._call("input_stream", int(points), 1, C.c_void_p(cur.cuda_stream), C.byref(s))
-        ext = self._ext_streams.get(s.value)
-        if ext is None:
-            ext = self._ext_streams[s.value] = torch.cuda.ExternalStream(s.value, device=tensors[0].device)
-        self._held.append((ext, tensors))
+        self._call("input_stream", int(points), 1, C.c_void_p(cur.cuda_stream), C.byref(self._c_stream))
+        self._pending_inputs = tensors
 
     def _release_device_inputs(self, force=False):
-        """Drop the references to input tensors whose frames have been read."""
+        """Drop the references to input tensors whose frames have been read (called right after the frame was queued)."""
         if force:
-            self._held.clear(); self._inflight.clear()
+            self._held.clear(); self._pending_inputs = None
             return
-        if self._held:
-            n = C.c_int32()
-            self._call("queued_frames", C.byref(n))
-            if n.value == 0:                                   # the batch went out: an event behind it on every stream that reads it
-                import torch
-                done = {}
-                for ext, tensors in self._held:
-                    if id(ext) not in done:
-                        done[id(ext)] = torch.cuda.Event()
-                        done[id(ext)].record(ext)
-                    self._inflight.append((done[id(ext)], tensors))
-                self._held.clear()
-        while self._inflight and self._inflight[0][0].query():
-            self._inflight.pop(0)
+        total, done = self._c_total, self._c_done                             # preallocated: no per-frame garbage for the cyclic GC
+        self._call("frames_consumed", C.byref(total), C.byref(done))          # host-side counters only: no device query
+        if self._pending_inputs is not None:
+            self._held.append((total.value - 1, self._pending_inputs))       # index of the frame just queued
+            self._pending_inputs = None
+        while self._held and self._held[0][0] < done.value:
+            self._held.pop(0)
 
     def sync(self):
         super().sync()
@@ -197,9 +186,9 @@ class DenseTSDF(BaseMap):
 
     def __del__(self):
         try:
-            if self.h is not None and (self._held or self._inflight):
+            if self.h is not None and (self._held or self._pending_inputs is not None):
                 super().sync()                                  # nothing may still read the tensors when they are released
-            self._held.clear(); self._inflight.clear()
+            self._held.clear(); self._pending_inputs = None
         except Exception:
             pass
         super().__del__()

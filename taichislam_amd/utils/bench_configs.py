@@ -8,6 +8,7 @@
 Byte models are SURVEY.md section 8d's: marching cubes 3*A + 72*Tri, Octomap 2*P_used + 8*P_valid, ESDF >= 8 bytes per cell relaxed.
 Kernel times come from HIP events on the handle's stream inside the run where the handle has them (marching cubes, ESDF); the Octomap
 kernel is timed by rocprofv3 (profiles/r02_octomap_kernel_stats.csv) and through the wall clock here."""
+import gc
 import time
 
 import numpy as np
@@ -42,11 +43,13 @@ def run(config, steps, warmup, dev):
             ms.generate_mesh(1)
         g.sync()
         g.enable_profiling(True, only=[_lib.K_MESH])
+        gc.collect(); gc.disable()      # as in bench.py: no ~35 ms full collection inside the timed region
         t0 = time.perf_counter()
         for _ in range(steps):
             ms.generate_mesh(1)
         g.sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         kms, kn = g.kernel_time(_lib.K_MESH)
         a, tri = g.count_active(), ms.num_facelets[None]
         us = 1000.0 * kms / kn
@@ -62,11 +65,13 @@ def run(config, steps, warmup, dev):
         for f in range(warmup):
             oc.recast_depth_to_map(host[f][0], host[f][1], depth_dev[f], None)
         oc.sync()
+        gc.collect(); gc.disable()      # as in bench.py: no ~35 ms full collection inside the timed region
         t0 = time.perf_counter()
         for f in range(warmup, nframes):
             oc.recast_depth_to_map(host[f][0], host[f][1], depth_dev[f], None)
         oc.sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         st = oc.last_frame_stats()
         alg = 2 * st["p_used"] + 8 * st["p_valid"]
         return _line("depth-frames/s inserted (640x480 -> Octomap 1024^3 / 5 cm)", steps / dt, "frames/s", steps, warmup, 1000.0 * dt / steps,
@@ -91,6 +96,7 @@ def run(config, steps, warmup, dev):
         m.sync()
         m.enable_profiling(True, only=[_lib.K_ESDF, _lib.K_MESH])
         relax = pushes = region = 0
+        gc.collect(); gc.disable()      # as in bench.py: no ~35 ms full collection inside the timed region
         t0 = time.perf_counter()
         for f in range(warmup, nframes):
             step(f)
@@ -98,6 +104,7 @@ def run(config, steps, warmup, dev):
             relax += st["brick_relaxations"]; pushes += st["voxel_pushes"]; region += st["region_bricks"]
         m.sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         ems, en = m.kernel_time(_lib.K_ESDF)
         mms, mn = m.kernel_time(_lib.K_MESH)
         a, tri = m.count_active(), mesher.num_facelets[None]

@@ -13,6 +13,7 @@ frames = list(syn.sphere_room_stream(N))
 dev = [torch.from_numpy(d.view(np.int16)).cuda() for _, _, d in frames]
 for i in range(20): m.recast_depth_to_map(frames[i][0], frames[i][1], dev[i], None)
 m.sync()
+import gc; gc.collect(); gc.disable()
 t0 = time.perf_counter()
 for i in range(20, N): m.recast_depth_to_map(frames[i][0], frames[i][1], dev[i], None)
 t1 = time.perf_counter(); m.sync(); t2 = time.perf_counter()
