@@ -26,9 +26,9 @@ PY
   rm -rf $O/pmc_$tag
 }
 : > $O/pmc_summary.txt
-cd $R && timeout 600 python bench.py --steps 300 --warmup 30 > $O/bench_default.json 2> $O/bench_default.err
+cd $R && timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 stats bench python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline
-for cfg in "" "--opt chunks=2"; do
+for cfg in ""; do
   t=$(echo "c$cfg" | tr -d ' =-')
   pmc fetch_$t "FETCH_SIZE" $cfg
   pmc write_$t "WRITE_SIZE" $cfg
