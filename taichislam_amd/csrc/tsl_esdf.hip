@@ -33,16 +33,24 @@ namespace tsl {
 #define EF_NODE 1
 #define EF_NEG 2
 #define EF_FIXED 4
-#define ESDF_SWEEPS 1
+#define ESDF_PAD (ESDF_T * ESDF_T + ESDF_T + 1)
 
+#ifdef TSL_TIMING
+// developer timing: thread 0 of every relaxation adds the clock ticks (100 MHz) of its phases to E.ctr64[k]
+#define ESDF_TICK(k) do { if (threadIdx.x == 0) { const long long _n = wall_clock64(); atomicAdd(&E.tm[k], (unsigned long long)(_n - _t)); _t = _n; } } while (0)
+#else
+#define ESDF_TICK(k) do {} while (0)
+#endif
 struct EsdfDev {
     float* mag;                // [max_bricks][4096] magnitude
     uint8_t* fl;               // [max_bricks][4096] EF_* of the voxel at the last (re)initialisation
     uint8_t* region;           // [max_bricks] 1: brick is part of this update's region, 2: relaxed once already
     int* stamp;                // [max_bricks] last round the brick was put on a work list for (dedupe)
     int* dirty;                // [max_bricks] dirty list
+    uint32_t* note;            // [2][max_bricks] per round parity: bit q = neighbour q (of 27) changed its boundary layer in the previous round
     int* work;                 // [3][max_bricks] work lists of rounds k, k+1, k+2 (mod 3)
     int cap;                   // max_bricks
+    unsigned long long* tm;    // developer timing (TSL_TIMING builds): ticks per phase, summed over relaxations
     int* ctr;                  // [0] dirty count [1] region count [2..4] work list lengths [5] brick relaxations [6] voxel pushes [7] rounds with work
 };
 
@@ -54,7 +62,7 @@ __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s
     if (p < nused) {
         const bool mine = M.owner[p] / M.nb3 == s;
         if (mine) { take = all || M.touch[p] != 0; M.touch[p] = 0; }
-        E.region[p] = 0; E.stamp[p] = -1;
+        E.region[p] = 0; E.stamp[p] = -1; E.note[p] = 0u; E.note[E.cap + p] = 0u;
     }
     const int q = wave_reserve(&E.ctr[0], take);
     if (take) E.dirty[q] = p;
@@ -103,13 +111,30 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, int nuse
 // 4. one relaxation round: every brick on this round's work list is staged in LDS with its one-voxel halo and relaxed to its local fixed
 //    point; a brick whose boundary layer improved puts the neighbours that see it on the next round's list.  Rounds are separate launches
 //    (the kernel boundary is the only synchronisation: no fences, no spinning); a launch whose list is empty returns at once.
-__global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, int round)
+//
+//    LDS layout.  s_d holds the 18^3 tile with a margin of one plane + one row + one entry on both sides, so that a neighbour is entry
+//    t + (dx*18 + dy)*18 + dz without any range check.  An entry of s_d is a TARGET word: side << 31 | magnitude bits for an interior,
+//    observed, non-fixed voxel -- the only kind a push may lower -- and 0 for everything else (halo, fixed band, unobserved, margin).
+//    With that encoding the 26 neighbour tests of a push need no flags: for a source on side sb the test "same side, is a target,
+//    candidate is lower" is the single signed comparison (int)(word ^ sb) > (int)candidate (positive floats order like integers; a
+//    target of the other side and the 0 of a non-target turn negative or stay 0).  Voxels that only ever push -- the halo and the fixed
+//    band -- keep their values in s_hv / s_old (side << 31 | magnitude, 0 = unobserved); they push once, in the first pass.
+__device__ __forceinline__ int esdf_halo_index(int tx, int ty, int tz)          // position of a halo entry in s_hv (inverse of the decode below)
 {
-    __shared__ uint32_t s_d[ESDF_T3];              // magnitude bits (non-negative floats order like unsigned integers)
-    __shared__ uint8_t s_f[ESDF_T3];
-    __shared__ uint32_t s_a[(ESDF_T3 + 31) / 32 + 1];   // active bits: the voxel pushes in the next pass (+ one spare word: 64-bit reads)
+    if (tx == 0 || tx == 17) return (tx / 17) * (ESDF_T * ESDF_T) + ty * ESDF_T + tz;
+    if (ty == 0 || ty == 17) return 2 * ESDF_T * ESDF_T + (tx - 1) * (2 * ESDF_T) + (ty / 17) * ESDF_T + tz;
+    return 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T + (tx - 1) * 32 + (ty - 1) * 2 + tz / 17;
+}
+__global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, float max_dist, int round)
+{
+    constexpr int NH = ESDF_T3 - TSL_BRK3, HPER = (NH + 255) / 256;       // 1736 halo entries, 7 per thread
+    __shared__ uint32_t s_dm[ESDF_T3 + 2 * ESDF_PAD];      // target words (see above)
+    __shared__ __attribute__((aligned(16))) uint32_t s_old[TSL_BRK3];   // the brick's voxels as staged, brick order: side << 31 | magnitude, 0 = unobserved
+    __shared__ uint32_t s_hv[HPER * 256];                  // the halo's values, same encoding
+    __shared__ uint32_t s_a[(ESDF_T3 + 31) / 32 + 2];      // active bits: the entry pushes in the next pass
     __shared__ int s_nb[27];                       // pool index of the 27 bricks around (and including) this one, -1 = absent
     __shared__ int s_notify;
+    uint32_t* const s_d = s_dm + ESDF_PAD;
     const int cur = round % 3, nxt = (round + 1) % 3, clr = (round + 2) % 3;
     const int n = E.ctr[2 + cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) E.ctr[7] = round + 1; }      // list (round+2) was consumed in round-1
@@ -117,7 +142,11 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
     const float cost[4] = { 0.0f, 1.0f * vs, sqrtf(2.0f) * vs, sqrtf(3.0f) * vs };              // dense_esdf.py:286
     const int* list = E.work + (size_t)cur * E.cap;
     int* next = E.work + (size_t)nxt * E.cap;
+    for (int i = threadIdx.x; i < ESDF_PAD; i += 256) { s_dm[i] = 0u; s_dm[ESDF_PAD + ESDF_T3 + i] = 0u; }
     for (int w = blockIdx.x; w < n; w += gridDim.x) {
+#ifdef TSL_TIMING
+        long long _t = wall_clock64();
+#endif
         const int p = list[w];
         const int b = M.owner[p] - s * M.nb3;
         const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
@@ -126,117 +155,155 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
             s_nb[threadIdx.x] = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
         }
         if (threadIdx.x == 0) s_notify = 0;
-        for (int i = threadIdx.x; i < (ESDF_T3 + 31) / 32 + 1; i += 256) s_a[i] = 0u;
+        for (int i = threadIdx.x; i < (ESDF_T3 + 31) / 32 + 2; i += 256) s_a[i] = 0u;
+        // first relaxation in this update: the band voxels push, and so does every halo voxel; afterwards only the halo voxels of the
+        // neighbours that changed their boundary layer since (the notification mask written for this round) push again
+        const bool first = E.region[p] == 1;
+        uint32_t* const my_note = E.note + (size_t)(round & 1) * E.cap + p;
+        const uint32_t note = first ? ~0u : *my_note;
         __syncthreads();
-        const bool first = E.region[p] == 1;                        // first relaxation in this update: the band voxels push too
-        // ---- stage brick + halo: a thread's 23 entries are requested in two batches of independent loads ----
-#pragma unroll 1
-        for (int q0 = 0; q0 < 24; q0 += 12) {
-            int np[12]; uint8_t f[12]; uint32_t d[12];
+        ESDF_TICK(0);
+        if (threadIdx.x == 0) *my_note = 0u;                        // this parity is written again in round + 1, after this launch
+        // ---- stage brick + halo as ONE batch of independent loads: thread tid owns the interior row (x, y) = (tid / 16, tid % 16) -- 16
+        //      voxels = 4 + 1 wide loads -- and <= 7 of the 1736 halo entries (loaded from a valid address unconditionally so that
+        //      nothing separates the requests) ----
+        {
+            const size_t v0 = (size_t)p * TSL_BRK3 + (size_t)threadIdx.x * 16;
+            uint4 dq[4];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                const int t = (q0 + q) * 256 + (int)threadIdx.x;
-                np[q] = -1;
-                if (t < ESDF_T3) {
-                    const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-                    np[q] = s_nb[(((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4)];             // 0, 1, 2 per axis: which neighbour brick
-                }
+            for (int q = 0; q < 4; ++q) dq[q] = reinterpret_cast<const uint4*>(E.mag + v0)[q];
+            const uint4 fq = *reinterpret_cast<const uint4*>(E.fl + v0);
+            int ht[HPER], hq[HPER]; uint8_t hf[HPER]; uint32_t hd[HPER]; bool hok[HPER];
+#pragma unroll
+            for (int q = 0; q < HPER; ++q) {
+                const int h = q * 256 + (int)threadIdx.x;
+                int tx, ty, tz;
+                if (h < 2 * ESDF_T * ESDF_T) { const int r = h % (ESDF_T * ESDF_T); tx = (h / (ESDF_T * ESDF_T)) * 17; ty = r / ESDF_T; tz = r % ESDF_T; }       // faces x = 0, 17
+                else if (h < 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T) { const int g = h - 2 * ESDF_T * ESDF_T, r = g % (2 * ESDF_T); tx = 1 + g / (2 * ESDF_T); ty = (r / ESDF_T) * 17; tz = r % ESDF_T; }   // rows y = 0, 17
+                else { const int g = h - (2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T); tx = 1 + g / 32; ty = 1 + (g % 32) / 2; tz = (g & 1) * 17; }                // entries z = 0, 17
+                ht[q] = h < NH ? (tx * ESDF_T + ty) * ESDF_T + tz : -1;
+                hq[q] = h < NH ? (((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4) : 13;     // which of the 27 bricks
+                const int np = s_nb[hq[q]];
+                hok[q] = h < NH && np >= 0;
+                const size_t v = (size_t)(np >= 0 ? np : p) * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+                hf[q] = E.fl[v]; hd[q] = __float_as_uint(E.mag[v]);
+            }
+            const uint32_t dl[16] = { dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w, dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w };
+            const uint32_t fw[4] = { fq.x, fq.y, fq.z, fq.w };
+            const int t0 = (((int)(threadIdx.x >> 4) + 1) * ESDF_T + (int)(threadIdx.x & 15) + 1) * ESDF_T + 1;
+            uint32_t am = 0u;                                        // active bits of the row
+            uint32_t enc[16];
+#pragma unroll
+            for (int z = 0; z < 16; ++z) {
+                const uint32_t f = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
+                enc[z] = (f & EF_NODE) ? (dl[z] | ((f & EF_NEG) ? 0x80000000u : 0u)) : 0u;
+                s_d[t0 + z] = (f & EF_FIXED) ? 0u : enc[z];
+                am |= ((f & (EF_NODE | EF_FIXED)) == (EF_NODE | EF_FIXED) ? 1u : 0u) << z;
             }
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                const int t = (q0 + q) * 256 + (int)threadIdx.x;
-                f[q] = 0; d[q] = 0u;
-                if (np[q] >= 0) {
-                    const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-                    const size_t v = (size_t)np[q] * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
-                    f[q] = E.fl[v]; d[q] = __float_as_uint(E.mag[v]);
-                }
+            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(s_old)[threadIdx.x * 4 + q] = make_uint4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3]);
+            if (first && am) {                                       // the row's 16 bits lie in one or two words
+                atomicOr(&s_a[t0 >> 5], am << (t0 & 31));
+                if ((t0 & 31) > 16) atomicOr(&s_a[(t0 >> 5) + 1], am >> (32 - (t0 & 31)));
             }
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                const int t = (q0 + q) * 256 + (int)threadIdx.x;
-                if (t >= ESDF_T3) continue;
-                const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-                const bool halo = tx == 0 || tx == 17 || ty == 0 || ty == 17 || tz == 0 || tz == 17;
-                s_f[t] = f[q]; s_d[t] = d[q];
-                if ((f[q] & EF_NODE) && (halo || (first && (f[q] & EF_FIXED)))) atomicOr(&s_a[t >> 5], 1u << (t & 31));
+            for (int q = 0; q < HPER; ++q) {
+                const int t = ht[q];
+                const uint32_t f = hok[q] ? (uint32_t)hf[q] : 0u;
+                s_hv[q * 256 + threadIdx.x] = (f & EF_NODE) ? (hd[q] | ((f & EF_NEG) ? 0x80000000u : 0u)) : 0u;
+                if (t < 0) continue;
+                s_d[t] = 0u;
+                // a source can only improve a target whose value exceeds its own by an edge cost, and no value exceeds max_dist
+                if ((f & EF_NODE) && ((note >> hq[q]) & 1u) && __uint_as_float(hd[q]) + vs < max_dist) atomicOr(&s_a[t >> 5], 1u << (t & 31));
             }
         }
         __syncthreads();
-        // ---- push relaxation: active voxels offer value + edge cost to their same-side, non-fixed neighbours INSIDE the brick.
+        ESDF_TICK(1);
+        // ---- push relaxation: active entries offer value + edge cost to the targets among their 26 neighbours.
         //      Entry t belongs to thread t mod 256 (a front -- a sheet of neighbouring voxels -- spreads over all threads).  Per pass a
         //      thread reads the active words of its 23 entries as one batch; an active entry is cleared with a non-returning atomic AND,
-        //      then its value and the 26 neighbours' flags and values are read as ONE batch of independent LDS loads, and non-returning
-        //      atomic mins + active-bit ORs go out for the candidates that beat what was read (a min that lost a race is a no-op and the
-        //      extra activation is harmless).  LDS operations of a wave execute in order: the value read follows the clear, the OR
-        //      follows the min. ----
+        //      then its word and the 26 neighbours' words are read as ONE batch of independent LDS loads (relaxed workgroup-scope
+        //      atomic loads: plain ds_read, but never cached in registers across passes), and non-returning atomic mins go out for the
+        //      candidates that beat what was read (a min that lost a race is a no-op and the extra activation is harmless); the active
+        //      bits of the three z-neighbours of a row are set with one OR.  LDS operations of a wave execute in order: the value read
+        //      follows the clear, the OR follows the min. ----
         long long pushes = 0; int passes = 0;
-        volatile uint32_t* vd = s_d;
-        volatile uint32_t* va = s_a;
+#define LDS_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
         for (;;) {
             bool act = false;
             constexpr int PER = (ESDF_T3 + 255) / 256;
-            // several scan + push sweeps per barrier: LDS atomics are visible to the other waves at once, the barrier is only needed to
-            // agree that nothing is active any more, so the front may advance a few voxels between two barriers
-#pragma unroll 1
-            for (int sweep = 0; sweep < ESDF_SWEEPS; ++sweep) {
             uint32_t mine = 0u;                                    // bit q: my q-th entry is active
+            {
+                uint32_t aw[PER];
 #pragma unroll
-            for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; if (t < ESDF_T3) mine |= ((va[t >> 5] >> (t & 31)) & 1u) << q; }
+                for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; aw[q] = t < ESDF_T3 ? LDS_LD(&s_a[t >> 5]) : 0u; }
+#pragma unroll
+                for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; mine |= ((aw[q] >> (t & 31)) & 1u) << q; }
+            }
 #pragma unroll 1
             for (; mine; mine &= mine - 1u) {
                 const int t = (int)__builtin_ctz(mine) * 256 + (int)threadIdx.x;
                 __hip_atomic_fetch_and(&s_a[t >> 5], ~(1u << (t & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-                const uint32_t cls = s_f[t] & (EF_NODE | EF_NEG);
-                const float dv = __uint_as_float(vd[t]);
+                uint32_t self = LDS_LD(&s_d[t]);
                 ++pushes;
-                uint32_t fn[26], dn[26], okm = 0u;
+                uint32_t dn[26];
 #pragma unroll
                 for (int c = 0; c < 27; ++c) {
                     if (c == 13) continue;
-                    const int qq = c < 13 ? c : c - 1;
-                    const int dx = c / 9 - 1, dy = (c / 3) % 3 - 1, dz = c % 3 - 1;
-                    const int x = tx + dx, y = ty + dy, z = tz + dz;
-                    const bool ok = x >= 1 && x <= 16 && y >= 1 && y <= 16 && z >= 1 && z <= 16;
-                    okm |= (ok ? 1u : 0u) << qq;
-                    const int j = ok ? t + (dx * ESDF_T + dy) * ESDF_T + dz : t;
-                    fn[qq] = s_f[j]; dn[qq] = vd[j];
+                    dn[c < 13 ? c : c - 1] = LDS_LD(&s_d[t + ((c / 9 - 1) * ESDF_T + ((c / 3) % 3 - 1)) * ESDF_T + (c % 3 - 1)]);
                 }
+                if (self == 0u) {                                  // not a target: a halo or band voxel, its value is kept aside (first pass only)
+                    const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
+                    const bool inner = tx >= 1 && tx <= 16 && ty >= 1 && ty <= 16 && tz >= 1 && tz <= 16;
+                    self = inner ? s_old[((tx - 1) << 8) | ((ty - 1) << 4) | (tz - 1)] : s_hv[esdf_halo_index(tx, ty, tz)];
+                }
+                const uint32_t sb = self & 0x80000000u;
+                const float dv = __uint_as_float(self & 0x7fffffffu);
 #pragma unroll
-                for (int c = 0; c < 27; ++c) {
-                    if (c == 13) continue;
-                    const int qq = c < 13 ? c : c - 1;
-                    const int dx = c / 9 - 1, dy = (c / 3) % 3 - 1, dz = c % 3 - 1;
-                    if (!((okm >> qq) & 1u) || (fn[qq] & (EF_NODE | EF_NEG | EF_FIXED)) != cls) continue;          // node, same side, not fixed
-                    const uint32_t cand = __float_as_uint(dv + cost[dx * dx + dy * dy + dz * dz]);
-                    if (cand < dn[qq]) {
-                        const int j = t + (dx * ESDF_T + dy) * ESDF_T + dz;
-                        __hip_atomic_fetch_min(&s_d[j], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_or(&s_a[j >> 5], 1u << (j & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int r = 0; r < 9; ++r) {                      // the nine (dx, dy) rows of the neighbourhood, three z-neighbours each
+                    const int dx = r / 3 - 1, dy = r % 3 - 1;
+                    const int j0 = t + (dx * ESDF_T + dy) * ESDF_T - 1;
+                    uint32_t bits = 0u;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int c = r * 3 + k;
+                        if (c == 13) continue;
+                        const float cf = dv + cost[dx * dx + dy * dy + (k - 1) * (k - 1)];
+                        const uint32_t cand = __float_as_uint(cf);
+                        if ((int)(dn[c < 13 ? c : c - 1] ^ sb) > (int)cand) {
+                            __hip_atomic_fetch_min(&s_d[j0 + k], sb | cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            bits |= (cf + vs < max_dist ? 1u : 0u) << k;         // else it cannot improve anything itself
+                        }
+                    }
+                    if (bits) {
+                        const int sh = j0 & 31;
+                        __hip_atomic_fetch_or(&s_a[j0 >> 5], bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (sh > 29) __hip_atomic_fetch_or(&s_a[(j0 >> 5) + 1], bits >> (32 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         act = true;
                     }
                 }
             }
-            }
             ++passes;
             if (!__syncthreads_or(act)) break;
         }
-        // ---- write back what changed (16 voxels per thread, their old values requested as one batch); a changed voxel of the boundary
-        //      layer puts the neighbours that hold it in their halo on the next round's list ----
+#undef LDS_LD
+#ifdef TSL_TIMING
+        if (threadIdx.x == 0) { const long long _n = wall_clock64(); const int pb = passes < 31 ? passes : 31;
+            atomicAdd(&E.tm[8 + pb], (unsigned long long)(_n - _t)); atomicAdd(&E.tm[40 + pb], 1ull); atomicMax(&E.tm[72], (unsigned long long)(_n - _t)); }
+        { const long long pw = wave_sum_ll(pushes); if (lane_id() == 0) atomicAdd(&E.tm[80 + (passes < 31 ? passes : 31)], (unsigned long long)pw); }
+#endif
+        ESDF_TICK(2);
+        // ---- write back the targets that changed (against the staged copy); a changed voxel of the boundary layer marks the neighbours
+        //      that hold it in their halo ----
         {
-            float old[TSL_BRK3 / 256];
             float* gm = E.mag + (size_t)p * TSL_BRK3;
-#pragma unroll
-            for (int q = 0; q < TSL_BRK3 / 256; ++q) old[q] = gm[q * 256 + threadIdx.x];
 #pragma unroll
             for (int q = 0; q < TSL_BRK3 / 256; ++q) {
                 const int l = q * 256 + threadIdx.x;
                 const int x = (l >> 8) + 1, y = ((l >> 4) & 15) + 1, z = (l & 15) + 1;
-                const float nv = __uint_as_float(s_d[(x * ESDF_T + y) * ESDF_T + z]);
-                if (nv != old[q]) {
-                    gm[l] = nv;
+                const uint32_t nv = s_d[(x * ESDF_T + y) * ESDF_T + z];
+                if (nv != 0u && nv != s_old[l]) {
+                    gm[l] = __uint_as_float(nv & 0x7fffffffu);
                     const int lx = x == 1 ? 0 : (x == 16 ? 2 : 1), ly = y == 1 ? 0 : (y == 16 ? 2 : 1), lz = z == 1 ? 0 : (z == 16 ? 2 : 1);
                     if (lx != 1 || ly != 1 || lz != 1) {
                         int m = 0;
@@ -249,22 +316,33 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
             }
         }
         __syncthreads();
+        ESDF_TICK(3);
         pushes = wave_sum_ll(pushes);
         if (lane_id() == 0 && pushes) __hip_atomic_fetch_add(&E.ctr[6], (int)pushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the neighbours that see a changed boundary voxel go on the next round's list: one lane per neighbour (the region check, the
+        // stamp exchange and the list reservation are dependent device-memory round trips)
+        if (threadIdx.x < 64) {
+            const int q = (int)threadIdx.x;
+            bool put = false; int np = -1;
+            if (q < 27 && ((s_notify >> q) & 1)) {
+                np = s_nb[q];
+                if (np >= 0 && E.region[np] != 0) {                                            // present and inside this update's region
+                    // seen from the neighbour this brick is neighbour 26 - q: its halo entries from here push in the next round
+                    __hip_atomic_fetch_or(E.note + (size_t)((round + 1) & 1) * E.cap + np, 1u << (26 - q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    put = __hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != round + 1;   // not listed yet
+                }
+            }
+            const int at = wave_reserve(&E.ctr[2 + nxt], put);
+            if (put) next[at] = np;
+        }
         if (threadIdx.x == 0) {
             E.region[p] = 2;
-            for (int m = s_notify, q = 0; m; m >>= 1, ++q) {
-                if (!(m & 1)) continue;
-                const int np = s_nb[q];
-                if (np < 0 || E.region[np] == 0) continue;                                     // absent, or outside this update's region
-                if (__hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round + 1) continue;   // already listed
-                next[__hip_atomic_fetch_add(&E.ctr[2 + nxt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = np;
-            }
             __hip_atomic_fetch_add(&E.ctr[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&E.ctr[8], passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_max(&E.ctr[9], passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
+        ESDF_TICK(4);
     }
 }
 
@@ -308,8 +386,9 @@ int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed
         if ((rc = dev_alloc(m, (void**)&m->esdf_region, (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_inq, sizeof(int) * (size_t)nb, 0xff))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_list, sizeof(int) * (size_t)nb, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_note, sizeof(uint32_t) * 2 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 12, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 256, 0))) return rc;
         m->esdf_valid = false;
     }
     int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;          // issues the queued frames first
@@ -318,12 +397,12 @@ int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed
     int reach = (int)std::ceil((double)max_dist / ((double)m->P.vs * 16.0)); if (reach < 1) reach = 1;
     const bool full = m->esdf_force_full || !m->esdf_valid || m->esdf_submap != s || m->esdf_gamma != gamma || m->esdf_maxd != max_dist ||
                       2 * reach + 1 >= m->nbx;              // the dilation would cover the grid anyway
-    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_queue, nb, m->esdf_ctr };
+    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_note, m->esdf_queue, nb, (unsigned long long*)(m->esdf_ctr + 16), m->esdf_ctr };
     tsl_esdf_stats st; std::memset(&st, 0, sizeof(st));
     st.incremental = full ? 0 : 1; st.total_bricks = nused;
     hipStream_t q = ms(m);
     if (nused > 0) {
-        TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 12, q));
+        TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 256, q));
         prof_begin(m, TSL_K_ESDF);                                   // one event pair around the update's launches (collect .. last round)
         m->prof_group = true;
         hipLaunchKernelGGL(k_esdf_collect, dim3((nused + 255) / 256), dim3(256), 0, q, m->M, E, s, nused, full ? 1 : 0);
@@ -336,15 +415,22 @@ int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed
         const int grid = 4 * m->ncu;
         for (;;) {
             const int batch = 2 * reach + 8;
-            for (int k = 0; k < batch; ++k, ++round) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(256), 0, q, m->M, E, s, m->P.vs, round);
+            for (int k = 0; k < batch; ++k, ++round) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(256), 0, q, m->M, E, s, m->P.vs, max_dist, round);
             if (m->prof_group) { m->prof_group = false; prof_end(m); }
-            TSL_HIP(hipMemcpyAsync(&m->h_ints[16], m->esdf_ctr, sizeof(int) * 12, hipMemcpyDeviceToHost, q));
+            TSL_HIP(hipMemcpyAsync(&m->h_ints[16], m->esdf_ctr, sizeof(int) * 256, hipMemcpyDeviceToHost, q));
             TSL_HIP(hipGetLastError());
             TSL_HIP(hipStreamSynchronize(q));
             if (m->h_ints[16 + 2 + round % 3] == 0 || round > 100000) break;
         }
         st.dirty_bricks = m->h_ints[16]; st.region_bricks = m->h_ints[17]; st.brick_relaxations = m->h_ints[21]; st.voxel_pushes = m->h_ints[22];
         st.rounds = m->h_ints[23]; st.passes = m->h_ints[24]; st.max_passes = m->h_ints[25];
+#ifdef TSL_TIMING
+        { const unsigned long long* tm = (const unsigned long long*)&m->h_ints[32]; const double n = st.brick_relaxations ? st.brick_relaxations : 1;
+          std::fprintf(stderr, "esdf timing: us per relaxation: setup %.2f stage %.2f relax %.2f writeback %.2f notify %.2f (%d relaxations)\n",
+                       tm[0] / n / 100.0, tm[1] / n / 100.0, tm[2] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, st.brick_relaxations);
+          std::fprintf(stderr, "esdf relax by passes (count: mean us, mean pushes); max relax %.1f us\n", tm[72] / 100.0);
+          for (int k = 0; k < 32; ++k) if (tm[40 + k]) std::fprintf(stderr, "  %2d passes: %5llu relaxations, %7.1f us, %7.0f pushes\n", k, tm[40 + k], tm[8 + k] / (double)tm[40 + k] / 100.0, tm[80 + k] / (double)tm[40 + k]); }
+#endif
     }
     m->esdf_stats = st;
     m->esdf_gamma = gamma; m->esdf_maxd = max_dist; m->esdf_submap = s; m->esdf_valid = true;

@@ -172,7 +172,7 @@ struct tsl_tsdf {
     float surf_thres, disp_floor, disp_ceiling;
     void* sort_temp; size_t sort_temp_bytes;
     tsl_frame_stats* h_stats;            // pinned
-    int* h_ints;                         // pinned scratch (16 ints)
+    int* h_ints;                         // pinned scratch (128 ints)
     // export buffers (export_TSDF_xyz / export_color / export_TSDF, num_TSDF_particles)  dense_tsdf.py:53-60
     float *exp_xyz, *exp_rgb, *exp_val; int* num_particles; int64_t max_disp;
     float* colormap;                     // [1024][3]
@@ -185,7 +185,7 @@ struct tsl_tsdf {
     uint8_t* mrg_mask; int *mrg_list, *mrg_count; int mrg_nunion;      // multi-GPU merge: touched-brick mask, union list (tsl_merge.hip)
     void *mrg_pacc, *mrg_pcnt; size_t mrg_pacc_bytes, mrg_pcnt_bytes;  // packed union bricks of the one-call form
     // esdf
-    float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq; int esdf_qcap;      // tsl_esdf.hip
+    float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
     bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
