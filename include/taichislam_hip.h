@@ -191,7 +191,7 @@ int  tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, flo
 /* ---- ESDF  (dense_esdf.py:228-333 as the definition) -----------------------------------------------------------------
  * |TSDF| < gamma: ESDF = TSDF; elsewhere the 26-neighbour quasi-Euclidean distance (edge cost |dir| * voxel) to that band along voxels
  * of the same sign, capped at max_dist.  tsl_esdf_update is INCREMENTAL: the integrate kernels mark the bricks they write, an update
- * re-initialises and relaxes only those bricks dilated by max_dist (device-side work lists, one host synchronisation at the end) and
+ * re-initialises and relaxes only those bricks dilated by max_dist (device-side work lists, no host synchronisation inside) and
  * yields exactly the map a full recompute yields.  The first update, one after reset / import / fusion or with other parameters, and
  * every update when option "esdf_full" is set, covers all bricks.  n_relaxed (nullable) = brick relaxations performed. */
 typedef struct {
@@ -204,8 +204,16 @@ typedef struct {
     int32_t rounds, max_passes;  /* relaxation rounds that had work; most LDS passes one brick relaxation needed */
     int64_t passes;              /* LDS passes over all brick relaxations */
 } tsl_esdf_stats;
+/* sums over the updates of the handle that have completed */
+typedef struct {
+    int64_t updates, incremental, dirty_bricks, region_bricks, brick_relaxations, voxel_pushes, passes;
+} tsl_esdf_totals_t;
+/* n_relaxed != NULL: waits for the update and returns its brick relaxations.  n_relaxed == NULL: ASYNCHRONOUS -- the update is only
+ * enqueued on the handle's stream (up to 4 may be in flight; the per-frame hook of dense_esdf.py:400-402 uses this form), nothing is
+ * waited for.  last_stats / totals / export wait for the outstanding updates first, so what they return is always complete. */
 int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed);
 int  tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out);
+int  tsl_esdf_totals(tsl_tsdf* m, tsl_esdf_totals_t* out);
 int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);
 
 /* backend knobs for A/B-ing kernel variants: name in
@@ -219,6 +227,7 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
                 workgroup and never merged through HBM
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
      "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)
+     "esdf_round_cap" n > 0 = launch at most n relaxation rounds per update (test knob: an update that stops early must be repaired)
      "fastdiv"  0 = force IEEE division
      "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);

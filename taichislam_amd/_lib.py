@@ -45,6 +45,13 @@ class EsdfStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class EsdfTotals(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("updates", "incremental", "dirty_bricks", "region_bricks", "brick_relaxations", "voxel_pushes", "passes")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class TslError(RuntimeError):
     pass
 
@@ -110,6 +117,7 @@ SIGNATURES = {
     "tsl_tsdf_query_raycast": (C.c_int, [vp, vp, vp, f32, i64, vp, vp, vp]),
     "tsl_esdf_update": (C.c_int, [vp, f32, f32, pi32]),
     "tsl_esdf_last_stats": (C.c_int, [vp, C.POINTER(EsdfStats)]),
+    "tsl_esdf_totals": (C.c_int, [vp, C.POINTER(EsdfTotals)]),
     "tsl_esdf_export": (C.c_int, [vp, vp, vp, i64, pi64]),
     "tsl_tsdf_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "tsl_tsdf_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),

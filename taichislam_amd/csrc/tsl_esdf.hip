@@ -34,6 +34,9 @@ namespace tsl {
 #define EF_NEG 2
 #define EF_FIXED 4
 #define ESDF_PAD (ESDF_T * ESDF_T + ESDF_T + 1)
+#ifndef ESDF_SWEEPS
+#define ESDF_SWEEPS 1
+#endif
 
 #ifdef TSL_TIMING
 // developer timing: thread 0 of every relaxation adds the clock ticks (100 MHz) of its phases to E.ctr64[k]
@@ -55,8 +58,9 @@ struct EsdfDev {
 };
 
 // 1. dirty bricks of submap s (and, when `all`, every brick of it); touch marks are consumed
-__global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s, int nused, int all)
+__global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s, int all)
 {
+    const int nused = min(*M.pool_top, M.max_bricks);              // read on the device: the host does not wait for the frames before it
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool take = false;
     if (p < nused) {
@@ -66,6 +70,7 @@ __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s
     }
     const int q = wave_reserve(&E.ctr[0], take);
     if (take) E.dirty[q] = p;
+    if (p == 0) E.ctr[10] = nused;
 }
 
 // 2. region = dirty bricks dilated by r bricks (existing bricks of the submap only)
@@ -86,8 +91,9 @@ __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s,
 }
 
 // 3. (re)initialise the region's voxels; every brick of the region is on the work list of round 0
-__global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, int nused, float gamma, float max_dist)
+__global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float gamma, float max_dist)
 {
+    const int nused = min(*M.pool_top, M.max_bricks);
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         if (E.region[p] != 1) continue;
         for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
@@ -232,6 +238,10 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
         for (;;) {
             bool act = false;
             constexpr int PER = (ESDF_T3 + 255) / 256;
+            // several scan + push sweeps per barrier: LDS atomics are visible to the other waves at once, the barrier is only needed to
+            // agree that nothing is active any more, so every wave follows the front at its own pace in between
+#pragma unroll 1
+            for (int sweep = 0; sweep < ESDF_SWEEPS; ++sweep) {
             uint32_t mine = 0u;                                    // bit q: my q-th entry is active
             {
                 uint32_t aw[PER];
@@ -259,6 +269,11 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
                 }
                 const uint32_t sb = self & 0x80000000u;
                 const float dv = __uint_as_float(self & 0x7fffffffu);
+                // the three candidates (face, edge, corner neighbour) and whether a voxel that takes one could improve anything itself
+                const float cf[3] = { dv + cost[1], dv + cost[2], dv + cost[3] };
+                const uint32_t cw[3] = { sb | __float_as_uint(cf[0]), sb | __float_as_uint(cf[1]), sb | __float_as_uint(cf[2]) };
+                const uint32_t live[3] = { cf[0] + vs < max_dist ? 1u : 0u, cf[1] + vs < max_dist ? 1u : 0u, cf[2] + vs < max_dist ? 1u : 0u };
+                uint32_t any = 0u;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {                      // the nine (dx, dy) rows of the neighbourhood, three z-neighbours each
                     const int dx = r / 3 - 1, dy = r % 3 - 1;
@@ -268,20 +283,24 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
                     for (int k = 0; k < 3; ++k) {
                         const int c = r * 3 + k;
                         if (c == 13) continue;
-                        const float cf = dv + cost[dx * dx + dy * dy + (k - 1) * (k - 1)];
-                        const uint32_t cand = __float_as_uint(cf);
-                        if ((int)(dn[c < 13 ? c : c - 1] ^ sb) > (int)cand) {
-                            __hip_atomic_fetch_min(&s_d[j0 + k], sb | cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            bits |= (cf + vs < max_dist ? 1u : 0u) << k;         // else it cannot improve anything itself
+                        const int e = dx * dx + dy * dy + (k - 1) * (k - 1) - 1;
+                        // same side, a target, and the candidate is lower <=> one signed comparison.  The minimum stays conditional: the
+                        // LDS atomics, not the VALU, bound this loop (26 unconditional ones per push were 30 % slower)
+                        if ((int)(dn[c < 13 ? c : c - 1] ^ sb) > (int)__float_as_uint(cf[e])) {
+                            __hip_atomic_fetch_min(&s_d[j0 + k], cw[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            bits |= live[e] << k;
                         }
                     }
                     if (bits) {
                         const int sh = j0 & 31;
                         __hip_atomic_fetch_or(&s_a[j0 >> 5], bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (sh > 29) __hip_atomic_fetch_or(&s_a[(j0 >> 5) + 1], bits >> (32 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        act = true;
                     }
+                    any |= bits;
                 }
+                act = act || any != 0u;
+            }
+            if (!__any(act)) break;                                // nothing pushed by this wave in this sweep: wait for the others
             }
             ++passes;
             if (!__syncthreads_or(act)) break;
@@ -304,12 +323,12 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
                 const uint32_t nv = s_d[(x * ESDF_T + y) * ESDF_T + z];
                 if (nv != 0u && nv != s_old[l]) {
                     gm[l] = __uint_as_float(nv & 0x7fffffffu);
-                    const int lx = x == 1 ? 0 : (x == 16 ? 2 : 1), ly = y == 1 ? 0 : (y == 16 ? 2 : 1), lz = z == 1 ? 0 : (z == 16 ? 2 : 1);
-                    if (lx != 1 || ly != 1 || lz != 1) {
-                        int m = 0;
-                        for (int ax = (lx == 0 ? 0 : 1); ax <= (lx == 2 ? 2 : 1); ++ax)
-                            for (int ay = (ly == 0 ? 0 : 1); ay <= (ly == 2 ? 2 : 1); ++ay)
-                                for (int az = (lz == 0 ? 0 : 1); az <= (lz == 2 ? 2 : 1); ++az) m |= 1 << ((ax * 3 + ay) * 3 + az);
+                    // the neighbours (ax, ay, az) in {0, 1, 2}^3 whose halo holds this voxel: per axis the centre, plus the lower / upper
+                    // neighbour when the voxel lies in the first / last layer -- a product of three small bit sets
+                    const int sx = x == 1 ? 3 : (x == 16 ? 6 : 2), sy = y == 1 ? 3 : (y == 16 ? 6 : 2), sz = z == 1 ? 3 : (z == 16 ? 6 : 2);
+                    if ((sx | sy | sz) != 2) {
+                        const int myz = ((sy & 1) ? sz : 0) | ((sy & 2) ? sz << 3 : 0) | ((sy & 4) ? sz << 6 : 0);
+                        const int m = ((sx & 1) ? myz : 0) | ((sx & 2) ? myz << 9 : 0) | ((sx & 4) ? myz << 18 : 0);
                         atomicOr(&s_notify, m & ~(1 << 13));
                     }
                 }
@@ -368,16 +387,41 @@ __global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused,
     }
 }
 
-}  // namespace tsl
-
-using namespace tsl;
-
-extern "C" {
-
-int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed)
+// ---- host side.  An update is a fixed sequence of launches on the handle's stream (collect, dilate, init, a batch of rounds sized by
+// max_dist -- a round without work returns at once) followed by a copy of the counters into a pinned slot and an event.  Whether the
+// last launched round still had work (never seen with this batch size) is all the host needs to know, and it does not need to know
+// it now: tsl_esdf_update with n_relaxed == NULL returns after the enqueue and the slot is looked at by a later call.  Everything that
+// hands ESDF values or statistics out (update with n_relaxed, last_stats, totals, export) goes through esdf_finish() first, which
+// waits for the outstanding updates and, should one have stopped early, recomputes -- so the values a caller sees are always the
+// fixed point of the current TSDF. ----
+static void esdf_retire(tsl_tsdf* m, bool wait_all)
 {
-    TSL_REQUIRE(m, "esdf_update: null handle"); TSL_REQUIRE(gamma > 0 && max_dist > 0, "esdf_update: gamma and max_dist must be positive");
-    TSL_HIP(hipSetDevice(m->device));
+    while (m->esdf_npend > 0) {
+        EsdfSlot& S = m->esdf_slot[m->esdf_tail];
+        if (!wait_all && hipEventQuery(S.ev) != hipSuccess) break;
+        if (wait_all) (void)hipEventSynchronize(S.ev);
+        const int* h = S.host;
+        tsl_esdf_stats st = S.st;
+        st.dirty_bricks = h[0]; st.region_bricks = h[1]; st.brick_relaxations = h[5]; st.voxel_pushes = h[6];
+        st.rounds = h[7]; st.passes = h[8]; st.max_passes = h[9]; st.total_bricks = h[10];
+        if (h[2 + S.rounds % 3] != 0) m->esdf_short = true;                  // the last launched round still had work
+        if (st.incremental && st.rounds > m->esdf_rounds_seen) m->esdf_rounds_seen = st.rounds;
+        m->esdf_stats = st;
+        m->esdf_tot.updates += 1; m->esdf_tot.incremental += st.incremental; m->esdf_tot.dirty_bricks += st.dirty_bricks; m->esdf_tot.region_bricks += st.region_bricks;
+        m->esdf_tot.brick_relaxations += st.brick_relaxations; m->esdf_tot.voxel_pushes += st.voxel_pushes; m->esdf_tot.passes += st.passes;
+#ifdef TSL_TIMING
+        { const unsigned long long* tm = (const unsigned long long*)&h[16]; const double n = st.brick_relaxations ? st.brick_relaxations : 1;
+          std::fprintf(stderr, "esdf timing: us per relaxation: setup %.2f stage %.2f relax %.2f writeback %.2f notify %.2f (%lld relaxations)\n",
+                       tm[0] / n / 100.0, tm[1] / n / 100.0, tm[2] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, (long long)st.brick_relaxations);
+          std::fprintf(stderr, "esdf relax by passes (count: mean us, mean pushes); max relax %.1f us\n", tm[72] / 100.0);
+          for (int k = 0; k < 32; ++k) if (tm[40 + k]) std::fprintf(stderr, "  %2d passes: %5llu relaxations, %7.1f us, %7.0f pushes\n", k, tm[40 + k], tm[8 + k] / (double)tm[40 + k] / 100.0, tm[80 + k] / (double)tm[40 + k]); }
+#endif
+        m->esdf_tail = (m->esdf_tail + 1) % TSL_ESDF_SLOTS; --m->esdf_npend;
+    }
+}
+
+static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_full, int extra_rounds)
+{
     int rc;
     const int nb = m->M.max_bricks;
     if (!m->esdf) {
@@ -389,62 +433,111 @@ int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed
         if ((rc = dev_alloc(m, (void**)&m->esdf_note, sizeof(uint32_t) * 2 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 256, 0))) return rc;
+        for (int i = 0; i < TSL_ESDF_SLOTS; ++i) {
+            TSL_HIP(hipEventCreateWithFlags(&m->esdf_slot[i].ev, hipEventDisableTiming));
+            TSL_HIP(hipHostMalloc((void**)&m->esdf_slot[i].host, sizeof(int) * 256, hipHostMallocDefault));
+        }
         m->esdf_valid = false;
     }
-    int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;          // issues the queued frames first
+    esdf_retire(m, false);
+    if (m->esdf_npend == TSL_ESDF_SLOTS) { EsdfSlot& S = m->esdf_slot[m->esdf_tail]; (void)hipEventSynchronize(S.ev); esdf_retire(m, false); }
+    hipStream_t q = ms(m);                                   // issues the queued frames first
     const int s = m->cfg.is_global_map ? 0 : m->active;
     // a changed voxel influences voxels up to max_dist away: that many voxels = `reach` bricks in every direction
     int reach = (int)std::ceil((double)max_dist / ((double)m->P.vs * 16.0)); if (reach < 1) reach = 1;
-    const bool full = m->esdf_force_full || !m->esdf_valid || m->esdf_submap != s || m->esdf_gamma != gamma || m->esdf_maxd != max_dist ||
+    const bool full = force_full || m->esdf_force_full || !m->esdf_valid || m->esdf_submap != s || m->esdf_gamma != gamma || m->esdf_maxd != max_dist ||
                       2 * reach + 1 >= m->nbx;              // the dilation would cover the grid anyway
     EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_note, m->esdf_queue, nb, (unsigned long long*)(m->esdf_ctr + 16), m->esdf_ctr };
-    tsl_esdf_stats st; std::memset(&st, 0, sizeof(st));
-    st.incremental = full ? 0 : 1; st.total_bricks = nused;
-    hipStream_t q = ms(m);
-    if (nused > 0) {
-        TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 256, q));
-        prof_begin(m, TSL_K_ESDF);                                   // one event pair around the update's launches (collect .. last round)
-        m->prof_group = true;
-        hipLaunchKernelGGL(k_esdf_collect, dim3((nused + 255) / 256), dim3(256), 0, q, m->M, E, s, nused, full ? 1 : 0);
-        hipLaunchKernelGGL(k_esdf_dilate, dim3(nused < 4096 ? nused : 4096), dim3(256), 0, q, m->M, E, s, full ? 0 : reach);
-        hipLaunchKernelGGL(k_esdf_init, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, q, m->M, E, nused, gamma, max_dist);
-        // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
-        // few more.  A batch of rounds is launched blind (a round without work returns at once), then ONE synchronisation reads the
-        // counters; only if the last launched round still had work (not seen in practice) another batch follows.
-        int round = 0;
-        const int grid = 4 * m->ncu;
-        for (;;) {
-            const int batch = 2 * reach + 8;
-            for (int k = 0; k < batch; ++k, ++round) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(256), 0, q, m->M, E, s, m->P.vs, max_dist, round);
-            if (m->prof_group) { m->prof_group = false; prof_end(m); }
-            TSL_HIP(hipMemcpyAsync(&m->h_ints[16], m->esdf_ctr, sizeof(int) * 256, hipMemcpyDeviceToHost, q));
-            TSL_HIP(hipGetLastError());
-            TSL_HIP(hipStreamSynchronize(q));
-            if (m->h_ints[16 + 2 + round % 3] == 0 || round > 100000) break;
-        }
-        st.dirty_bricks = m->h_ints[16]; st.region_bricks = m->h_ints[17]; st.brick_relaxations = m->h_ints[21]; st.voxel_pushes = m->h_ints[22];
-        st.rounds = m->h_ints[23]; st.passes = m->h_ints[24]; st.max_passes = m->h_ints[25];
-#ifdef TSL_TIMING
-        { const unsigned long long* tm = (const unsigned long long*)&m->h_ints[32]; const double n = st.brick_relaxations ? st.brick_relaxations : 1;
-          std::fprintf(stderr, "esdf timing: us per relaxation: setup %.2f stage %.2f relax %.2f writeback %.2f notify %.2f (%d relaxations)\n",
-                       tm[0] / n / 100.0, tm[1] / n / 100.0, tm[2] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, st.brick_relaxations);
-          std::fprintf(stderr, "esdf relax by passes (count: mean us, mean pushes); max relax %.1f us\n", tm[72] / 100.0);
-          for (int k = 0; k < 32; ++k) if (tm[40 + k]) std::fprintf(stderr, "  %2d passes: %5llu relaxations, %7.1f us, %7.0f pushes\n", k, tm[40 + k], tm[8 + k] / (double)tm[40 + k] / 100.0, tm[80 + k] / (double)tm[40 + k]); }
-#endif
-    }
-    m->esdf_stats = st;
+    EsdfSlot& S = m->esdf_slot[(m->esdf_tail + m->esdf_npend) % TSL_ESDF_SLOTS];
+    std::memset(&S.st, 0, sizeof(S.st));
+    S.st.incremental = full ? 0 : 1;
+    TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 256, q));
+    prof_begin(m, TSL_K_ESDF);                                   // one event pair around the update's launches (collect .. last round)
+    m->prof_group = true;
+    const int nbk = (nb + 255) / 256;
+    hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0);
+    hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach);
+    hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, gamma, max_dist);
+    // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
+    // few more (8 rounds had work at reach = 4 on the benchmark stream).
+    // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards three more than the most any
+    // completed update of this handle needed (a round without work costs ~5 us; stopping early costs a full recompute, see esdf_finish).
+    int rounds = ((full || m->esdf_rounds_seen == 0) ? 2 * reach + 8 : std::min(2 * reach + 8, std::max(reach + 3, m->esdf_rounds_seen + 3))) + extra_rounds;
+    const int grid = 4 * m->ncu;
+    if (m->esdf_round_cap > 0 && extra_rounds == 0 && rounds > m->esdf_round_cap) rounds = m->esdf_round_cap;      // test knob: provoke the repair path
+    for (int k = 0; k < rounds; ++k) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(256), 0, q, m->M, E, s, m->P.vs, max_dist, k);
+    m->prof_group = false; prof_end(m);
+    TSL_HIP(hipMemcpyAsync(S.host, m->esdf_ctr, sizeof(int) * 256, hipMemcpyDeviceToHost, q));
+    TSL_HIP(hipEventRecord(S.ev, q));
+    TSL_HIP(hipGetLastError());
+    S.rounds = rounds;
+    ++m->esdf_npend;
     m->esdf_gamma = gamma; m->esdf_maxd = max_dist; m->esdf_submap = s; m->esdf_valid = true;
-    if (n_relaxed) *n_relaxed = (int32_t)st.brick_relaxations;
     return TSL_OK;
 }
 
-int tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out) { TSL_REQUIRE(m && out, "null"); *out = m->esdf_stats; return TSL_OK; }
+// wait for the outstanding updates; if one of them stopped with work left, recompute everything with ever longer batches
+int esdf_finish(tsl_tsdf* m)
+{
+    if (!m->esdf) return TSL_OK;
+    TSL_HIP(hipSetDevice(m->device));
+    esdf_retire(m, true);
+    for (int extra = 16; m->esdf_short; extra *= 2) {
+        m->esdf_short = false;
+        const int rc = esdf_enqueue(m, m->esdf_gamma, m->esdf_maxd, true, extra); if (rc) return rc;
+        esdf_retire(m, true);
+        TSL_REQUIRE(extra < (1 << 16), "esdf: the relaxation does not terminate");
+    }
+    return TSL_OK;
+}
+
+void esdf_release(tsl_tsdf* m)
+{
+    esdf_retire(m, true);
+    for (int i = 0; i < TSL_ESDF_SLOTS; ++i) {
+        if (m->esdf_slot[i].ev) (void)hipEventDestroy(m->esdf_slot[i].ev);
+        if (m->esdf_slot[i].host) (void)hipHostFree(m->esdf_slot[i].host);
+        m->esdf_slot[i].ev = nullptr; m->esdf_slot[i].host = nullptr;
+    }
+}
+
+}  // namespace tsl
+
+using namespace tsl;
+
+extern "C" {
+
+int tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed)
+{
+    TSL_REQUIRE(m, "esdf_update: null handle"); TSL_REQUIRE(gamma > 0 && max_dist > 0, "esdf_update: gamma and max_dist must be positive");
+    TSL_HIP(hipSetDevice(m->device));
+    int rc;
+    if (m->esdf_short && (rc = esdf_finish(m))) return rc;       // an earlier update stopped early: repair before building on it
+    if ((rc = esdf_enqueue(m, gamma, max_dist, false, 0))) return rc;
+    if (n_relaxed) { if ((rc = esdf_finish(m))) return rc; *n_relaxed = (int32_t)m->esdf_stats.brick_relaxations; }
+    return TSL_OK;
+}
+
+int tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out)
+{
+    TSL_REQUIRE(m && out, "null");
+    const int rc = esdf_finish(m); if (rc) return rc;
+    *out = m->esdf_stats; return TSL_OK;
+}
+
+int tsl_esdf_totals(tsl_tsdf* m, tsl_esdf_totals_t* out)
+{
+    TSL_REQUIRE(m && out, "null");
+    const int rc = esdf_finish(m); if (rc) return rc;
+    *out = m->esdf_tot; return TSL_OK;
+}
 
 int tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n)
 {
     TSL_REQUIRE(m && n && cap >= 0, "esdf_export: bad argument"); TSL_REQUIRE(m->esdf, "esdf_export: call tsl_esdf_update first");
     TSL_HIP(hipSetDevice(m->device));
-    int nused = 0; int rc = tsl_tsdf_bricks_in_use(m, &nused); if (rc) return rc;
+    int rc = esdf_finish(m); if (rc) return rc;
+    int nused = 0; rc = tsl_tsdf_bricks_in_use(m, &nused); if (rc) return rc;
     const size_t need = (((size_t)cap * 6 + 15) / 16) * 16 + (size_t)cap * 4 + 64;
     rc = grow(&m->xbuf, &m->xbuf_bytes, need); if (rc) return rc;
     int16_t* didx = (int16_t*)m->xbuf; float* dval = (float*)((char*)m->xbuf + (((size_t)cap * 6 + 15) / 16) * 16);

@@ -1025,6 +1025,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         if (S.stage_tex) (void)hipFree(S.stage_tex);
 
     }
+    esdf_release(m);
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket, m->F.npf,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_note, m->M.touch, m->M.slab_of, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
@@ -1415,6 +1416,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
+    if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }

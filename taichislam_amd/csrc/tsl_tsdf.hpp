@@ -146,8 +146,12 @@ struct ParamPack { FrameParams p[TSL_NB]; };
 struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; };
 #define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
+int esdf_finish(tsl_tsdf* m);            // tsl_esdf.hip: wait for the ESDF updates in flight (repairing one that stopped early)
+void esdf_release(tsl_tsdf* m);
 }  // namespace tsl
 
+#define TSL_ESDF_SLOTS 4
+struct EsdfSlot { hipEvent_t ev; int* host; int rounds; tsl_esdf_stats st; };      // one ESDF update in flight: its counters land in `host`
 struct tsl_tsdf {
     tsl_tsdf_cfg cfg;
     int device;
@@ -187,6 +191,7 @@ struct tsl_tsdf {
     // esdf
     float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
     bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
+    EsdfSlot esdf_slot[TSL_ESDF_SLOTS]; int esdf_tail, esdf_npend, esdf_rounds_seen, esdf_round_cap; bool esdf_short; tsl_esdf_totals_t esdf_tot;   // updates in flight (tsl_esdf.hip)
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];

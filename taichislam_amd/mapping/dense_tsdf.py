@@ -435,15 +435,26 @@ class DenseTSDF(BaseMap):
         return hit.astype(bool), end, ln
 
     # ---- ESDF (definition from the legacy dense_esdf.py:228-333) -----------------------------------
-    def update_esdf(self, gamma=None, max_dist=None):
+    def update_esdf(self, gamma=None, max_dist=None, wait=True):
         """Bring the ESDF of the active submap up to date with its TSDF -- incrementally: only the bricks integrated into since
         the previous call (dilated by max_dist) are recomputed, with the result of a full recompute.  Returns the number of brick
-        relaxations; `esdf_stats()` has the breakdown.  The reference's hook ran after every frame (dense_esdf.py:400-402)."""
-        it = C.c_int32()
+        relaxations; `esdf_stats()` has the breakdown.  The reference's hook ran after every frame (dense_esdf.py:400-402); for that use
+        pass wait=False: the update is only enqueued behind the frame (returns None) and `export_esdf` / `esdf_stats` / `esdf_totals`
+        wait for whatever is still in flight."""
         g = self.voxel_scale if gamma is None else gamma                 # dense_esdf.py:40 gamma = voxel_scale
         md = self.max_ray_length if max_dist is None else max_dist       # dense_esdf.py:265 sign * max_ray_length
+        if not wait:
+            _lib.check(self.L.tsl_esdf_update(self.h, float(g), float(md), None))
+            return None
+        it = C.c_int32()
         _lib.check(self.L.tsl_esdf_update(self.h, float(g), float(md), C.byref(it)))
         return it.value
+
+    def esdf_totals(self):
+        """Sums over the completed ESDF updates of this map (waits for the ones in flight)."""
+        st = _lib.EsdfTotals()
+        _lib.check(self.L.tsl_esdf_totals(self.h, C.byref(st)))
+        return st.as_dict()
 
     def esdf_stats(self):
         st = _lib.EsdfStats()

@@ -102,3 +102,30 @@ def test_incremental_update_at_benchmark_size(hip_lib):
     si, sf = inc.esdf_stats(), full.esdf_stats()
     assert si["incremental"] == 1 and si["dirty_bricks"] <= si["region_bricks"] <= sf["region_bricks"] == sf["total_bricks"]
     assert si["brick_relaxations"] <= sf["brick_relaxations"] * 1.05          # (work counters depend on the order in which lanes meet: not exactly reproducible)
+
+
+def test_asynchronous_updates_and_repair_of_a_short_update(hip_lib):
+    """The per-frame hook form: update_esdf(wait=False) only enqueues (up to four updates in flight); what export_esdf / esdf_totals
+    return is complete.  With the round cap knob an update stops while bricks are still listed: the next reader must get the repaired
+    (fully recomputed) map, equal to a synchronous full recompute."""
+    from taichislam_amd.mapping import DenseTSDF
+    K, frames = small_stream(12)
+    a = DenseTSDF(**SMALL); a.set_dep_camera_intrinsic(K)
+    short = DenseTSDF(**SMALL); short.set_dep_camera_intrinsic(K)
+    short.set_option("esdf_round_cap", 2)
+    full = DenseTSDF(**SMALL); full.set_dep_camera_intrinsic(K)
+    full.set_option("esdf_full", 1)
+    md = 0.5
+    for f, (R, T, d) in enumerate(frames):
+        for m in (a, short):
+            m.recast_depth_to_map(R, T, d, None)
+            assert m.update_esdf(max_dist=md, wait=False) is None
+        full.recast_depth_to_map(R, T, d, None)
+        full.update_esdf(max_dist=md)
+        if f in (5, 11):
+            (ai, ae), (si, se), (fi, fe) = _esdf_sorted(a), _esdf_sorted(short), _esdf_sorted(full)
+            assert np.array_equal(ai, fi) and np.array_equal(ae, fe), f"frame {f}: asynchronous != full at {(ae != fe).sum()} voxels"
+            assert np.array_equal(si, fi) and np.array_equal(se, fe), f"frame {f}: repaired != full at {(se != fe).sum()} voxels"
+    ta, ts = a.esdf_totals(), short.esdf_totals()
+    assert ta["updates"] == len(frames) and ta["incremental"] == len(frames) - 1
+    assert ts["updates"] > len(frames)             # the repairs are updates of their own
