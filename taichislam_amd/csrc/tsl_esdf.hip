@@ -96,15 +96,28 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float ga
     const int nused = min(*M.pool_top, M.max_bricks);
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         if (E.region[p] != 1) continue;
-        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
-            const size_t v = (size_t)p * TSL_BRK3 + l;
-            uint8_t f = 0; float mg = max_dist;
-            if (M.obs[v] > 0) {
-                const float t = h2f((h16)(M.tw[v] & 0xffffu));
-                f = EF_NODE | (t < 0.0f ? EF_NEG : 0);
-                if (fabsf(t) < gamma) { f |= EF_FIXED; mg = fabsf(t); }
+        {   // a thread's 16 consecutive voxels: 1 + 4 wide loads, 1 + 4 wide stores
+            const size_t v = (size_t)p * TSL_BRK3 + (size_t)threadIdx.x * 16;
+            const uint4 ob = *reinterpret_cast<const uint4*>(M.obs + v);
+            uint4 tw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tw[q] = reinterpret_cast<const uint4*>(M.tw + v)[q];
+            const uint32_t ow[4] = { ob.x, ob.y, ob.z, ob.w };
+            const uint32_t tv[16] = { tw[0].x, tw[0].y, tw[0].z, tw[0].w, tw[1].x, tw[1].y, tw[1].z, tw[1].w, tw[2].x, tw[2].y, tw[2].z, tw[2].w, tw[3].x, tw[3].y, tw[3].z, tw[3].w };
+            uint32_t fo[4] = { 0u, 0u, 0u, 0u }; float mo[16];
+#pragma unroll
+            for (int z = 0; z < 16; ++z) {
+                uint32_t f = 0u; float mg = max_dist;
+                if ((int8_t)((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu) > 0) {
+                    const float t = h2f((h16)(tv[z] & 0xffffu));
+                    f = EF_NODE | (t < 0.0f ? EF_NEG : 0);
+                    if (fabsf(t) < gamma) { f |= EF_FIXED; mg = fabsf(t); }
+                }
+                fo[z >> 2] |= f << ((z & 3) * 8); mo[z] = mg;
             }
-            E.fl[v] = f; E.mag[v] = mg;
+            *reinterpret_cast<uint4*>(E.fl + v) = make_uint4(fo[0], fo[1], fo[2], fo[3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(E.mag + v)[q] = make_float4(mo[4 * q], mo[4 * q + 1], mo[4 * q + 2], mo[4 * q + 3]);
         }
         if (threadIdx.x == 0) {
             const int q = __hip_atomic_fetch_add(&E.ctr[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
