@@ -107,6 +107,12 @@ def relaunch(args):
 
 
 def main():
+    # the contract is ONE JSON line on stdout: everything the shims print on the way (the reference's own progress prints) goes to stderr
+    real_stdout, sys.stdout = sys.stdout, sys.stderr
+
+    def emit(obj):
+        real_stdout.write(json.dumps(obj) + "\n"); real_stdout.flush()
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -140,7 +146,7 @@ def main():
         if distributed:
             raise SystemExit("--config 1/3/4 are single-GPU measurements")
         from taichislam_amd.utils import bench_configs
-        print(json.dumps(bench_configs.run(args.config, args.steps, args.warmup, dev)))
+        emit(bench_configs.run(args.config, args.steps, args.warmup, dev))
         return
 
     from taichislam_amd import _lib
@@ -321,7 +327,7 @@ def main():
                 out["parity_vs_faithful"] = parity_vs_faithful(dev, sample[:n_done], omap)
             except Exception as e:
                 out["parity_vs_faithful"] = {"error": repr(e)[:200]}
-        print(json.dumps(out))
+        emit(out)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

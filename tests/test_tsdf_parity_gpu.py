@@ -290,6 +290,24 @@ def test_queue_keeps_every_frames_own_parameters(hip_lib):
     del g                                                                  # two frames still queued
 
 
+@pytest.mark.parametrize("queued", [1, 2, 3])
+def test_queue_is_flushed_by_every_reader(hip_lib, tmp_path, queued):
+    """saveMap-then-exit style callers: 1-3 frames are still queued (a batch is four) when the map is read -- every reader must see them."""
+    from oracle import BATCHED
+    from taichislam_amd.mapping import DenseTSDF
+    K, frames = small_stream(4 + queued)
+    g, o = make_pair(SMALL, K)
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None); o.integrate_depth(R, T, d, mode=BATCHED)
+    want = o.export_sparse()
+    path = str(tmp_path / "map.npy")
+    g.saveMap(path)                                                        # first reader after the queued frames
+    back = DenseTSDF.loadMap(path)
+    assert back.count_active() == want["TSDF"].shape[0] == g.count_active()
+    assert_export_equal(back.export_submap(), want, f"saveMap / loadMap with {queued} queued frames")
+    assert_export_equal(g.export_submap(), want, f"export_submap with {queued} queued frames")
+
+
 def test_particle_exports(hip_lib):
     """cvt_TSDF_surface_to_voxels / cvt_TSDF_to_voxels_slice (dense_tsdf.py:339-389) as sorted sets."""
     K, frames = small_stream(3)
