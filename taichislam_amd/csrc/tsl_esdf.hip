@@ -34,6 +34,7 @@ namespace tsl {
 #define EF_NEG 2
 #define EF_FIXED 4
 #define ESDF_PAD (ESDF_T * ESDF_T + ESDF_T + 1)
+#define ESDF_QCAP 256          // queue entries per wave and hand-over (four per lane)
 #ifndef ESDF_SWEEPS
 #define ESDF_SWEEPS 1
 #endif
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
     __shared__ __attribute__((aligned(16))) uint32_t s_old[TSL_BRK3];   // the brick's voxels as staged, brick order: side << 31 | magnitude, 0 = unobserved
     __shared__ uint32_t s_hv[HPER * 256];                  // the halo's values, same encoding
     __shared__ uint32_t s_a[(ESDF_T3 + 31) / 32 + 2];      // active bits: the entry pushes in the next pass
+    __shared__ uint16_t s_q[4 * ESDF_QCAP];                // per wave: the entries it pushes next (compacted)
     __shared__ int s_nb[27];                       // pool index of the 27 bricks around (and including) this one, -1 = absent
     __shared__ int s_notify;
     uint32_t* const s_d = s_dm + ESDF_PAD;
@@ -263,10 +265,31 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
 #pragma unroll
                 for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; mine |= ((aw[q] >> (t & 31)) & 1u) << q; }
             }
+            // The wave's active entries are COMPACTED before they are pushed: every lane hands up to four of its entries to the wave's
+            // queue (a prefix sum over the lanes gives the positions), then lane i pushes entries i, i + 64, ...  Without this a wave
+            // iterates as often as its busiest lane has entries (~35 % of the lanes busy on average); the push body is ~450
+            // instructions, the hand-over ~40.  LDS operations of one wave execute in order: no barrier between the queue's writes and reads.
 #pragma unroll 1
-            for (; mine; mine &= mine - 1u) {
-                const int t = (int)__builtin_ctz(mine) * 256 + (int)threadIdx.x;
-                __hip_atomic_fetch_and(&s_a[t >> 5], ~(1u << (t & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__any(mine != 0u)) {
+            const int lane = (int)(threadIdx.x & 63u);
+            uint16_t* const wq = s_q + (threadIdx.x >> 6) * ESDF_QCAP;
+            const int c = min((int)__builtin_popcount(mine), ESDF_QCAP / 64);
+            int inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            const int total = __shfl(inc, 63);
+#pragma unroll
+            for (int k = 0; k < ESDF_QCAP / 64; ++k) {
+                if (k < c) {
+                    const int t = (int)__builtin_ctz(mine) * 256 + (int)threadIdx.x; mine &= mine - 1u;
+                    __hip_atomic_fetch_and(&s_a[t >> 5], ~(1u << (t & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&wq[inc - c + k], (uint16_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int qi = lane; qi < total; qi += 64) {
+                const int t = (int)__hip_atomic_load(&wq[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 uint32_t self = LDS_LD(&s_d[t]);
                 ++pushes;
                 uint32_t dn[26];
@@ -312,6 +335,7 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
                     any |= bits;
                 }
                 act = act || any != 0u;
+            }
             }
             if (!__any(act)) break;                                // nothing pushed by this wave in this sweep: wait for the others
             }
