@@ -237,7 +237,7 @@ struct MapDev {
     uint16_t* col;             // [max_bricks][4096][4] f16 rgb (+pad) or nullptr
     int* owner;                // [max_bricks] -> s*nb3 + b
     uint8_t* touch;            // [max_bricks] set by the integrate kernels when they write a brick's TSDF (consumed by the incremental ESDF)
-    unsigned long long* slab_of;   // [max_bricks] batch generation << 20 | first merge-slab slot of the brick in that batch (k_plan; stale generations mean none)
+    unsigned long long* slab_of;   // [batch slots][max_bricks] batch generation << 20 | first merge-slab slot of the brick in that batch (k_plan; stale generations mean none)
     int* pool_top;             // bricks handed out so far
     int* err;                  // sticky device error flags (bit 0 brick pool full, 1 frame scratch, 2 ray segments, 3 crowded sensor voxel)
 };

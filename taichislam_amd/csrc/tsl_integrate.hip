@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 #define HDR_PARTS 16           //   [16..19] parts per class
 #define HDR_UNITS 20           //   batch: [20..23] units per class
 __device__ __forceinline__ int plan_class(int w) { return w >= 2560 ? 0 : (w >= 1280 ? 1 : (w >= 512 ? 2 : 3)); }
-__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max, unsigned long long gen)
+__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max, unsigned long long gen, int bslot)
 {
     if ((int)blockIdx.y >= B.n) return;
     const int y = blockIdx.y;
@@ -498,13 +498,14 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
             // (the brick's first frame of the batch claims them, the other frames' threads -- other blocks of this small grid, all resident --
             //  wait for its tag)
             unsigned long long cur;
+            unsigned long long* const slab_of = M.slab_of + (size_t)bslot * M.max_bricks;       // the batch slot's own words: phase A of two batches may run side by side
             if ((tm & -tm) == (1 << y)) {
                 const int mine = __hip_atomic_fetch_add(&B.f[0].counters[HDR_SLAB], TSL_NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cur = (gen << 20) | (unsigned long long)min(mine, (1 << 20) - 1);
-                __hip_atomic_store(&M.slab_of[pool], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slab_of[pool], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 int spins = 0;
-                while (((cur = __hip_atomic_load(&M.slab_of[pool], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != gen && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(2);
+                while (((cur = __hip_atomic_load(&slab_of[pool], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != gen && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(2);
                 if ((cur >> 20) != gen) cur = (1u << 20) - 1u;                      // cannot happen; fails the capacity check below
             }
             const int base = (int)(cur & ((1u << 20) - 1u));
@@ -1078,7 +1079,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     prof_end(m, st);
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024), m->unit_max, (unsigned long long)++m->batch_gen);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024), m->unit_max, (unsigned long long)++m->batch_gen, m->cur);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;
@@ -1089,7 +1090,7 @@ int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P)
 {
     // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
 #define TSL_LAUNCH_IB(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, B); \
-                                     else hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3((TEXV ? 1 : 2) * m->ncu), dim3(256), 0, m->stream_, m->M, B); } while (0)
+                                     else hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3(((TEXV ? 1 : 2) * m->ncu * m->bgrid + 99) / 100), dim3(256), 0, m->stream_, m->M, B); } while (0)
     if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
     else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }
 #undef TSL_LAUNCH_IB

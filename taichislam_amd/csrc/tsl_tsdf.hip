@@ -737,9 +737,9 @@ static int ensure_frame_scratch(tsl_tsdf* m)
         S.F = F;
         FrameDev& G = S.F;
         auto own = [&](void** p, size_t bytes) -> int { int r = dev_alloc(m, p, bytes, 0); if (!r) S.owned.push_back(*p); return r; };
-        if (si >= TSL_NB) {         // the second batch in flight merges its split bricks through its own slab (owned by its first set)
-            FrameDev& G0 = m->fset[TSL_NB].F;
-            if (si == TSL_NB) {
+        if (si >= TSL_NB) {         // every further batch slot merges its split bricks through its own slab (owned by the slot's first set)
+            FrameDev& G0 = m->fset[(si / TSL_NB) * TSL_NB].F;
+            if (si % TSL_NB == 0) {
                 if ((rc = own((void**)&G.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3))) return rc;
                 if ((rc = own((void**)&G.ticket, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
                 if ((rc = own((void**)&G.npf, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
@@ -916,7 +916,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256; m->chunks = 2; m->unit_max = 4096; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 256; m->bgrid = 100; m->chunks = 2; m->unit_max = 4096; m->batch_gen = 0;
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -942,7 +942,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&M.col, sizeof(uint16_t) * 4 * (size_t)want * TSL_BRK3, 0))) return rc; }
     if ((rc = dev_alloc(m, (void**)&M.owner, sizeof(int) * (size_t)want, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.touch, (size_t)want, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&M.slab_of, sizeof(unsigned long long) * (size_t)want, 0))) return rc;
+    if ((rc = dev_alloc(m, (void**)&M.slab_of, sizeof(unsigned long long) * (size_t)want * TSL_NBATCH, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
     M.err = M.pool_top + 1;
 
@@ -1419,6 +1419,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
+    if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 100, "bgrid must be 10..100 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NB ? TSL_NB : value); for (auto& H : m->batch) H.b_pending = false; return TSL_OK; }

@@ -132,7 +132,7 @@ struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 // Frames are queued and processed TSL_NB at a time: phase A of a whole batch runs as one sequence of launches (grid.y = frame)
 // on the batch's stream while phase B of the previous batch runs on the main stream; two batches are in flight.
 #define TSL_NB 4
-#define TSL_NBATCH 2
+#define TSL_NBATCH 3          // batch slots: phase A of two batches may run beside phase B of a third
 #define TSL_NSETS (TSL_NB * TSL_NBATCH)
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
@@ -195,7 +195,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, ncu, chunks, unit_max; uint64_t batch_gen;
+    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid; uint64_t batch_gen;
     int64_t bytes;
 };
 

@@ -1,17 +1,8 @@
 #!/bin/bash
-# A/B bench lines; usage: gpu_ab.sh "bench args" "bench args" ...
-mkdir -p gpurun_out; O=gpurun_out
-i=0
-for a in "$@"; do
-  i=$((i+1))
-  timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline $a > $O/ab_$i.json 2> $O/ab_$i.err
-  python - << PY
-import json
-try:
-    d=json.loads(open("$O/ab_$i.json").read().strip().splitlines()[-1])
-    k=d['config']['kernels_us']
-    print("[$a] %.0f fps  "%d['value'] + "  ".join(f"{n}={v['avg_us']:.1f}" for n,v in k.items()))
-except Exception as e:
-    print("[$a] FAILED", e); print(open("$O/ab_$i.err").read()[-1500:])
-PY
+# A/B of bench.py option strings: gpu_ab.sh "opt1=v opt2=v" "..."   ("" = defaults); two runs each
+cd $GRAFT_REPO_ROOT
+for o in "$@"; do
+  args=""; for kv in $o; do args="$args --opt $kv"; done
+  for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); k=j['config']['kernels_us']; print('[$o]', round(j['value'],1), 'fps | integrate us', round(j['roofline']['avg_launch_us'],1), '| host input', {a:round(b) for a,b in j['value_host_input'].items() if a!='note'})"; done
 done
