@@ -178,7 +178,8 @@ def main():
         step(f)
     m.sync()
     # timed region: only the dominant kernel is bracketed by HIP events (one pair per batch of its launches)
-    m.enable_profiling(True, only=[_lib.K_INTEGRATE])
+    if not os.environ.get("TSL_BENCH_NOPROF"):      # developer A/B: what the event pair around every phase-B launch costs
+        m.enable_profiling(True, only=[_lib.K_INTEGRATE])
 
     def barrier():
         if distributed:
