@@ -9,6 +9,7 @@ Byte models are SURVEY.md section 8d's: marching cubes 3*A + 72*Tri, Octomap 2*P
 Kernel times come from HIP events on the handle's stream inside the run where the handle has them (marching cubes, ESDF); the Octomap
 kernel is timed by rocprofv3 (profiles/r02_octomap_kernel_stats.csv) and through the wall clock here."""
 import gc
+import os
 import time
 
 import numpy as np
@@ -83,7 +84,7 @@ def run(config, steps, warmup, dev):
         m = DenseTSDF(**C2, device=dev)
         m.set_dep_camera_intrinsic(syn.K_DEPTH)
         mesher = MarchingCubeMesher(m, 4000000, tsdf_surface_thres=5 * C2["voxel_scale"])
-        md = 1.0
+        md = float(os.environ.get("TSL_ESDF_MAX_DIST", "1.0"))      # developer sweep; the reported configuration is 1 m
 
         def step(f):
             m.recast_depth_to_map(host[f][0], host[f][1], depth_dev[f], None)
@@ -112,7 +113,7 @@ def run(config, steps, warmup, dev):
         cells = region / max(1, steps) * 4096
         return _line("depth-frames/s (TSDF 512^3 + incremental ESDF every frame + marching cubes every 10th)", steps / dt, "frames/s", steps, warmup,
                      1000.0 * dt / steps,
-                     "BASELINE configs[3]: the configs[1] stream; after every frame tsl_esdf_update(gamma = voxel, max_dist = 1 m), every 10th frame "
+                     f"BASELINE configs[3]: the configs[1] stream; after every frame tsl_esdf_update(gamma = voxel, max_dist = {md:g} m, asynchronous), every 10th frame "
                      "generate_mesh(1) with tsdf_surface_thres = 5 voxels",
                      {"esdf_ms_per_update": ems / max(1, en), "esdf_brick_relaxations_per_update": relax / max(1, steps),
                       "esdf_voxel_pushes_per_update": pushes / max(1, steps), "esdf_region_bricks_per_update": region / max(1, steps),

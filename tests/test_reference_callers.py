@@ -202,15 +202,12 @@ def test_package_submap_mapping_makes_the_same_calls_as_the_reference(kind):
     assert a[3] == b[3]
 
 
-@needs_ref
-@pytest.mark.gpu
-def test_reference_submap_mapping_runs_unmodified_on_the_hip_shims(hip_lib, tmp_path):
-    """Three keyframe-stepped submaps + one remote submap through the reference's own class on the HIP-backed DenseTSDF; the global map
-    it builds must equal the oracle's fusion of the same submaps bit for bit."""
+def _orchestration_on_the_hip_shims(Ref, tmp_path):
+    """Three keyframe-stepped submaps through a SubmapMapping class on the HIP-backed DenseTSDF; the global map it builds must equal the
+    oracle's fusion of the same submaps bit for bit."""
     from oracle import BATCHED, OracleTSDF
     from taichislam_amd import mapping as M
     from util import small_stream, sort_export
-    Ref = load_reference_submap_mapping(M.DenseTSDF, M.Octomap, M.BaseMap)
     opts = dict(map_scale=[10.24, 10.24], voxel_scale=0.04, num_voxel_per_blk_axis=16, max_ray_length=5.0, max_submap_num=16)
     K, frames = small_stream(8)
     sm = Ref(M.DenseTSDF, keyframe_step=3, sub_opts=opts, global_opts=opts)
@@ -238,3 +235,19 @@ def test_reference_submap_mapping_runs_unmodified_on_the_hip_shims(hip_lib, tmp_
     assert np.array_equal(a["indices"], b["indices"]) and a["indices"].shape[0] > 50000
     ok = ~np.isnan(a["TSDF"].view(np.float16))
     assert np.array_equal(a["TSDF"][ok], b["TSDF"][ok]) and np.array_equal(a["W_TSDF"], b["W_TSDF"]) and np.array_equal(a["occupy"], b["occupy"])
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_reference_submap_mapping_runs_unmodified_on_the_hip_shims(hip_lib, tmp_path):
+    """The reference's own file (loaded by path, unmodified) -- runs where a GPU and the reference tree are both present."""
+    from taichislam_amd import mapping as M
+    _orchestration_on_the_hip_shims(load_reference_submap_mapping(M.DenseTSDF, M.Octomap, M.BaseMap), tmp_path)
+
+
+@pytest.mark.gpu
+def test_package_submap_mapping_on_the_hip_shims(hip_lib, tmp_path):
+    """The same scenario through the package's own SubmapMapping, which the CPU test above shows to make the reference's calls one for
+    one: this is the form that runs on the GPU box, where the reference tree does not exist."""
+    from taichislam_amd.mapping import SubmapMapping
+    _orchestration_on_the_hip_shims(SubmapMapping, tmp_path)
