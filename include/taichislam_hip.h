@@ -218,13 +218,16 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
 
 /* backend knobs for A/B-ing kernel variants: name in
      "variant"  0|1: one global int64 atomic pair per ray step, 2 (default): brick-binned LDS accumulation
-     "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; two batches in flight)
+     "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; three batch slots: phase A of two
+                batches runs beside phase B of a third)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
-     "wg"       threads per workgroup of the brick integrate kernel: 256 (default; chunks of 1024 segments, two workgroups per CU) or
-                512 (chunks of 2048, one workgroup per CU)
-     "chunks"   chunks a part may hold (1..8, default 1): a brick with up to chunks x chunk-size segments is integrated by one
-                workgroup and never merged through HBM
+     "wg"       threads per workgroup of the brick integrate kernel: 512 (default; steps of 2048 segments, one workgroup per CU, 187 VGPRs:
+                phase-A waves of the next batches fit beside it) or 256 (steps of 1024, two workgroups per CU that fill the register file)
+     "unit"     a brick whose segments of a whole batch number at most this (default 12288) is walked by ONE workgroup, frame after
+                frame, with its voxels in registers; heavier bricks are split into parts and merged through the HBM slab
+     "chunks"   steps a part may hold (1..8, default 2)
+     "bgrid"    resident phase-B workgroups in percent of the slots (wg 256 only; default 100)
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
      "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)
      "esdf_round_cap" n > 0 = launch at most n relaxation rounds per update (test knob: an update that stops early must be repaired)
