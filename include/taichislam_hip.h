@@ -218,8 +218,8 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
 
 /* backend knobs for A/B-ing kernel variants: name in
      "variant"  0|1: one global int64 atomic pair per ray step, 2 (default): brick-binned LDS accumulation
-     "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; three batch slots: phase A of two
-                batches runs beside phase B of a third)
+     "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; four batch slots on three
+                phase-A streams: phase A of up to three batches is in flight beside phase B of a fourth)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
      "wg"       threads per workgroup of the brick integrate kernel: 512 (default; steps of 2048 segments, one workgroup per CU, 187 VGPRs:

@@ -959,7 +959,9 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
     for (int bi = 0; bi < TSL_NBATCH; ++bi) {
         BatchHost& H = m->batch[bi];
-        TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking));
+        // more batch slots than streams: the device runs four hardware queues efficiently (main + TSL_NSTREAMS), a slot beyond that shares
+        // the stream of slot bi - TSL_NSTREAMS (its phase A is ordered behind that slot's, which is two or three batches older)
+        if (bi < TSL_NSTREAMS) TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking)); else H.st = m->batch[bi % TSL_NSTREAMS].st;
         TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
         TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
     }
@@ -1013,8 +1015,9 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     for (auto& H : m->batch) if (H.st) (void)hipStreamSynchronize(H.st);
     if (m->stream_) (void)hipStreamSynchronize(m->stream_);
     (void)hipDeviceSynchronize();
-    for (auto& H : m->batch) {
-        if (H.st) (void)hipStreamDestroy(H.st);
+    for (int bi = 0; bi < TSL_NBATCH; ++bi) {
+        BatchHost& H = m->batch[bi];
+        if (H.st && bi < TSL_NSTREAMS) (void)hipStreamDestroy(H.st);
         if (H.a_done) (void)hipEventDestroy(H.a_done);
         if (H.b_done) (void)hipEventDestroy(H.b_done);
     }

@@ -132,7 +132,8 @@ struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 // Frames are queued and processed TSL_NB at a time: phase A of a whole batch runs as one sequence of launches (grid.y = frame)
 // on the batch's stream while phase B of the previous batch runs on the main stream; two batches are in flight.
 #define TSL_NB 4
-#define TSL_NBATCH 3          // batch slots: phase A of two batches may run beside phase B of a third
+#define TSL_NBATCH 4          // batch slots: phase A of up to three batches is in flight beside phase B of a fourth
+#define TSL_NSTREAMS 3        // phase-A streams shared by the batch slots (the device runs main + 3 queues efficiently)
 #define TSL_NSETS (TSL_NB * TSL_NBATCH)
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
