@@ -1089,7 +1089,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
 int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P)
 {
     // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
-#define TSL_LAUNCH_IB(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3(m->ncu), dim3(512), 0, m->stream_, m->M, B); \
+#define TSL_LAUNCH_IB(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3((m->ncu * m->bgrid + 99) / 100), dim3(512), 0, m->stream_, m->M, B); \
                                      else hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3(((TEXV ? 1 : 2) * m->ncu * m->bgrid + 99) / 100), dim3(256), 0, m->stream_, m->M, B); } while (0)
     if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
     else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }

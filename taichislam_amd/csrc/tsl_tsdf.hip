@@ -1422,7 +1422,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
-    if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 100, "bgrid must be 10..100 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
+    if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 200, "bgrid must be 10..200 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NB ? TSL_NB : value); for (auto& H : m->batch) H.b_pending = false; return TSL_OK; }
