@@ -653,7 +653,7 @@ static int launch_batch_t(tsl_tsdf* m)
     if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
     m->frames_issued += n;
     if (!serial) {
-        TSL_HIP(hipEventRecord(H.a_done, sa));
+        TSL_HIP(hipEventRecord(H.a_done, sa)); H.a_recorded = true;
         TSL_HIP(hipStreamWaitEvent(m->stream_, H.a_done, 0));
     }
     // ---- phase B: apply to the map on the main stream: the brick kernel takes the whole batch in one launch (frame order is kept per
@@ -699,11 +699,17 @@ static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
     *set_index = m->cur * TSL_NB + m->npend;
     return TSL_OK;
 }
-// host buffers are copied into the staging area of the frame's working set on the stream that will run its phase A
+// host buffers are copied into the staging area of the frame's working set; the host waits for the copy, so phase A needs no event
 static int stage_host(tsl_tsdf* m, int si, const void* in, size_t in_bytes, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev)
 {
     FSet& S = m->fset[si];
-    hipStream_t sc = m->overlap == 0 ? m->stream_ : m->batch[si / TSL_NB].st;
+    // a stream of its own for the copies: on a phase-A stream the copy (and the wait below) would queue behind phase A of an older batch
+    hipStream_t sc = m->stream_;
+    if (m->overlap != 0) {
+        sc = m->copy_st;
+        BatchHost& H = m->batch[si / TSL_NB];
+        if (H.a_recorded) TSL_HIP(hipStreamWaitEvent(sc, H.a_done, 0));       // phase A of the slot's previous batch read this staging area
+    }
     int rc = grow(&S.stage_in, &S.stage_in_bytes, in_bytes + 16); if (rc) return rc;
     if (in_bytes) TSL_HIP(hipMemcpyAsync(S.stage_in, in, in_bytes, hipMemcpyHostToDevice, sc));
     *in_dev = S.stage_in; *tex_dev = nullptr;
@@ -871,7 +877,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
     m->overlap = TSL_NB; m->last_set = 0;
     for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; }
-    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.b_pending = false; }
+    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.b_pending = false; H.a_recorded = false; }
     m->frames_issued = 0; m->frames_consumed = 0; m->batch_seq = 0;
     for (int k = 0; k < TSL_INFLIGHT; ++k) { m->ring_ev[k] = nullptr; m->ring_upto[k] = 0; }
     m->cur = 0; m->npend = 0; m->pend_points = 0; m->deferred_rc = 0;
@@ -966,6 +972,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
         TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
     }
     for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], hipEventDisableTiming));
+    TSL_HIP(hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking));
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 256, hipHostMallocDefault));
     std::memset(m->h_stats, 0, sizeof(tsl_frame_stats));
@@ -1040,6 +1047,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     for (auto& e : m->prof_free) (void)hipEventDestroy(e);
     for (auto& e : m->in_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->ring_ev) if (e) (void)hipEventDestroy(e);
+    if (m->copy_st) (void)hipStreamDestroy(m->copy_st);
     if (m->stream_) (void)hipStreamDestroy(m->stream_);
     delete m;
 }

@@ -144,7 +144,7 @@ struct FSet {
 // kernel argument of the batched phase-A kernels: the working sets and (device) parameter blocks of the frames of one batch
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
 struct ParamPack { FrameParams p[TSL_NB]; };
-struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending; };
+struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending, a_recorded; };
 #define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
 int esdf_finish(tsl_tsdf* m);            // tsl_esdf.hip: wait for the ESDF updates in flight (repairing one that stopped early)
@@ -157,7 +157,7 @@ struct tsl_tsdf {
     tsl_tsdf_cfg cfg;
     int device;
     hipStream_t stream_;                 // phase B + everything else; entry points take it through tsl::ms(), which first issues queued frames
-    tsl::FSet fset[TSL_NSETS]; tsl::BatchHost batch[TSL_NBATCH];
+    tsl::FSet fset[TSL_NSETS]; tsl::BatchHost batch[TSL_NBATCH]; hipStream_t copy_st;   // copy_st: H2D copies of host-pointer inputs
     int overlap;                         // frames per batch (0 = one frame at a time on the main stream)
     int cur, npend, pend_points; tsl::FrameParams pend[TSL_NB]; int deferred_rc;      // frames queued for batch `cur`
     int64_t frames_issued, frames_consumed;  // frames handed to the device so far / of those, frames whose inputs have been read
