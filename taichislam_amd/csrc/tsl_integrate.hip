@@ -1078,8 +1078,11 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     if (P.group) hipLaunchKernelGGL(k_segments<true>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     else hipLaunchKernelGGL(k_segments<false>, dim3(iblocks, B.n), dim3(256), 0, st, m->M, B);
     prof_end(m, st);
+    // the unit limit is quoted for a full batch; a shorter batch (one frame when something reads the map after every frame) scales it:
+    // a unit is walked by one workgroup frame after frame, and with few frames a long unit is just a long serial item
+    const int unit_max = m->unit_max <= 4096 ? m->unit_max : std::max(4096, (int)((long long)m->unit_max * B.n / TSL_NB));
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024), m->unit_max, (unsigned long long)++m->batch_gen, m->cur);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024), unit_max, (unsigned long long)++m->batch_gen, m->cur);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;

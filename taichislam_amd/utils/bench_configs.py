@@ -84,6 +84,8 @@ def run(config, steps, warmup, dev):
         m = DenseTSDF(**C2, device=dev)
         m.set_dep_camera_intrinsic(syn.K_DEPTH)
         mesher = MarchingCubeMesher(m, 4000000, tsdf_surface_thres=5 * C2["voxel_scale"])
+        for kv in os.environ.get("TSL_C4_OPTS", "").split():          # developer A/B of backend options
+            k, v = kv.split("="); m.set_option(k, int(v))
         md = float(os.environ.get("TSL_ESDF_MAX_DIST", "1.0"))      # developer sweep; the reported configuration is 1 m
 
         def step(f):
