@@ -158,6 +158,27 @@ def test_queued_batches_bit_exact(hip_lib, overlap):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"queued batches, overlap {overlap}")
 
 
+@pytest.mark.parametrize("host_input", [False, True])
+def test_long_stream_cycles_every_batch_slot(hip_lib, host_input):
+    """34 frames without a read in between: every batch slot (four, sharing three phase-A streams) is reused at least twice, the
+    last batch is partial; with numpy inputs every frame also goes through the copy stream into its set's staging area, and the
+    caller's buffer is overwritten right after each call."""
+    from oracle import BATCHED
+    import torch
+    K, frames = small_stream(34)
+    g, o = make_pair(SMALL, K)
+    scratch = np.empty_like(frames[0][2])
+    for R, T, d in frames:
+        if host_input:
+            scratch[...] = d
+            g.recast_depth_to_map(R, T, scratch, None)
+            scratch[...] = 0                                               # the library must have taken its copy
+        else:
+            g.recast_depth_to_map(R, T, torch.from_numpy(d.view(np.int16)).cuda(), None)
+        o.integrate_depth(R, T, d, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"34 queued frames, host_input {host_input}")
+
+
 @pytest.mark.parametrize("group", [0, 1])
 def test_pixel_grouping_paths(hip_lib, group):
     """Pixels of one sensor voxel are summed in raster order with per-add f16 rounding (dense_tsdf.py:230-234) whether the
