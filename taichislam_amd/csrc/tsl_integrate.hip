@@ -450,10 +450,11 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 // (frame, brick)'s slot of the batch's merge slab, and the workgroup that arrives last at the brick -- over all its frames -- applies
 // the frames in order.  Items are binned into PLAN_NCLS classes by the segments they walk (long first).
 // Nothing has to be in any particular order inside a class, so block-aggregated reservations replace a prefix scan.
-// unit = { brick id, segments of the batch | frames with segments << 28, pool index (claimed here, on the brick's first touch ever), - }
-// part = { first segment, segments | parts of the (frame, brick) << 16 | frames of the batch with segments << 28, pool index,
-//          slab slot of the (frame, brick) = the brick's first slot + frame }
+// unit = { brick id, segments of the batch, pool index (claimed here, on the brick's first touch ever), frames of the batch with segments }
+// part = { first segment, segments | parts of the (frame, brick) << 16, pool index,
+//          slab slot of the (frame, brick) = the brick's first slot + frame | frames of the batch with segments << 24 }
 #define PART_NP_BITS 12
+#define PART_TM_SHIFT 24          // slab slots are < 2^20
 #define PLAN_NCLS 4
 #define HDR_FAIL 11            // header words (FrameDev.counters): frame overflow bits
 #define HDR_CLAIM 12           //   batch (first frame's header): next rank to claim
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
         F.bnseg[b] = v;
         const int pool = (np || ucls >= 0) ? pool_claim<false>(M, B.p[y]->slot, b) : -1;      // < 0: pool exhausted (reported through M.err), the item is skipped
         if (ucls >= 0) {
-            if (u0 < B.f[0].unit_cap) B.f[0].unit_tab[(size_t)ucls * B.f[0].unit_cap + u0] = make_int4(b, (int)((uint32_t)wb | ((uint32_t)tm << 28)), pool, 0);
+            if (u0 < B.f[0].unit_cap) B.f[0].unit_tab[(size_t)ucls * B.f[0].unit_cap + u0] = make_int4(b, wb, pool, tm);
             else for (int q = 0; q < B.n; ++q) if ((tm >> q) & 1) frame_fail(M, B.f[q], 2);
         }
         if (np && pool >= 0) {
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
                 int4* tab = F.part_tab + (size_t)pcls * F.part_cap;
                 for (int k = 0; k < np; ++k) {
                     const int pos = k * per, n = min(v, pos + per) - pos;
-                    if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, (int)((uint32_t)n | ((uint32_t)np << 16) | ((uint32_t)tm << 28)), pool, base + y); else frame_fail(M, F, 2);
+                    if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, (int)((uint32_t)n | ((uint32_t)np << 16)), pool, (base + y) | (tm << PART_TM_SHIFT)); else frame_fail(M, F, 2);
                 }
             }
         }
@@ -643,9 +644,9 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 #define IT_NP   3       // parts: parts of the (frame, brick)
 #define IT_TMALL 4      // parts: frames of the batch that integrate into the brick
 #define IT_FMASK 5      // frames this item walks
-#define IT_OFF  6       // [6..9] first segment per frame
-#define IT_N    10      // [10..13] segments per frame
-#define IT_WORDS 16
+#define IT_OFF  6                     // [IT_OFF + q] first segment of frame q
+#define IT_N    (IT_OFF + TSL_NB)     // [IT_N + q] segments of frame q
+#define IT_WORDS (IT_N + TSL_NB + 2)
 #define NRANGE (PLAN_NCLS * (TSL_NB + 1))
 
 template <bool TEX, bool FASTDIV, int NT>
@@ -701,7 +702,7 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_ba
         *io = 0; *in = 0;
         const int q = threadIdx.x;
         if (q < TSL_NB) {
-            if (kq < 0) { if ((((uint32_t)e.y >> 28) & okmask) >> q & 1u) { *io = B.f[q].boffset[e.x]; *in = B.f[q].bnseg[e.x]; } }
+            if (kq < 0) { if ((((uint32_t)e.w) & okmask) >> q & 1u) { *io = B.f[q].boffset[e.x]; *in = B.f[q].bnseg[e.x]; } }
             else if (q == kq) { *io = e.x; *in = e.y & 0xffff; }
         }
     };
@@ -709,11 +710,11 @@ __global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_ba
         int* it = s_it[slot];
         if (threadIdx.x < TSL_NB) { it[IT_OFF + threadIdx.x] = io; it[IT_N + threadIdx.x] = in; }
         if (threadIdx.x == 0) {
-            const uint32_t tm = ((uint32_t)e.y >> 28) & okmask;
+            const uint32_t tm = (kq < 0 ? (uint32_t)e.w : (uint32_t)e.w >> PART_TM_SHIFT) & okmask;
             uint32_t fm = kq < 0 ? tm : 1u << kq;
             int pool = e.z;
             if (fm == 0u) { fm = 1u; pool = -1; }                  // a unit whose frames all overflowed: nothing to walk, nothing to apply
-            it[IT_UNIT] = kq < 0 ? 1 : 0; it[IT_POOL] = pool; it[IT_SLAB] = e.w; it[IT_NP] = kq < 0 ? 1 : (e.y >> 16) & ((1 << PART_NP_BITS) - 1);
+            it[IT_UNIT] = kq < 0 ? 1 : 0; it[IT_POOL] = pool; it[IT_SLAB] = e.w & ((1 << PART_TM_SHIFT) - 1); it[IT_NP] = kq < 0 ? 1 : (e.y >> 16) & ((1 << PART_NP_BITS) - 1);
             it[IT_TMALL] = (int)tm; it[IT_FMASK] = (int)fm;
         }
     };

@@ -575,10 +575,10 @@ static PoseF pose_of(const tsl_tsdf* m, int s)
 }
 
 // per-frame prologue of a working set: publish the frame's parameters, clear stats | nrays | counters (256 bytes)
-__global__ void k_set_params(ParamPack PP, BatchDev B)
+__global__ void k_set_params(ParamPack PP, SetPtrs S)
 {
-    if (threadIdx.x == 0) *const_cast<FrameParams*>(B.p[blockIdx.x]) = PP.p[blockIdx.x];
-    reinterpret_cast<int*>(B.f[blockIdx.x].stats)[threadIdx.x] = 0;          // stats | nrays | counters: the set's 256-byte header
+    if (threadIdx.x == 0) *S.p[blockIdx.x] = PP.p[blockIdx.x];
+    S.header[blockIdx.x][threadIdx.x] = 0;                                    // stats | nrays | counters: the set's 256-byte header
 }
 
 // phase A of a batch of n frames on stream `sa`: depth -> rays -> brick-sorted segments, every kernel once with grid.y = frame.
@@ -636,6 +636,10 @@ static int launch_batch_t(tsl_tsdf* m)
     const int bi = m->cur;
     BatchHost& H = m->batch[bi];
     const bool serial = m->overlap == 0;
+    {   // has the pipeline run dry?  (phase B of the batch issued last has completed)
+        const BatchHost& L = m->batch[(bi + TSL_NBATCH - 1) % TSL_NBATCH];
+        if (!L.b_pending || hipEventQuery(L.b_done) == hipSuccess) m->ramp = 0; else if (m->ramp < 1000) ++m->ramp;
+    }
     hipStream_t sa = serial ? m->stream_ : H.st;
     // back-pressure: the host never runs more than TSL_INFLIGHT batches ahead of the device (bounded queues, bounded lifetime of the
     // callers' input buffers); waiting for the batch issued TSL_INFLIGHT batches ago also tells which frames have been consumed
@@ -645,11 +649,21 @@ static int launch_batch_t(tsl_tsdf* m)
         if (m->ring_upto[ring] > m->frames_consumed) m->frames_consumed = m->ring_upto[ring];
     }
     if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
+    for (int k = 0; k < m->nproducers; ++k) {       // device inputs: phase A waits for what their producers had queued (tsl_tsdf_input_stream)
+        if (m->producers[k] == sa) continue;
+        if (!m->in_ev[0]) for (auto& e : m->in_ev) TSL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipEvent_t e = m->in_ev[m->in_ev_next]; m->in_ev_next = (m->in_ev_next + 1) % 8;
+        TSL_HIP(hipEventRecord(e, m->producers[k]));
+        TSL_HIP(hipStreamWaitEvent(sa, e, 0));
+    }
+    m->nproducers = 0;
     BatchDev B; ParamPack PP;
     for (int q = 0; q < n; ++q) { FSet& S = m->fset[bi * TSL_NB + q]; B.f[q] = S.F; B.p[q] = S.Pd; PP.p[q] = m->pend[q]; }
     for (int q = n; q < TSL_NB; ++q) { B.f[q] = B.f[0]; B.p[q] = B.p[0]; PP.p[q] = PP.p[0]; }
     B.n = n;
-    hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, B);
+    SetPtrs SP;                                     // (the parameter blocks and the working sets together exceed the 4 KiB of kernel arguments)
+    for (int q = 0; q < TSL_NB; ++q) { SP.p[q] = const_cast<FrameParams*>(B.p[q]); SP.header[q] = reinterpret_cast<int*>(B.f[q].stats); }
+    hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, SP);
     if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
     m->frames_issued += n;
     if (!serial) {
@@ -814,7 +828,19 @@ static int queue_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, 
     m->pend[m->npend] = P;
     m->last_set = m->cur * TSL_NB + m->npend;
     m->npend++;
-    if (m->npend >= cap) return flush_pending(m);
+    // ramp-up: the first batches after the pipeline ran dry are half batches -- a burst gets its first phase A (and with it the
+    // whole chain) started sooner, a steady stream is back at full batches after two of them
+    if (m->npend >= cap || (cap > 4 && m->ramp < 2 && m->npend >= cap / 2)) return flush_pending(m);
+    // Option "adaptive": frames are only held back while the device has phase-A work to do.  When phase A of the batch issued last has
+    // completed (or nothing was issued yet), the queued frames go out at once -- a 30 Hz sensor gets every frame integrated on arrival
+    // -- and when the producer outruns the device the batches fill up by themselves.  One event query per queued frame.  Off by
+    // default: a burst then starts with a batch of one, and the serial head of the phase-B chain costs it 10 % (20 frames: 13.0 k vs
+    // 14.4 k frames/s).
+    if (cap > 1 && m->adaptive) {
+        const int last = (m->cur + TSL_NBATCH - 1) % TSL_NBATCH;
+        const BatchHost& H = m->batch[last];
+        if (!H.a_recorded || hipEventQuery(H.a_done) == hipSuccess) return flush_pending(m);
+    }
     return TSL_OK;
 }
 
@@ -922,7 +948,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->bgrid = 100; m->chunks = 2; m->unit_max = 12288; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->adaptive = 0; m->bgrid = 100; m->chunks = 2; m->unit_max = 3072 * TSL_NB; m->batch_gen = 0;
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -1210,17 +1236,31 @@ int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
  * `ordered` = 0 skips the ordering (the caller guarantees the buffers are complete). */
 int tsl_tsdf_input_stream(tsl_tsdf* m, int points, int ordered, void* producer, void** hip_stream)
 {
-    TSL_REQUIRE(m && hip_stream, "input_stream: null argument"); TSL_HIP(hipSetDevice(m->device));
-    int si = 0; int rc = reserve_slot(m, points ? 1 : 0, &si); if (rc) return rc;
+    TSL_REQUIRE(m, "input_stream: null argument"); TSL_HIP(hipSetDevice(m->device));
+    int si = 0; int rc = reserve_slot(m, points ? 1 : 0, &si); if (rc) return rc;        // may issue the queued frames first
     hipStream_t consumer = m->overlap == 0 ? m->stream_ : m->batch[si / TSL_NB].st;
-    *hip_stream = (void*)consumer;
+    if (hip_stream) *hip_stream = (void*)consumer;
+    // The ordering is established when the batch is ISSUED (launch_batch_t): one event per distinct producer stream and batch instead
+    // of one per frame.  An event recorded later on the producer's stream also covers the work that was queued there before this call.
     if (ordered && (hipStream_t)producer != consumer) {
-        if (!m->in_ev[0]) for (auto& e : m->in_ev) TSL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        hipEvent_t e = m->in_ev[m->in_ev_next]; m->in_ev_next = (m->in_ev_next + 1) % 8;
-        TSL_HIP(hipEventRecord(e, (hipStream_t)producer));
-        TSL_HIP(hipStreamWaitEvent(consumer, e, 0));
+        bool seen = false;
+        for (int k = 0; k < m->nproducers; ++k) seen = seen || m->producers[k] == (hipStream_t)producer;
+        if (!seen) {
+            if (m->nproducers == 4) { rc = flush_pending(m); if (rc) return rc; }          // a fifth stream inside one batch: issue what is queued
+            m->producers[m->nproducers++] = (hipStream_t)producer;
+        }
     }
     return TSL_OK;
+}
+
+/* one call per frame for callers that hand over device buffers filled on a stream of their own: tsl_tsdf_input_stream(ordered) +
+ * tsl_tsdf_integrate_depth_dev + tsl_tsdf_frames_consumed */
+int tsl_tsdf_integrate_depth_stream(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
+                                    const void* tex_dev, int th, int tw, void* producer, int64_t* queued_total, int64_t* consumed)
+{
+    int rc = tsl_tsdf_input_stream(m, 0, 1, producer, nullptr); if (rc) return rc;
+    rc = tsl_tsdf_integrate_depth_dev(m, R, T, depth_dev, h, w, tex_dev, th, tw); if (rc) return rc;
+    return tsl_tsdf_frames_consumed(m, queued_total, consumed);
 }
 
 /* frames queued but not yet issued to the device (0 right after a batch went out) */
@@ -1386,6 +1426,10 @@ int tsl_tsdf_prof_enable(tsl_tsdf* m, int on)
     TSL_REQUIRE(m, "null");
     m->prof_on = on != 0;
     m->prof_mask = (on == 0 || on == 1) ? ~0u : (unsigned)on >> 1;      // on = 1: every kernel; on = 2*mask: only the kernel ids in mask
+    if (on) {   // a pool of timing events up front: creating them inside the measured region would cost what is being measured
+        TSL_HIP(hipSetDevice(m->device));
+        while (m->prof_free.size() < 256) { hipEvent_t e; TSL_HIP(hipEventCreate(&e)); m->prof_free.push_back(e); }
+    }
     return TSL_OK;
 }
 int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launches)
@@ -1430,6 +1474,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
+    if (!std::strcmp(name, "adaptive")) { m->adaptive = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 200, "bgrid must be 10..200 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)

@@ -131,8 +131,8 @@ struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 
 // Frames are queued and processed TSL_NB at a time: phase A of a whole batch runs as one sequence of launches (grid.y = frame)
 // on the batch's stream while phase B of the previous batch runs on the main stream; two batches are in flight.
-#define TSL_NB 4
-#define TSL_NBATCH 4          // batch slots: phase A of up to three batches is in flight beside phase B of a fourth
+#define TSL_NB 8
+#define TSL_NBATCH 3          // batch slots: phase A of up to two batches is in flight beside phase B of a third
 #define TSL_NSTREAMS 3        // phase-A streams shared by the batch slots (the device runs main + 3 queues efficiently)
 #define TSL_NSETS (TSL_NB * TSL_NBATCH)
 struct FSet {
@@ -144,6 +144,7 @@ struct FSet {
 // kernel argument of the batched phase-A kernels: the working sets and (device) parameter blocks of the frames of one batch
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
 struct ParamPack { FrameParams p[TSL_NB]; };
+struct SetPtrs { FrameParams* p[TSL_NB]; int* header[TSL_NB]; };        // k_set_params: where the parameters go, the headers to clear
 struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending, a_recorded; };
 #define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
@@ -163,6 +164,7 @@ struct tsl_tsdf {
     int64_t frames_issued, frames_consumed;  // frames handed to the device so far / of those, frames whose inputs have been read
     int64_t batch_seq; hipEvent_t ring_ev[TSL_INFLIGHT]; int64_t ring_upto[TSL_INFLIGHT];      // back-pressure ring: end of phase B of the last TSL_INFLIGHT batches
     int last_set;
+    hipStream_t producers[4]; int nproducers;   // producer streams of the queued device inputs (ordered before phase A when the batch is issued)
     hipEvent_t in_ev[8]; int in_ev_next;  // cached events ordering callers' producer streams before the input-reading stream (tsl_tsdf_input_stream)
     bool scratch_ready;                  // frame scratch allocated (first integrate call)
     int N, Nz, nbx, nbz, nb3, nsub, npose;
@@ -196,7 +198,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid; uint64_t batch_gen;
+    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid, adaptive, ramp; uint64_t batch_gen;
     int64_t bytes;
 };
 

@@ -24,6 +24,33 @@ def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_TORCH = None
+
+
+def _torch():
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        _TORCH = torch
+    return _TORCH
+
+
+def _DEPTH_DTYPES(torch, _cache=[]):
+    if not _cache:
+        _cache.append((torch.int16, getattr(torch, "uint16", torch.int16)))
+    return _cache[0]
+
+
+def _f64(a, n):
+    """`a` as a C-contiguous float64 array of n values; the array itself when it already is one (the common case)."""
+    if type(a) is np.ndarray and a.dtype == np.float64 and a.size == n and a.flags.c_contiguous:
+        return a
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
 class DenseTSDF(BaseMap):
     _prefix = "tsl_tsdf"
 
@@ -60,6 +87,8 @@ class DenseTSDF(BaseMap):
         self.device = device
         self._held, self._pending_inputs = [], None
         self._c_total, self._c_done, self._c_stream = C.c_int64(), C.c_int64(), C.c_void_p()
+        self._ref_total, self._ref_done = C.byref(self._c_total), C.byref(self._c_done)
+        self._integrate_depth_stream = self.L.tsl_tsdf_integrate_depth_stream
         self.mem_per_voxel = 2 + 2 + 1 + 1 + (6 if texture_enabled else 0)
 
         cfg = _lib.TsdfCfg(float(map_scale[0]), float(map_scale[1]), float(voxel_scale), int(num_voxel_per_blk_axis),
@@ -217,22 +246,31 @@ class DenseTSDF(BaseMap):
         self._call("integrate_points", r, t, _vp(xyz), _vp(rgb), int(xyz.shape[0]))
 
     def recast_depth_to_map(self, R, T, depthmap, texture=None):
-        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
         if _is_device_tensor(depthmap):
-            import torch
-            assert depthmap.dim() == 2 and depthmap.is_contiguous() and \
-                depthmap.dtype in (torch.int16, getattr(torch, "uint16", torch.int16)), \
+            # the per-frame path of a device-resident stream: ONE crossing into the library (input ordering against torch's current
+            # stream + queueing + the consumed-frames count), no numpy / ctypes temporaries for poses that already are float64 arrays
+            torch = _torch()
+            assert depthmap.dim() == 2 and depthmap.is_contiguous() and depthmap.dtype in _DEPTH_DTYPES(torch), \
                 "device depth must be a contiguous [h,w] uint16 tensor of millimetres (int16 = the same bits)"
-            ins, tex_ptr, th, tw = [depthmap], None, 0, 0
+            ins, tex_ptr, th, tw = (depthmap,), None, 0, 0
             if self.enable_texture and texture is not None and _is_device_tensor(texture):
                 assert texture.dtype == torch.uint8 and texture.is_contiguous() and texture.dim() == 3 and texture.shape[2] == 3
-                ins.append(texture)
-                tex_ptr, th, tw = C.c_void_p(texture.data_ptr()), int(texture.shape[0]), int(texture.shape[1])
-            self._adopt_device_inputs(0, *ins)
-            self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]),
-                       int(depthmap.shape[1]), tex_ptr, th, tw)
-            self._release_device_inputs()
+                ins = (depthmap, texture)
+                tex_ptr, th, tw = texture.data_ptr(), int(texture.shape[0]), int(texture.shape[1])
+            Ra, Ta = _f64(R, 9), _f64(T, 3)
+            total, done = self._c_total, self._c_done                         # preallocated: no per-frame garbage for the cyclic GC
+            shape = depthmap.shape
+            _lib.check(self._integrate_depth_stream(self.h, Ra.ctypes.data, Ta.ctypes.data, depthmap.data_ptr(), shape[0], shape[1],
+                                                    tex_ptr, th, tw, torch.cuda.current_stream(depthmap.device).cuda_stream,
+                                                    self._ref_total, self._ref_done))
+            # keep the tensors referenced until the device has read them (see _adopt_device_inputs)
+            held = self._held
+            held.append((total.value - 1, ins))
+            d = done.value
+            while held and held[0][0] < d:
+                held.pop(0)
             return
+        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
         depth = np.ascontiguousarray(np.asarray(depthmap, dtype=np.uint16))
         if depth.ndim != 2:
             raise ValueError("depthmap must be a 2-d uint16 array")
