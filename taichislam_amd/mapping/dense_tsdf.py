@@ -185,11 +185,11 @@ class DenseTSDF(BaseMap):
     # ---- integration (dense_tsdf.py:157-165) -----------------------------------------------------------------
     def _adopt_device_inputs(self, points, *tensors):
         """The reference's recast_* calls are synchronous; here a frame is only queued and its kernels are enqueued later (when
-        its batch of four is full, or when anything else needs the map) on the library's own streams.  For torch tensors the
+        its batch is full, or when anything else needs the map) on the library's own streams.  For torch tensors the
         shim therefore (1) has the stream that will read the frame wait for the work already queued on torch's current
         stream (the tensor may still be being produced; tsl_tsdf_input_stream) and (2) keeps the tensors referenced until the
         device has read them (tsl_tsdf_frames_consumed; the library never lets the host run more than eight batches ahead,
-        so at most ~36 frames are held), so a tensor the caller drops right after the call is not recycled by torch's
+        so at most ~72 frames are held), so a tensor the caller drops right after the call is not recycled by torch's
         caching allocator under a queued frame.  No torch stream / event queries: they cost ~100 us each while the GPU is busy."""
         import torch
         cur = torch.cuda.current_stream(tensors[0].device)
