@@ -24,6 +24,7 @@
 //                               workgroups add their partial sums to an HBM slab; the last workgroup to arrive (ticket)
 //                               finalises from there.
 #include "tsl_tsdf.hpp"
+#include <hip/hip_ext.h>
 
 namespace tsl {
 
@@ -1090,11 +1091,13 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
 }
 
 // phase B of a batch on the main stream: one launch of the brick kernel (variant 2), or per frame the global-atomics kernels (variants 0/1)
-int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P)
+int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start, hipEvent_t stop)
 {
-    // resident workgroups: two 256-thread ones per CU (74 KiB of LDS each; textured 90 KiB: one), or one 512-thread one
-#define TSL_LAUNCH_IB(TEXV, FD) do { if (m->wg == 512) hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3((m->ncu * m->bgrid + 99) / 100), dim3(512), 0, m->stream_, m->M, B); \
-                                     else hipLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3(((TEXV ? 1 : 2) * m->ncu * m->bgrid + 99) / 100), dim3(256), 0, m->stream_, m->M, B); } while (0)
+    // resident workgroups: one 512-thread one per CU (82 KiB of LDS, textured 98 KiB), or two 256-thread ones (74 KiB each; textured 90 KiB: one).
+    // With start / stop events the launch goes through hipExtLaunchKernelGGL, which records them in the dispatch itself.
+#define TSL_LAUNCH_IB(TEXV, FD) do { \
+        if (m->wg == 512) hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3((m->ncu * m->bgrid + 99) / 100), dim3(512), 0, m->stream_, start, stop, 0, m->M, B); \
+        else hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3(((TEXV ? 1 : 2) * m->ncu * m->bgrid + 99) / 100), dim3(256), 0, m->stream_, start, stop, 0, m->M, B); } while (0)
     if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
     else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }
 #undef TSL_LAUNCH_IB

@@ -198,7 +198,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid, adaptive, ramp; uint64_t batch_gen;
+    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid, adaptive, ramp; bool clean; uint64_t batch_gen;
     int64_t bytes;
 };
 
@@ -208,10 +208,11 @@ hipStream_t ms(tsl_tsdf* m);                                                 // 
 int  flush_pending(tsl_tsdf* m);
 void prof_begin(tsl_tsdf* m, int kid, hipStream_t st = nullptr, int count = 1);
 void prof_end(tsl_tsdf* m, hipStream_t st = nullptr);
+bool prof_slot(tsl_tsdf* m, int kid, int count, hipEvent_t* a, hipEvent_t* b);
 void convert_pose(const double* Rb, const double* Tb, const double* R, const double* T, float* outR, float* outT);
 int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B, variants 0/1: apply one frame to the map
-int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // phase B, variant 2: apply a batch of frames (one launch)
+int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);      // phase B, variant 2: apply a batch of frames (one launch)
 }
