@@ -201,11 +201,13 @@ int  tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, flo
 typedef struct {
     int32_t incremental;         /* 0: all bricks were recomputed */
     int32_t dirty_bricks;        /* bricks written since the previous update */
+    int32_t changed_bricks;      /* ... of which the ESDF inputs (observed / sign / band membership / band value of a voxel) changed */
     int32_t region_bricks;       /* bricks re-initialised and relaxed (dirty bricks dilated by max_dist) */
     int32_t total_bricks;        /* bricks of the handle */
     int64_t brick_relaxations;   /* LDS relaxations run (a brick is revisited when its surroundings change) */
     int64_t voxel_pushes;        /* active voxels expanded */
     int32_t rounds, max_passes;  /* relaxation rounds that had work; most LDS passes one brick relaxation needed */
+    int32_t reserved_;
     int64_t passes;              /* LDS passes over all brick relaxations */
 } tsl_esdf_stats;
 /* sums over the updates of the handle that have completed */

@@ -74,13 +74,49 @@ __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s
     if (p == 0) E.ctr[10] = nused;
 }
 
-// 2. region = dirty bricks dilated by r bricks (existing bricks of the submap only)
-__global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s, int r)
+// class flags and band value of a voxel from its TSDF (what the relaxation depends on)
+__device__ __forceinline__ void esdf_inputs(uint32_t obs_byte, uint32_t tw, float gamma, float max_dist, uint32_t* f, float* mg)
+{
+    *f = 0u; *mg = max_dist;
+    if ((int8_t)obs_byte > 0) {
+        const float t = h2f((h16)(tw & 0xffffu));
+        *f = EF_NODE | (t < 0.0f ? EF_NEG : 0);
+        if (fabsf(t) < gamma) { *f |= EF_FIXED; *mg = fabsf(t); }
+    }
+}
+
+// 2. region = the bricks whose ESDF INPUTS changed, dilated by r bricks (existing bricks of the submap only).  A brick an integrate
+//    kernel wrote to is only a candidate: most of what a frame touches is free space between the sensor and the surface, where the
+//    TSDF value changes but neither the class (observed, sign, band membership) nor a band value does -- such a brick cannot change
+//    any distance.  The stored flags / band values are those of the brick's last (re)initialisation.
+__global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s, int r, int all, float gamma, float max_dist)
 {
     const int nd = E.ctr[0];
     const int side = 2 * r + 1, vol = side * side * side;
     for (int d = blockIdx.x; d < nd; d += gridDim.x) {
-        const int b = M.owner[E.dirty[d]] - s * M.nb3;
+        const int pd = E.dirty[d];
+        if (!all) {
+            const size_t v = (size_t)pd * TSL_BRK3 + (size_t)threadIdx.x * 16;
+            const uint4 ob = *reinterpret_cast<const uint4*>(M.obs + v);
+            const uint4 fo = *reinterpret_cast<const uint4*>(E.fl + v);
+            uint4 tw[4], mo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tw[q] = reinterpret_cast<const uint4*>(M.tw + v)[q]; mo[q] = reinterpret_cast<const uint4*>(E.mag + v)[q]; }
+            const uint32_t ow[4] = { ob.x, ob.y, ob.z, ob.w }, fw[4] = { fo.x, fo.y, fo.z, fo.w };
+            const uint32_t tv[16] = { tw[0].x, tw[0].y, tw[0].z, tw[0].w, tw[1].x, tw[1].y, tw[1].z, tw[1].w, tw[2].x, tw[2].y, tw[2].z, tw[2].w, tw[3].x, tw[3].y, tw[3].z, tw[3].w };
+            const uint32_t mv[16] = { mo[0].x, mo[0].y, mo[0].z, mo[0].w, mo[1].x, mo[1].y, mo[1].z, mo[1].w, mo[2].x, mo[2].y, mo[2].z, mo[2].w, mo[3].x, mo[3].y, mo[3].z, mo[3].w };
+            bool changed = false;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) {
+                uint32_t f; float mg;
+                esdf_inputs((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu, tv[z], gamma, max_dist, &f, &mg);
+                const uint32_t fs = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
+                changed = changed || f != fs || ((f & EF_FIXED) && __float_as_uint(mg) != mv[z]);
+            }
+            if (!__syncthreads_or(changed)) continue;                 // (uniform: every thread of the workgroup leaves or stays)
+        }
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&E.ctr[11], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int b = M.owner[pd] - s * M.nb3;
         const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
         for (int t = threadIdx.x; t < vol; t += 256) {
             const int i = bi + t / (side * side) - r, j = bj + (t / side) % side - r, k = bk + t % side - r;
@@ -108,12 +144,8 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float ga
             uint32_t fo[4] = { 0u, 0u, 0u, 0u }; float mo[16];
 #pragma unroll
             for (int z = 0; z < 16; ++z) {
-                uint32_t f = 0u; float mg = max_dist;
-                if ((int8_t)((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu) > 0) {
-                    const float t = h2f((h16)(tv[z] & 0xffffu));
-                    f = EF_NODE | (t < 0.0f ? EF_NEG : 0);
-                    if (fabsf(t) < gamma) { f |= EF_FIXED; mg = fabsf(t); }
-                }
+                uint32_t f; float mg;
+                esdf_inputs((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu, tv[z], gamma, max_dist, &f, &mg);
                 fo[z >> 2] |= f << ((z & 3) * 8); mo[z] = mg;
             }
             *reinterpret_cast<uint4*>(E.fl + v) = make_uint4(fo[0], fo[1], fo[2], fo[3]);
@@ -439,7 +471,7 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         if (wait_all) (void)hipEventSynchronize(S.ev);
         const int* h = S.host;
         tsl_esdf_stats st = S.st;
-        st.dirty_bricks = h[0]; st.region_bricks = h[1]; st.brick_relaxations = h[5]; st.voxel_pushes = h[6];
+        st.dirty_bricks = h[0]; st.changed_bricks = h[11]; st.region_bricks = h[1]; st.brick_relaxations = h[5]; st.voxel_pushes = h[6];
         st.rounds = h[7]; st.passes = h[8]; st.max_passes = h[9]; st.total_bricks = h[10];
         if (h[2 + S.rounds % 3] != 0) m->esdf_short = true;                  // the last launched round still had work
         if (st.incremental && st.rounds > m->esdf_rounds_seen) m->esdf_rounds_seen = st.rounds;
@@ -493,7 +525,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     m->prof_group = true;
     const int nbk = (nb + 255) / 256;
     hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0);
-    hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach);
+    hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
     hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, gamma, max_dist);
     // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
     // few more (8 rounds had work at reach = 4 on the benchmark stream).

@@ -67,7 +67,8 @@ def test_incremental_update_equals_full_recompute_after_every_frame(hip_lib):
         o.integrate_depth(R, T, d, mode=BATCHED)
         si, sf = inc.esdf_stats(), full.esdf_stats()
         assert sf["incremental"] == 0 and sf["region_bricks"] == sf["total_bricks"]
-        assert si["incremental"] == (1 if f else 0) and 0 < si["dirty_bricks"] <= si["region_bricks"] <= si["total_bricks"] == sf["total_bricks"]
+        assert si["incremental"] == (1 if f else 0) and 0 < si["dirty_bricks"] and si["changed_bricks"] <= si["region_bricks"] <= si["total_bricks"] == sf["total_bricks"]
+        assert not f or 0 < si["changed_bricks"] <= si["dirty_bricks"]      # (a full update does not look at what changed)
         part.append(si["region_bricks"] / si["total_bricks"])
         (ii, ie), (fi, fe) = _esdf_sorted(inc), _esdf_sorted(full)
         assert np.array_equal(ii, fi) and np.array_equal(ie, fe), f"frame {f}: incremental != full at {(ie != fe).sum()} voxels"
@@ -100,7 +101,7 @@ def test_incremental_update_at_benchmark_size(hip_lib):
     (ii, ie), (fi, fe) = _esdf_sorted(inc), _esdf_sorted(full)
     assert ii.shape[0] > 1_000_000 and np.array_equal(ii, fi) and np.array_equal(ie, fe)
     si, sf = inc.esdf_stats(), full.esdf_stats()
-    assert si["incremental"] == 1 and si["dirty_bricks"] <= si["region_bricks"] <= sf["region_bricks"] == sf["total_bricks"]
+    assert si["incremental"] == 1 and si["changed_bricks"] <= si["region_bricks"] <= sf["region_bricks"] == sf["total_bricks"]
     assert si["brick_relaxations"] <= sf["brick_relaxations"] * 1.05          # (work counters depend on the order in which lanes meet: not exactly reproducible)
 
 
