@@ -285,8 +285,9 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
         for (;;) {
             bool act = false;
             constexpr int PER = (ESDF_T3 + 255) / 256;
-            // several scan + push sweeps per barrier: LDS atomics are visible to the other waves at once, the barrier is only needed to
-            // agree that nothing is active any more, so every wave follows the front at its own pace in between
+            // ESDF_SWEEPS scan + push sweeps per barrier (LDS atomics are visible to the other waves at once, the barrier is only needed to
+            // agree that nothing is active any more).  One is the default: with two or four the front loses its order, voxels are
+            // pushed 6 - 13 % more often and the update gets slower (0.84 / 1.06 ms against 0.80)
 #pragma unroll 1
             for (int sweep = 0; sweep < ESDF_SWEEPS; ++sweep) {
             uint32_t mine = 0u;                                    // bit q: my q-th entry is active
