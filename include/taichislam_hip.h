@@ -229,6 +229,7 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame
                 integrated on arrival; full batches form by themselves when the producer outruns the device), 0 (default) = a batch is
                 issued when it is full -- half full for the first two batches after the pipeline ran dry -- or when anything reads the map
+     "ramp"     half batches issued after the pipeline ran dry before full ones are waited for (default 2)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
      "wg"       threads per workgroup of the brick integrate kernel: 512 (default; steps of 2048 segments, one workgroup per CU, 187 VGPRs:

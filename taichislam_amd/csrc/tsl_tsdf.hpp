@@ -198,7 +198,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid, adaptive, ramp; bool clean; uint64_t batch_gen;
+    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid, adaptive, ramp, ramp_batches; bool clean; uint64_t batch_gen;
     int64_t bytes;
 };
 
