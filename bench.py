@@ -307,7 +307,7 @@ def main():
         bytes_b = 9 * stats["unique"] + stats["v_pcl"]
         roof = None
         if "integrate" in kern:
-            # one launch of the brick kernel integrates a whole batch of queued frames (up to 4): algorithmic bytes per launch =
+            # one launch of the brick kernel integrates a whole batch of queued frames (up to 8): algorithmic bytes per launch =
             # 9 B per distinct voxel a frame updates (4 B read + 4 B + 1 B written) x the frames the launch covers
             fpl = args.steps / max(1, kern["integrate"]["launches"])
             alg = 9 * stats["unique"] * fpl
@@ -334,7 +334,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 + int64 fixed-point arithmetic",
             "data": "synthetic",
             "config": {"workload": WORKLOAD, "frame_stats": stats, "kernels_us": kern,
-                       "kernels_us_note": "every kernel is launched once per batch of up to 4 queued frames",
+                       "kernels_us_note": "every kernel is launched once per batch of up to 8 queued frames",
                        "updates_per_s": stats["steps"] * fps, "per_rank_frames_per_s": per_rank, "merge": merge},
             "roofline": roof,
             "value_host_input": host_rates,
