@@ -92,6 +92,28 @@ def test_full_size_c2_bit_exact(hip_lib):
     assert_export_equal(g.export_submap(), o.export_sparse(), "C2")
 
 
+def test_full_size_full_batches_bit_exact(hip_lib):
+    """The benchmark configuration with nothing read between the frames: 20 frames go out as [8][8][4] (ramp 0) and as [4][4][8][4]
+    (default) -- a full batch walks units over eight frames and merges the bricks next to the sensor through eight slab slots applied
+    in frame order by the last arriver.  Both must equal the oracle bit for bit, frame counters included."""
+    from oracle import BATCHED
+    from taichislam_amd.mapping import DenseTSDF
+    frames = list(syn.sphere_room_stream(20))
+    g, o = make_pair(C2, syn.K_DEPTH)
+    g.set_option("ramp", 0)
+    h = DenseTSDF(**C2); h.set_dep_camera_intrinsic(syn.K_DEPTH)
+    so = None
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+        h.recast_depth_to_map(R, T, d, None)
+        so = o.integrate_depth(R, T, d, mode=BATCHED)
+    want = o.export_sparse()
+    for m, what in ((g, "[8][8][4]"), (h, "[4][4][8][4]")):
+        sg = m.last_frame_stats()
+        assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}, what
+        assert_export_equal(m.export_submap(), want, f"C2, 20 frames as {what}")
+
+
 def test_full_size_properties(hip_lib):
     """Size-independent properties at the benchmark size: determinism across runs and variants, export/import
     round trip, count == export length, W monotone and clamped."""
