@@ -44,6 +44,22 @@ def test_depth_with_texture(hip_lib, same_proj):
     assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
 
 
+@pytest.mark.parametrize("unit,ramp", [(64, 0), (64, 2), (0, 0)])
+def test_textured_batches_through_units_and_parts(hip_lib, unit, ramp):
+    """Ten textured frames with nothing read in between: one full batch of eight + a rest (ramp 0) or half batches first.  With the
+    unit limit forced down, every brick with more than 64 segments is split into parts: the colour winners then travel through the
+    per-(frame, brick) slots of the merge slab and are applied in frame order by the last arriver; unit 0 sends everything there."""
+    from oracle import BATCHED
+    K, frames = small_stream(10)
+    g, o = make_pair(TEX, K)
+    g.set_option("unit", unit); g.set_option("ramp", ramp)
+    for f, (R, T, d) in enumerate(frames):
+        tex = _texture(d.shape[0], d.shape[1], f)
+        g.recast_depth_to_map(R, T, d, tex)
+        o.integrate_depth(R, T, d, tex, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"textured batches, unit {unit}, ramp {ramp}")
+
+
 @pytest.mark.parametrize("group", [0, 1])
 def test_points_with_colour(hip_lib, group):
     from oracle import BATCHED

@@ -55,6 +55,21 @@ def test_integrate_workgroup_and_part_sizes(hip_lib, wg, chunks):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} chunks {chunks}")
 
 
+@pytest.mark.parametrize("wg,unit,ramp", [(512, 0, 0), (256, 0, 0), (512, 200, 2), (256, 1 << 20, 0)])
+def test_units_and_parts_over_full_batches(hip_lib, wg, unit, ramp):
+    """Eleven frames with nothing read in between (a full batch of eight + three, or half batches first): with the unit limit at 0
+    every brick is split into parts and merged through the per-(frame, brick) slab slots, with a huge limit every brick is a unit
+    walked by one workgroup over all frames of the batch; any mix in between must give the same map."""
+    from oracle import BATCHED
+    K, frames = small_stream(11)
+    g, o = make_pair(SMALL, K)
+    g.set_option("wg", wg); g.set_option("unit", unit); g.set_option("ramp", ramp)
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+        o.integrate_depth(R, T, d, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} unit {unit} ramp {ramp}")
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_arithmetic_shortcuts_hold_for_every_float(hip_lib, which):
     """The kernels round half away from zero with add+truncate and take square roots without the library's rescaling;
