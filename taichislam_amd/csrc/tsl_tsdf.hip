@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_group_scan(BatchDev B)
     __shared__ int s_base;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int nact = F.counters[6];
-    if (blockIdx.x * 256 >= nact) return;
+    if ((int)blockIdx.x * 256 >= nact) return;
     const int sl = i < nact ? F.act[i] : 0;
     const int c = i < nact ? F.hcnt[sl] : 0;
     int inc = c;
