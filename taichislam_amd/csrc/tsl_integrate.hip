@@ -238,7 +238,7 @@ __device__ __forceinline__ int axis_cell(int c, int h, int N, int nb) { const in
 // Smallest step e in (j, jb] at which the ray's cell along one axis differs from `cell` (the cell at step j), or jb+1.
 // The coordinate is a monotone function of the step (every operation in axis_coord is monotone), so the event is
 // located from a real-arithmetic estimate and then fixed up with exact evaluations -- typically two.
-__device__ __forceinline__ int next_axis_event(float d, float T, const FrameParams& P, float t_over_vs, int j, int jb, int cell, int h, int N, int nb)
+__device__ __forceinline__ int next_axis_event(float d, float inv_d, float T, const FrameParams& P, float t_over_vs, int j, int jb, int cell, int h, int N, int nb)
 {
     if (j >= jb) return jb + 1;
     int bound;                       // first coordinate that belongs to the next cell in the direction of travel
@@ -246,7 +246,7 @@ __device__ __forceinline__ int next_axis_event(float d, float T, const FramePara
     if (d > 0.0f) { if (cell >= nb) return jb + 1; up = true; bound = (cell < 0 ? 0 : min((cell + 1) * 16, N)) - h; }
     else if (d < 0.0f) { if (cell < 0) return jb + 1; up = false; bound = (cell >= nb ? N - 1 : cell * 16 - 1) - h; }
     else return jb + 1;
-    const float est = ((float)bound + (up ? -0.5f : 0.5f) - t_over_vs) / d;      // real-valued crossing step
+    const float est = ((float)bound + (up ? -0.5f : 0.5f) - t_over_vs) * inv_d;  // real-valued crossing step; only an estimate (inv_d ~ 1/d): the exact evaluations below decide
     int e = (int)fminf(fmaxf(ceilf(est), (float)(j + 1)), (float)jb);
     #define TSL_PRED(q) (up ? (axis_coord(d, T, P, (q)) >= bound) : (axis_coord(d, T, P, (q)) <= bound))
     if (TSL_PRED(e)) { while (e - 1 > j && TSL_PRED(e - 1)) --e; }
@@ -374,6 +374,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
         const int len = (R.n + split - 1) / split;
         const int ja = 1 + sub * len, jb = min(R.n, ja + len - 1);
         const float d[3] = { R.d0, R.d1, R.d2 };
+        const float id[3] = { __builtin_amdgcn_rcpf(R.d0), __builtin_amdgcn_rcpf(R.d1), __builtin_amdgcn_rcpf(R.d2) };
         const float tv[3] = { P.T[0] / P.vs, P.T[1] / P.vs, P.T[2] / P.vs };
         const int hh[3] = { M.hN, M.hN, M.hNz }, NN[3] = { M.N, M.N, M.Nz }, nb[3] = { M.nbx, M.nbx, M.nbz };
         if (ja <= jb) {
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 cell[a] = axis_cell(axis_coord(d[a], P.T[a], P, ja), hh[a], NN[a], nb[a]);
-                ev[a] = next_axis_event(d[a], P.T[a], P, tv[a], ja, jb, cell[a], hh[a], NN[a], nb[a]);
+                ev[a] = next_axis_event(d[a], id[a], P.T[a], P, tv[a], ja, jb, cell[a], hh[a], NN[a], nb[a]);
             }
             int j = ja;
             while (j <= jb) {
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 #pragma unroll
                 for (int a = 0; a < 3; ++a) if (ev[a] == j) {
                     cell[a] = axis_cell(axis_coord(d[a], P.T[a], P, j), hh[a], NN[a], nb[a]);
-                    ev[a] = next_axis_event(d[a], P.T[a], P, tv[a], j, jb, cell[a], hh[a], NN[a], nb[a]);
+                    ev[a] = next_axis_event(d[a], id[a], P.T[a], P, tv[a], j, jb, cell[a], hh[a], NN[a], nb[a]);
                 }
             }
         }
@@ -650,12 +651,15 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 #define IT_WORDS (IT_N + TSL_NB + 2)
 #define NRANGE (PLAN_NCLS * (TSL_NB + 1))
 
-template <bool TEX, bool FASTDIV, int NT>
-__global__ void __launch_bounds__(NT, (TEX && NT == 256) ? 1 : 2) k_integrate_batch(MapDev M, BatchDev B)
+template <bool TEX, bool FASTDIV, int NT, int SPT, int WPE>
+__global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev B)
 {
-    // NT threads walk a step of up to CSEGS = 4 * NT segments (4 per thread).  NT = 256: two workgroups per CU; NT = 512: one (8 waves
-    // on one brick: half the walk latency per brick, half as many bricks in flight).
-    constexpr int CSEGS = 4 * NT, SPT = 4, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
+    // NT threads walk a step of up to CSEGS = SPT * NT segments (SPT per thread), WPE = waves per SIMD the register budget allows.
+    //   NT 256, SPT 4, WPE 2: two workgroups per CU (74 KiB of LDS each), 8 waves per CU;
+    //   NT 512, SPT 4, WPE 2: one workgroup per CU (82 KiB), 8 waves on one brick: half the walk latency per brick, half as many bricks in flight;
+    //   NT 512, SPT 2, WPE 4: steps of 1024 segments, 74 KiB of LDS and at most 128 VGPRs: TWO 512-thread workgroups per CU = 16 waves per CU,
+    //                         a workgroup's barriers and LDS round trips are covered by the other's walk.
+    constexpr int CSEGS = SPT * NT, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
     static_assert(VPT <= 16, "the written / first-touch masks hold 16 voxels per thread");
     __shared__ unsigned long long s_num[TSL_BRK3];              // 32 KiB
     __shared__ unsigned long long s_den[TSL_BRK3];              // 32 KiB
@@ -1084,7 +1088,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     // a unit is walked by one workgroup frame after frame, and with few frames a long unit is just a long serial item
     const int unit_max = m->unit_max <= 4096 ? m->unit_max : std::max(4096, (int)((long long)m->unit_max * B.n / TSL_NB));
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * (m->wg == 512 ? 2048 : 1024), unit_max, (unsigned long long)++m->batch_gen, m->cur);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max, (unsigned long long)++m->batch_gen, m->cur);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;
@@ -1096,8 +1100,9 @@ int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hip
     // resident workgroups: one 512-thread one per CU (82 KiB of LDS, textured 98 KiB), or two 256-thread ones (74 KiB each; textured 90 KiB: one).
     // With start / stop events the launch goes through hipExtLaunchKernelGGL, which records them in the dispatch itself.
 #define TSL_LAUNCH_IB(TEXV, FD) do { \
-        if (m->wg == 512) hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512>), dim3((m->ncu * m->bgrid + 99) / 100), dim3(512), 0, m->stream_, start, stop, 0, m->M, B); \
-        else hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256>), dim3(((TEXV ? 1 : 2) * m->ncu * m->bgrid + 99) / 100), dim3(256), 0, m->stream_, start, stop, 0, m->M, B); } while (0)
+        if (m->wg == 512 && m->spt == 2 && !TEXV) hipExtLaunchKernelGGL((k_integrate_batch<false, FD, 512, 2, 4>), dim3((2 * m->ncu * m->bgrid + 99) / 100), dim3(512), 0, m->stream_, start, stop, 0, m->M, B); \
+        else if (m->wg == 512) hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512, 4, 2>), dim3((m->ncu * m->bgrid + 99) / 100), dim3(512), 0, m->stream_, start, stop, 0, m->M, B); \
+        else hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256, 4, (TEXV ? 1 : 2)>), dim3(((TEXV ? 1 : 2) * m->ncu * m->bgrid + 99) / 100), dim3(256), 0, m->stream_, start, stop, 0, m->M, B); } while (0)
     if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
     else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }
 #undef TSL_LAUNCH_IB

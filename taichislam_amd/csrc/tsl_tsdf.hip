@@ -56,7 +56,7 @@ template <> struct KeyOps<uint64_t> {
 // ------------------------------------------------------------------------------------------------------
 // K1: depth image -> sensor-centred voxel key + f16 payload       dense_tsdf.py:188-213, process_point :227-229
 // ------------------------------------------------------------------------------------------------------
-template <typename K> __device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first);
+template <typename K> __device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first, int log2n);
 
 template <typename K>
 __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
             }
         }
         F.pix[p] = payload;
-        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened); F.slot_of_pix[p] = slot; }
+        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened, P.hlog2); F.slot_of_pix[p] = slot; }
         else { keys[p] = key; F.vals[p] = (uint32_t)p; }
     }
     if (P.group) { const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot; }
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) k_voxelize_points(BatchDev B)
             }
         }
         F.pix[p] = payload;
-        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened); F.slot_of_pix[p] = slot; }
+        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened, P.hlog2); F.slot_of_pix[p] = slot; }
         else { keys[p] = key; F.vals[p] = (uint32_t)p; }
     }
     if (P.group) { const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot; }
@@ -196,11 +196,11 @@ template <typename K> __device__ __forceinline__ uint32_t h_hash(K key, int log2
 
 // insert pixel p's sensor voxel; returns the table slot.  *first = this pixel opened the voxel in this frame
 template <typename K>
-__device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first)
+__device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first, int log2n)
 {
     K* tab = reinterpret_cast<K*>(F.hkey);
-    const uint32_t mask = (1u << F.hlog2) - 1u;
-    uint32_t h = h_hash<K>(key, F.hlog2);
+    const uint32_t mask = (1u << log2n) - 1u;
+    uint32_t h = h_hash<K>(key, log2n);
     for (;;) {
         const K cur = atomicCAS(&tab[h], h_empty<K>(), key);
         if (cur == h_empty<K>() || cur == key) break;
@@ -837,6 +837,10 @@ static int queue_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, 
     { int rc = ensure_frame_scratch(m); if (rc) return rc; }
     if (P.variant == 2) { int rc = check_variant2(m); if (rc) return rc; }
     P.input = xyz_dev ? xyz_dev : depth_dev; P.total = total; P.points = xyz_dev ? 1 : 0;
+    {   // the table is empty between frames, so every frame may use its own power-of-two part of it
+        int lg = 10; while ((1ll << lg) < 2 * (long long)total) ++lg;
+        P.hlog2 = lg < m->fset[0].F.hlog2 ? lg : m->fset[0].F.hlog2;
+    }
     TSL_REQUIRE(!P.tex || P.variant == 2, "texture integration needs the brick-binned path (variant 2)");
     const int cap = batch_cap(m);
     { int si = 0; int rc = reserve_slot(m, P.points, &si); if (rc) return rc; }
@@ -965,7 +969,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 100; m->chunks = 2; m->unit_max = 3072 * TSL_NB; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 4; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 100; m->chunks = 2; m->unit_max = 3072 * TSL_NB; m->batch_gen = 0;
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -1500,6 +1504,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "adaptive")) { m->adaptive = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "ramp")) { TSL_REQUIRE(value >= 0 && value <= 16, "ramp must be 0..16 half batches"); m->ramp_batches = value; return TSL_OK; }
     if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 200, "bgrid must be 10..200 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
+    if (!std::strcmp(name, "spt")) { TSL_REQUIRE(value == 2 || value == 4, "spt must be 2 or 4"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->spt = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }
     if (!std::strcmp(name, "phases")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->phases = value & 3; return TSL_OK; }      // developer timing aid: 1 = phase A only, 2 = phase B only (map contents are then meaningless)
     if (!std::strcmp(name, "overlap")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->overlap = value < 0 ? 0 : (value > TSL_NB ? TSL_NB : value); for (auto& H : m->batch) H.b_pending = false; return TSL_OK; }

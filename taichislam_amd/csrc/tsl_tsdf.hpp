@@ -21,6 +21,7 @@ struct FrameParams {
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
     int   group;                       // 1: group pixels per sensor voxel through a hash table, 0: stable radix sort (rocPRIM)
+    int   hlog2;                       // log2 of the part of the set's hash table this frame uses (>= 2 slots per visited pixel: the table stays cache-resident)
     const void* input; int total;      // device pointer of the depth image / point array of this frame, pixels or points to visit
     const uint8_t* tex_input; int points;   // texture [th][tw][3] (depth input) or rgb [n][3] (point input); input kind
 };
@@ -198,7 +199,7 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
-    int variant, split, phases, wg, ncu, chunks, unit_max, bgrid, adaptive, ramp, ramp_batches; bool clean; uint64_t batch_gen;
+    int variant, split, phases, wg, spt, ncu, chunks, unit_max, bgrid, adaptive, ramp, ramp_batches; bool clean; uint64_t batch_gen;
     int64_t bytes;
 };
 

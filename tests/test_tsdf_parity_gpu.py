@@ -43,31 +43,32 @@ def test_kernel_variants_agree(hip_lib, variant, split):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"variant {variant} split {split}")
 
 
-@pytest.mark.parametrize("wg,chunks", [(256, 1), (256, 2), (256, 8), (512, 1), (512, 3)])
-def test_integrate_workgroup_and_part_sizes(hip_lib, wg, chunks):
+@pytest.mark.parametrize("wg,spt,chunks", [(256, 4, 1), (256, 4, 2), (256, 4, 8), (512, 4, 1), (512, 4, 3), (512, 2, 1), (512, 2, 2), (512, 2, 5)])
+def test_integrate_workgroup_and_part_sizes(hip_lib, wg, spt, chunks):
     """The brick kernel's geometry (threads per workgroup, chunks per part: which bricks are split over workgroups and merged through
     HBM) must not show in the result."""
     K, frames = small_stream(2)
     g, o = make_pair(SMALL, K)
     g.set_option("wg", wg)
+    g.set_option("spt", spt)
     g.set_option("chunks", chunks)
     _run_both(g, o, frames)
-    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} chunks {chunks}")
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} chunks {chunks}")
 
 
-@pytest.mark.parametrize("wg,unit,ramp", [(512, 0, 0), (256, 0, 0), (512, 200, 2), (256, 1 << 20, 0)])
-def test_units_and_parts_over_full_batches(hip_lib, wg, unit, ramp):
+@pytest.mark.parametrize("wg,spt,unit,ramp", [(512, 4, 0, 0), (256, 4, 0, 0), (512, 4, 200, 2), (256, 4, 1 << 20, 0), (512, 2, 0, 0), (512, 2, 200, 2), (512, 2, 1 << 20, 0)])
+def test_units_and_parts_over_full_batches(hip_lib, wg, spt, unit, ramp):
     """Eleven frames with nothing read in between (a full batch of eight + three, or half batches first): with the unit limit at 0
     every brick is split into parts and merged through the per-(frame, brick) slab slots, with a huge limit every brick is a unit
     walked by one workgroup over all frames of the batch; any mix in between must give the same map."""
     from oracle import BATCHED
     K, frames = small_stream(11)
     g, o = make_pair(SMALL, K)
-    g.set_option("wg", wg); g.set_option("unit", unit); g.set_option("ramp", ramp)
+    g.set_option("wg", wg); g.set_option("spt", spt); g.set_option("unit", unit); g.set_option("ramp", ramp)
     for R, T, d in frames:
         g.recast_depth_to_map(R, T, d, None)
         o.integrate_depth(R, T, d, mode=BATCHED)
-    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} unit {unit} ramp {ramp}")
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} unit {unit} ramp {ramp}")
 
 
 @pytest.mark.parametrize("which", [0, 1])
