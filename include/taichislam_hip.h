@@ -143,6 +143,9 @@ int  tsl_tsdf_surface_voxels(tsl_tsdf* m, tsl_tsdf* dst /* NULL = m itself */, i
 int  tsl_tsdf_slice_voxels(tsl_tsdf* m, float z, float dz, int clear_last, int32_t* n);
 /* read back export_TSDF_xyz / export_color / export_TSDF (any may be NULL), rows [0, n) */
 int  tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64_t n);
+/* the same three buffers as DEVICE pointers (f32 [max_disp_particles][3] / [3] / [1], valid for the lifetime of the handle) + the count
+ * of the last cvt_* call: the form taichislam_node.py:350-351 would use if its consumer stayed on the GPU.  Synchronises. */
+int  tsl_tsdf_exports_dev(tsl_tsdf* m, void** xyz_dev, void** rgb_dev, void** val_dev, int32_t* n);
 /* export_TSDF_xyz[row] = v (field 0) / export_color[row] = v (field 1): callers append marker points to the particle list (tests/gen_topo_graph.py:64-65) */
 int  tsl_tsdf_set_export_row(tsl_tsdf* m, int field, int64_t row, const float v[3]);
 /* the first n exported particles as the data block of a sensor_msgs/PointCloud2: interleaved float32 rows x y z [r g b], point_step 12 / 24
@@ -185,12 +188,21 @@ int   tsl_tsdf_merge_finish(tsl_tsdf* global, const void* acc_dev, const void* c
  * n_tri is the true triangle count.  read with tsl_mesh_read. */
 int  tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tri, int32_t* n_tri);
 int  tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int64_t n_vertices);
+/* mesh_vertices / mesh_normals / mesh_colors (marching_cube_mesher.py:16-22) as DEVICE pointers, f32 [3 * max_triangles][3] (colours NULL
+ * for untextured maps), + num_facelets of the last generate: taichislam_node.py:342 without the host copy */
+int  tsl_mesh_buffers_dev(tsl_tsdf* m, void** verts_dev, void** normals_dev, void** colors_dev, int32_t* n_tri);
 
 /* ---- batched map queries  (mapping_common.py:165-204, dense_tsdf.py:148-155; consumers: topo_graph.py:444-507) ---------- */
 /* mode 0: is_pos_occupy, 1: is_pos_unobserved, 2: is_near_pos_occupy(param voxels); xyz f32 [n][3] in the active submap's frame */
 int  tsl_tsdf_query_points(tsl_tsdf* m, int mode, int param, const float* xyz, int64_t n, uint8_t* out);
 /* raycast(pos, dir, max_dist) per query: hit flag, last evaluated position, length travelled */
 int  tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, float max_dist, int64_t n, uint8_t* hit, float* end_xyz, float* len);
+/* the same with DEVICE buffers, asynchronous: launched on the handle's stream (behind every queued frame) after the work already queued
+ * on `user_stream` (a hipStream_t, e.g. torch's current stream; NULL = the legacy default stream), and `user_stream` waits for the
+ * result -- no host round trip per 64-128-ray node expansion (topo_graph.py:444-507). */
+int  tsl_tsdf_query_points_dev(tsl_tsdf* m, int mode, int param, const void* xyz_dev, int64_t n, void* out_u8_dev, void* user_stream);
+int  tsl_tsdf_query_raycast_dev(tsl_tsdf* m, const void* pos_dev, const void* dir_dev, float max_dist, int64_t n,
+                                void* hit_u8_dev, void* end_xyz_dev, void* len_dev, void* user_stream);
 
 /* ---- ESDF  (dense_esdf.py:228-333 as the definition) -----------------------------------------------------------------
  * |TSDF| < gamma: ESDF = TSDF; elsewhere the 26-neighbour quasi-Euclidean distance (edge cost |dir| * voxel) to that band along voxels
@@ -221,6 +233,15 @@ int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxe
 int  tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out);
 int  tsl_esdf_totals(tsl_tsdf* m, tsl_esdf_totals_t* out);
 int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n);
+/* the same compaction left on the device: *idx_dev = int16 [min(n, cap)][3], *val_dev = f32 [min(n, cap)] in the handle's staging buffer
+ * (valid until the next exporting / importing / host-buffer query call on the handle) */
+int  tsl_esdf_export_dev(tsl_tsdf* m, int64_t cap, void** idx_dev, void** val_dev, int64_t* n);
+/* cvt_ESDF_to_voxels_slice(z)  dense_esdf.py:498-509: ESDF of the voxel layer at height z of the active submap -> export_ESDF_xyz /
+ * export_ESDF (max_disp_particles rows on the device), *n = num_export_ESDF_particles; read back with tsl_esdf_read_slice or take the
+ * device pointers (valid for the lifetime of the handle) with tsl_esdf_slice_dev */
+int  tsl_esdf_slice(tsl_tsdf* m, float z, int32_t* n);
+int  tsl_esdf_read_slice(tsl_tsdf* m, float* xyz, float* val, int64_t n);
+int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n);
 
 /* backend knobs for A/B-ing kernel variants: name in
      "variant"  0|1: one global int64 atomic pair per ray step, 2 (default): brick-binned LDS accumulation
@@ -232,10 +253,11 @@ int  tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_
      "ramp"     half batches issued after the pipeline ran dry before full ones are waited for (default 2)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
-     "wg"       threads per workgroup of the brick integrate kernel: 512 (default; steps of 2048 segments, one workgroup per CU, 187 VGPRs:
-                phase-A waves of the next batches fit beside it) or 256 (steps of 1024, two workgroups per CU that fill the register file)
-     "unit"     a brick whose segments of a whole batch number at most this (default 12288) is walked by ONE workgroup, frame after
-                frame, with its voxels in registers; heavier bricks are split into parts and merged through the HBM slab
+     "wg"       threads per workgroup of the brick integrate kernel: 512 (default) or 256 (two workgroups per CU)
+     "spt"      segments per thread and step of the brick kernel: 4 (steps of 2048 segments, one 512-thread workgroup per CU) or 2 (steps of 1024,
+                <= 128 VGPRs: two 512-thread workgroups = 16 waves per CU)
+     "unit"     a brick whose segments of a whole batch number at most this is walked by ONE workgroup, frame after frame, with its voxels in
+                registers; heavier bricks are split into parts that leave their sums in slab slots of their own, applied by k_apply_slab
      "chunks"   steps a part may hold (1..8, default 2)
      "bgrid"    resident phase-B workgroups in percent of the slots (wg 256 only; default 100)
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
@@ -281,12 +303,17 @@ int  tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3],
 int  tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
                                   const void* tex_dev, int th, int tw);
 int  tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n);   /* :126-128,134-145 */
+int  tsl_octo_integrate_points_dev(tsl_octo* m, const double R[9], const double T[3], const void* xyz_dev, const void* rgb_dev, int64_t n);   /* device buffers: f32 [n][3], u8 [n][3] or NULL */
 int  tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out);
 /* every touched leaf of the active submap: index, hit count and (textured maps; else zeros) colour f32[n][3]; rgb may be NULL */
 int  tsl_octo_export_leaves(tsl_octo* m, int32_t* idx, float* cnt, float* rgb, int64_t cap, int64_t* n);
 /* cvt_occupy_to_voxels(level) / cvt_occupy_voxels_to(...)  :90-114 */
 int  tsl_octo_occupied_voxels(tsl_octo* m, tsl_octo* dst /* NULL = m */, int level, int add_to_cur, int32_t* n);
 int  tsl_octo_read_exports(tsl_octo* m, float* xyz, float* rgb, int64_t n);
+int  tsl_octo_exports_dev(tsl_octo* m, void** xyz_dev, void** rgb_dev, int32_t* n);   /* export_x / export_color as device pointers + num_export_particles (taichislam_node.py:330-333) */
+/* the first n rows of export_x [+ export_color] as a sensor_msgs/PointCloud2 data block (interleaved f32 x y z [r g b]): the publisher of
+ * scripts/taichislam_node.py:330-333 + utils/ros_pcl_transfer.py:96-136, interleaved on the device */
+int  tsl_octo_pack_pointcloud2(tsl_octo* m, int has_rgb, int64_t n, void* out_host);
 int  tsl_octo_num_particles(tsl_octo* m, int32_t* n);
 int  tsl_octo_fuse_submaps(tsl_octo* global, tsl_octo* submaps);                     /* :171-199 */
 

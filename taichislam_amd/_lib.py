@@ -97,6 +97,7 @@ SIGNATURES = {
     "tsl_tsdf_surface_voxels": (C.c_int, [vp, vp, C.c_int, pi32]),
     "tsl_tsdf_slice_voxels": (C.c_int, [vp, f32, f32, C.c_int, pi32]),
     "tsl_tsdf_read_exports": (C.c_int, [vp, vp, vp, vp, i64]),
+    "tsl_tsdf_exports_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), pi32]),
     "tsl_tsdf_set_export_row": (C.c_int, [vp, C.c_int, i64, vp]),
     "tsl_tsdf_pack_pointcloud2": (C.c_int, [vp, C.c_int, i64, vp]),
     "tsl_tsdf_num_particles": (C.c_int, [vp, pi32]),
@@ -114,12 +115,19 @@ SIGNATURES = {
     "tsl_tsdf_merge_finish": (C.c_int, [vp, vp, vp]),
     "tsl_mesh_generate": (C.c_int, [vp, C.c_int, f32, i64, pi32]),
     "tsl_mesh_read": (C.c_int, [vp, vp, vp, vp, i64]),
+    "tsl_mesh_buffers_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), pi32]),
     "tsl_tsdf_query_points": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp]),
     "tsl_tsdf_query_raycast": (C.c_int, [vp, vp, vp, f32, i64, vp, vp, vp]),
+    "tsl_tsdf_query_points_dev": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "tsl_tsdf_query_raycast_dev": (C.c_int, [vp, vp, vp, f32, i64, vp, vp, vp, vp]),
     "tsl_esdf_update": (C.c_int, [vp, f32, f32, pi32]),
     "tsl_esdf_last_stats": (C.c_int, [vp, C.POINTER(EsdfStats)]),
     "tsl_esdf_totals": (C.c_int, [vp, C.POINTER(EsdfTotals)]),
     "tsl_esdf_export": (C.c_int, [vp, vp, vp, i64, pi64]),
+    "tsl_esdf_export_dev": (C.c_int, [vp, i64, C.POINTER(vp), C.POINTER(vp), pi64]),
+    "tsl_esdf_slice": (C.c_int, [vp, f32, pi32]),
+    "tsl_esdf_read_slice": (C.c_int, [vp, vp, vp, i64]),
+    "tsl_esdf_slice_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), pi32]),
     "tsl_tsdf_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "tsl_tsdf_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),
     "tsl_tsdf_prof_enable": (C.c_int, [vp, C.c_int]),
@@ -136,10 +144,13 @@ SIGNATURES = {
     "tsl_octo_integrate_depth": (C.c_int, [vp, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     "tsl_octo_integrate_depth_dev": (C.c_int, [vp, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     "tsl_octo_integrate_points": (C.c_int, [vp, dp, dp, vp, vp, i64]),
+    "tsl_octo_integrate_points_dev": (C.c_int, [vp, dp, dp, vp, vp, i64]),
     "tsl_octo_last_frame_stats": (C.c_int, [vp, C.POINTER(FrameStats)]),
     "tsl_octo_export_leaves": (C.c_int, [vp, vp, vp, vp, i64, pi64]),
     "tsl_octo_occupied_voxels": (C.c_int, [vp, vp, C.c_int, C.c_int, pi32]),
     "tsl_octo_read_exports": (C.c_int, [vp, vp, vp, i64]),
+    "tsl_octo_exports_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), pi32]),
+    "tsl_octo_pack_pointcloud2": (C.c_int, [vp, C.c_int, i64, vp]),
     "tsl_octo_num_particles": (C.c_int, [vp, pi32]),
     "tsl_octo_fuse_submaps": (C.c_int, [vp, vp]),
 }

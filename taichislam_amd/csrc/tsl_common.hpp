@@ -190,9 +190,12 @@ __device__ __forceinline__ int claim_index_1(int* entry, int* counter, int cap)
         if (v == TSL_EMPTY) {
             int old = atomicCAS(entry, TSL_EMPTY, TSL_LOCKED);
             if (old == TSL_EMPTY) {
-                int idx = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // out of capacity: the entry goes back to EMPTY (a later reset / larger pool can allocate it) and the caller
-                // reports the failure; TSL_FULL is only ever a return value, never a table entry
+                // reports the failure; TSL_FULL is only ever a return value, never a table entry.  The counter is looked at first:
+                // once the pool is full it is not bumped any more (every later access of an absent brick repeats this claim -- the
+                // counter stays within `cap` + the claims that were in flight when it filled up, and is not an atomic hot spot)
+                int idx = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (idx < cap) idx = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(entry, idx >= cap ? TSL_EMPTY : idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return idx >= cap ? TSL_FULL : idx;
             }
@@ -237,7 +240,6 @@ struct MapDev {
     uint16_t* col;             // [max_bricks][4096][4] f16 rgb (+pad) or nullptr
     int* owner;                // [max_bricks] -> s*nb3 + b
     uint8_t* touch;            // [max_bricks] set by the integrate kernels when they write a brick's TSDF (consumed by the incremental ESDF)
-    unsigned long long* slab_of;   // [batch slots][max_bricks] batch generation << 20 | first merge-slab slot of the brick in that batch (k_plan; stale generations mean none)
     int* pool_top;             // bricks handed out so far
     int* err;                  // sticky device error flags (bit 0 brick pool full, 1 frame scratch, 2 ray segments, 3 crowded sensor voxel)
 };

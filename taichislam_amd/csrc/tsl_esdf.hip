@@ -61,7 +61,11 @@ struct EsdfDev {
 // 1. dirty bricks of submap s (and, when `all`, every brick of it); touch marks are consumed
 __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s, int all)
 {
-    const int nused = min(*M.pool_top, M.max_bricks);              // read on the device: the host does not wait for the frames before it
+    // the brick count of this update: a snapshot of the pool counter copied into ctr[10] ahead of this kernel (on the device: the host
+    // does not wait for the frames before it).  Phase A of frames queued AFTER the update may allocate bricks while it runs (their
+    // phase A starts once this kernel has finished, esdf_gate): every kernel of the update ignores pool indices >= the snapshot, so a
+    // brick that appears meanwhile -- owner / flags not written yet -- is simply not there for this update.
+    const int nused = min(E.ctr[10], M.max_bricks);
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool take = false;
     if (p < nused) {
@@ -71,7 +75,6 @@ __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s
     }
     const int q = wave_reserve(&E.ctr[0], take);
     if (take) E.dirty[q] = p;
-    if (p == 0) E.ctr[10] = nused;
 }
 
 // class flags and band value of a voxel from its TSDF (what the relaxation depends on)
@@ -91,7 +94,7 @@ __device__ __forceinline__ void esdf_inputs(uint32_t obs_byte, uint32_t tw, floa
 //    any distance.  The stored flags / band values are those of the brick's last (re)initialisation.
 __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s, int r, int all, float gamma, float max_dist)
 {
-    const int nd = E.ctr[0];
+    const int nd = E.ctr[0], nsnap = min(E.ctr[10], M.max_bricks);
     const int side = 2 * r + 1, vol = side * side * side;
     for (int d = blockIdx.x; d < nd; d += gridDim.x) {
         const int pd = E.dirty[d];
@@ -122,7 +125,7 @@ __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s,
             const int i = bi + t / (side * side) - r, j = bj + (t / side) % side - r, k = bk + t % side - r;
             if (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) continue;
             const int p = pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
-            if (p >= 0) E.region[p] = 1;
+            if (p >= 0 && p < nsnap) E.region[p] = 1;
         }
     }
 }
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s,
 // 3. (re)initialise the region's voxels; every brick of the region is on the work list of round 0
 __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float gamma, float max_dist)
 {
-    const int nused = min(*M.pool_top, M.max_bricks);
+    const int nused = min(E.ctr[10], M.max_bricks);
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         if (E.region[p] != 1) continue;
         {   // a thread's 16 consecutive voxels: 1 + 4 wide loads, 1 + 4 wide stores
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
     __shared__ int s_notify;
     uint32_t* const s_d = s_dm + ESDF_PAD;
     const int cur = round % 3, nxt = (round + 1) % 3, clr = (round + 2) % 3;
-    const int n = E.ctr[2 + cur];
+    const int n = E.ctr[2 + cur], nsnap = min(E.ctr[10], M.max_bricks);
     if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) E.ctr[7] = round + 1; }      // list (round+2) was consumed in round-1
     if (n == 0) return;
     const float cost[4] = { 0.0f, 1.0f * vs, sqrtf(2.0f) * vs, sqrtf(3.0f) * vs };              // dense_esdf.py:286
@@ -205,7 +208,8 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
         const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
         if (threadIdx.x < 27) {
             const int i = bi + (int)threadIdx.x / 9 - 1, j = bj + ((int)threadIdx.x / 3) % 3 - 1, k = bk + (int)threadIdx.x % 3 - 1;
-            s_nb[threadIdx.x] = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+            const int np = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+            s_nb[threadIdx.x] = np < nsnap ? np : -1;                 // a brick allocated after the update's snapshot is not part of it
         }
         if (threadIdx.x == 0) s_notify = 0;
         for (int i = threadIdx.x; i < (ESDF_T3 + 31) / 32 + 2; i += 256) s_a[i] = 0u;
@@ -457,6 +461,35 @@ __global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused,
     }
 }
 
+// cvt_ESDF_to_voxels_slice  dense_esdf.py:498-509: every observed voxel of the active submap with _index - 0.5 < k < _index + 0.5
+// (k counted from the bottom of the volume, as the legacy module does) -> export_ESDF / export_ESDF_xyz, num_export_ESDF_particles
+struct PoseE { float R[9], T[3]; };
+__global__ void __launch_bounds__(256) k_esdf_slice(MapDev M, int s, int nused, const float* esdf, float gamma, PoseE B, int is_global, float vs, float index_f,
+                                                    float* xyz, float* val, long long cap, int* counter)
+{
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        const int owner = M.owner[p];
+        if (owner / M.nb3 != s) continue;
+        const int b = owner - s * M.nb3;
+        const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
+            const int l = l0 + threadIdx.x;
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            const int ku = bk * 16 + (l & 15);                                                   // k from the bottom of the volume
+            const bool pred = M.obs[v] > 0 && index_f - 0.5f < (float)ku && (float)ku < index_f + 0.5f;      // :504
+            const int o = wave_reserve(counter, pred);                                            // :505
+            if (pred && o < cap) {
+                const float t = h2f((h16)(M.tw[v] & 0xffffu));
+                val[o] = fabsf(t) < gamma ? t : (float)sgn_f(t) * esdf[v];                        // :507
+                const int i = bi * 16 + (l >> 8) - M.hN, j = bj * 16 + ((l >> 4) & 15) - M.hN, k = ku - M.hNz;
+                const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;           // :508  submap_i_j_k_to_xyz (mapping_common.py:221-232)
+                if (is_global) { xyz[(size_t)o * 3] = p0; xyz[(size_t)o * 3 + 1] = p1; xyz[(size_t)o * 3 + 2] = p2; }
+                else for (int a = 0; a < 3; ++a) xyz[(size_t)o * 3 + a] = ((B.R[a * 3] * p0 + B.R[a * 3 + 1] * p1) + B.R[a * 3 + 2] * p2) + B.T[a];
+            }
+        }
+    }
+}
+
 // ---- host side.  An update is a fixed sequence of launches on the handle's stream (collect, dilate, init, a batch of rounds sized by
 // max_dist -- a round without work returns at once) followed by a copy of the counters into a pinned slot and an event.  Whether the
 // last launched round still had work (never seen with this batch size) is all the host needs to know, and it does not need to know
@@ -473,7 +506,7 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         const int* h = S.host;
         tsl_esdf_stats st = S.st;
         st.dirty_bricks = h[0]; st.changed_bricks = h[11]; st.region_bricks = h[1]; st.brick_relaxations = h[5]; st.voxel_pushes = h[6];
-        st.rounds = h[7]; st.passes = h[8]; st.max_passes = h[9]; st.total_bricks = h[10];
+        st.rounds = h[7]; st.passes = h[8]; st.max_passes = h[9]; st.total_bricks = h[10] < m->M.max_bricks ? h[10] : m->M.max_bricks;
         if (h[2 + S.rounds % 3] != 0) m->esdf_short = true;                  // the last launched round still had work
         if (st.incremental && st.rounds > m->esdf_rounds_seen) m->esdf_rounds_seen = st.rounds;
         m->esdf_stats = st;
@@ -507,6 +540,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
             TSL_HIP(hipEventCreateWithFlags(&m->esdf_slot[i].ev, hipEventDisableTiming));
             TSL_HIP(hipHostMalloc((void**)&m->esdf_slot[i].host, sizeof(int) * 256, hipHostMallocDefault));
         }
+        TSL_HIP(hipEventCreateWithFlags(&m->esdf_gate, hipEventDisableTiming));
         m->esdf_valid = false;
     }
     esdf_retire(m, false);
@@ -522,10 +556,14 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     std::memset(&S.st, 0, sizeof(S.st));
     S.st.incremental = full ? 0 : 1;
     TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 256, q));
+    TSL_HIP(hipMemcpyAsync(m->esdf_ctr + 10, m->M.pool_top, sizeof(int), hipMemcpyDeviceToDevice, q));      // the update's brick-count snapshot
     prof_begin(m, TSL_K_ESDF);                                   // one event pair around the update's launches (collect .. last round)
     m->prof_group = true;
     const int nbk = (nb + 255) / 256;
     hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0);
+    // phase A of frames queued from now on allocates bricks (pool counter, table entry, owner -- in that order): it starts after the
+    // snapshot + collect, so that every pool index below the snapshot has its owner written (launch_batch_t waits for the gate)
+    TSL_HIP(hipEventRecord(m->esdf_gate, q)); m->esdf_gate_set = true;
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
     hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, gamma, max_dist);
     // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
@@ -569,6 +607,7 @@ void esdf_release(tsl_tsdf* m)
         if (m->esdf_slot[i].host) (void)hipHostFree(m->esdf_slot[i].host);
         m->esdf_slot[i].ev = nullptr; m->esdf_slot[i].host = nullptr;
     }
+    if (m->esdf_gate) { (void)hipEventDestroy(m->esdf_gate); m->esdf_gate = nullptr; }
 }
 
 }  // namespace tsl
@@ -602,26 +641,93 @@ int tsl_esdf_totals(tsl_tsdf* m, tsl_esdf_totals_t* out)
     *out = m->esdf_tot; return TSL_OK;
 }
 
-int tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n)
+// compaction of the observed voxels into the handle's staging buffer: int16 idx[cap][3] | f32 esdf[cap]; *c = true count
+static int esdf_export_stage(tsl_tsdf* m, int64_t cap, int16_t** didx, float** dval, int* c)
 {
-    TSL_REQUIRE(m && n && cap >= 0, "esdf_export: bad argument"); TSL_REQUIRE(m->esdf, "esdf_export: call tsl_esdf_update first");
+    TSL_REQUIRE(m->esdf, "esdf_export: call tsl_esdf_update first");
     TSL_HIP(hipSetDevice(m->device));
     int rc = esdf_finish(m); if (rc) return rc;
     int nused = 0; rc = tsl_tsdf_bricks_in_use(m, &nused); if (rc) return rc;
     const size_t need = (((size_t)cap * 6 + 15) / 16) * 16 + (size_t)cap * 4 + 64;
     rc = grow(&m->xbuf, &m->xbuf_bytes, need); if (rc) return rc;
-    int16_t* didx = (int16_t*)m->xbuf; float* dval = (float*)((char*)m->xbuf + (((size_t)cap * 6 + 15) / 16) * 16);
+    *didx = (int16_t*)m->xbuf; *dval = (float*)((char*)m->xbuf + (((size_t)cap * 6 + 15) / 16) * 16);
     int* counter = m->num_particles + 2;
     TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), ms(m)));
     const int s = m->cfg.is_global_map ? 0 : m->active;
-    if (nused > 0) hipLaunchKernelGGL(k_esdf_export, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, didx, dval, (long long)cap, counter);
+    if (nused > 0) hipLaunchKernelGGL(k_esdf_export, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, *didx, *dval, (long long)cap, counter);
     TSL_HIP(hipMemcpyAsync(m->h_ints, counter, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
     TSL_HIP(hipStreamSynchronize(ms(m)));
-    const int c = m->h_ints[0];
+    *c = m->h_ints[0];
+    return TSL_OK;
+}
+
+int tsl_esdf_export(tsl_tsdf* m, int16_t* idx, float* esdf, int64_t cap, int64_t* n)
+{
+    TSL_REQUIRE(m && n && cap >= 0, "esdf_export: bad argument");
+    int16_t* didx; float* dval; int c = 0;
+    int rc = esdf_export_stage(m, cap, &didx, &dval, &c); if (rc) return rc;
     *n = c;
     const size_t k = (size_t)(c < cap ? c : cap);
     if (k && idx) TSL_HIP(hipMemcpy(idx, didx, k * 6, hipMemcpyDeviceToHost));
     if (k && esdf) TSL_HIP(hipMemcpy(esdf, dval, k * 4, hipMemcpyDeviceToHost));
+    return TSL_OK;
+}
+
+/* the same compaction, left on the device: *idx_dev = int16 [min(n, cap)][3], *val_dev = f32 [min(n, cap)] inside the handle's staging
+ * buffer (valid until the next call on this handle that exports, imports or queries through host buffers) */
+int tsl_esdf_export_dev(tsl_tsdf* m, int64_t cap, void** idx_dev, void** val_dev, int64_t* n)
+{
+    TSL_REQUIRE(m && n && idx_dev && val_dev && cap >= 0, "esdf_export_dev: bad argument");
+    int16_t* didx; float* dval; int c = 0;
+    int rc = esdf_export_stage(m, cap, &didx, &dval, &c); if (rc) return rc;
+    *n = c; *idx_dev = didx; *val_dev = dval;
+    return TSL_OK;
+}
+
+/* cvt_ESDF_to_voxels_slice(z)  dense_esdf.py:498-509: the ESDF of the voxel layer at height z of the active submap -> the handle's
+ * export_ESDF_xyz / export_ESDF buffers (max_disp_particles rows, device-resident), *n = num_export_ESDF_particles (true count) */
+int tsl_esdf_slice(tsl_tsdf* m, float z, int32_t* n)
+{
+    TSL_REQUIRE(m && n, "esdf_slice: bad argument"); TSL_REQUIRE(m->esdf, "esdf_slice: call tsl_esdf_update first");
+    TSL_HIP(hipSetDevice(m->device));
+    int rc = esdf_finish(m); if (rc) return rc;
+    if (!m->esdf_exp_xyz) {
+        if ((rc = dev_alloc(m, (void**)&m->esdf_exp_xyz, sizeof(float) * 3 * (size_t)m->max_disp, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_exp_val, sizeof(float) * (size_t)m->max_disp, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_exp_count, sizeof(int) * 4, 0))) return rc;
+    }
+    int nused = 0; rc = tsl_tsdf_bricks_in_use(m, &nused); if (rc) return rc;
+    TSL_HIP(hipMemsetAsync(m->esdf_exp_count, 0, sizeof(int), ms(m)));                    // :500
+    const int s = m->cfg.is_global_map ? 0 : m->active;
+    PoseE B;
+    for (int a = 0; a < 9; ++a) B.R[a] = m->baseRf[(size_t)m->active * 9 + a];
+    for (int a = 0; a < 3; ++a) B.T[a] = m->baseTf[(size_t)m->active * 3 + a];
+    // _index = (z + map_size_[2] / 2) / voxel_scale: Python floats at trace time (z is a ti.template()), an f32 constant in the kernel (:503)
+    const float index_f = (float)(((double)z + (double)m->Nz * m->cfg.voxel_scale / 2.0) / m->cfg.voxel_scale);
+    if (nused > 0) hipLaunchKernelGGL(k_esdf_slice, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, B, m->cfg.is_global_map, m->P.vs,
+                                      index_f, m->esdf_exp_xyz, m->esdf_exp_val, (long long)m->max_disp, m->esdf_exp_count);
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->esdf_exp_count, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
+    m->esdf_exp_n = m->h_ints[0];
+    *n = m->esdf_exp_n;
+    return TSL_OK;
+}
+/* rows [0, n) of export_ESDF_xyz / export_ESDF (either may be NULL) */
+int tsl_esdf_read_slice(tsl_tsdf* m, float* xyz, float* val, int64_t n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "esdf_read_slice: n out of range"); TSL_HIP(hipSetDevice(m->device));
+    if (n == 0) return TSL_OK;
+    TSL_REQUIRE(m->esdf_exp_xyz, "esdf_read_slice: call tsl_esdf_slice first");
+    TSL_HIP(hipStreamSynchronize(ms(m)));
+    if (xyz) TSL_HIP(hipMemcpy(xyz, m->esdf_exp_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    if (val) TSL_HIP(hipMemcpy(val, m->esdf_exp_val, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    return TSL_OK;
+}
+/* the same buffers as device pointers (valid for the lifetime of the handle) + the count of the last tsl_esdf_slice */
+int tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
+{
+    TSL_REQUIRE(m && m->esdf_exp_xyz, "esdf_slice_dev: call tsl_esdf_slice first");
+    if (xyz_dev) *xyz_dev = m->esdf_exp_xyz; if (val_dev) *val_dev = m->esdf_exp_val; if (n) *n = m->esdf_exp_n;
     return TSL_OK;
 }
 

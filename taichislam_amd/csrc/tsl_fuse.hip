@@ -100,23 +100,36 @@ static int upload_poses(tsl_tsdf* g, const tsl_tsdf* sub)
 
 static int used_bricks(tsl_tsdf* m, int* n) { return tsl_tsdf_bricks_in_use(m, n); }
 
-// reset `g` and splat every submap of `sub` into g's per-brick accumulators (allocated on first use); *ndst = bricks of g touched
-int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst)
+// reset `g` and splat every submap of `sub` into g's per-brick accumulators (allocated on first use); *ndst = bricks of g touched.
+// with_colour: also sum the colour channels (single-GPU fusion of textured maps); the multi-GPU merge exchanges {sum w*t, sum w, count}
+// only, so it passes false and a merged map carries no colour.
+// The accumulators are all zero between uses: k_fuse_finalize / k_merge_pack zero what they read.  A caller that stopped in between (a
+// step-protocol merge abandoned after merge_begin, a failed launch) leaves them dirty -- `fuse_dirty` -- and the next splat clears
+// them wholesale first (the pool indices they were written under are gone after the reset).
+int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst, bool with_colour)
 {
     int rc = tsl_tsdf_sync(sub); if (rc) return rc;
     rc = tsl_tsdf_reset(g); if (rc && rc != TSL_ERR_CAPACITY) return rc;                  // :313 (a capacity error of the discarded contents does not matter here)
+    const size_t nv = (size_t)g->M.max_bricks * TSL_BRK3;
     if (!g->fuse_acc) {
-        const size_t nv = (size_t)g->M.max_bricks * TSL_BRK3;
         if ((rc = dev_alloc(g, &g->fuse_acc, nv * 16, 0))) return rc;
         if ((rc = dev_alloc(g, &g->fuse_cnt, nv * 4, 0))) return rc;
         if (g->M.col) { if ((rc = dev_alloc(g, &g->fuse_cacc, nv * 24, 0))) return rc; }
+        g->fuse_dirty = false;
     }
-    unsigned long long* cacc = (g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
+    if (g->fuse_dirty) {
+        TSL_HIP(hipMemsetAsync(g->fuse_acc, 0, nv * 16, ms(g)));
+        TSL_HIP(hipMemsetAsync(g->fuse_cnt, 0, nv * 4, ms(g)));
+        if (g->fuse_cacc) TSL_HIP(hipMemsetAsync(g->fuse_cacc, 0, nv * 24, ms(g)));
+        g->fuse_dirty = false;
+    }
+    unsigned long long* cacc = (with_colour && g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
     if ((rc = upload_poses(g, sub))) return rc;
     int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
     *ndst = 0;
     if (nsrc > 0) {
         PoseTab pt = { g->pose_dev };
+        g->fuse_dirty = true;
         prof_begin(g, TSL_K_FUSE);
         hipLaunchKernelGGL(k_fuse_splat, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, ms(g), sub->M, g->M, pt, g->P.vs, nsrc,
                            (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, g->npose, cacc);
@@ -140,11 +153,12 @@ int tsl_tsdf_fuse_submaps(tsl_tsdf* g, tsl_tsdf* sub)
     TSL_REQUIRE(g->device == sub->device, "fuse_submaps: maps live on different devices");
     TSL_HIP(hipSetDevice(g->device));
     int ndst = 0;
-    int rc = fuse_splat_into_global(g, sub, &ndst); if (rc) return rc;
+    int rc = fuse_splat_into_global(g, sub, &ndst, true); if (rc) return rc;
     unsigned long long* cacc = (g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
     if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, ms(g), g->M, ndst,
                                      (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, cacc);
     TSL_HIP(hipGetLastError());
+    g->fuse_dirty = false;                                      // the finalise pass zeroed every sum it read
     return tsl_tsdf_sync(g);                                    // reports an exhausted brick pool of the global map (TSL_ERR_CAPACITY)
 }
 

@@ -316,48 +316,83 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
         bool big = false;
         int gn = 0, sl = 0;
         uint32_t first = 0;
+        unsigned long long vkey = 0ull;
         ok = false;
         if (r < nrays && sub == 0) {
             sl = F.act[r];
-            gn = F.hcnt[sl];
-            if (gn > GROUP_SMALL) big = true;
+            // the voxel's slot: key, count and the ids of its first H_INL pixels -- one 64-byte line
+            const uint4* sp = reinterpret_cast<const uint4*>(F.htab + sl);
+            const uint4 w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
+            vkey = ((unsigned long long)w0.x | ((unsigned long long)w0.y << 32)) - 1ull;      // the slot holds h_key(voxel key, 0)
+            gn = (int)w0.z;
+            if (gn > H_INL) big = true;
             else {
-                const uint32_t* ids = F.plist + F.hoff[sl];
+                uint32_t id[H_INL] = { w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w };
+                uint2 pl[H_INL];
+#pragma unroll
+                for (int q = 0; q < H_INL; ++q) {                                // all payloads are requested together, then replayed from registers
+                    if (q >= gn) id[q] = 0xffffffffu;
+                    pl[q] = q < gn ? F.pix[id[q]] : make_uint2(0u, 0u);
+                }
                 PixAcc A = {};
-                long long last = -1;
-                for (int k = 0; k < gn; ++k) {                                   // next pixel in raster order
-                    uint32_t best = 0xffffffffu;
-                    for (int q = 0; q < gn; ++q) { const uint32_t v = ids[q]; if ((long long)v > last && v < best) best = v; }
+                for (int k = 0; k < gn; ++k) {                                   // next pixel in raster order = smallest id not yet taken
+                    uint32_t best = 0xffffffffu; uint2 bp = make_uint2(0u, 0u);
+#pragma unroll
+                    for (int q = 0; q < H_INL; ++q) { const bool t = id[q] < best; best = t ? id[q] : best; bp.x = t ? pl[q].x : bp.x; bp.y = t ? pl[q].y : bp.y; }
+#pragma unroll
+                    for (int q = 0; q < H_INL; ++q) id[q] = id[q] == best ? 0xffffffffu : id[q];
                     if (k == 0) first = best;
-                    acc_pixel(P, F, best, A);
-                    last = (long long)best;
+                    if (P.tex) acc_colour(P, F, best, A);
+                    acc_payload(bp, A);
                 }
                 ok = finish_ray(P, F, A, first, &rec, &nsteps);
             }
         }
-        for (unsigned long long bm = __ballot(big); bm; bm &= bm - 1ull) {       // crowded voxels: the whole wave selects the next id
+        // crowded voxels (more than H_INL pixels): the whole wave replays them.  Pixel ranks b * H_INL .. of the voxel live in the slot keyed
+        // (voxel, block b); lane b resolves block b (b, b + 64, ...), every selection step takes the smallest id above the last one.
+        for (unsigned long long bm = __ballot(big); bm; bm &= bm - 1ull) {
             const int src = (int)__builtin_ctzll(bm);
-            const int n = __shfl(gn, src);
-            const uint32_t* gid_list = F.plist + F.hoff[__shfl(sl, src)];
+            const int n = __shfl(gn, src), sl0 = __shfl(sl, src);
+            const unsigned long long vk = ((unsigned long long)(uint32_t)__shfl((int)(vkey >> 32), src) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)vkey, src);
+            const int nblk = (n + H_INL - 1) / H_INL;
+            const uint32_t hmask = (1u << P.hlog2) - 1u;
+            auto find_block = [&](int bq) -> int {
+                if (bq == 0) return sl0;
+                const unsigned long long k2 = h_key(vk, bq);
+                uint32_t h = h_hash64(k2, P.hlog2);
+                for (uint32_t probe = 0; probe <= hmask; ++probe) {
+                    const unsigned long long cur = F.htab[h].key;
+                    if (cur == k2) return (int)h;
+                    if (cur == H_EMPTY) return -1;
+                    h = (h + 1u) & hmask;
+                }
+                return -1;
+            };
+            const int mine = lane < nblk ? find_block(lane) : -1;                // the block this lane reads in every selection step
+            const bool too_many = n > GROUP_BIG_CAP;
+            if (too_many && lane == 0) atomicOr(M.err, 8);
             PixAcc A = {};
             long long last = -1; uint32_t f0 = 0;
-            for (int k = 0; k < n; ++k) {
+            for (int k = 0; k < n && !too_many; ++k) {
                 uint32_t best = 0xffffffffu;
-                for (int q = lane; q < n; q += 64) { const uint32_t v = gid_list[q]; if ((long long)v > last && v < best) best = v; }
+                for (int bq = lane; bq < nblk; bq += 64) {
+                    const int hs = bq == lane ? mine : find_block(bq);
+                    if (hs < 0) continue;
+                    const int cb = min(H_INL, n - bq * H_INL);
+                    const uint32_t* ids = F.htab[hs].pix;
+                    for (int q = 0; q < cb; ++q) { const uint32_t v = ids[q]; if ((long long)v > last && v < best) best = v; }
+                }
                 best = wave_min_u32(best);
+                if (best == 0xffffffffu) break;                                  // (a block went missing: cannot happen, the ray is dropped below)
                 if (k == 0) f0 = best;
                 acc_pixel(P, F, best, A);
                 last = (long long)best;
             }
             uint4 rc; int ns = 0;
-            const bool k2 = finish_ray(P, F, A, f0, &rc, &ns, lane == src);
+            const bool k2 = A.cnt == n && finish_ray(P, F, A, f0, &rc, &ns, lane == src);
             if (lane == src) { rec = rc; nsteps = ns; ok = k2; first = f0; }
         }
-        if (r < nrays && sub == 0) {
-            F.rayA[r] = rec; F.rayFirst[r] = first;
-            if (F.hwide) reinterpret_cast<unsigned long long*>(F.hkey)[sl] = ~0ull; else reinterpret_cast<uint32_t*>(F.hkey)[sl] = ~0u;
-            F.hcnt[sl] = 0; F.hfill[sl] = 0;                                     // the table is empty again for the next frame of this set
-        }
+        if (r < nrays && sub == 0) { F.rayA[r] = rec; F.rayFirst[r] = first; }
         block_count_add(&F.stats->v_pcl, r < nrays && sub == 0);
         block_count_add(&F.stats->v_skipped, r < nrays && sub == 0 && !ok);
         if (gid == 0) *F.nrays = nrays;
@@ -448,23 +483,26 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 // K4b: lay out the frame's active bricks (listed by k_segments) -- a range of the sorted segment array per brick -- and the batch's
 // integrate work list.  A brick whose segments of ALL frames of the batch together number at most `unit_max` becomes one UNIT: one
 // workgroup walks its frames in order and keeps the voxels in registers in between (one read and one write of the brick per batch,
-// no ordering traffic).  A heavier brick is walked in PARTS of at most `psegs` segments of one frame; every part adds its sums into the
-// (frame, brick)'s slot of the batch's merge slab, and the workgroup that arrives last at the brick -- over all its frames -- applies
-// the frames in order.  Items are binned into PLAN_NCLS classes by the segments they walk (long first).
-// Nothing has to be in any particular order inside a class, so block-aggregated reservations replace a prefix scan.
-// unit = { brick id, segments of the batch, pool index (claimed here, on the brick's first touch ever), frames of the batch with segments }
-// part = { first segment, segments | parts of the (frame, brick) << 16, pool index,
-//          slab slot of the (frame, brick) = the brick's first slot + frame | frames of the batch with segments << 24 }
+// no ordering traffic).  A heavier brick is walked in PARTS of at most `psegs` segments of one frame; every part owns ONE slot of the
+// batch's merge slab and stores its 4096 {num, den} sums there (plain coalesced stores: no atomics, no tickets), and k_apply_slab,
+// launched behind the brick kernel, sums the parts of every (frame, brick) and applies the frames in order.
+// Items are binned into PLAN_NCLS classes by the segments they walk (long first).  Nothing has to be in any particular order inside a
+// class, so block-aggregated reservations replace a prefix scan, and no thread waits for another: the slots of a (frame, brick) are
+// recorded in the FRAME's own per-brick word (bslab), the brick's first frame of the batch lists it as heavy.
+// unit  = { brick id, segments of the batch, pool index (claimed here, on the brick's first touch ever), frames of the batch with segments }
+// part  = { first segment, segments | parts of the (frame, brick) << 16, pool index, slab slot }
+// heavy = { brick id, pool index, frames of the batch with segments, - }
 #define PART_NP_BITS 12
-#define PART_TM_SHIFT 24          // slab slots are < 2^20
+#define SLAB_SLOT_BITS 20         // bslab word: first slot | parts << 20
 #define PLAN_NCLS 4
 #define HDR_FAIL 11            // header words (FrameDev.counters): frame overflow bits
 #define HDR_CLAIM 12           //   batch (first frame's header): next rank to claim
 #define HDR_SLAB 13            //   batch: merge-slab slots handed out
+#define HDR_HEAVY 14           //   batch: heavy bricks listed
 #define HDR_PARTS 16           //   [16..19] parts per class
 #define HDR_UNITS 20           //   batch: [20..23] units per class
 __device__ __forceinline__ int plan_class(int w) { return w >= 2560 ? 0 : (w >= 1280 ? 1 : (w >= 512 ? 2 : 3)); }
-__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max, unsigned long long gen, int bslot)
+__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max)
 {
     if ((int)blockIdx.y >= B.n) return;
     const int y = blockIdx.y;
@@ -477,12 +515,12 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
     if (i < nact) {
         b = F.act_b[i];
         v = F.bhist[b];
-        int vmax = 0;
-        for (int q = 0; q < B.n; ++q) { const int vq = B.f[q].bhist[b]; if (vq > 0) tm |= 1 << q; wb += vq; vmax = max(vmax, vq); }
+        for (int q = 0; q < B.n; ++q) { const int vq = B.f[q].bhist[b]; if (vq > 0) tm |= 1 << q; wb += vq; }
         if (wb <= unit_max) { if ((tm & -tm) == (1 << y)) ucls = plan_class(wb); }         // the brick's first frame lists the unit
-        else if (v > 0) { np = (v + psegs - 1) / psegs; pcls = plan_class(min(psegs, vmax)); }
+        else if (v > 0) { np = (v + psegs - 1) / psegs; pcls = plan_class((v + np - 1) / np); }
     }
     const int off = block_reserve_n(&F.counters[3], v);
+    const int s0 = block_reserve_n(&B.f[0].counters[HDR_SLAB], np);                       // one slab slot per part, consecutive per (frame, brick)
     int p0 = 0, u0 = 0;
     for (int c = 0; c < PLAN_NCLS; ++c) {
         const int q = block_reserve_n(&F.counters[HDR_PARTS + c], pcls == c ? np : 0); if (pcls == c) p0 = q;
@@ -497,29 +535,19 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
             else for (int q = 0; q < B.n; ++q) if ((tm >> q) & 1) frame_fail(M, B.f[q], 2);
         }
         if (np && pool >= 0) {
-            // the brick's TSL_NB consecutive slots of the batch's merge slab (one per frame)
-            // (the brick's first frame of the batch claims them, the other frames' threads -- other blocks of this small grid, all resident --
-            //  wait for its tag)
-            unsigned long long cur;
-            unsigned long long* const slab_of = M.slab_of + (size_t)bslot * M.max_bricks;       // the batch slot's own words: phase A of two batches may run side by side
-            if ((tm & -tm) == (1 << y)) {
-                const int mine = __hip_atomic_fetch_add(&B.f[0].counters[HDR_SLAB], TSL_NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cur = (gen << 20) | (unsigned long long)min(mine, (1 << 20) - 1);
-                __hip_atomic_store(&slab_of[pool], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                int spins = 0;
-                while (((cur = __hip_atomic_load(&slab_of[pool], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != gen && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(2);
-                if ((cur >> 20) != gen) cur = (1u << 20) - 1u;                      // cannot happen; fails the capacity check below
+            if ((tm & -tm) == (1 << y)) {                                                 // the brick's first frame of the batch lists it for k_apply_slab
+                const int hi = __hip_atomic_fetch_add(&B.f[0].counters[HDR_HEAVY], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hi < B.f[0].max_frame_bricks) B.f[0].heavy_tab[hi] = make_int4(b, pool, tm, 0);
+                else for (int q = 0; q < B.n; ++q) if ((tm >> q) & 1) frame_fail(M, B.f[q], 2);
             }
-            const int base = (int)(cur & ((1u << 20) - 1u));
-            if (base + TSL_NB > F.max_frame_bricks || np >= (1 << PART_NP_BITS)) frame_fail(M, F, 2);
+            if (s0 + np > F.max_frame_bricks || np >= (1 << PART_NP_BITS) || p0 + np > F.part_cap) frame_fail(M, F, 2);      // this frame is not integrated at all
             else {
-                F.npf[base + y] = np;
+                F.bslab[b] = s0 | (np << SLAB_SLOT_BITS);
                 const int per = (v + np - 1) / np;
                 int4* tab = F.part_tab + (size_t)pcls * F.part_cap;
                 for (int k = 0; k < np; ++k) {
                     const int pos = k * per, n = min(v, pos + per) - pos;
-                    if (p0 + k < F.part_cap) tab[p0 + k] = make_int4(off + pos, (int)((uint32_t)n | ((uint32_t)np << 16)), pool, (base + y) | (tm << PART_TM_SHIFT)); else frame_fail(M, F, 2);
+                    tab[p0 + k] = make_int4(off + pos, (int)((uint32_t)n | ((uint32_t)np << 16)), pool, s0 + k);
                 }
             }
         }
@@ -535,6 +563,13 @@ __global__ void __launch_bounds__(256) k_scatter(BatchDev B)
     __shared__ int s_key[LH_SIZE];
     __shared__ int s_cnt[LH_SIZE];
     __shared__ int s_base[LH_SIZE];
+    if (B.p[blockIdx.y]->group) {       // k_segments has read the frame's sensor-voxel table: the slots the frame opened are emptied for the set's next frame
+        const int na = F.counters[6], nx = F.counters[7];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nx; i += gridDim.x * 256) {
+            HSlot* const hs = F.htab + (i < na ? F.act[i] : F.actx[i - na]);
+            hs->key = H_EMPTY; hs->cnt = 0;
+        }
+    }
     const int total = (int)min((long long)*F.nrays * SEG_RAY_SLOTS + F.counters[2], (long long)F.seg_cap);
     const int ntiles = (total + SCATTER_TILE - 1) / SCATTER_TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -642,9 +677,9 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // item record in LDS
 #define IT_UNIT 0       // 1: unit
 #define IT_POOL 1       // pool index of the brick (< 0: skip)
-#define IT_SLAB 2       // parts: slab slot
+#define IT_SLAB 2       // parts: the part's slab slot
 #define IT_NP   3       // parts: parts of the (frame, brick)
-#define IT_TMALL 4      // parts: frames of the batch that integrate into the brick
+#define IT_TMALL 4      // units: frames of the batch that integrate into the brick
 #define IT_FMASK 5      // frames this item walks
 #define IT_OFF  6                     // [IT_OFF + q] first segment of frame q
 #define IT_N    (IT_OFF + TSL_NB)     // [IT_N + q] segments of frame q
@@ -666,7 +701,6 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     __shared__ unsigned long long s_keys[CSEGS];                // 8 / 16 KiB: length sort of the NEXT step's keys while the planes hold the current sums
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
     __shared__ int s_bin[64];
-    __shared__ int s_last;
     __shared__ int s_claim[2];
     __shared__ int s_cum[NRANGE + 1];                           // first rank of every range of the work list (class-major: units, frame 0, 1, ...)
     __shared__ int s_it[3][IT_WORDS];
@@ -715,11 +749,11 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
         int* it = s_it[slot];
         if (threadIdx.x < TSL_NB) { it[IT_OFF + threadIdx.x] = io; it[IT_N + threadIdx.x] = in; }
         if (threadIdx.x == 0) {
-            const uint32_t tm = (kq < 0 ? (uint32_t)e.w : (uint32_t)e.w >> PART_TM_SHIFT) & okmask;
-            uint32_t fm = kq < 0 ? tm : 1u << kq;
+            const uint32_t tm = kq < 0 ? (uint32_t)e.w & okmask : 1u << kq;
+            uint32_t fm = tm;
             int pool = e.z;
             if (fm == 0u) { fm = 1u; pool = -1; }                  // a unit whose frames all overflowed: nothing to walk, nothing to apply
-            it[IT_UNIT] = kq < 0 ? 1 : 0; it[IT_POOL] = pool; it[IT_SLAB] = e.w & ((1 << PART_TM_SHIFT) - 1); it[IT_NP] = kq < 0 ? 1 : (e.y >> 16) & ((1 << PART_NP_BITS) - 1);
+            it[IT_UNIT] = kq < 0 ? 1 : 0; it[IT_POOL] = pool; it[IT_SLAB] = kq < 0 ? 0 : e.w; it[IT_NP] = kq < 0 ? 1 : (e.y >> 16) & ((1 << PART_NP_BITS) - 1);
             it[IT_TMALL] = (int)tm; it[IT_FMASK] = (int)fm;
         }
     };
@@ -792,13 +826,12 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     uint32_t old[VPT];
     uint32_t vmask = 0u;                                       // bits 0..15: voxel written by this item, 16..31: its weight was zero when the item began
     bool have_old = false;
-    int target = 0;                                            // parts: arrivals the brick expects in this batch
     for (;;) {
         const int* const it = s_it[slot];
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;
         const bool unit = uni(it[IT_UNIT]) != 0;
         const int p = uni(it[IT_POOL]), rk = uni(it[IT_SLAB]);
-        const uint32_t fmask = (uint32_t)uni(it[IT_FMASK]), tmall = (uint32_t)uni(it[IT_TMALL]);
+        const uint32_t fmask = (uint32_t)uni(it[IT_FMASK]);
         const int n_f = uni(it[IT_N + f]);
         const FrameDev& F = B.f[f];
         const FrameParams& P = *B.p[f];
@@ -815,12 +848,6 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
         if (n_known >= 1) known += steps_of(slot1, (uint32_t)uni(s_it[slot1][IT_FMASK]));
         const bool do_claim = !exhausted && n_known < 2 && known <= 1;
         if (do_claim && threadIdx.x == 0) s_claim[0] = __hip_atomic_fetch_add(claim, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // parts: arrivals the brick expects in this batch (the parts of all its frames); requested early, used after the walk
-        if (!unit && c == 0 && p >= 0) {
-            target = 0;
-#pragma unroll
-            for (int q = 0; q < TSL_NB; ++q) if ((tmall >> q) & 1u) target += F.npf[rk - f + q];
-        }
 #ifdef TSL_TIMING
         long long* const _rec = F.dbg + 131072 + (size_t)blockIdx.x * 128 + (size_t)(t < 16 ? t : 15) * 8;
         if (threadIdx.x == 0 && first_step) { _rec[0] = wall_clock64(); _rec[1] = (unit ? 1 : 0) | (uni(it[IT_NP]) << 8) | ((long long)fmask << 32); _rec[2] = 0; _rec[5] = 0; }
@@ -952,92 +979,16 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
                 }
             }
         } else if (p >= 0) {
-            // part of a heavy brick: add the sums into the (frame, brick)'s slot of the batch's HBM slab; the workgroup that arrives last at
-            // the brick (arrival ticket over the parts of all its frames, agent-scope release/acquire) applies the frames in order.
-            const int base = rk - f;
-            {
-                unsigned long long* acc = F.acc + (size_t)rk * (TSL_BRK3 * 2);
+            // part of a heavy brick: its sums go to the part's own slot of the batch's slab -- every entry, zeros included, as plain 16-byte
+            // stores (a slot is written by exactly one workgroup, so nothing has to be cleared or ordered); k_apply_slab, the next launch on
+            // this stream, adds the parts of each (frame, brick) and applies the frames in order
+            ulonglong2* acc = reinterpret_cast<ulonglong2*>(F.acc) + (size_t)rk * TSL_BRK3;
 #pragma unroll
-                for (int q = 0; q < VPT; ++q) {
-                    const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
-                    const unsigned long long d = s_den[ls];
-                    if (d != 0ull) {
-                        __hip_atomic_fetch_add(acc + l * 2, s_num[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(acc + l * 2 + 1, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (TEX) atomicMax(F.accw + (size_t)rk * TSL_BRK3 + l, s_win[ls]);
-                    }
-                    s_num[ls] = 0ull; s_den[ls] = 0ull;
-                    if (TEX) s_win[ls] = 0u;
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int tk = __hip_atomic_fetch_add(&F.ticket[base], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = (tk == target - 1) ? 1 : 0;
-                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); F.ticket[base] = 0; }
-            }
-            __syncthreads();
-            if (s_last) {
-                uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
-                int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
-#ifdef TSL_TIMING
-                if (threadIdx.x == 0) _rec[5] = wall_clock64();
-#endif
-                vmask = 0u;                                      // a part item: the unit registers are free
-#pragma unroll
-                for (int q = 0; q < VPT; ++q) { old[q] = tw[q * NT + threadIdx.x]; }
-#pragma unroll
-                for (int q = 0; q < VPT; ++q) vmask |= ((old[q] >> 16) == 0u ? 1u : 0u) << (16 + q);
-                for (int g = 0; g < TSL_NB; ++g) {
-                    if (!((tmall >> g) & 1u)) continue;
-                    const FrameDev& Fg = B.f[g];
-                    unsigned long long* accg = Fg.acc + (size_t)(base + g) * (TSL_BRK3 * 2);
-                    ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(accg);
-                    long long ug = 0;
-                    // the sums were produced by L2 atomics of other CUs: read them at L2 as well, CH voxels in flight per thread
-#pragma unroll
-                    for (int h = 0; h < VPT; h += CH) {
-                        long long qn[CH], qd[CH]; uint32_t nv[CH]; bool small = true;
-#pragma unroll
-                        for (int q = 0; q < CH; ++q) {
-                            const int l = (h + q) * NT + threadIdx.x;
-                            qn[q] = (long long)__hip_atomic_load(&accg[l * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            qd[q] = (long long)__hip_atomic_load(&accg[l * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-#pragma unroll
-                        for (int q = 0; q < CH; ++q) small = small && fits_i32(qn[q]) && fits_i32(qd[q]);
-                        apply_chunk<CH>(old + h, qn, qd, nv, __all(small));
-#pragma unroll
-                        for (int q = 0; q < CH; ++q) {
-                            const int l = (h + q) * NT + threadIdx.x;
-                            if (qd[q] != 0) {
-                                old[h + q] = nv[q];
-                                vmask |= 1u << (h + q);
-                                acc2[l] = make_ulonglong2(0ull, 0ull);
-                                if (TEX) {
-                                    uint32_t* wv = Fg.accw + (size_t)(base + g) * TSL_BRK3 + l;
-                                    const uint32_t wsel = __hip_atomic_load(wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l] = Fg.colpix[wsel - 1u];
-                                    *wv = 0u;
-                                }
-                                ++ug;
-                            }
-                        }
-                    }
-                    ug = wave_sum_ll(ug);
-                    if (lane_id() == 0 && ug) atomic_add_i64(&Fg.stats->unique, ug);
-                }
-#pragma unroll
-                for (int q = 0; q < VPT; ++q) {
-                    const int l = q * NT + threadIdx.x;
-                    if ((vmask >> q) & 1u) {
-                        tw[l] = old[q];
-                        if ((vmask >> (16 + q)) & 1u) obs[l] = 1;
-                    }
-                }
+            for (int q = 0; q < VPT; ++q) {
+                const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
+                acc[l] = make_ulonglong2(s_num[ls], s_den[ls]);
+                s_num[ls] = 0ull; s_den[ls] = 0ull;
+                if (TEX) { F.accw[(size_t)rk * TSL_BRK3 + l] = s_win[ls]; s_win[ls] = 0u; }
             }
         } else {                                                          // brick pool exhausted (reported by k_plan): drop the sums
             ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
@@ -1068,9 +1019,94 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
 #undef TSL_SORT_DEAL
 }
 
+// =====================================================================================================
+// k_apply_slab: the heavy bricks of a batch (k_plan's list), behind the brick kernel on the same stream.  Every part of a heavy brick
+// left its 4096 {num, den} sums in a slab slot of its own; here the parts of each (frame, brick) are added (int64: exact, order-free)
+// and the frames are applied in frame order, exactly as per-frame launches would apply them -- the brick is read once and written once
+// per batch.  One workgroup takes an eighth of a brick (2 voxels per thread): the loads of ALL frames are independent of the apply chain,
+// so they are in flight together, and the heavy bricks of a batch spread over eight workgroups each instead of serialising behind the last
+// part to arrive (round 2's ticket scheme: 25-33 us per brick on the critical path of the persistent kernel, plus an L2 atomic pair per
+// voxel and part).
+// =====================================================================================================
+#define APPLY_SPLIT 8
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_apply_slab(MapDev M, BatchDev B)
+{
+    constexpr int VP = TSL_BRK3 / APPLY_SPLIT / 256;           // voxels per thread
+    uint32_t okmask = 0u;
+#pragma unroll
+    for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
+    const int nheavy = min(B.f[0].counters[HDR_HEAVY], B.f[0].max_frame_bricks);
+    const ulonglong2* const slab = reinterpret_cast<const ulonglong2*>(B.f[0].acc);
+    for (int item = blockIdx.x; item < nheavy * APPLY_SPLIT; item += gridDim.x) {
+        const int4 e = B.f[0].heavy_tab[item / APPLY_SPLIT];
+        const int b = e.x, p = e.y;
+        const uint32_t tm = (uint32_t)e.z & okmask;
+        if (p < 0 || tm == 0u) continue;
+        const int l0 = (item % APPLY_SPLIT) * (TSL_BRK3 / APPLY_SPLIT) + (int)threadIdx.x;
+        uint32_t* tw = M.tw + (size_t)p * TSL_BRK3;
+        // three rounds of independent loads: the frames' slot words and the voxels, the first part of every frame, then the further
+        // parts of the few (frame, brick)s that have them; only then the apply chain, which is pure arithmetic
+        int w[TSL_NB];
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) w[q] = ((tm >> q) & 1u) ? B.f[q].bslab[b] : 0;
+        uint32_t cur[VP], first[VP];
+#pragma unroll
+        for (int k = 0; k < VP; ++k) { cur[k] = tw[l0 + k * 256]; first[k] = cur[k]; }
+        ulonglong2 a[TSL_NB][VP]; uint32_t win[TSL_NB][VP];
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {
+            const bool on = (tm >> q) & 1u;
+            const size_t base = (size_t)(w[q] & ((1 << SLAB_SLOT_BITS) - 1)) * TSL_BRK3 + l0;
+#pragma unroll
+            for (int k = 0; k < VP; ++k) {
+                a[q][k] = on ? slab[base + k * 256] : make_ulonglong2(0ull, 0ull);
+                win[q][k] = (TEX && on) ? B.f[q].accw[base + k * 256] : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {
+            const int np = w[q] >> SLAB_SLOT_BITS;
+            for (int j = 1; j < np; ++j) {
+                const size_t base = (size_t)((w[q] & ((1 << SLAB_SLOT_BITS) - 1)) + j) * TSL_BRK3 + l0;
+#pragma unroll
+                for (int k = 0; k < VP; ++k) {
+                    const ulonglong2 x = slab[base + k * 256];
+                    a[q][k].x += x.x; a[q][k].y += x.y;
+                    if (TEX) win[q][k] = max(win[q][k], B.f[q].accw[base + k * 256]);
+                }
+            }
+        }
+        bool changed[VP];
+#pragma unroll
+        for (int k = 0; k < VP; ++k) changed[k] = false;
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {
+            if (!((tm >> q) & 1u)) continue;                     // (uniform)
+            long long ug = 0;
+#pragma unroll
+            for (int k = 0; k < VP; ++k) {
+                if (a[q][k].y != 0ull) {
+                    cur[k] = apply_update(cur[k], (long long)a[q][k].x, (long long)a[q][k].y);
+                    changed[k] = true; ++ug;
+                    if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l0 + k * 256] = B.f[q].colpix[win[q][k] - 1u];
+                }
+            }
+            ug = wave_sum_ll(ug);
+            if (lane_id() == 0 && ug) atomic_add_i64(&B.f[q].stats->unique, ug);
+        }
+        int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
+#pragma unroll
+        for (int k = 0; k < VP; ++k) if (changed[k]) {
+            tw[l0 + k * 256] = cur[k];
+            if ((first[k] >> 16) == 0u) obs[l0 + k * 256] = 1;          // W == 0 <=> never integrated (imported voxels already carry observed = 1)
+        }
+    }
+}
+
 int check_variant2(tsl_tsdf* m)
 {
-    TSL_REQUIRE(m->F.max_frame_bricks <= 4096 && m->P.max_steps_f < (float)(1 << SEG_J_BITS) && m->F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24),
+    TSL_REQUIRE(m->F.max_frame_bricks <= 4096 && m->P.max_steps_f < (float)(1 << SEG_J_BITS) && m->F.max_points < (1 << STG_RAY_BITS) && m->nb3 < (1 << 24) && 3 * m->pcl_bits <= H_BLOCK_SHIFT,
                 "variant 2: ray too long / too many points / too many bricks for the segment key (use variant 1)");
     return TSL_OK;
 }
@@ -1088,7 +1124,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     // a unit is walked by one workgroup frame after frame, and with few frames a long unit is just a long serial item
     const int unit_max = m->unit_max <= 4096 ? m->unit_max : std::max(4096, (int)((long long)m->unit_max * B.n / TSL_NB));
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max, (unsigned long long)++m->batch_gen, m->cur);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;
@@ -1106,6 +1142,11 @@ int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hip
     if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
     else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }
 #undef TSL_LAUNCH_IB
+    // the batch's heavy bricks: parts -> map (the count lives on the device: the grid covers what a batch can list, idle workgroups leave at once)
+    prof_begin(m, TSL_K_FINALIZE);
+    if (P.tex) hipLaunchKernelGGL(k_apply_slab<true>, dim3(8 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
+    else hipLaunchKernelGGL(k_apply_slab<false>, dim3(8 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
+    prof_end(m);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }

@@ -20,7 +20,7 @@
 namespace tsl {
 
 struct PoseTab { const float* p; };
-int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst);          // tsl_fuse.hip
+int fuse_splat_into_global(tsl_tsdf* g, tsl_tsdf* sub, int* ndst, bool with_colour);          // tsl_fuse.hip
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_merge_mask(MapDev G, int nused, uint8_t* mask)
@@ -122,7 +122,7 @@ static int merge_state(tsl_tsdf* g)            // per-handle exchange scratch: m
 {
     if (g->mrg_mask) return TSL_OK;
     int rc;
-    if ((rc = dev_alloc(g, (void**)&g->mrg_mask, (size_t)g->nb3, 0))) return rc;
+    if ((rc = dev_alloc(g, (void**)&g->mrg_mask, (size_t)g->nb3 + 16, 0))) return rc;      // + a status byte that travels with the mask
     if ((rc = dev_alloc(g, (void**)&g->mrg_list, sizeof(int) * (size_t)(g->nb3 + 4), 0))) return rc;
     g->mrg_count = g->mrg_list + g->nb3;
     return TSL_OK;
@@ -145,7 +145,7 @@ int tsl_tsdf_merge_begin(tsl_tsdf* g, tsl_tsdf* sub, void* mask_dev, int64_t mas
     TSL_HIP(hipSetDevice(g->device));
     int rc = merge_state(g); if (rc) return rc;
     int ndst = 0;
-    if ((rc = fuse_splat_into_global(g, sub, &ndst))) return rc;
+    if ((rc = fuse_splat_into_global(g, sub, &ndst, false))) return rc;      // the exchange carries {sum w*t, sum w, count}: merged maps have no colour
     TSL_HIP(hipMemsetAsync(mask_dev, 0, (size_t)mask_bytes, ms(g)));
     if (ndst > 0) hipLaunchKernelGGL(k_merge_mask, dim3((ndst + 255) / 256), dim3(256), 0, ms(g), g->M, ndst, (uint8_t*)mask_dev);
     TSL_HIP(hipGetLastError());
@@ -178,6 +178,7 @@ int tsl_tsdf_merge_pack(tsl_tsdf* g, void* acc_dev, void* cnt_dev)
                                   (unsigned long long*)g->fuse_acc, (int*)g->fuse_cnt, (ulonglong2*)acc_dev, (int*)cnt_dev);
     TSL_HIP(hipGetLastError());
     TSL_HIP(hipStreamSynchronize(ms(g)));
+    g->fuse_dirty = false;                          // every brick this rank splatted into is in the union: its sums were moved out and zeroed
     return TSL_OK;
 }
 
@@ -213,23 +214,52 @@ int tsl_comm_create(const char id[128], int nranks, int rank, int device, tsl_co
 void tsl_comm_destroy(tsl_comm* c) { if (!c) return; if (g_rccl.CommDestroy && c->comm) (void)g_rccl.CommDestroy(c->comm); delete c; }
 void* tsl_comm_handle(tsl_comm* c) { return c ? (void*)c->comm : nullptr; }
 
+// A rank that fails locally (capacity error of its submaps, an allocation, RCCL not loadable) must not leave the others inside a
+// collective: every rank always runs the mask all-reduce -- a failed rank contributes an empty mask -- and a status byte travels behind
+// the mask (MAX), so that after the first exchange every rank knows whether all of them can go on.  A failure after that point (the
+// packed buffers) is exchanged the same way through a one-word all-reduce before the payload.  The error is returned on every rank.
 int tsl_tsdf_allreduce_merge(tsl_tsdf* g, tsl_tsdf* sub, void* rccl_comm, int64_t* bytes_per_rank)
 {
     TSL_REQUIRE(g && sub, "allreduce_merge: null handle");
     TSL_HIP(hipSetDevice(g->device));
-    int rc = merge_state(g); if (rc) return rc;
-    if (rccl_comm) { rc = rccl_load(); if (rc) return rc; }
+    if (rccl_comm) { const int rc0 = rccl_load(); if (rc0) return rc0; }          // nothing collective can be issued without it
     ncclComm_t comm = (ncclComm_t)rccl_comm;
-    if ((rc = tsl_tsdf_merge_begin(g, sub, g->mrg_mask, g->nb3))) return rc;
-    hipStream_t st = ms(g);
+    int rc = merge_state(g);
+    if (rc) return rc;                              // (out of memory before anything was exchanged: the peers see the communicator fail)
+    std::string first_err;
+    int local = tsl_tsdf_merge_begin(g, sub, g->mrg_mask, g->nb3);
+    if (local) { first_err = tsl_last_error(); (void)hipMemsetAsync(g->mrg_mask, 0, (size_t)g->nb3, g->stream_); }
+    hipStream_t st = g->stream_;
     int64_t bytes = 0;
-    if (comm) { TSL_NCCL(g_rccl.AllReduce(g->mrg_mask, g->mrg_mask, (size_t)g->nb3, ncclUint8, ncclMax, comm, st)); bytes += g->nb3; }
+    uint8_t status = local ? 1 : 0;
+    TSL_HIP(hipMemcpyAsync(g->mrg_mask + g->nb3, &status, 1, hipMemcpyHostToDevice, st));
+    TSL_HIP(hipStreamSynchronize(st));
+    if (comm) { TSL_NCCL(g_rccl.AllReduce(g->mrg_mask, g->mrg_mask, (size_t)g->nb3 + 1, ncclUint8, ncclMax, comm, st)); bytes += g->nb3 + 1; }
+    TSL_HIP(hipMemcpyAsync(&status, g->mrg_mask + g->nb3, 1, hipMemcpyDeviceToHost, st));
+    TSL_HIP(hipStreamSynchronize(st));
+    if (status) {
+        g->mrg_nunion = -1;
+        if (local) { set_error("allreduce_merge: " + first_err); return local; }
+        set_error("allreduce_merge: another rank failed before the exchange; nothing was merged");
+        return TSL_ERR_HIP;
+    }
     int32_t n = 0;
-    if ((rc = tsl_tsdf_merge_union(g, g->mrg_mask, &n))) return rc;
-    const size_t nv = (size_t)n * TSL_BRK3;
-    if ((rc = grow(&g->mrg_pacc, &g->mrg_pacc_bytes, nv * 16 + 16))) return rc;
-    if ((rc = grow(&g->mrg_pcnt, &g->mrg_pcnt_bytes, nv * 4 + 16))) return rc;
-    if ((rc = tsl_tsdf_merge_pack(g, g->mrg_pacc, g->mrg_pcnt))) return rc;
+    local = tsl_tsdf_merge_union(g, g->mrg_mask, &n);
+    const size_t nv = (size_t)(local ? 0 : n) * TSL_BRK3;
+    if (!local) local = grow(&g->mrg_pacc, &g->mrg_pacc_bytes, nv * 16 + 16);
+    if (!local) local = grow(&g->mrg_pcnt, &g->mrg_pcnt_bytes, nv * 4 + 16);
+    if (!local) local = tsl_tsdf_merge_pack(g, g->mrg_pacc, g->mrg_pcnt);
+    if (local) first_err = tsl_last_error();
+    if (comm) {                                     // second status exchange: one word
+        int* word = g->mrg_list + g->nb3 + 1;
+        int hs = local ? 1 : 0;
+        TSL_HIP(hipMemcpyAsync(word, &hs, sizeof(int), hipMemcpyHostToDevice, st));
+        TSL_NCCL(g_rccl.AllReduce(word, word, 1, ncclInt32, ncclMax, comm, st));
+        TSL_HIP(hipMemcpyAsync(&hs, word, sizeof(int), hipMemcpyDeviceToHost, st));
+        TSL_HIP(hipStreamSynchronize(st));
+        if (hs && !local) { set_error("allreduce_merge: another rank failed while packing; nothing was merged"); g->mrg_nunion = -1; return TSL_ERR_HIP; }
+    }
+    if (local) { set_error("allreduce_merge: " + first_err); g->mrg_nunion = -1; return local; }
     if (comm && n > 0) {
         TSL_NCCL(g_rccl.AllReduce(g->mrg_pacc, g->mrg_pacc, nv * 2, ncclInt64, ncclSum, comm, st));
         TSL_NCCL(g_rccl.AllReduce(g->mrg_pcnt, g->mrg_pcnt, nv, ncclInt32, ncclSum, comm, st));

@@ -299,4 +299,18 @@ int tsl_mesh_read(tsl_tsdf* m, float* verts, float* normals, float* colors, int6
     return TSL_OK;
 }
 
+/* mesh_vertices / mesh_normals / mesh_colors as DEVICE pointers (f32 [3 * max_triangles][3]; colours NULL for untextured maps) and the
+ * triangle count of the last tsl_mesh_generate -- taichislam_node.py:342 hands the mesh to the renderer without a host copy.  The
+ * pointers change when a later tsl_mesh_generate asks for a larger max_triangles. */
+int tsl_mesh_buffers_dev(tsl_tsdf* m, void** verts_dev, void** normals_dev, void** colors_dev, int32_t* n_tri)
+{
+    TSL_REQUIRE(m, "mesh_buffers_dev: null handle"); TSL_REQUIRE(m->mesh_v && m->mesh_count, "mesh_buffers_dev: call tsl_mesh_generate first");
+    TSL_HIP(hipSetDevice(m->device));
+    if (verts_dev) *verts_dev = m->mesh_v; if (normals_dev) *normals_dev = m->mesh_n; if (colors_dev) *colors_dev = m->mesh_c;
+    TSL_HIP(hipMemcpyAsync(m->h_ints, m->mesh_count, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
+    TSL_HIP(hipStreamSynchronize(ms(m)));
+    if (n_tri) *n_tri = m->h_ints[0];
+    return TSL_OK;
+}
+
 }  // extern "C"

@@ -432,24 +432,36 @@ int tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], 
     TSL_HIP(hipStreamSynchronize(m->stream));
     return tsl_octo_integrate_depth_dev(m, R, T, m->stage, h, w, use_tex ? m->stage_tex : nullptr, th, tw);
 }
+/* recast_pcl_to_map with DEVICE buffers: xyz f32 [n][3], rgb u8 [n][3] or NULL (taichi_octomap.py:126-128,134-145).  Enqueued on the
+ * handle's stream; the buffers must be complete (the caller's producing stream synchronised) and stay unchanged until tsl_octo_sync. */
+int tsl_octo_integrate_points_dev(tsl_octo* m, const double R[9], const double T[3], const void* xyz_dev, const void* rgb_dev, int64_t n)
+{
+    TSL_REQUIRE(m && R && T, "octo integrate_points: null argument"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz_dev) && n < (1ll << 31), "octo integrate_points: bad input");
+    TSL_HIP(hipSetDevice(m->device));
+    octo_fill_pose(m, R, T);
+    m->p_used = n;
+    const bool use_tex = m->M.col && rgb_dev && n > 0;
+    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    if (n == 0) return TSL_OK;
+    if (use_tex) { int rc = octo_leaf_scratch(m, (size_t)n); if (rc) return rc; }
+    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)xyz_dev, (int)n, m->stats, use_tex ? m->leaf_of : nullptr);
+    if (use_tex) hipLaunchKernelGGL(k_octo_colour, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, (const uint8_t*)rgb_dev, (const long long*)m->leaf_of, (int)n, 1);
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
 int tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n)
 {
     TSL_REQUIRE(m && R && T, "octo integrate_points: null argument"); TSL_REQUIRE(n >= 0 && (n == 0 || xyz) && n < (1ll << 31), "octo integrate_points: bad input");
     TSL_HIP(hipSetDevice(m->device));
-    octo_fill_pose(m, R, T);
-    m->p_used = n;
     const bool use_tex = m->M.col && rgb && n > 0;
-    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
-    if (n == 0) return TSL_OK;
-    const size_t nb = (size_t)n * 12;
-    if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
-    TSL_HIP(hipMemcpyAsync(m->stage, xyz, nb, hipMemcpyHostToDevice, m->stream));
-    if (use_tex) { int rc = octo_stage_tex(m, rgb, (size_t)n * 3); if (rc) return rc; rc = octo_leaf_scratch(m, (size_t)n); if (rc) return rc; }
-    TSL_HIP(hipStreamSynchronize(m->stream));
-    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)m->stage, (int)n, m->stats, use_tex ? m->leaf_of : nullptr);
-    if (use_tex) hipLaunchKernelGGL(k_octo_colour, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, (const uint8_t*)m->stage_tex, (const long long*)m->leaf_of, (int)n, 1);
-    TSL_HIP(hipGetLastError());
-    return TSL_OK;
+    if (n > 0) {
+        const size_t nb = (size_t)n * 12;
+        if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
+        TSL_HIP(hipMemcpyAsync(m->stage, xyz, nb, hipMemcpyHostToDevice, m->stream));
+        if (use_tex) { int rc = octo_stage_tex(m, rgb, (size_t)n * 3); if (rc) return rc; }
+        TSL_HIP(hipStreamSynchronize(m->stream));
+    }
+    return tsl_octo_integrate_points_dev(m, R, T, m->stage, use_tex ? m->stage_tex : nullptr, n);
 }
 int tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out)
 {
@@ -508,6 +520,38 @@ int tsl_octo_read_exports(tsl_octo* m, float* xyz, float* rgb, int64_t n)
     TSL_HIP(hipStreamSynchronize(m->stream));
     if (n && xyz) TSL_HIP(hipMemcpy(xyz, m->exp_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
     if (n && rgb) TSL_HIP(hipMemcpy(rgb, m->exp_rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    return TSL_OK;
+}
+/* export_x / export_color as DEVICE pointers (f32 [max_disp_particles][3], valid for the lifetime of the handle) + num_export_particles */
+int tsl_octo_exports_dev(tsl_octo* m, void** xyz_dev, void** rgb_dev, int32_t* n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
+    if (xyz_dev) *xyz_dev = m->exp_xyz; if (rgb_dev) *rgb_dev = m->exp_rgb;
+    int v = 0; const int rc = octo_read_int(m, m->num_particles, &v); if (rc) return rc;
+    if (n) *n = v;
+    return TSL_OK;
+}
+/* the first n rows of export_x [+ export_color] as the data block of a sensor_msgs/PointCloud2 (interleaved f32 x y z [r g b], point_step
+ * 12 / 24): what scripts/taichislam_node.py:330-333 + utils/ros_pcl_transfer.py:96-136 assemble from the numpy copies, interleaved on
+ * the device */
+__global__ void __launch_bounds__(256) k_octo_pack_pointcloud2(const float* __restrict__ xyz, const float* __restrict__ rgb, float* __restrict__ out, long long n, int stride)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n * stride) return;
+    const long long row = q / stride; const int c = (int)(q - row * stride);
+    out[q] = c < 3 ? xyz[row * 3 + c] : rgb[row * 3 + c - 3];
+}
+int tsl_octo_pack_pointcloud2(tsl_octo* m, int has_rgb, int64_t n, void* out_host)
+{
+    TSL_REQUIRE(m && (n == 0 || out_host), "octo pack_pointcloud2: null argument"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "octo pack_pointcloud2: n out of range");
+    TSL_HIP(hipSetDevice(m->device));
+    if (n == 0) return TSL_OK;
+    const int stride = has_rgb ? 6 : 3;
+    const size_t need = sizeof(float) * (size_t)stride * (size_t)n;
+    if (m->xbuf_bytes < need) { if (m->xbuf) (void)hipFree(m->xbuf); m->xbuf = nullptr; TSL_HIP(hipMalloc(&m->xbuf, need + 4096)); m->xbuf_bytes = need + 4096; }
+    hipLaunchKernelGGL(k_octo_pack_pointcloud2, dim3((unsigned)(((long long)n * stride + 255) / 256)), dim3(256), 0, m->stream, m->exp_xyz, m->exp_rgb, (float*)m->xbuf, (long long)n, stride);
+    TSL_HIP(hipMemcpyAsync(out_host, m->xbuf, need, hipMemcpyDeviceToHost, m->stream));
+    TSL_HIP(hipStreamSynchronize(m->stream));
     return TSL_OK;
 }
 int tsl_octo_num_particles(tsl_octo* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device)); int v = 0; int rc = octo_read_int(m, m->num_particles, &v); *n = v; return rc; }

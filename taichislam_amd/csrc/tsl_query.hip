@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_query_points(MapDev M, int s, float vs,
 __global__ void __launch_bounds__(256) k_query_raycast(MapDev M, int s, float vs_f, float vs_len, float thres, float max_dist, const float* __restrict__ pos,
                                                        const float* __restrict__ dir, long long n, uint8_t* hit, float* end_xyz, float* len)
 {
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const int steps = (int)(max_dist / vs_f);                                                                // :167, range() truncates
     float x[3] = { 0.0f, 0.0f, 0.0f }, l = 0.0f; bool succ = false;
@@ -91,6 +91,55 @@ int tsl_tsdf_query_raycast(tsl_tsdf* m, const float* pos, const float* dir, floa
     TSL_HIP(hipMemcpy(end_xyz, dend, c * 12, hipMemcpyDeviceToHost));
     TSL_HIP(hipMemcpy(len, dlen, c * 4, hipMemcpyDeviceToHost));
     return TSL_OK;
+}
+
+// ---- device-buffer forms: nothing is staged, nothing is waited for.  The queries are launched on the handle's stream -- behind every frame
+// queued so far -- after what `user_stream` (a hipStream_t, e.g. torch's current stream; NULL = the legacy default stream, which is what
+// torch uses unless told otherwise) has queued, and `user_stream` is made to wait for them: a planner that expands a node with 64-128
+// rays (topo_graph.py:444-507) pays two event operations and one launch, no host round trip.
+static int order_before(tsl_tsdf* m, hipStream_t user, hipStream_t q)
+{
+    if (user == q) return TSL_OK;
+    if (!m->in_ev[0]) for (auto& e : m->in_ev) TSL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t e = m->in_ev[m->in_ev_next]; m->in_ev_next = (m->in_ev_next + 1) % 8;
+    TSL_HIP(hipEventRecord(e, user));
+    TSL_HIP(hipStreamWaitEvent(q, e, 0));
+    return TSL_OK;
+}
+static int order_after(tsl_tsdf* m, hipStream_t user, hipStream_t q)
+{
+    if (user == q) return TSL_OK;
+    hipEvent_t e = m->in_ev[m->in_ev_next]; m->in_ev_next = (m->in_ev_next + 1) % 8;
+    TSL_HIP(hipEventRecord(e, q));
+    TSL_HIP(hipStreamWaitEvent(user, e, 0));
+    return TSL_OK;
+}
+
+int tsl_tsdf_query_points_dev(tsl_tsdf* m, int mode, int param, const void* xyz_dev, int64_t n, void* out_dev, void* user_stream)
+{
+    TSL_REQUIRE(m && n >= 0 && (n == 0 || (xyz_dev && out_dev)), "query_points_dev: bad argument"); TSL_REQUIRE(mode >= 0 && mode <= 2 && param >= 0 && param <= 16, "query_points_dev: bad mode");
+    if (n == 0) return TSL_OK;
+    TSL_HIP(hipSetDevice(m->device));
+    hipStream_t q = ms(m);
+    int rc = order_before(m, (hipStream_t)user_stream, q); if (rc) return rc;
+    hipLaunchKernelGGL(k_query_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, m->M, m->cfg.is_global_map ? 0 : m->active, m->P.vs, m->surf_thres, mode, param,
+                       (const float*)xyz_dev, (long long)n, (uint8_t*)out_dev);
+    TSL_HIP(hipGetLastError());
+    return order_after(m, (hipStream_t)user_stream, q);
+}
+
+int tsl_tsdf_query_raycast_dev(tsl_tsdf* m, const void* pos_dev, const void* dir_dev, float max_dist, int64_t n, void* hit_dev, void* end_xyz_dev, void* len_dev, void* user_stream)
+{
+    TSL_REQUIRE(m && n >= 0 && (n == 0 || (pos_dev && dir_dev && hit_dev && end_xyz_dev && len_dev)), "query_raycast_dev: bad argument");
+    if (n == 0) return TSL_OK;
+    TSL_HIP(hipSetDevice(m->device));
+    hipStream_t q = ms(m);
+    int rc = order_before(m, (hipStream_t)user_stream, q); if (rc) return rc;
+    // rays are short serial chains (max_dist / voxel steps of dependent gathers): 64 threads per workgroup spread a 128-ray batch over two CUs
+    hipLaunchKernelGGL(k_query_raycast, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, q, m->M, m->cfg.is_global_map ? 0 : m->active, m->P.vs, (float)m->cfg.voxel_scale,
+                       m->surf_thres, max_dist, (const float*)pos_dev, (const float*)dir_dev, (long long)n, (uint8_t*)hit_dev, (float*)end_xyz_dev, (float*)len_dev);
+    TSL_HIP(hipGetLastError());
+    return order_after(m, (hipStream_t)user_stream, q);
 }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ template <> struct KeyOps<uint64_t> {
 // ------------------------------------------------------------------------------------------------------
 // K1: depth image -> sensor-centred voxel key + f16 payload       dense_tsdf.py:188-213, process_point :227-229
 // ------------------------------------------------------------------------------------------------------
-template <typename K> __device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first, int log2n);
+__device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long long vkey, uint32_t pid, int log2n, bool* opened, int* xslot);
 
 template <typename K>
 __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
     const int jj = ty * 16 + ((int)threadIdx.x >> 4), ii = tx * 16 + ((int)threadIdx.x & 15);
     const int p = jj * P.ww + ii;                                                    // pixel id = raster order
     bool gate = false, inside = false, opened = false;
-    int slot = -1;
+    int slot = -1, xslot = -1;
     if (jj < P.hh && ii < P.ww) {
         const int j = jj * P.step, i = ii * P.step;
         const uint16_t d = depth[(size_t)j * P.W + i];
@@ -101,10 +101,13 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
             }
         }
         F.pix[p] = payload;
-        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened, P.hlog2); F.slot_of_pix[p] = slot; }
+        if (P.group) { if (inside) slot = group_insert(F, (unsigned long long)key, (uint32_t)p, P.hlog2, &opened, &xslot); }
         else { keys[p] = key; F.vals[p] = (uint32_t)p; }
     }
-    if (P.group) { const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot; }
+    if (P.group) {
+        const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot;          // position in the list = ray id
+        const int x = wave_reserve(&F.counters[7], xslot >= 0); if (xslot >= 0) F.actx[x] = xslot;   // (rare) overflow slots: listed to be cleared
+    }
     block_count_add(&F.stats->p_valid, inside);
     block_count_add(&F.stats->p_oob, gate && !inside);
 }
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(256) k_voxelize_points(BatchDev B)
     const int n = P.total;
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool gate = false, inside = false, opened = false;
-    int slot = -1;
+    int slot = -1, xslot = -1;
     if (p < n) {
         const float px = xyz[(size_t)p * 3], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
         const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;                   // :175
@@ -143,10 +146,13 @@ __global__ void __launch_bounds__(256) k_voxelize_points(BatchDev B)
             }
         }
         F.pix[p] = payload;
-        if (P.group) { if (inside) slot = group_insert<K>(F, key, &opened, P.hlog2); F.slot_of_pix[p] = slot; }
+        if (P.group) { if (inside) slot = group_insert(F, (unsigned long long)key, (uint32_t)p, P.hlog2, &opened, &xslot); }
         else { keys[p] = key; F.vals[p] = (uint32_t)p; }
     }
-    if (P.group) { const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot; }
+    if (P.group) {
+        const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot;          // position in the list = ray id
+        const int x = wave_reserve(&F.counters[7], xslot >= 0); if (xslot >= 0) F.actx[x] = xslot;   // (rare) overflow slots: listed to be cleared
+    }
     block_count_add(&F.stats->p_valid, inside);
     block_count_add(&F.stats->p_oob, gate && !inside);
 }
@@ -183,150 +189,36 @@ __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restric
     block_count_add(&F.stats->v_skipped, head && !ok);
 }
 
-// (b) pixels grouped through a hash table of sensor voxels (no sort): k_voxelize_* insert every pixel and count per voxel,
-// k_group_scan lays the groups out, k_group_fill writes each pixel id into its group (arrival order), and here one thread
-// per voxel walks its group in ASCENDING pixel id -- i.e. raster order -- by repeated selection of the next larger id.
-// Groups are small (a sensor voxel rarely sees more than a dozen pixels); groups above GROUP_SMALL are sorted by a whole
-// workgroup in k_build_rays_big.
-#define GROUP_BIG_CAP 16384
-#define H_EMPTY32 0xffffffffu
-template <typename K> __device__ __forceinline__ K h_empty() { return (K)~(K)0; }
-template <typename K> __device__ __forceinline__ uint32_t h_hash(K key, int log2n)
-{ return (uint32_t)(((unsigned long long)key * 0x9E3779B97F4A7C15ull) >> (64 - log2n)); }
-
-// insert pixel p's sensor voxel; returns the table slot.  *first = this pixel opened the voxel in this frame
-template <typename K>
-__device__ __forceinline__ int group_insert(const FrameDev& F, K key, bool* first, int log2n)
+// (b) pixels grouped through a hash table of sensor voxels (no sort, brick-binned path): k_voxelize_* insert every pixel into its
+// voxel's slot -- find-or-insert CAS on the key, a returning add on the count, and the pixel id goes into the slot itself (HSlot,
+// tsl_tsdf.hpp) -- and k_segments reads a voxel's pixels back with one 64-byte load and replays them in ASCENDING pixel id, i.e. raster
+// order.  Returns the slot of the voxel; *opened = this pixel opened the voxel in this frame; *xslot = overflow slot this pixel opened (or -1).
+__device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long long vkey, uint32_t pid, int log2n, bool* opened, int* xslot)
 {
-    K* tab = reinterpret_cast<K*>(F.hkey);
+    HSlot* const tab = F.htab;
     const uint32_t mask = (1u << log2n) - 1u;
-    uint32_t h = h_hash<K>(key, log2n);
+    const unsigned long long k0 = h_key(vkey, 0);
+    uint32_t h = h_hash64(k0, log2n);
     for (;;) {
-        const K cur = atomicCAS(&tab[h], h_empty<K>(), key);
-        if (cur == h_empty<K>() || cur == key) break;
+        const unsigned long long cur = atomicCAS(&tab[h].key, H_EMPTY, k0);
+        if (cur == H_EMPTY) { *opened = true; break; }
+        if (cur == k0) break;
         h = (h + 1u) & mask;
     }
-    *first = atomicAdd(&F.hcnt[h], 1) == 0;
+    const int r = atomicAdd(&tab[h].cnt, 1);
+    if (r < H_INL) tab[h].pix[r] = pid;
+    else {      // crowded voxel: pixels H_INL.. live in slots keyed (voxel, block)
+        const unsigned long long k2 = h_key(vkey, r / H_INL);
+        uint32_t h2 = h_hash64(k2, log2n);
+        for (;;) {
+            const unsigned long long cur = atomicCAS(&tab[h2].key, H_EMPTY, k2);
+            if (cur == H_EMPTY) { *xslot = (int)h2; break; }
+            if (cur == k2) break;
+            h2 = (h2 + 1u) & mask;
+        }
+        tab[h2].pix[r % H_INL] = pid;
+    }
     return (int)h;
-}
-
-__global__ void __launch_bounds__(256) k_group_scan(BatchDev B)
-{
-    if ((int)blockIdx.y >= B.n) return;
-    const FrameDev& F = B.f[blockIdx.y];
-    // list position of every group: groups only have to be contiguous, not ordered, so a block-aggregated reservation
-    // of `count` entries replaces a prefix scan
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int nact = F.counters[6];
-    if ((int)blockIdx.x * 256 >= nact) return;
-    const int sl = i < nact ? F.act[i] : 0;
-    const int c = i < nact ? F.hcnt[sl] : 0;
-    int inc = c;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-    if (lane == 63) s_wave[w] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = atomicAdd(&F.counters[0], s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
-    __syncthreads();
-    int off = s_base + inc - c;
-    for (int q = 0; q < w; ++q) off += s_wave[q];
-    if (i < nact) F.hoff[sl] = off;
-}
-
-__global__ void __launch_bounds__(256) k_group_fill(BatchDev B)
-{
-    if ((int)blockIdx.y >= B.n) return;
-    const FrameDev& F = B.f[blockIdx.y];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= B.p[blockIdx.y]->total) return;
-    const int sl = F.slot_of_pix[p];
-    if (sl < 0) return;
-    F.plist[F.hoff[sl] + atomicAdd(&F.hfill[sl], 1)] = (uint32_t)p;
-}
-
-template <typename K>
-__global__ void __launch_bounds__(256) k_build_rays_hash(const FrameParams* __restrict__ Pp, FrameDev F)
-{
-    const FrameParams& P = *Pp;
-    const int nact = F.counters[6];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool head = false, ok = false, big = false;
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    int nsteps = 0;
-    uint32_t first = 0;
-    if (i < nact) {
-        const int sl = F.act[i];
-        const int n = F.hcnt[sl];
-        const uint32_t* ids = F.plist + F.hoff[sl];
-        if (n > GROUP_SMALL) big = true;
-        else {
-            head = true;
-            PixAcc A = {};
-            long long last = -1;
-            for (int k = 0; k < n; ++k) {                                            // next pixel in raster order
-                uint32_t best = 0xffffffffu;
-                for (int q = 0; q < n; ++q) { const uint32_t v = ids[q]; if ((long long)v > last && v < best) best = v; }
-                if (k == 0) first = best;
-                acc_pixel(P, F, best, A);
-                last = (long long)best;
-            }
-            ok = finish_ray(P, F, A, first, &rec, &nsteps);
-            reinterpret_cast<K*>(F.hkey)[sl] = h_empty<K>(); F.hcnt[sl] = 0; F.hfill[sl] = 0;      // table is empty again for the next frame of this set
-        }
-    }
-    const int bq = block_reserve(&F.counters[7], big);
-    if (big) F.big[bq] = F.act[i];
-    const int r = block_reserve(F.nrays, ok);
-    if (ok) { F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = first; }
-    block_count_add(&F.stats->v_pcl, head);
-    block_count_add(&F.stats->v_skipped, head && !ok);
-}
-
-// big groups: one workgroup per sensor voxel, ids bitonic-sorted in LDS, thread 0 replays them
-template <typename K>
-__global__ void __launch_bounds__(256) k_build_rays_big(const FrameParams* __restrict__ Pp, FrameDev F, MapDev M)
-{
-    const FrameParams& P = *Pp;
-    __shared__ uint32_t s_id[GROUP_BIG_CAP];
-    const int nbig = F.counters[7];
-    for (int g = blockIdx.x; g < nbig; g += gridDim.x) {
-        const int sl = F.big[g];
-        const int n = F.hcnt[sl];
-        const uint32_t* ids = F.plist + F.hoff[sl];
-        if (n > GROUP_BIG_CAP) { if (threadIdx.x == 0) atomicOr(M.err, 8); }
-        else {
-            int m2 = 1; while (m2 < n) m2 <<= 1;
-            for (int q = threadIdx.x; q < m2; q += 256) s_id[q] = q < n ? ids[q] : 0xffffffffu;
-            __syncthreads();
-            for (int k = 2; k <= m2; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int q = threadIdx.x; q < m2; q += 256) {
-                        const int x = q ^ j;
-                        if (x > q) {
-                            const uint32_t a = s_id[q], b = s_id[x];
-                            const bool up = (q & k) == 0;
-                            if ((a > b) == up) { s_id[q] = b; s_id[x] = a; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            if (threadIdx.x == 0) {
-                PixAcc A = {};
-                for (int q = 0; q < n; ++q) acc_pixel(P, F, s_id[q], A);
-                uint4 rec; int nsteps = 0;
-                const bool ok = finish_ray(P, F, A, s_id[0], &rec, &nsteps);
-                if (ok) {
-                    const int r = __hip_atomic_fetch_add(F.nrays, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    F.rayA[r] = rec; F.rayN[r] = nsteps; F.rayFirst[r] = s_id[0];
-                } else atomic_add_i64(&F.stats->v_skipped, 1);
-                atomic_add_i64(&F.stats->v_pcl, 1);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { reinterpret_cast<K*>(F.hkey)[sl] = h_empty<K>(); F.hcnt[sl] = 0; F.hfill[sl] = 0; }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -612,18 +504,7 @@ static int enqueue_phase_a(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp
     if (any_points) hipLaunchKernelGGL(k_voxelize_points<K>, dim3(blocks, n), dim3(256), 0, sa, B);
     if (any_depth) hipLaunchKernelGGL(k_voxelize_depth<K>, dim3(tiles, n), dim3(256), 0, sa, B);
     prof_end(m, sa);
-    if (P0.group) {
-        prof_begin(m, TSL_K_SORT, sa);
-        hipLaunchKernelGGL(k_group_scan, dim3(blocks, n), dim3(256), 0, sa, B);
-        hipLaunchKernelGGL(k_group_fill, dim3(blocks, n), dim3(256), 0, sa, B);
-        prof_end(m, sa);
-        if (P0.variant != 2) {      // variant 2 builds the rays inside k_segments
-            prof_begin(m, TSL_K_RAYS, sa);
-            hipLaunchKernelGGL(k_build_rays_hash<K>, dim3(blocks), dim3(256), 0, sa, B.p[0], B.f[0]);
-            hipLaunchKernelGGL(k_build_rays_big<K>, dim3(64), dim3(256), 0, sa, B.p[0], B.f[0], m->M);
-            prof_end(m, sa);
-        }
-    } else {
+    if (!P0.group) {          // stable radix sort of the sensor-voxel keys (per frame: batches of one)
         const FrameDev& F = B.f[0];
         prof_begin(m, TSL_K_SORT, sa);
         size_t tb = m->sort_temp_bytes;
@@ -661,6 +542,7 @@ static int launch_batch_t(tsl_tsdf* m)
         if (m->ring_upto[ring] > m->frames_consumed) m->frames_consumed = m->ring_upto[ring];
     }
     if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
+    if (!serial && m->esdf_gate_set) { TSL_HIP(hipStreamWaitEvent(sa, m->esdf_gate, 0)); m->esdf_gate_set = false; }      // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip)
     for (int k = 0; k < m->nproducers; ++k) {       // device inputs: phase A waits for what their producers had queued (tsl_tsdf_input_stream)
         if (m->producers[k] == sa) continue;
         if (!m->in_ev[0]) for (auto& e : m->in_ev) TSL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -765,8 +647,6 @@ static int ensure_frame_scratch(tsl_tsdf* m)
     if ((rc = dev_alloc(m, (void**)&F.touched_b, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&F.dbg, sizeof(long long) * 16384 * 16, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.ticket, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&F.npf, sizeof(int) * (size_t)F.max_frame_bricks, 0))) return rc;
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&F.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3, 0))) return rc; }
     for (int si = 0; si < TSL_NSETS; ++si) {
         FSet& S = m->fset[si];
@@ -777,10 +657,8 @@ static int ensure_frame_scratch(tsl_tsdf* m)
             FrameDev& G0 = m->fset[(si / TSL_NB) * TSL_NB].F;
             if (si % TSL_NB == 0) {
                 if ((rc = own((void**)&G.acc, 16 * (size_t)F.max_frame_bricks * TSL_BRK3))) return rc;
-                if ((rc = own((void**)&G.ticket, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
-                if ((rc = own((void**)&G.npf, sizeof(int) * (size_t)F.max_frame_bricks))) return rc;
                 if (cfg->texture_enabled) { if ((rc = own((void**)&G.accw, 4 * (size_t)F.max_frame_bricks * TSL_BRK3))) return rc; }
-            } else { G.acc = G0.acc; G.ticket = G0.ticket; G.npf = G0.npf; G.accw = G0.accw; }
+            } else { G.acc = G0.acc; G.accw = G0.accw; }
         }
         if ((rc = own((void**)&G.keys, 8 * np))) return rc;
         if ((rc = own((void**)&G.keys_s, 8 * np))) return rc;
@@ -790,18 +668,14 @@ static int ensure_frame_scratch(tsl_tsdf* m)
         if ((rc = own((void**)&G.rayA, 16 * np))) return rc;
         if ((rc = own((void**)&G.rayN, 4 * np))) return rc;
         if ((rc = own((void**)&G.rayFirst, 4 * np))) return rc;
-        {   // sensor-voxel hash table (>= 4 entries per possible point) and the group lists
-            int lg = 10; while ((1ll << lg) < 4 * (long long)np) ++lg;
-            G.hlog2 = lg; G.hwide = m->pcl_bits > 10;
-            const size_t hs = (size_t)1 << lg;
-            if ((rc = dev_alloc(m, &G.hkey, 8 * hs, 0xff))) return rc; S.owned.push_back(G.hkey);
-            if ((rc = own((void**)&G.hcnt, 4 * hs))) return rc;
-            if ((rc = own((void**)&G.hoff, 4 * hs))) return rc;
-            if ((rc = own((void**)&G.hfill, 4 * hs))) return rc;
-            if ((rc = own((void**)&G.slot_of_pix, 4 * np))) return rc;
+        {   // sensor-voxel hash table: >= 2 slots per possible point (a frame uses the power-of-two part that holds 2 per VISITED pixel)
+            int lg = 10; while ((1ll << lg) < 2 * (long long)np) ++lg;
+            G.hlog2 = lg;
+            void* tab = nullptr;
+            if ((rc = dev_alloc(m, &tab, sizeof(HSlot) << lg, 0))) return rc;         // all slots empty
+            S.owned.push_back(tab); G.htab = static_cast<HSlot*>(tab);
             if ((rc = own((void**)&G.act, 4 * np))) return rc;
-            if ((rc = own((void**)&G.plist, 4 * np))) return rc;
-            if ((rc = own((void**)&G.big, 4 * (np / GROUP_SMALL + 16)))) return rc;
+            if ((rc = own((void**)&G.actx, 4 * np))) return rc;
         }
         if (cfg->texture_enabled) { if ((rc = own((void**)&G.colpix, 8 * np))) return rc; }
         S.header_bytes = 256;
@@ -815,11 +689,15 @@ static int ensure_frame_scratch(tsl_tsdf* m)
         if ((rc = own((void**)&G.bcursor, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.boffset, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.bnseg, sizeof(int) * (size_t)m->nb3))) return rc;
+        if ((rc = own((void**)&G.bslab, sizeof(int) * (size_t)m->nb3))) return rc;
         if ((rc = own((void**)&G.act_b, sizeof(int) * (size_t)(F.max_frame_bricks + 8)))) return rc;
         G.part_cap = F.seg_cap / 256 + F.max_frame_bricks + 8;
         if ((rc = own((void**)&G.part_tab, sizeof(int4) * 4 * (size_t)G.part_cap))) return rc;
         G.unit_cap = TSL_NB * F.max_frame_bricks;
-        if (si % TSL_NB == 0) { if ((rc = own((void**)&G.unit_tab, sizeof(int4) * 4 * (size_t)G.unit_cap))) return rc; }
+        if (si % TSL_NB == 0) {
+            if ((rc = own((void**)&G.unit_tab, sizeof(int4) * 4 * (size_t)G.unit_cap))) return rc;
+            if ((rc = own((void**)&G.heavy_tab, sizeof(int4) * (size_t)(F.max_frame_bricks + 8)))) return rc;
+        }
         if ((rc = own(&S.sort_temp, m->sort_temp_bytes + 256))) return rc;
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
     }
@@ -847,6 +725,7 @@ static int queue_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, 
     m->clean = false;
     m->pend_points = P.points;
     m->pend[m->npend] = P;
+    m->pend[m->npend].group = (P.group && P.variant == 2) ? 1 : 0;      // the hash grouping feeds the brick-binned path; the global-atomics variants group by sorting
     m->last_set = m->cur * TSL_NB + m->npend;
     m->npend++;
     // ramp-up: the first batches after the pipeline ran dry are half batches -- a burst gets its first phase A (and with it the
@@ -975,8 +854,8 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
-    m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
+    m->esdf = nullptr; m->esdf_gate = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
@@ -995,7 +874,6 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     if (cfg->texture_enabled) { if ((rc = dev_alloc(m, (void**)&M.col, sizeof(uint16_t) * 4 * (size_t)want * TSL_BRK3, 0))) return rc; }
     if ((rc = dev_alloc(m, (void**)&M.owner, sizeof(int) * (size_t)want, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.touch, (size_t)want, 0))) return rc;
-    if ((rc = dev_alloc(m, (void**)&M.slab_of, sizeof(unsigned long long) * (size_t)want * TSL_NBATCH, 0))) return rc;
     if ((rc = dev_alloc(m, (void**)&M.pool_top, sizeof(int) * 4, 0))) return rc;
     M.err = M.pool_top + 1;
 
@@ -1083,9 +961,9 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
 
     }
     esdf_release(m);
-    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg, m->F.ticket, m->F.npf,
+    void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
-                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_note, m->M.touch, m->M.slab_of, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_note, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
                      m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
@@ -1416,6 +1294,17 @@ int tsl_tsdf_read_exports(tsl_tsdf* m, float* xyz, float* rgb, float* val, int64
     if (val) TSL_HIP(hipMemcpy(val, m->exp_val, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     return TSL_OK;
 }
+/* export_TSDF_xyz / export_color / export_TSDF as DEVICE pointers (f32 [max_disp_particles][3] / [3] / [1], valid for the lifetime of the
+ * handle) and the particle count of the last cvt_* call: what taichislam_node.py:350-351 copies to numpy with .to_numpy(), for consumers
+ * that stay on the GPU (torch tensors, a renderer).  Synchronises the handle's stream: the buffers are complete on return. */
+int tsl_tsdf_exports_dev(tsl_tsdf* m, void** xyz_dev, void** rgb_dev, void** val_dev, int32_t* n)
+{
+    TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
+    if (xyz_dev) *xyz_dev = m->exp_xyz; if (rgb_dev) *rgb_dev = m->exp_rgb; if (val_dev) *val_dev = m->exp_val;
+    int v = 0; const int rc = read_int(m, m->num_particles, &v); if (rc) return rc;      // (synchronises)
+    if (n) *n = v;
+    return TSL_OK;
+}
 int tsl_tsdf_set_export_row(tsl_tsdf* m, int field, int64_t row, const float v[3])
 {
     TSL_REQUIRE(m && v && (field == 0 || field == 1), "set_export_row: bad argument"); TSL_REQUIRE(row >= 0 && row < m->max_disp, "set_export_row: row out of range");
@@ -1492,6 +1381,13 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     TSL_REQUIRE(m && name, "null");
     if (!std::strcmp(name, "variant")) {
         TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2");
+        if (value != 2 && m->variant == 2 && m->scratch_ready) {
+            // the global-atomics variants expect their brick scratch to be zero between launches; the brick-binned path leaves the
+            // parts' sums of its last batches in the same buffers
+            int rc = tsl_tsdf_sync(m); if (rc) return rc;
+            for (int bi = 0; bi < TSL_NBATCH; ++bi) TSL_HIP(hipMemsetAsync(m->fset[bi * TSL_NB].F.acc, 0, 16 * (size_t)m->F.max_frame_bricks * TSL_BRK3, m->stream_));
+            TSL_HIP(hipStreamSynchronize(m->stream_));
+        }
         m->variant = value; return TSL_OK;
     }
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }

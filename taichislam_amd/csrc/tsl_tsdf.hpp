@@ -37,33 +37,31 @@ struct FrameDev {
     uint4* rayA;                                 // per ray: {p01, p2|d0, d12, w bits}
     int*   rayN;                                 // per ray: step count
     uint32_t* rayFirst;                          // per ray: index of the first pixel / point of its sensor voxel (texture: colour winner order)
-    void*  hkey; int *hcnt, *hoff, *hfill; int hlog2;   // sensor-voxel hash table: key, pixel count, first list position, fill cursor
-    int*   slot_of_pix;                          // [pixel] -> table slot or -1
+    struct HSlot* htab; int hlog2;               // sensor-voxel hash table (open addressing, 64-byte slots with the pixel ids inline); hlog2 = log2 of the allocated slots
     int*   act;                                  // sensor voxels opened in this frame (arrival order), count in counters[6]
-    uint32_t* plist;                             // pixel ids grouped per sensor voxel (arrival order inside a group)
-    int*   big;                                  // groups larger than GROUP_SMALL, count in counters[7]
+    int*   actx;                                 // overflow slots (pixels 14, 15, ... of a crowded sensor voxel) opened in this frame, count in counters[7]; listed to be cleared
     uint2* colpix;                               // [pixel] f16 colour {r|g<<16, b} of the ray opened by that pixel (texture)
     tsl_frame_stats* stats;                      // header: stats | nrays | counters[8], zeroed by one memset per frame
     int*   nrays;                                // ray count of this frame
-    int*   counters;                             // [0] grouped pixels [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] crowded voxels [11] frame overflow bits
+    int*   counters;                             // [1] active bricks [2] appended segments [3] segments laid out [6] sensor voxels [7] overflow slots of crowded voxels [11] frame overflow bits
                                                  // [16..19] parts per class; in the header of a batch's FIRST frame: [12] next rank to claim [13] merge-slab slots [20..23] units per class
     unsigned long long *seg, *seg_sorted;        // ray segments (one brick each), unsorted / sorted by brick
     int   *bhist, *bcursor, *boffset, *bnseg;    // [nb3] per-brick segment count / scatter cursor (zero between uses) / first segment, segment count (valid for this frame's bricks)
+    int   *bslab;                                // [nb3] heavy bricks of the frame: first slab slot | parts << 20 (k_plan; valid for the bricks the batch lists as heavy)
     int   *act_b;                                // [max_frame_bricks] active bricks of the frame, in the order they were listed
     int4  *part_tab; int part_cap;               // integrate work list of the frame's heavy bricks, one table per length class (k_plan)
     int4  *unit_tab; int unit_cap;               // first set of a batch: the batch's units (bricks integrated for all frames by one workgroup), one table per class
-    // ---- shared by the sets of a batch (acc / ticket / accw) or by all sets: only touched in phase B, i.e. serially on the main stream ----
+    int4  *heavy_tab;                            // first set of a batch: [max_frame_bricks] the batch's heavy bricks { brick id, pool index, frames with segments, - } (k_plan -> k_apply_slab)
+    // ---- shared by the sets of a batch (acc / accw) or by all sets: only touched in phase B, i.e. serially on the main stream ----
     int*   slot_tab;                             // variants 0/1: [nb3] brick id -> frame scratch slot, EMPTY between frames
     int*   touched;                              // variants 0/1: [max_frame_bricks] -> pool brick
     int*   touched_b;                            // variants 0/1: [max_frame_bricks] -> brick id
-    unsigned long long* acc;                     // merge slab [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point (zero between launches)
-    int* ticket;                                 // [max_frame_bricks] arrival tickets of the batch's heavy bricks, at the brick's first slot (zero between launches)
-    int* npf;                                    // [max_frame_bricks] parts of the (frame, brick) that owns the slot
-    uint32_t* accw;                              // [max_frame_bricks][4096] colour winner (first pixel + 1) of bricks split over workgroups (texture)
+    unsigned long long* acc;                     // merge slab [max_frame_bricks][4096][2]  {num, den} 2^-24 fixed point: one slot per part of a heavy brick (variant 2), written whole by that part;
+                                                 //   variants 0/1: per-frame brick scratch, zero between launches
+    uint32_t* accw;                              // [max_frame_bricks][4096] colour winner (first pixel + 1) per slab slot (texture)
     long long* dbg;                              // developer timing counters (TSL_TIMING builds)
     int    seg_cap;
     int    max_frame_bricks;
-    int    hwide;                                // sensor-voxel keys are 64 bit
     int    max_points;
 };
 
@@ -73,32 +71,52 @@ struct FrameDev {
 __device__ __forceinline__ void frame_fail(const MapDev& M, const FrameDev& F, int bits) { atomicOr(&F.counters[11], bits); atomicOr(M.err, bits); }
 
 // ---- sensor voxel -> ray  (process_point dense_tsdf.py:230-234, process_new_pcl :242-249); citations are to dense_tsdf.py ----
-#define GROUP_SMALL 48        // sensor voxels with more pixels are replayed by a whole wave / workgroup
+// Sensor-voxel hash table of a frame's working set (hash grouping of the pixels, k_voxelize_* -> k_segments).  One 64-byte slot = one cache
+// line: the voxel's key, its pixel count and the ids of its first H_INL pixels in arrival order.  Pixels H_INL, H_INL + 1, ... of a crowded voxel
+// go to further slots keyed (voxel, block = rank / H_INL): same table, same probing, no second pass over the pixels and nothing to wait for.
+// An empty slot is all zero (key 0, count 0): the table starts as a zero fill, the slots a frame opened are listed (act / actx) and zeroed
+// again by k_scatter, so the table is empty between frames.
+#define H_INL 13
+#define H_BLOCK_SHIFT 44      // key = (voxel key (3 x <= 14 bits, Morton) | block << 44) + 1
+#define H_EMPTY 0ull
+__device__ __forceinline__ unsigned long long h_key(unsigned long long vkey, int block) { return (vkey | ((unsigned long long)block << H_BLOCK_SHIFT)) + 1ull; }
+#define GROUP_BIG_CAP 16384   // pixels one sensor voxel may hold (beyond: error bit 3, the ray is dropped)
+struct HSlot { unsigned long long key; int cnt; uint32_t pix[H_INL]; };
+static_assert(sizeof(HSlot) == 64, "one slot per 64 bytes");
+__device__ __forceinline__ uint32_t h_hash64(unsigned long long key, int log2n) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2n)); }
+
 struct PixAcc { int cnt; h16 sx, sy, sz, zs, cr, cg, cb; };
 
-__device__ __forceinline__ void acc_pixel(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
+// new_pcl_sum_color += rgb  (:234)
+__device__ __forceinline__ void acc_colour(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
 {
-    if (P.tex) {                                                                     // new_pcl_sum_color += rgb  (:234)
-        const uint8_t* rgb;
-        if (P.points) rgb = P.tex_input + (size_t)pid * 3;                           // :179-183
-        else {
-            const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
-            const int pj = jj * P.step, pi = ii * P.step;
-            if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;       // :206
-            else {                                                                   // color_ind_from_depth_pt  mapping_common.py:43-58
-                int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
-                int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
-                if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }          // the reference tests column against rows (:56)
-                if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                            // keep the read inside the buffer
-                rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
-            }
+    const uint8_t* rgb;
+    if (P.points) rgb = P.tex_input + (size_t)pid * 3;                           // :179-183
+    else {
+        const int jj = (int)pid / P.ww, ii = (int)pid - jj * P.ww;
+        const int pj = jj * P.step, pi = ii * P.step;
+        if (P.same_proj) rgb = P.tex_input + ((size_t)pj * P.tw + pi) * 3;       // :206
+        else {                                                                   // color_ind_from_depth_pt  mapping_common.py:43-58
+            int ci = (int)((((float)pi - P.cx) / P.fx) * P.fxc + P.cxc);
+            int cj = (int)((((float)pj - P.cy) / P.fy) * P.fyc + P.cyc);
+            if (ci < 0 || ci >= P.th || cj < 0 || cj >= P.tw) { ci = 0; cj = 0; }          // the reference tests column against rows (:56)
+            if (cj >= P.th || ci >= P.tw) { ci = 0; cj = 0; }                            // keep the read inside the buffer
+            rgb = P.tex_input + ((size_t)cj * P.tw + ci) * 3;
         }
-        A.cr = hadd(A.cr, f2h((float)rgb[0])); A.cg = hadd(A.cg, f2h((float)rgb[1])); A.cb = hadd(A.cb, f2h((float)rgb[2]));
     }
-    const uint2 pl = F.pix[pid];
+    A.cr = hadd(A.cr, f2h((float)rgb[0])); A.cg = hadd(A.cg, f2h((float)rgb[1])); A.cb = hadd(A.cb, f2h((float)rgb[2]));
+}
+// the pixel's f16 payload {x,y | z,depth} joins the voxel's sums: per-add f16 rounding, so the ORDER of the calls is part of the result
+__device__ __forceinline__ void acc_payload(const uint2 pl, PixAcc& A)
+{
     A.sx = hadd(A.sx, (h16)(pl.x & 0xffffu)); A.sy = hadd(A.sy, (h16)(pl.x >> 16));              // :231
     A.sz = hadd(A.sz, (h16)(pl.y & 0xffffu)); A.zs = hadd(A.zs, (h16)(pl.y >> 16));              // :232
     ++A.cnt;                                                                                       // :230
+}
+__device__ __forceinline__ void acc_pixel(const FrameParams& P, const FrameDev& F, uint32_t pid, PixAcc& A)
+{
+    if (P.tex) acc_colour(P, F, pid, A);
+    acc_payload(F.pix[pid], A);
 }
 
 // mean point -> ray record; false for degenerate rays (zero length / z^2 not in (0, inf))
@@ -189,12 +207,14 @@ struct tsl_tsdf {
     void* xbuf; size_t xbuf_bytes;
     // mesh buffers (mesh_vertices / mesh_normals / mesh_colors, num_facelets)  marching_cube_mesher.py:16-22
     float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap; int mesh_gather;      // mesh_gather: option, 1 = global-gather kernel also for step 1 (A/B)
-    void *fuse_acc, *fuse_cnt, *fuse_cacc;           // global-map fusion scratch ({num,den} int64 pairs, count|occupancy)
+    void *fuse_acc, *fuse_cnt, *fuse_cacc; bool fuse_dirty;      // global-map fusion scratch ({num,den} int64 pairs, count|occupancy, colour sums); dirty: a splat was not followed by its finalise / pack
     uint8_t* mrg_mask; int *mrg_list, *mrg_count; int mrg_nunion;      // multi-GPU merge: touched-brick mask, union list (tsl_merge.hip)
     void *mrg_pacc, *mrg_pcnt; size_t mrg_pacc_bytes, mrg_pcnt_bytes;  // packed union bricks of the one-call form
     // esdf
     float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
+    float *esdf_exp_xyz, *esdf_exp_val; int* esdf_exp_count; int esdf_exp_n;      // export_ESDF_xyz / export_ESDF / num_export_ESDF_particles (dense_esdf.py:498-509), allocated by the first slice
     bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
+    hipEvent_t esdf_gate; bool esdf_gate_set;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
     EsdfSlot esdf_slot[TSL_ESDF_SLOTS]; int esdf_tail, esdf_npend, esdf_rounds_seen, esdf_round_cap; bool esdf_short; tsl_esdf_totals_t esdf_tot;   // updates in flight (tsl_esdf.hip)
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;

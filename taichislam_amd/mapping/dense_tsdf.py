@@ -109,13 +109,19 @@ class DenseTSDF(BaseMap):
     def initialize_fields(self):
         self.num_TSDF_particles = ScalarField(self._get_num_particles, self._set_num_particles, "num_TSDF_particles")
         self.num_export_particles = ScalarField(lambda: 0, None, "num_export_particles")
-        self.num_export_ESDF_particles = ScalarField(lambda: 0, None, "num_export_ESDF_particles")
         md = self.max_disp_particles
+        self.num_export_ESDF_particles = ScalarField(lambda: self._esdf_slice_n, None, "num_export_ESDF_particles")
+        self._esdf_slice_n = 0
         self.export_TSDF_xyz = DeviceArrayField(self, lambda n: self._read_exports(n)[0], md, 3, "export_TSDF_xyz",
-                                                writer=lambda row, v: self._call("set_export_row", 0, row, _vp(np.ascontiguousarray(v[:3], np.float32))))
+                                                writer=lambda row, v: self._call("set_export_row", 0, row, _vp(np.ascontiguousarray(v[:3], np.float32))),
+                                                dev=lambda: self._exports_dev(0))
         self.export_color = DeviceArrayField(self, lambda n: self._read_exports(n)[1], md, 3, "export_color",
-                                             writer=lambda row, v: self._call("set_export_row", 1, row, _vp(np.ascontiguousarray(v[:3], np.float32))))
-        self.export_TSDF = DeviceArrayField(self, lambda n: self._read_exports(n)[2], md, 1, "export_TSDF")
+                                             writer=lambda row, v: self._call("set_export_row", 1, row, _vp(np.ascontiguousarray(v[:3], np.float32))),
+                                             dev=lambda: self._exports_dev(1))
+        self.export_TSDF = DeviceArrayField(self, lambda n: self._read_exports(n)[2], md, 1, "export_TSDF", dev=lambda: self._exports_dev(2))
+        # dense_esdf.py:112-113 (legacy module): the ESDF slice exports
+        self.export_ESDF_xyz = DeviceArrayField(self, lambda n: self._read_esdf_slice(n)[0], md, 3, "export_ESDF_xyz", dev=lambda: self._esdf_slice_dev(0))
+        self.export_ESDF = DeviceArrayField(self, lambda n: self._read_esdf_slice(n)[1], md, 1, "export_ESDF", dev=lambda: self._esdf_slice_dev(1))
         self.export_x = self.export_TSDF_xyz
         self.TSDF = MapFieldRef(self, "TSDF")
         self.W_TSDF = MapFieldRef(self, "W_TSDF")
@@ -141,6 +147,26 @@ class DenseTSDF(BaseMap):
         val = np.empty(n, np.float32)
         self._call("read_exports", _vp(xyz), _vp(rgb), _vp(val), n)
         return xyz, rgb, val
+
+    def _exports_dev(self, which):
+        """(device pointer of export_TSDF_xyz / export_color / export_TSDF, particles of the last cvt_* call)"""
+        p = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+        n = C.c_int32()
+        self._call("exports_dev", C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(n))
+        return p[which].value, max(0, min(n.value, self.max_disp_particles))
+
+    def _read_esdf_slice(self, n):
+        n = int(max(0, min(n, self.max_disp_particles, self._esdf_slice_n)))
+        xyz = np.empty((n, 3), np.float32)
+        val = np.empty(n, np.float32)
+        _lib.check(self.L.tsl_esdf_read_slice(self.h, _vp(xyz), _vp(val), n))
+        return xyz, val
+
+    def _esdf_slice_dev(self, which):
+        p = [C.c_void_p(), C.c_void_p()]
+        n = C.c_int32()
+        _lib.check(self.L.tsl_esdf_slice_dev(self.h, C.byref(p[0]), C.byref(p[1]), C.byref(n)))
+        return p[which].value, max(0, min(n.value, self.max_disp_particles))
 
     # ---- backend knobs ---------------------------------------------------------------------------------
     def set_option(self, name, value):
@@ -448,6 +474,15 @@ class DenseTSDF(BaseMap):
 
     # ---- batched map queries (mapping_common.py:165-204; the reference exposes them as ti.funcs for TopoGraphGen) ----
     def _query_points(self, mode, xyz, param=0):
+        if _is_device_tensor(xyz):
+            # device tensors in, device tensor out, nothing waited for: the query runs on the map's stream behind every queued frame and
+            # torch's current stream is ordered after it (tsl_tsdf_query_points_dev)
+            torch = _torch()
+            x = xyz.reshape(-1, 3).contiguous().float()
+            out = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+            _lib.check(self.L.tsl_tsdf_query_points_dev(self.h, mode, int(param), x.data_ptr(), x.shape[0], out.data_ptr(),
+                                                        torch.cuda.current_stream(x.device).cuda_stream))
+            return out.bool()
         xyz = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32).reshape(-1, 3))
         out = np.zeros(xyz.shape[0], np.uint8)
         _lib.check(self.L.tsl_tsdf_query_points(self.h, mode, int(param), _vp(xyz), xyz.shape[0], _vp(out)))
@@ -463,7 +498,18 @@ class DenseTSDF(BaseMap):
         return self._query_points(2, xyz, voxel)
 
     def raycast(self, pos, dir, max_dist):
-        """Batched BaseMap.raycast: returns (hit bool[n], end xyz f32[n,3], length f32[n])."""
+        """Batched BaseMap.raycast: returns (hit bool[n], end xyz f32[n,3], length f32[n]); torch CUDA tensors in -> torch CUDA tensors
+        out, asynchronously (the planner's 64-128 rays per node expansion, topo_graph.py:444-507, without a host round trip)."""
+        if _is_device_tensor(pos):
+            torch = _torch()
+            p = pos.reshape(-1, 3).contiguous().float(); d = dir.reshape(-1, 3).contiguous().float()
+            assert p.shape == d.shape and d.is_cuda
+            n = p.shape[0]
+            hit = torch.empty(n, dtype=torch.uint8, device=p.device); end = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+            ln = torch.empty(n, dtype=torch.float32, device=p.device)
+            _lib.check(self.L.tsl_tsdf_query_raycast_dev(self.h, p.data_ptr(), d.data_ptr(), float(max_dist), n, hit.data_ptr(), end.data_ptr(),
+                                                         ln.data_ptr(), torch.cuda.current_stream(p.device).cuda_stream))
+            return hit.bool(), end, ln
         pos = np.ascontiguousarray(np.asarray(pos, dtype=np.float32).reshape(-1, 3))
         dir = np.ascontiguousarray(np.asarray(dir, dtype=np.float32).reshape(-1, 3))
         assert pos.shape == dir.shape
@@ -481,6 +527,7 @@ class DenseTSDF(BaseMap):
         wait for whatever is still in flight."""
         g = self.voxel_scale if gamma is None else gamma                 # dense_esdf.py:40 gamma = voxel_scale
         md = self.max_ray_length if max_dist is None else max_dist       # dense_esdf.py:265 sign * max_ray_length
+        self._esdf_ever = True
         if not wait:
             _lib.check(self.L.tsl_esdf_update(self.h, float(g), float(md), None))
             return None
@@ -498,6 +545,29 @@ class DenseTSDF(BaseMap):
         st = _lib.EsdfStats()
         _lib.check(self.L.tsl_esdf_last_stats(self.h, C.byref(st)))
         return st.as_dict()
+
+    def cvt_ESDF_to_voxels_slice(self, z):
+        """dense_esdf.py:498-509: ESDF values of the voxel layer at height z -> export_ESDF / export_ESDF_xyz (device-resident;
+        `.to_numpy()` / `.to_torch()`), count in num_export_ESDF_particles[None].  The ESDF is brought up to date first."""
+        if not getattr(self, "_esdf_ever", False):
+            self.update_esdf()
+        n = C.c_int32()
+        _lib.check(self.L.tsl_esdf_slice(self.h, float(z), C.byref(n)))
+        self._esdf_slice_n = n.value
+
+    def get_voxels_ESDF_slice(self, z):
+        self.cvt_ESDF_to_voxels_slice(z)
+        return self._read_esdf_slice(self._esdf_slice_n)
+
+    def export_esdf_torch(self):
+        """(indices int16[n,3], esdf f32[n]) as torch tensors on the device: zero-copy views of the map's staging buffer, valid until the
+        next exporting call on this map (clone them to keep them)."""
+        from .fields import device_view
+        n = self.count_active()
+        pi, pv, cnt = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _lib.check(self.L.tsl_esdf_export_dev(self.h, n, C.byref(pi), C.byref(pv), C.byref(cnt)))
+        k = min(n, cnt.value)
+        return device_view(pi.value, (k, 3), "<i2", self, self.device), device_view(pv.value, (k,), "<f4", self, self.device)
 
     def export_esdf(self):
         """(indices int16[n,3], esdf f32[n]) for every observed voxel of the active submap."""

@@ -26,11 +26,41 @@ class ScalarField:
         return f"<{self._name}={self._get()}>"
 
 
-class DeviceArrayField:
-    """1-d vector field living in a device export buffer; `.to_numpy()` copies `rows` rows back."""
+class _DevicePointer:
+    """A device buffer of the C-ABI handle presented through `__cuda_array_interface__` (version 2), which torch-ROCm (and cupy /
+    numba) accept without copying.  `keep` pins the owning map for as long as a view made from this object lives."""
 
-    def __init__(self, owner, reader, rows, width, name, writer=None):
+    def __init__(self, ptr, shape, typestr, keep):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+        self._keep = keep
+
+
+def device_view(ptr, shape, typestr="<f4", keep=None, device=0):
+    """torch tensor over `shape` elements at device pointer `ptr` (zero-copy; the buffer belongs to the handle `keep`)."""
+    import torch
+    if not ptr or any(int(x) == 0 for x in shape):
+        dt = {"<f4": torch.float32, "<i2": torch.int16, "|u1": torch.uint8}[typestr]
+        return torch.empty(tuple(int(x) for x in shape), dtype=dt, device=f"cuda:{device}")
+    return torch.as_tensor(_DevicePointer(ptr, shape, typestr, keep), device=f"cuda:{device}")
+
+
+class DeviceArrayField:
+    """1-d vector field living in a device export buffer; `.to_numpy()` copies `rows` rows back, `.to_torch()` is a zero-copy
+    view of the device buffer (include/taichislam_hip.h: the *_dev entry points)."""
+
+    def __init__(self, owner, reader, rows, width, name, writer=None, dev=None):
         self._owner, self._reader, self._rows, self._width, self._name, self._writer = owner, reader, rows, width, name, writer
+        self._dev = dev                      # () -> (device pointer, rows valid) of the buffer
+
+    def to_torch(self, n=None):
+        """The first `n` rows (default: the rows the last export / mesh call produced) as a torch tensor ON THE DEVICE, without a copy.
+        The view stays valid as long as the owning map lives; a later export overwrites its contents."""
+        if self._dev is None:
+            raise TypeError(f"{self._name} has no device view")
+        ptr, valid = self._dev()
+        n = int(valid if n is None else min(int(n), self._rows))
+        shape = (n,) if self._width == 1 else (n, self._width)
+        return device_view(ptr, shape, "<f4", keep=self._owner, device=getattr(self._owner, "device", 0))
 
     @property
     def shape(self):

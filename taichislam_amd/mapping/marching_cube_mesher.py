@@ -18,9 +18,10 @@ class MarchingCubeMesher:
         self.enable_texture = mapping.enable_texture
         self.tsdf_surface_thres = tsdf_surface_thres
         self._n_tri = 0
-        self.mesh_vertices = DeviceArrayField(self, lambda n: self._read(n)[0], self.max_triangles * 3, 3, "mesh_vertices")
-        self.mesh_normals = DeviceArrayField(self, lambda n: self._read(n)[1], self.max_triangles * 3, 3, "mesh_normals")
-        self.mesh_colors = DeviceArrayField(self, lambda n: self._read(n)[2], self.max_triangles * 3, 3, "mesh_colors")
+        self.device = getattr(mapping, "device", 0)
+        self.mesh_vertices = DeviceArrayField(self, lambda n: self._read(n)[0], self.max_triangles * 3, 3, "mesh_vertices", dev=lambda: self._dev(0))
+        self.mesh_normals = DeviceArrayField(self, lambda n: self._read(n)[1], self.max_triangles * 3, 3, "mesh_normals", dev=lambda: self._dev(1))
+        self.mesh_colors = DeviceArrayField(self, lambda n: self._read(n)[2], self.max_triangles * 3, 3, "mesh_colors", dev=lambda: self._dev(2))
         self.mesh_indices = None
         self.num_facelets = ScalarField(lambda: self._n_tri, None, "num_facelets")
         # the reference never updates num_vertices although the node uses it as the mesh size
@@ -35,6 +36,13 @@ class MarchingCubeMesher:
         _lib.check(_lib.lib().tsl_mesh_read(self.mapping.h, v.ctypes.data_as(C.c_void_p), nr.ctypes.data_as(C.c_void_p),
                                             col.ctypes.data_as(C.c_void_p) if self.enable_texture else None, n))
         return v, nr, col
+
+    def _dev(self, which):
+        """(device pointer of mesh_vertices / mesh_normals / mesh_colors, vertices of the last generate_mesh): `.to_torch()` of the fields"""
+        p = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+        n = C.c_int32()
+        _lib.check(_lib.lib().tsl_mesh_buffers_dev(self.mapping.h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(n)))
+        return p[which].value, 3 * min(n.value, self.max_triangles)
 
     def vertice_num(self):
         return self.num_facelets[None] * 3

@@ -48,13 +48,20 @@ class Octomap(BaseMap):
         _lib.check(self.L.tsl_octo_create(C.byref(cfg), int(device), C.byref(h)))
         self.h = h
         self.num_export_particles = ScalarField(self._get_num, None, "num_export_particles")
-        self.export_x = DeviceArrayField(self, lambda n: self._read(n)[0], max_disp_particles, 3, "export_x")
-        self.export_color = DeviceArrayField(self, lambda n: self._read(n)[1], max_disp_particles, 3, "export_color")
+        self.device = device
+        self.export_x = DeviceArrayField(self, lambda n: self._read(n)[0], max_disp_particles, 3, "export_x", dev=lambda: self._exports_dev(0))
+        self.export_color = DeviceArrayField(self, lambda n: self._read(n)[1], max_disp_particles, 3, "export_color", dev=lambda: self._exports_dev(1))
         self.occupy = MapFieldRef(self, "occupy")
         self.color = MapFieldRef(self, "color") if texture_enabled else None
         self.initialize_submap_fields(self.max_submap_num)
         print(f'The map voxel is:[{self.max_submap_num}x{self.N}x{self.N}x{self.Nz}] voxel scale {self.voxel_scale:3.3f}^3 '
               f'map scale:[{self.map_size_xy}mx{self.map_size_xy}mx{self.map_size_z}m] tree depth [{self.Rxy}, {self.Rz}]')
+
+    def _exports_dev(self, which):
+        p = [C.c_void_p(), C.c_void_p()]
+        n = C.c_int32()
+        self._call("exports_dev", C.byref(p[0]), C.byref(p[1]), C.byref(n))
+        return p[which].value, max(0, min(n.value, self.max_disp_particles))
 
     def _get_num(self):
         v = C.c_int32()
@@ -80,6 +87,18 @@ class Octomap(BaseMap):
         return count > self.min_occupy_thres
 
     def recast_pcl_to_map(self, R, T, xyz_array, rgb_array=None, n=None):
+        if hasattr(xyz_array, "data_ptr") and getattr(xyz_array, "is_cuda", False):
+            import torch
+            x = xyz_array.reshape(-1, 3).contiguous().float()
+            if n is not None:
+                x = x[:int(n)].contiguous()
+            c = None
+            if self.enable_texture and rgb_array is not None and hasattr(rgb_array, "data_ptr") and rgb_array.numel() >= 3 * x.shape[0] > 0:
+                c = rgb_array.reshape(-1, 3)[:x.shape[0]].contiguous().to(torch.uint8)
+            torch.cuda.current_stream(x.device).synchronize()          # the tensors are complete; the map's stream reads them
+            self._call("integrate_points_dev", _dptr(R, 9)[1], _dptr(T, 3)[1], C.c_void_p(x.data_ptr()), C.c_void_p(c.data_ptr()) if c is not None else None, int(x.shape[0]))
+            self._call("sync")                                         # ... and has read them before they can be freed
+            return
         xyz = np.ascontiguousarray(np.asarray(xyz_array, dtype=np.float32).reshape(-1, 3))
         if n is not None:
             xyz = xyz[:int(n)]
@@ -104,6 +123,17 @@ class Octomap(BaseMap):
             self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], _vp(tex), tex.shape[0], tex.shape[1])
         else:
             self._call("integrate_depth", r, t, _vp(depth), depth.shape[0], depth.shape[1], None, 0, 0)
+
+    def pointcloud2(self, n=None, has_rgb=None):
+        """The first `n` occupied voxels of the last cvt_occupy_to_voxels call as a sensor_msgs/PointCloud2 payload (scripts/taichislam_node.py:330-333
+        + utils/ros_pcl_transfer.py:96-136), interleaved on the device; see taichislam_amd.utils.ros_adapters."""
+        from ..utils import ros_adapters
+        n = self.num_export_particles[None] if n is None else int(n)
+        n = max(0, min(n, self.max_disp_particles))
+        has_rgb = self.enable_texture if has_rgb is None else bool(has_rgb)
+        data = np.empty((n, 6 if has_rgb else 3), np.float32)
+        self._call("pack_pointcloud2", int(has_rgb), n, _vp(data))
+        return ros_adapters.pointcloud2_payload(data, has_rgb)
 
     def cvt_occupy_to_voxels(self, level=0):
         n = C.c_int32()
