@@ -392,7 +392,25 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
             const bool k2 = A.cnt == n && finish_ray(P, F, A, f0, &rc, &ns, lane == src);
             if (lane == src) { rec = rc; nsteps = ns; ok = k2; first = f0; }
         }
-        if (r < nrays && sub == 0) { F.rayA[r] = rec; F.rayFirst[r] = first; }
+        if (r < nrays && sub == 0) {
+            F.rayA[r] = rec; F.rayFirst[r] = first;
+            if (P.seq) {      // sequential semantics: the ray's step count and its place in Taichi's struct-for order over the sensor grid
+                // (pointer block lexicographic, then dense cell: assumption A6 of SURVEY.md section 8c) -- the Morton key is taken apart again
+                uint32_t u[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    unsigned long long x = (vkey >> (2 - a)) & 0x1249249249249249ull;
+                    x = (x | (x >> 2)) & 0x10c30c30c30c30c3ull; x = (x | (x >> 4)) & 0x100f00f00f00f00full; x = (x | (x >> 8)) & 0x1f0000ff0000ffull;
+                    x = (x | (x >> 16)) & 0x1f00000000ffffull; x = (x | (x >> 32)) & 0x1fffffull;
+                    u[a] = (uint32_t)x;
+                }
+                const unsigned long long nblk = (unsigned long long)(P.pcl_ext / P.pcl_blk), blk = (unsigned long long)P.pcl_blk;
+                const unsigned long long kb = ((u[0] / P.pcl_blk) * nblk + (u[1] / P.pcl_blk)) * nblk + (u[2] / P.pcl_blk);
+                const unsigned long long kl = ((u[0] % P.pcl_blk) * blk + (u[1] % P.pcl_blk)) * blk + (u[2] % P.pcl_blk);
+                reinterpret_cast<unsigned long long*>(F.keys)[r] = kb * blk * blk * blk + kl;
+                F.rayN[r] = ok ? nsteps : 0;
+            }
+        }
         block_count_add(&F.stats->v_pcl, r < nrays && sub == 0);
         block_count_add(&F.stats->v_skipped, r < nrays && sub == 0 && !ok);
         if (gid == 0) *F.nrays = nrays;
@@ -1023,12 +1041,13 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
 // k_apply_slab: the heavy bricks of a batch (k_plan's list), behind the brick kernel on the same stream.  Every part of a heavy brick
 // left its 4096 {num, den} sums in a slab slot of its own; here the parts of each (frame, brick) are added (int64: exact, order-free)
 // and the frames are applied in frame order, exactly as per-frame launches would apply them -- the brick is read once and written once
-// per batch.  One workgroup takes an eighth of a brick (2 voxels per thread): the loads of ALL frames are independent of the apply chain,
-// so they are in flight together, and the heavy bricks of a batch spread over eight workgroups each instead of serialising behind the last
+// per batch.  One workgroup takes a sixteenth of a brick (one voxel per thread): the loads of ALL frames are independent of the apply chain,
+// so they are in flight together, and the heavy bricks of a batch spread over sixteen workgroups each instead of serialising behind the last
 // part to arrive (round 2's ticket scheme: 25-33 us per brick on the critical path of the persistent kernel, plus an L2 atomic pair per
 // voxel and part).
 // =====================================================================================================
-#define APPLY_SPLIT 8
+#define APPLY_SPLIT 16
+#define APPLY_ROUND 3
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_apply_slab(MapDev M, BatchDev B)
 {
@@ -1064,18 +1083,33 @@ __global__ void __launch_bounds__(256) k_apply_slab(MapDev M, BatchDev B)
                 win[q][k] = (TEX && on) ? B.f[q].accw[base + k * 256] : 0u;
             }
         }
+        // further parts (only the bricks next to the sensor have more than one or two per frame): APPLY_ROUND slots per round, all frames of a
+        // round in flight together -- the rounds, not the frames, are the dependent chain
+        int npmax = 0;
 #pragma unroll
-        for (int q = 0; q < TSL_NB; ++q) {
-            const int np = w[q] >> SLAB_SLOT_BITS;
-            for (int j = 1; j < np; ++j) {
-                const size_t base = (size_t)((w[q] & ((1 << SLAB_SLOT_BITS) - 1)) + j) * TSL_BRK3 + l0;
+        for (int q = 0; q < TSL_NB; ++q) npmax = max(npmax, w[q] >> SLAB_SLOT_BITS);
+        for (int j0 = 1; j0 < npmax; j0 += APPLY_ROUND) {
+            ulonglong2 x[TSL_NB][APPLY_ROUND][VP];
 #pragma unroll
-                for (int k = 0; k < VP; ++k) {
-                    const ulonglong2 x = slab[base + k * 256];
-                    a[q][k].x += x.x; a[q][k].y += x.y;
-                    if (TEX) win[q][k] = max(win[q][k], B.f[q].accw[base + k * 256]);
+            for (int q = 0; q < TSL_NB; ++q) {
+                const int np = w[q] >> SLAB_SLOT_BITS, s0 = w[q] & ((1 << SLAB_SLOT_BITS) - 1);
+#pragma unroll
+                for (int t = 0; t < APPLY_ROUND; ++t) {
+                    const bool on = j0 + t < np;
+                    const size_t base = (size_t)(s0 + (on ? j0 + t : 0)) * TSL_BRK3 + l0;
+#pragma unroll
+                    for (int k = 0; k < VP; ++k) {
+                        x[q][t][k] = on ? slab[base + k * 256] : make_ulonglong2(0ull, 0ull);
+                        if (TEX && on) win[q][k] = max(win[q][k], B.f[q].accw[base + k * 256]);
+                    }
                 }
             }
+#pragma unroll
+            for (int q = 0; q < TSL_NB; ++q)
+#pragma unroll
+                for (int t = 0; t < APPLY_ROUND; ++t)
+#pragma unroll
+                    for (int k = 0; k < VP; ++k) { a[q][k].x += x[q][t][k].x; a[q][k].y += x[q][t][k].y; }
         }
         bool changed[VP];
 #pragma unroll
@@ -1144,8 +1178,8 @@ int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hip
 #undef TSL_LAUNCH_IB
     // the batch's heavy bricks: parts -> map (the count lives on the device: the grid covers what a batch can list, idle workgroups leave at once)
     prof_begin(m, TSL_K_FINALIZE);
-    if (P.tex) hipLaunchKernelGGL(k_apply_slab<true>, dim3(8 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
-    else hipLaunchKernelGGL(k_apply_slab<false>, dim3(8 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
+    if (P.tex) hipLaunchKernelGGL(k_apply_slab<true>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
+    else hipLaunchKernelGGL(k_apply_slab<false>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
     prof_end(m);
     TSL_HIP(hipGetLastError());
     return TSL_OK;

@@ -573,7 +573,8 @@ static int launch_batch_t(tsl_tsdf* m)
             if (any) {
                 hipEvent_t ea = nullptr, eb = nullptr;
                 const bool timed = prof_slot(m, TSL_K_INTEGRATE, 1, &ea, &eb);
-                rc = launch_apply_batch(m, B, m->pend[0], timed ? ea : nullptr, timed ? eb : nullptr);
+                if (m->pend[0].seq) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_apply_sequential(m, B, m->pend[0]); prof_end(m); }
+                else rc = launch_apply_batch(m, B, m->pend[0], timed ? ea : nullptr, timed ? eb : nullptr);
             }
         } else {
             for (int q = 0; q < n && !rc; ++q) {
@@ -602,7 +603,7 @@ int flush_pending(tsl_tsdf* m)
 hipStream_t ms(tsl_tsdf* m) { m->clean = false; (void)flush_pending(m); return m->stream_; }
 
 static int batch_cap(const tsl_tsdf* m)
-{ return (m->overlap > 0 && m->variant == 2 && m->P.group) ? (m->overlap < TSL_NB ? m->overlap : TSL_NB) : 1; }
+{ return (m->overlap > 0 && m->variant == 2 && m->P.group && !m->semantics) ? (m->overlap < TSL_NB ? m->overlap : TSL_NB) : 1; }
 // working set the next queued frame will use; issues the queued frames first when the new one cannot join them
 static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
 {
@@ -838,7 +839,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     P.max_ray_f = (float)cfg->max_ray_length;
     P.max_steps_f = (float)(cfg->max_ray_length / cfg->voxel_scale);
     P.internal_f = (float)cfg->internal_voxels;
-    P.pcl_lo = m->pcl_lo; P.pcl_ext = m->pcl_ext; P.pcl_bits = m->pcl_bits;
+    P.pcl_lo = m->pcl_lo; P.pcl_ext = m->pcl_ext; P.pcl_bits = m->pcl_bits; P.pcl_blk = blk; P.seq = 0;
     P.step = cfg->recast_step; P.same_proj = cfg->color_same_proj;
     m->surf_thres = (float)(cfg->voxel_scale * 1.8);                                        // dense_tsdf.py:39
     m->disp_floor = (float)cfg->disp_floor; m->disp_ceiling = (float)cfg->disp_ceiling;
@@ -963,7 +964,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     esdf_release(m);
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
-                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_note, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_note, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
                      m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
@@ -1030,6 +1031,7 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
 {
     TSL_REQUIRE(m && name && value, "null");
     if (!std::strcmp(name, "group")) { *value = m->P.group; return TSL_OK; }
+    if (!std::strcmp(name, "semantics")) { *value = m->semantics; return TSL_OK; }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
     if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }
@@ -1391,6 +1393,12 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
         m->variant = value; return TSL_OK;
     }
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
+    if (!std::strcmp(name, "semantics")) {
+        TSL_REQUIRE(value == 0 || value == 1, "semantics must be 0 (batched exact sums) or 1 (sequential replay of the reference)");
+        TSL_REQUIRE(value == 0 || (!m->cfg.texture_enabled && m->M.max_bricks <= (1 << 17)), "sequential semantics: untextured maps with at most 2^17 bricks");
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        m->semantics = value; m->P.seq = value; return TSL_OK;
+    }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }

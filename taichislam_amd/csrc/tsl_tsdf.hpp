@@ -21,6 +21,7 @@ struct FrameParams {
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
     int   group;                       // 1: group pixels per sensor voxel through a hash table, 0: stable radix sort (rocPRIM)
+    int   seq, pcl_blk;                // sequential semantics (tsl_sequential.hip): k_segments leaves every ray's struct-for key and step count; block size of the sensor grid
     int   hlog2;                       // log2 of the part of the set's hash table this frame uses (>= 2 slots per visited pixel: the table stays cache-resident)
     const void* input; int total;      // device pointer of the depth image / point array of this frame, pixels or points to visit
     const uint8_t* tex_input; int points;   // texture [th][tw][3] (depth input) or rgb [n][3] (point input); input kind
@@ -219,6 +220,8 @@ struct tsl_tsdf {
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
+    int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
+    unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, bgrid, adaptive, ramp, ramp_batches; bool clean; uint64_t batch_gen;
     int64_t bytes;
 };
@@ -235,5 +238,6 @@ int  dev_alloc(tsl_tsdf* m, void** p, size_t bytes, int fill);
 int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B, variants 0/1: apply one frame to the map
-int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);      // phase B, variant 2: apply a batch of frames (one launch)
+int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+int  launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // tsl_sequential.hip: phase B of one frame, sequential semantics      // phase B, variant 2: apply a batch of frames (one launch)
 }

@@ -1,0 +1,51 @@
+"""Option "semantics" = 1: the reference-literal sequential replay of process_new_pcl (taichi_slam/mapping/dense_tsdf.py:236-270) on the
+GPU (csrc/tsl_sequential.hip) must equal the oracle's FAITHFUL mode -- raster-order f16 pixel sums, rays in Taichi's struct-for order,
+every ray step applied on its own with f16 rounding and the W clamp at 1000 -- BIT FOR BIT: voxel sets, TSDF and W bits, occupancy and
+the frame counters.  A sequential schedule is a legal outcome of the racy reference, so this is the strongest parity statement available
+without Taichi; the default (batched) path is measured against the same yardstick in test_parity_vs_faithful_gpu.py."""
+import numpy as np
+import pytest
+
+from taichislam_amd.utils import synthetic as syn
+from util import C2, SMALL, assert_export_equal, make_pair, small_stream
+
+pytestmark = pytest.mark.gpu
+STAT_KEYS = ("p_used", "p_valid", "p_oob", "v_pcl", "v_skipped", "steps", "steps_oob", "unique", "bricks")
+
+
+def test_sequential_mode_equals_faithful_small(hip_lib):
+    from oracle import FAITHFUL
+    K, frames = small_stream(5)
+    g, o = make_pair(SMALL, K)
+    g.set_option("semantics", 1)
+    assert g.get_option("semantics") == 1
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+        so = o.integrate_depth(R, T, d, mode=FAITHFUL)
+        sg = g.last_frame_stats()
+        assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    assert_export_equal(g.export_submap(), o.export_sparse(), "sequential vs FAITHFUL, small stream")
+    # back to the default semantics on the same map: the next frames are the batched sums again, applied to the sequential map
+    from oracle import BATCHED
+    g.set_option("semantics", 0)
+    for R, T, d in frames[:2]:
+        g.recast_depth_to_map(R, T, d, None)
+        o.integrate_depth(R, T, d, mode=BATCHED)
+    assert_export_equal(g.export_submap(), o.export_sparse(), "batched frames on top of the sequential map")
+
+
+def test_sequential_mode_equals_faithful_at_the_benchmark_size(hip_lib):
+    """BASELINE configs[1], 12 frames: HIP(sequential) == oracle FAITHFUL on every TSDF / W bit of 1.4 M voxels."""
+    import torch
+    from oracle import FAITHFUL
+    g, o = make_pair(C2, syn.K_DEPTH)
+    g.set_option("semantics", 1)
+    so = None
+    for R, T, d in syn.sphere_room_stream(12):
+        g.recast_depth_to_map(R, T, torch.from_numpy(d.view(np.int16)).cuda(), None)
+        so = o.integrate_depth(R, T, d, mode=FAITHFUL)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS} and sg["steps"] > 3_000_000
+    e = g.export_submap()
+    assert e["TSDF"].shape[0] > 1_300_000
+    assert_export_equal(e, o.export_sparse(), "sequential vs FAITHFUL, C2, 12 frames")
