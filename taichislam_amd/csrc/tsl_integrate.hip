@@ -492,9 +492,19 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 #endif
     (void)working;
     n_ok = wave_sum_ll(n_ok); n_oob = wave_sum_ll(n_oob);
-    if (lane_id() == 0) {
-        if (n_ok) atomic_add_i64(&F.stats->steps, n_ok);
-        if (n_oob) atomic_add_i64(&F.stats->steps_oob, n_oob);
+    {   // one atomic pair per workgroup (not per wave): the counters of a frame are single addresses
+        __shared__ long long s_steps[2];
+        if (threadIdx.x == 0) { s_steps[0] = 0; s_steps[1] = 0; }
+        __syncthreads();
+        if (lane_id() == 0) {
+            if (n_ok) atomicAdd(reinterpret_cast<unsigned long long*>(&s_steps[0]), (unsigned long long)n_ok);
+            if (n_oob) atomicAdd(reinterpret_cast<unsigned long long*>(&s_steps[1]), (unsigned long long)n_oob);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (s_steps[0]) atomic_add_i64(&F.stats->steps, s_steps[0]);
+            if (s_steps[1]) atomic_add_i64(&F.stats->steps_oob, s_steps[1]);
+        }
     }
 }
 
@@ -720,6 +730,7 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
     __shared__ int s_bin[64];
     __shared__ int s_claim[2];
+    __shared__ int s_uq[TSL_NB];                                // distinct voxels this workgroup updated, per frame of the batch
     __shared__ int s_cum[NRANGE + 1];                           // first rank of every range of the work list (class-major: units, frame 0, 1, ...)
     __shared__ int s_it[3][IT_WORDS];
     uint32_t okmask = 0u;
@@ -731,6 +742,7 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
         const int nact = min(Fq.counters[1], Fq.max_frame_bricks);
         for (int i = blockIdx.x * NT + threadIdx.x; i < nact; i += gridDim.x * NT) { const int b = Fq.act_b[i]; Fq.bhist[b] = 0; Fq.bcursor[b] = 0; }
     }
+    if (threadIdx.x < TSL_NB) s_uq[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         int acc = 0, k = 0;
         for (int c = 0; c < PLAN_NCLS; ++c) {
@@ -1016,9 +1028,10 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
 #ifdef TSL_TIMING
         const long long _td = wall_clock64();
 #endif
-        {   // this frame's distinct-voxel count
+        {   // this frame's distinct-voxel count: collected in LDS, one global atomic per workgroup and frame at the end of the launch
+            // (same-address atomics serialise at ~12 ns each at the L2: per wave and frame they were ~3 600 per counter and batch)
             const long long u = wave_sum_ll(uniq);
-            if (lane_id() == 0 && u) atomic_add_i64(&F.stats->unique, u);
+            if (lane_id() == 0 && u) atomicAdd(&s_uq[f], (int)u);
             uniq = 0;
         }
         if (fetching) { commit(n_known == 0 ? slot1 : slot2, ne, nkq, nio, nin); ++n_known; }
@@ -1035,28 +1048,33 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     }
 #undef TSL_PRIME
 #undef TSL_SORT_DEAL
+    __syncthreads();
+    if (threadIdx.x < TSL_NB && s_uq[threadIdx.x]) atomic_add_i64(&B.f[threadIdx.x].stats->unique, (long long)s_uq[threadIdx.x]);
 }
 
 // =====================================================================================================
 // k_apply_slab: the heavy bricks of a batch (k_plan's list), behind the brick kernel on the same stream.  Every part of a heavy brick
 // left its 4096 {num, den} sums in a slab slot of its own; here the parts of each (frame, brick) are added (int64: exact, order-free)
 // and the frames are applied in frame order, exactly as per-frame launches would apply them -- the brick is read once and written once
-// per batch.  One workgroup takes a sixteenth of a brick (one voxel per thread): the loads of ALL frames are independent of the apply chain,
-// so they are in flight together, and the heavy bricks of a batch spread over sixteen workgroups each instead of serialising behind the last
+// per batch.  One workgroup takes an eighth of a brick (two voxels per thread): the loads of ALL frames are independent of the apply chain,
+// so they are in flight together, and the heavy bricks of a batch spread over eight workgroups each instead of serialising behind the last
 // part to arrive (round 2's ticket scheme: 25-33 us per brick on the critical path of the persistent kernel, plus an L2 atomic pair per
 // voxel and part).
 // =====================================================================================================
-#define APPLY_SPLIT 16
-#define APPLY_ROUND 3
+#define APPLY_SPLIT 8
+#define APPLY_ROUND 2
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_apply_slab(MapDev M, BatchDev B)
 {
+    __shared__ int s_uq[TSL_NB];                                // distinct voxels this workgroup updated, per frame
     constexpr int VP = TSL_BRK3 / APPLY_SPLIT / 256;           // voxels per thread
     uint32_t okmask = 0u;
 #pragma unroll
     for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
     const int nheavy = min(B.f[0].counters[HDR_HEAVY], B.f[0].max_frame_bricks);
     const ulonglong2* const slab = reinterpret_cast<const ulonglong2*>(B.f[0].acc);
+    if (threadIdx.x < TSL_NB) s_uq[threadIdx.x] = 0;
+    __syncthreads();
     for (int item = blockIdx.x; item < nheavy * APPLY_SPLIT; item += gridDim.x) {
         const int4 e = B.f[0].heavy_tab[item / APPLY_SPLIT];
         const int b = e.x, p = e.y;
@@ -1126,9 +1144,12 @@ __global__ void __launch_bounds__(256) k_apply_slab(MapDev M, BatchDev B)
                     if (TEX) reinterpret_cast<uint2*>(M.col)[(size_t)p * TSL_BRK3 + l0 + k * 256] = B.f[q].colpix[win[q][k] - 1u];
                 }
             }
+            // (one same-address atomic costs ~12 ns at the L2 and they serialise: the counts go through LDS, one atomic per workgroup and frame)
             ug = wave_sum_ll(ug);
-            if (lane_id() == 0 && ug) atomic_add_i64(&B.f[q].stats->unique, ug);
+            if (lane_id() == 0 && ug) atomicAdd(&s_uq[q], (int)ug);
         }
+        __syncthreads();
+        if (threadIdx.x < TSL_NB && s_uq[threadIdx.x]) { atomic_add_i64(&B.f[threadIdx.x].stats->unique, (long long)s_uq[threadIdx.x]); s_uq[threadIdx.x] = 0; }
         int8_t* obs = M.obs + (size_t)p * TSL_BRK3;
 #pragma unroll
         for (int k = 0; k < VP; ++k) if (changed[k]) {

@@ -585,8 +585,10 @@ static int launch_batch_t(tsl_tsdf* m)
         }
         if (rc) return rc;
     }
-    if (!serial) { TSL_HIP(hipEventRecord(H.b_done, m->stream_)); H.b_pending = true; }
+    // one event marks the end of the batch's phase B: the back-pressure ring's, which the batch slot borrows as its "sets are free again"
+    // event (a ring entry is recorded again TSL_INFLIGHT batches later, a slot is reused after TSL_NBATCH)
     TSL_HIP(hipEventRecord(m->ring_ev[ring], m->stream_)); m->ring_upto[ring] = m->frames_issued; m->batch_seq++;
+    if (!serial) { H.b_done = m->ring_ev[ring]; H.b_pending = true; }
     m->cur = (bi + 1) % TSL_NBATCH;
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -849,7 +851,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 4; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 100; m->chunks = 2; m->unit_max = 3072 * TSL_NB; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 100; m->chunks = 2; m->unit_max = 1024 * TSL_NB; m->batch_gen = 0;
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -895,7 +897,6 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
         // the stream of slot bi - TSL_NSTREAMS (its phase A is ordered behind that slot's, which is two or three batches older)
         if (bi < TSL_NSTREAMS) TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking)); else H.st = m->batch[bi % TSL_NSTREAMS].st;
         TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
-        TSL_HIP(hipEventCreateWithFlags(&H.b_done, hipEventDisableTiming));
     }
     for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], hipEventDisableTiming));
     TSL_HIP(hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking));
@@ -952,7 +953,6 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         BatchHost& H = m->batch[bi];
         if (H.st && bi < TSL_NSTREAMS) (void)hipStreamDestroy(H.st);
         if (H.a_done) (void)hipEventDestroy(H.a_done);
-        if (H.b_done) (void)hipEventDestroy(H.b_done);
     }
     for (auto& S : m->fset) {
 
@@ -1032,6 +1032,16 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
     TSL_REQUIRE(m && name && value, "null");
     if (!std::strcmp(name, "group")) { *value = m->P.group; return TSL_OK; }
     if (!std::strcmp(name, "semantics")) { *value = m->semantics; return TSL_OK; }
+    if (!std::strcmp(name, "last_heavy_bricks") || !std::strcmp(name, "last_slab_slots")) {
+        // developer statistics of the batch issued last: bricks walked in parts / slab slots (= parts) they used
+        TSL_REQUIRE(m->scratch_ready, "nothing integrated yet");
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        const int bi = (m->cur + TSL_NBATCH - 1) % TSL_NBATCH;
+        int v[40];
+        TSL_HIP(hipMemcpy(v, m->fset[bi * TSL_NB].F.counters, sizeof(v), hipMemcpyDeviceToHost));
+        *value = name[5] == 'h' ? v[14] : v[13];
+        return TSL_OK;
+    }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
     if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }

@@ -30,3 +30,9 @@ for kid, name in _lib.KERNEL_NAMES.items():
     if n: out.append(f"{name} {1000.0 * ms / n:.1f}")
 m.enable_profiling(False)
 print(" ".join(sys.argv[1:]) or "default", "| serial batches of 8, us per launch:", ", ".join(out), f"| {ser:.1f} us/frame incl. sync")
+try:
+    for i in range(128, 136):
+        m.recast_depth_to_map(frames[i][0], frames[i][1], dev[i], None)
+    print("   last batch: heavy bricks", m.get_option("last_heavy_bricks"), "slab slots", m.get_option("last_slab_slots"), "frame bricks", m.last_frame_stats()["bricks"])
+except Exception as e:
+    print("   (no batch statistics:", e, ")")
