@@ -92,8 +92,89 @@ def parity_vs_faithful(dev, frames, oracle_map):
     out = parity.short_summary(rep)
     out["frames"] = len(frames)
     out["note"] = ("HIP == oracle BATCHED bit for bit (tests); this is HIP vs the reference-literal sequential f16 replay (oracle FAITHFUL). "
-                   "Parity unpinned by the reference (no golden vectors, Taichi not installable). Histogram: profiles/r02_parity_vs_faithful.json")
+                   "Parity unpinned by the reference (no golden vectors, Taichi not installable). Histogram, growth with the stream length, fusion and mesh deviation: profiles/r03_parity_vs_faithful.json")
     return out
+
+
+def cpu_baseline_config(config, budget_s=10.0):
+    """The CPU restatement timed on one host core for a bounded sample of configs 1 / 3 / 4 (the oracle is the measured baseline here, nothing else)."""
+    from oracle import FAITHFUL, OracleOctomap, OracleTSDF
+    from taichislam_amd.utils import synthetic as syn
+    if config == 1:
+        o = OracleTSDF(map_scale=[6.4, 6.4], voxel_scale=0.05, num_voxel_per_blk_axis=16)
+        r = np.arange(-50, 50, dtype=np.int16)
+        ii, jj, kk = np.meshgrid(r, r, r, indexing="ij")
+        idx = np.stack([ii, jj, kk], -1).reshape(-1, 3)
+        p = idx.astype(np.float32) * np.float32(0.05)
+        t = (np.sqrt((p * p).sum(1)) - np.float32(1.5)).astype(np.float16)
+        o.import_sparse(0, idx, t, np.ones(len(t), np.float16), np.zeros(len(t), np.int8))
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tri = o.generate_mesh(1, 0.1, 1000000)[3]
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "meshes/s", "cores": 1, "kind": "port", "sample": f"{n} meshes of the same 128^3 sphere map ({tri} triangles), {dt:.1f} s, 1 thread, "
+                "CPU restatement of marching_cube_mesher.py:127-187"}
+    frames = list(syn.sphere_room_stream(40))
+    if config == 3:
+        o = OracleOctomap(map_scale=[51.2, 51.2], voxel_scale=0.05, K=2, max_ray_length=5.0, max_submap_num=4)
+        o.set_intrinsics(syn.K_DEPTH)
+        n, t0 = 0, time.perf_counter()
+        for R, T, d in frames:
+            o.integrate_depth(R, T, d)
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"first {n} frames of the same stream into the same Octomap, {dt:.1f} s, 1 thread, "
+                "CPU restatement of taichi_octomap.py:116-169"}
+    o = OracleTSDF(**C2)
+    o.set_intrinsics(syn.K_DEPTH)
+    n, t0 = 0, time.perf_counter()
+    for f, (R, T, d) in enumerate(frames):
+        o.integrate_depth(R, T, d, mode=FAITHFUL)
+        o.esdf(max_dist=1.0)                                   # the restatement has no incremental form: a full Dijkstra per frame
+        if f % 10 == 9:
+            o.generate_mesh(1, 5 * C2["voxel_scale"], 4000000)
+        n += 1
+        if time.perf_counter() - t0 > 2 * budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"first {n} frames of the same stream: FAITHFUL integration + full ESDF recompute (Dijkstra over the "
+            f"observed voxels; the CPU restatement has no incremental update) per frame + mesh every 10th, {dt:.1f} s, 1 thread"}
+
+
+def sequential_leg(dev, frames, oracle_map):
+    """Option semantics = 1 (csrc/tsl_sequential.hip): the reference-literal sequential replay on the GPU, for the frames the FAITHFUL
+    baseline integrated -- its rate, and whether the map equals the FAITHFUL map bit for bit."""
+    import torch
+    from taichislam_amd.mapping import DenseTSDF
+    from taichislam_amd.utils import synthetic as syn
+    g = DenseTSDF(**C2, device=dev)
+    g.set_dep_camera_intrinsic(syn.K_DEPTH)
+    g.set_option("semantics", 1)
+    dd = [torch.from_numpy(d.view(np.int16)).cuda(dev) for _, _, d in frames]
+    g.recast_depth_to_map(frames[0][0], frames[0][1], dd[0], None)      # first touch: scratch allocation
+    g.sync()
+    t0 = time.perf_counter()
+    for (R, T, _), d in zip(frames[1:], dd[1:]):
+        g.recast_depth_to_map(R, T, d, None)
+    g.sync()
+    dt = time.perf_counter() - t0
+    a, b = g.export_submap(), oracle_map.export_sparse()
+
+    def srt(e):
+        i = e["indices"].astype(np.int64)
+        o = np.argsort(((i[:, 0] + 32768) << 32) | ((i[:, 1] + 32768) << 16) | (i[:, 2] + 32768))
+        return e["indices"][o], np.asarray(e["TSDF"])[o].view(np.uint16), np.asarray(e["W_TSDF"])[o].view(np.uint16), e["occupy"][o]
+    x, y = srt(a), srt(b)
+    exact = all(u.shape == v.shape and np.array_equal(u, v) for u, v in zip(x, y))
+    return {"value": (len(frames) - 1) / max(dt, 1e-9), "unit": "frames/s", "frames": len(frames), "voxels": int(x[0].shape[0]),
+            "bit_exact_with_oracle_FAITHFUL": bool(exact),
+            "note": "tsl_tsdf_set_option(semantics, 1): rays in Taichi's struct-for order, every ray step applied on its own in f16 with the W clamp "
+                    "(dense_tsdf.py:264-267) -- a legal schedule of the racy reference, equal to the sequential CPU replay on every TSDF / W bit"}
 
 
 def relaunch(args):
@@ -121,6 +202,10 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="backend option for A/B runs (tsl_tsdf_set_option)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merge", action="store_true", help="also run the configs[4] global-map merge on one GPU (always on when --gpus > 1)")
+    ap.add_argument("--as-rank", type=int, default=None, metavar="R", help="dry run of the multi-rank branch on ONE GPU: behave as rank R of --of N (stream offset, "
+                    "submap id, pose table of N submaps, merge leg) without any collective; the line is marked dry_run and its value is this rank's alone")
+    ap.add_argument("--of", type=int, default=8, metavar="N", help="world size of the --as-rank dry run")
+    ap.add_argument("--steady", type=int, default=300, help="frames of the steady-state leg behind the contract region (0 = off)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -131,6 +216,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    dry = args.as_rank is not None
+    if dry:
+        if distributed or args.gpus != 1 or not (0 <= args.as_rank < args.of):
+            raise SystemExit("--as-rank R --of N is a single-process dry run: --gpus 1, 0 <= R < N")
+        rank, world = args.as_rank, args.of             # every rank-dependent line below runs as that rank; `distributed` stays False
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if distributed and world != args.gpus:
@@ -146,7 +236,19 @@ def main():
         if distributed:
             raise SystemExit("--config 1/3/4 are single-GPU measurements")
         from taichislam_amd.utils import bench_configs
-        emit(bench_configs.run(args.config, args.steps, args.warmup, dev))
+        line = bench_configs.run(args.config, args.steps, args.warmup, dev)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_config(args.config)
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if os.path.exists(tpath) and line.get("roofline"):
+            try:
+                tj = json.load(open(tpath)).get(f"config{args.config}")
+                if tj:
+                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = tj.get("command")
+            except Exception:
+                pass
+        emit(line)
         return
 
     from taichislam_amd import _lib
@@ -156,7 +258,9 @@ def main():
     # ---- synthetic stream: each rank starts 45 degrees further round the room ----
     nframes = args.warmup + args.steps
     from taichislam_amd import distributed as D
-    host = list(syn.sphere_room_stream(nframes, start_deg=D.stream_start_deg(rank)))
+    nsteady = args.steady if (args.steady > 0 and (rank == 0 or dry)) else 0
+    ngen = nframes + max(0, nsteady - args.steps)            # the steady-state leg goes over the timed frames again and on along the stream
+    host = list(syn.sphere_room_stream(ngen, start_deg=D.stream_start_deg(rank)))
     depth_dev = torch.from_numpy(np.stack([d for _, _, d in host]).view(np.int16)).cuda(dev)   # resident in HBM
     poses = [(np.ascontiguousarray(R), np.ascontiguousarray(T)) for R, T, _ in host]
 
@@ -170,7 +274,7 @@ def main():
         k, v = kv.split("=")
         m.set_option(k, int(v))
 
-    frames_dev = [depth_dev[f] for f in range(nframes)]     # one [480, 640] view per frame, made before the timed region
+    frames_dev = [depth_dev[f] for f in range(ngen)]        # one [480, 640] view per frame, made before the timed region
 
     def step(f):
         R, T = poses[f]
@@ -237,6 +341,21 @@ def main():
             host_rates[label] = nh / (time.perf_counter() - th)
         host_rates["note"] = f"{nh} frames, 614 kB uint16 numpy image per call through tsl_tsdf_integrate_depth (copy + stream sync per frame), rank 0 only"
 
+    # ---- steady state, driver-visible: >= 300 frames behind the contract region, same map, same clock (the contract's K may be a 20-frame
+    #      burst, which is dominated by filling and draining the batch pipeline) ----
+    steady = None
+    if nsteady > 0:
+        m.sync()
+        gc.collect(); gc.disable()
+        ts = time.perf_counter()
+        for i in range(nsteady):
+            step(args.warmup + i)
+        m.sync(); torch.cuda.synchronize()
+        steady_dt = time.perf_counter() - ts
+        gc.enable()
+        steady = {"value": nsteady / steady_dt, "unit": "frames/s", "frames": nsteady,
+                  "note": "same handle, same map, frames resident in HBM, timed like `value` (sync on both sides); rank 0 only"}
+
     per_rank = None
     if distributed:
         tr = torch.zeros(world, dtype=torch.float64, device=f"cuda:{dev}")
@@ -292,7 +411,7 @@ def main():
         merge_box["done"] = True
 
     merge_timed_out = False
-    if distributed or args.merge:
+    if distributed or args.merge or dry:
         import threading
         th = threading.Thread(target=merge_leg, daemon=True)
         th.start()
@@ -300,8 +419,8 @@ def main():
         merge_timed_out = not merge_box["done"]
     merge = {"error": "timeout: the merge leg did not finish (first multi-rank run on hardware?)"} if merge_timed_out else merge_box["merge"]
 
-    if rank == 0:
-        fps = world * args.steps / dt
+    if rank == 0 or dry:
+        fps = (1 if dry else world) * args.steps / dt
         # algorithmic bytes (SURVEY.md section 8d / DESIGN.md): phase A = 2*P_used + 24*P_valid, phase B = 9*U + V_pcl
         bytes_a = 2 * stats["p_used"] + 24 * stats["p_valid"]
         bytes_b = 9 * stats["unique"] + stats["v_pcl"]
@@ -313,16 +432,24 @@ def main():
             alg = 9 * stats["unique"] * fpl
             us = kern["integrate"]["avg_us"]
             ach = alg / (us * 1e-6) / 1e9
-            traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            traffic, traffic_src, valu = None, None, None
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     traffic, traffic_src = tj["integrate"]["hbm_bytes_per_launch"], tj.get("command")
+                    # what actually bounds the kernel: its VALU issue rate.  SQ_INSTS_VALU (wave instructions per launch, PMC pass of the same
+                    # command) x 4 cycles per wave64 instruction / (SIMDs x cycles of THIS run's average launch)
+                    vi, fpl_p = tj["integrate"].get("valu_wave_insts_per_launch"), tj["integrate"].get("frames_per_launch")
+                    if vi and fpl_p:
+                        simds, mhz = 4 * 256, 2400.0
+                        valu = {"valu_wave_insts_per_frame": vi / fpl_p, "cycles_per_inst": 4, "simds": simds, "clock_mhz": mhz,
+                                "frac": (vi / fpl_p * fpl) * 4.0 / (simds * us * mhz)}
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": "tsl::k_integrate_batch", "frames_per_launch": fpl, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "valu_frac": valu["frac"] if valu else None, "valu": valu,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": us,
                     "frame_bytes": bytes_a + bytes_b, "frame_gbs": (bytes_a + bytes_b) * fps / world / 1e9,
                     "frame_frac": (bytes_a + bytes_b) * fps / world / 1e9 / HBM_PEAK_GBS,
@@ -337,8 +464,12 @@ def main():
                        "kernels_us_note": "every kernel is launched once per batch of up to 8 queued frames",
                        "updates_per_s": stats["steps"] * fps, "per_rank_frames_per_s": per_rank, "merge": merge},
             "roofline": roof,
+            "value_steady": steady,
             "value_host_input": host_rates,
         }
+        if dry:
+            out["dry_run"] = {"as_rank": rank, "of": world, "note": "single-process dry run of the multi-rank branch: this rank's stream offset, submap id and pose table, "
+                              "merge leg without a communicator; `value` is this rank's rate alone, n_gpus is the simulated world size"}
         if not args.no_cpu_baseline:
             sample = [(R, T, d) for R, T, d in host[: max(8, min(len(host), 200))]]
             one, allc, omap, n_done = cpu_baselines(sample)
@@ -348,6 +479,10 @@ def main():
                 out["parity_vs_faithful"] = parity_vs_faithful(dev, sample[:n_done], omap)
             except Exception as e:
                 out["parity_vs_faithful"] = {"error": repr(e)[:200]}
+            try:
+                out["value_sequential"] = sequential_leg(dev, sample[:n_done], omap)
+            except Exception as e:
+                out["value_sequential"] = {"error": repr(e)[:200]}
         emit(out)
     if merge_timed_out:
         sys.stderr.write("bench.py: merge leg timed out; leaving without further collectives\n"); real_stdout.flush()

@@ -643,7 +643,11 @@ __global__ void __launch_bounds__(256) k_scatter(BatchDev B)
 //   * the flush computes all 16 voxels of a thread without branches (stores are predicated), and converts the sums
 //     through the 32-bit path when every sum of the wave fits.
 // =====================================================================================================
+#ifdef TSL_NOSWZ      // developer A/B: the accumulator planes without the bank swizzle
+__device__ __forceinline__ int acc_swz5(int l) { return l; }
+#else
 __device__ __forceinline__ int acc_swz5(int l) { return l ^ (((l >> 8) ^ (l >> 5)) & 31); }
+#endif
 struct StepK { float vs, rvs, T0, T1, T2; int hN, hNz; };
 
 template <bool FASTDIV>

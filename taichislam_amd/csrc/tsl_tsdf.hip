@@ -56,7 +56,7 @@ template <> struct KeyOps<uint64_t> {
 // ------------------------------------------------------------------------------------------------------
 // K1: depth image -> sensor-centred voxel key + f16 payload       dense_tsdf.py:188-213, process_point :227-229
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long long vkey, uint32_t pid, int log2n, bool* opened, int* xslot);
+__device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long long vkey, bool inside, uint32_t pid, int log2n, bool* opened, int* xslot);
 
 template <typename K>
 __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
     const int p = jj * P.ww + ii;                                                    // pixel id = raster order
     bool gate = false, inside = false, opened = false;
     int slot = -1, xslot = -1;
+    unsigned long long vkey = 0ull;
     if (jj < P.hh && ii < P.ww) {
         const int j = jj * P.step, i = ii * P.step;
         const uint16_t d = depth[(size_t)j * P.W + i];
@@ -101,10 +102,11 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
             }
         }
         F.pix[p] = payload;
-        if (P.group) { if (inside) slot = group_insert(F, (unsigned long long)key, (uint32_t)p, P.hlog2, &opened, &xslot); }
-        else { keys[p] = key; F.vals[p] = (uint32_t)p; }
+        if (!P.group) { keys[p] = key; F.vals[p] = (uint32_t)p; }
+        vkey = (unsigned long long)key;
     }
     if (P.group) {
+        slot = group_insert(F, vkey, inside, (uint32_t)p, P.hlog2, &opened, &xslot);      // wave-cooperative: reached by every lane
         const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot;          // position in the list = ray id
         const int x = wave_reserve(&F.counters[7], xslot >= 0); if (xslot >= 0) F.actx[x] = xslot;   // (rare) overflow slots: listed to be cleared
     }
@@ -127,6 +129,7 @@ __global__ void __launch_bounds__(256) k_voxelize_points(BatchDev B)
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool gate = false, inside = false, opened = false;
     int slot = -1, xslot = -1;
+    unsigned long long vkey = 0ull;
     if (p < n) {
         const float px = xyz[(size_t)p * 3], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
         const float mx = (P.R[0] * px + P.R[1] * py) + P.R[2] * pz;                   // :175
@@ -146,10 +149,11 @@ __global__ void __launch_bounds__(256) k_voxelize_points(BatchDev B)
             }
         }
         F.pix[p] = payload;
-        if (P.group) { if (inside) slot = group_insert(F, (unsigned long long)key, (uint32_t)p, P.hlog2, &opened, &xslot); }
-        else { keys[p] = key; F.vals[p] = (uint32_t)p; }
+        if (!P.group) { keys[p] = key; F.vals[p] = (uint32_t)p; }
+        vkey = (unsigned long long)key;
     }
     if (P.group) {
+        slot = group_insert(F, vkey, inside, (uint32_t)p, P.hlog2, &opened, &xslot);      // wave-cooperative: reached by every lane
         const int q = block_reserve(&F.counters[6], opened); if (opened) F.act[q] = slot;          // position in the list = ray id
         const int x = wave_reserve(&F.counters[7], xslot >= 0); if (xslot >= 0) F.actx[x] = xslot;   // (rare) overflow slots: listed to be cleared
     }
@@ -190,22 +194,44 @@ __global__ void __launch_bounds__(256) k_build_rays(const FrameParams* __restric
 }
 
 // (b) pixels grouped through a hash table of sensor voxels (no sort, brick-binned path): k_voxelize_* insert every pixel into its
-// voxel's slot -- find-or-insert CAS on the key, a returning add on the count, and the pixel id goes into the slot itself (HSlot,
-// tsl_tsdf.hpp) -- and k_segments reads a voxel's pixels back with one 64-byte load and replays them in ASCENDING pixel id, i.e. raster
-// order.  Returns the slot of the voxel; *opened = this pixel opened the voxel in this frame; *xslot = overflow slot this pixel opened (or -1).
-__device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long long vkey, uint32_t pid, int log2n, bool* opened, int* xslot)
+// voxel's slot and k_segments reads a voxel's pixels back with one 64-byte load and replays them in ASCENDING pixel id, i.e. raster
+// order (HSlot, tsl_tsdf.hpp).  Neighbouring pixels fall into the same voxel (2-3 per voxel and more), and the L2 executes ~23 G
+// scattered atomics per second chip-wide -- one find-or-insert CAS + one returning add PER PIXEL made this kernel the atomics' speed.
+// So a wave first groups its lanes by key (pure lane arithmetic: one iteration per distinct key), the first lane of every group does the
+// CAS and reserves the whole group's ranks with ONE add, and the slot / first rank travel back to the group's lanes.
+// Must be reached by every lane of the wave.  Returns the slot of the voxel (-1 for lanes without a pixel);
+// *opened = this lane opened the voxel in this frame; *xslot = overflow slot this lane opened (or -1).
+__device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long long vkey, bool inside, uint32_t pid, int log2n, bool* opened, int* xslot)
 {
     HSlot* const tab = F.htab;
     const uint32_t mask = (1u << log2n) - 1u;
-    const unsigned long long k0 = h_key(vkey, 0);
-    uint32_t h = h_hash64(k0, log2n);
-    for (;;) {
-        const unsigned long long cur = atomicCAS(&tab[h].key, H_EMPTY, k0);
-        if (cur == H_EMPTY) { *opened = true; break; }
-        if (cur == k0) break;
-        h = (h + 1u) & mask;
+    const int lane = lane_id();
+    const uint32_t klo = (uint32_t)vkey, khi = (uint32_t)(vkey >> 32);
+    int leader = lane, grank = 0, gsize = 1;
+    for (unsigned long long todo = __ballot(inside); todo; ) {
+        const int l0 = (int)__builtin_ctzll(todo);                                   // (uniform)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)klo, l0), hi = (uint32_t)__builtin_amdgcn_readlane((int)khi, l0);
+        const bool mine = inside && klo == lo && khi == hi;
+        const unsigned long long grp = __ballot(mine);
+        if (mine) { leader = l0; grank = rank_below(grp); gsize = popc64(grp); }
+        todo &= ~grp;
     }
-    const int r = atomicAdd(&tab[h].cnt, 1);
+    int h = -1, r0 = 0;
+    if (inside && lane == leader) {
+        const unsigned long long k0 = h_key(vkey, 0);
+        uint32_t hh = h_hash64(k0, log2n);
+        for (;;) {
+            const unsigned long long cur = atomicCAS(&tab[hh].key, H_EMPTY, k0);
+            if (cur == H_EMPTY) { *opened = true; break; }
+            if (cur == k0) break;
+            hh = (hh + 1u) & mask;
+        }
+        h = (int)hh;
+        r0 = atomicAdd(&tab[hh].cnt, gsize);
+    }
+    h = __shfl(h, leader); r0 = __shfl(r0, leader);
+    if (!inside) return -1;
+    const int r = r0 + grank;
     if (r < H_INL) tab[h].pix[r] = pid;
     else {      // crowded voxel: pixels H_INL.. live in slots keyed (voxel, block)
         const unsigned long long k2 = h_key(vkey, r / H_INL);
@@ -218,7 +244,7 @@ __device__ __forceinline__ int group_insert(const FrameDev& F, unsigned long lon
         }
         tab[h2].pix[r % H_INL] = pid;
     }
-    return (int)h;
+    return h;
 }
 
 // ------------------------------------------------------------------------------------------------------

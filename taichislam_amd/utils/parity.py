@@ -30,13 +30,17 @@ def _pct(d, qs=(50, 90, 99, 99.9, 100)):
 
 
 def field_deviation(a, ref):
-    """a, ref: float16 arrays of one field over the same voxels."""
+    """a, ref: float16 arrays of one field over the same voxels.  NaNs (a fusion's 0 / 0, dense_tsdf.py:275) are counted on each side and
+    left out of the distance statistics; `identical` compares bits over everything."""
     a64, r64 = a.astype(np.float64), ref.astype(np.float64)
-    d = np.abs(a64 - r64)
-    u = d / f16_ulp(r64)
-    return {"n": int(d.size), "identical": float(np.mean(a.view(np.uint16) == ref.view(np.uint16))) if d.size else None,
-            "within_1ulp": float(np.mean(u <= 1.0)) if d.size else None, "abs": _pct(d), "ulps": _pct(u),
-            "mean_abs": float(d.mean()) if d.size else None}
+    fin = np.isfinite(a64) & np.isfinite(r64)
+    out = {"n": int(a64.size), "identical": float(np.mean(a.view(np.uint16) == ref.view(np.uint16))) if a64.size else None}
+    if not fin.all():
+        out["nan_test"], out["nan_ref"], out["nan_both"] = int(np.isnan(a64).sum()), int(np.isnan(r64).sum()), int((np.isnan(a64) & np.isnan(r64)).sum())
+    d = np.abs(a64[fin] - r64[fin])
+    u = d / f16_ulp(r64[fin])
+    out.update({"within_1ulp": float(np.mean(u <= 1.0)) if d.size else None, "abs": _pct(d), "ulps": _pct(u), "mean_abs": float(d.mean()) if d.size else None})
+    return out
 
 
 def deviation_report(test, ref, voxel_scale, sensor_xyz=None, ideal=None, dist_bins=(0.0, 0.3, 1.0, 2.0, 3.0, 1e9)):
@@ -53,10 +57,12 @@ def deviation_report(test, ref, voxel_scale, sensor_xyz=None, ideal=None, dist_b
     out["tsdf"] = field_deviation(t["TSDF"], r["TSDF"])
     out["w"] = field_deviation(t["W_TSDF"], r["W_TSDF"])
     rt = r["TSDF"].astype(np.float64)
-    band = np.abs(rt) < 1.8 * vs                                        # the reference's surface threshold (dense_tsdf.py:39)
+    with np.errstate(invalid="ignore"):
+        band = np.abs(rt) < 1.8 * vs                                        # the reference's surface threshold (dense_tsdf.py:39)
     out["tsdf_surface_band"] = field_deviation(t["TSDF"][band], r["TSDF"][band])
     rel = np.abs(t["TSDF"].astype(np.float64) - rt) / np.maximum(np.abs(rt), vs)
-    out["tsdf_relative_floor_voxel"] = dict(_pct(rel), frac_le_1e4=float(np.mean(rel <= 1e-4)))
+    rel = rel[np.isfinite(rel)]
+    out["tsdf_relative_floor_voxel"] = dict(_pct(rel), frac_le_1e4=float(np.mean(rel <= 1e-4)) if rel.size else None)
     i = None
     if ideal is not None:
         i = _sorted(ideal)
@@ -81,6 +87,30 @@ def deviation_report(test, ref, voxel_scale, sensor_xyz=None, ideal=None, dist_b
                 row["ref_vs_ideal"] = field_deviation(r["TSDF"][s], i["TSDF"][s])
             rows.append(row)
         out["by_distance_from_sensor"] = rows
+    return out
+
+
+def mesh_deviation(v_test, v_ref, voxel_scale):
+    """Two triangle soups (vertices [3n, 3] in metres): nearest-vertex distances in both directions (scipy k-d tree).  The meshes come from
+    maps that differ in the last f16 bits, so their triangulations differ where a cube's case flips; distance between the vertex sets is the
+    geometric statement (marching_cube_mesher.py:44-60 interpolates vertices from TSDF values)."""
+    from scipy.spatial import cKDTree
+    a, b = np.asarray(v_test, dtype=np.float64).reshape(-1, 3), np.asarray(v_ref, dtype=np.float64).reshape(-1, 3)
+    out = {"triangles_test": int(a.shape[0] // 3), "triangles_ref": int(b.shape[0] // 3)}
+    # vertexInterp divides by the difference of two corner values (marching_cube_mesher.py:44-60): equal corners give non-finite vertices,
+    # in the reference as in both implementations -- counted, not compared
+    fa, fb = np.isfinite(a).all(1), np.isfinite(b).all(1)
+    out["nonfinite_vertices_test"], out["nonfinite_vertices_ref"] = int((~fa).sum()), int((~fb).sum())
+    a, b = a[fa], b[fb]
+    if a.size == 0 or b.size == 0:
+        return out
+    d_ab = cKDTree(b).query(a)[0]
+    d_ba = cKDTree(a).query(b)[0]
+    vs = float(voxel_scale)
+    out["test_to_ref_m"] = _pct(d_ab); out["ref_to_test_m"] = _pct(d_ba)
+    out["frac_within_1e-4_of_a_voxel"] = float(np.mean(np.concatenate([d_ab, d_ba]) <= 1e-4 * vs))
+    out["frac_within_1_percent_of_a_voxel"] = float(np.mean(np.concatenate([d_ab, d_ba]) <= 1e-2 * vs))
+    out["identical_vertex_fraction"] = float(np.mean(np.concatenate([d_ab, d_ba]) == 0.0))
     return out
 
 

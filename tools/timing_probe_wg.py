@@ -6,7 +6,7 @@ from taichislam_amd import _lib
 from taichislam_amd.mapping import DenseTSDF
 from taichislam_amd.utils import synthetic as syn
 C2 = dict(map_scale=[10.24, 10.24], voxel_scale=0.02, num_voxel_per_blk_axis=16, max_ray_length=5.0, min_ray_length=0.3, internal_voxels=10, recast_step=2)
-m = DenseTSDF(**C2); m.set_dep_camera_intrinsic(syn.K_DEPTH)
+m = DenseTSDF(**C2); m.set_dep_camera_intrinsic(syn.K_DEPTH); m.set_option("ramp", 0)
 for a in sys.argv[1:]:
     k, v = a.split("="); m.set_option(k, int(v))
 frames = list(syn.sphere_room_stream(14))
@@ -17,7 +17,8 @@ NF = 16
 for i in range(16): m.recast_depth_to_map(frames[i % 14][0], frames[i % 14][1], dev[i % 14], None)
 m.sync()
 L.tsl_tsdf_debug_counters(m.h, out.ctypes.data_as(ctypes.c_void_p), 1)
-for i in range(4): m.recast_depth_to_map(frames[10 + i][0], frames[10 + i][1], dev[10 + i], None)
+NB = int(os.environ.get("NB", "8"))
+for i in range(NB): m.recast_depth_to_map(frames[(4 + i) % 14][0], frames[(4 + i) % 14][1], dev[(4 + i) % 14], None)
 m.sync()
 L.tsl_tsdf_debug_counters(m.h, out.ctypes.data_as(ctypes.c_void_p), 1)
 # per workgroup 16 item records of 8: [0] start [1] unit | np << 8 | frame mask << 32 | kdep << 40 [2] segments walked [3] end of the last walk [4] item end [5] end of the wait for the previous frame (0: none)
@@ -48,7 +49,7 @@ for kind, selk in (("unit", isu), ("part whole", (~isu) & (npp == 1)), ("part sp
         if sel.any():
             print(f"  {kind:10s} segs [{lo},{hi}): {sel.sum():4d} items  start p50 {np.median(st[sel]):5.1f}  walk mean {walk[sel].mean():5.1f} p90 {np.percentile(walk[sel],90):5.1f}  apply mean {fl[sel].mean():5.1f} p90 {np.percentile(fl[sel],90):5.1f} max {fl[sel].max():5.1f}")
 busy = np.where(used, rec[:, :, 4] - rec[:, :, 0], 0).sum(1) / 100.0
-print("busy us per workgroup: mean %.1f min %.1f max %.1f; launch span %.1f us for 4 frames" % (busy.mean(), busy.min(), busy.max(), (end.max() - t0) / 100.0))
+print("busy us per workgroup: mean %.1f min %.1f max %.1f; launch span %.1f us for the last batch" % (busy.mean(), busy.min(), busy.max(), (end.max() - t0) / 100.0))
 ph = out.reshape(-1)[196608:196608 + 512 * 128].reshape(512, 16, 8)
 for kind, selk in (("unit", isu), ("part", ~isu)):
     for lo, hi in ((0, 256), (256, 1024), (1024, 2048), (2048, 4097)):
