@@ -258,7 +258,9 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 <= 128 VGPRs: two 512-thread workgroups = 16 waves per CU)
      "unit"     a brick whose segments of a whole batch number at most this is walked by ONE workgroup, frame after frame, with its voxels in
                 registers; heavier bricks are split into parts that leave their sums in slab slots of their own, applied by k_apply_slab
-     "chunks"   steps a part may hold (1..8, default 2)
+     "unit_half" bricks with more segments per batch than this (and at most "unit") are walked half as a unit (their first frames) and half as
+                parts (their later frames): halves the longest serial chain of a launch; >= "unit" disables the middle tier
+     "chunks"   steps a part may hold (1..8, default 4)
      "bgrid"    resident phase-B workgroups in percent of the slots (wg 256 only; default 100)
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
      "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)

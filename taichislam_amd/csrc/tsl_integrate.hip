@@ -530,7 +530,14 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 #define HDR_PARTS 16           //   [16..19] parts per class
 #define HDR_UNITS 20           //   batch: [20..23] units per class
 __device__ __forceinline__ int plan_class(int w) { return w >= 2560 ? 0 : (w >= 1280 ? 1 : (w >= 512 ? 2 : 3)); }
-__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max)
+// Three tiers by the brick's segments of the whole batch (wb):
+//   wb <= unit_half            UNIT over all its frames;
+//   unit_half < wb <= unit_max the brick's FIRST frames (about half of its segments) are a unit, its later frames are walked as parts and
+//                              applied by k_apply_slab on top of what the unit wrote (the apply kernel is the next launch on the stream, and
+//                              the split follows the frame order, so the frames are still applied in order): the longest chain of a launch
+//                              -- a unit near the limit, walked by one workgroup -- halves for four instead of eight slab slots per brick;
+//   wb > unit_max              parts for every frame.
+__global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, int unit_max, int unit_half)
 {
     if ((int)blockIdx.y >= B.n) return;
     const int y = blockIdx.y;
@@ -539,13 +546,22 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
     const int nact = min(listed, F.max_frame_bricks);
     if ((int)blockIdx.x * 256 >= nact && blockIdx.x) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int v = 0, b = 0, np = 0, pcls = -1, ucls = -1, tm = 0, wb = 0;
+    int v = 0, b = 0, np = 0, pcls = -1, ucls = -1, tm = 0, wb = 0, tmu = 0, tmp = 0, wu = 0;
     if (i < nact) {
         b = F.act_b[i];
         v = F.bhist[b];
-        for (int q = 0; q < B.n; ++q) { const int vq = B.f[q].bhist[b]; if (vq > 0) tm |= 1 << q; wb += vq; }
-        if (wb <= unit_max) { if ((tm & -tm) == (1 << y)) ucls = plan_class(wb); }         // the brick's first frame lists the unit
-        else if (v > 0) { np = (v + psegs - 1) / psegs; pcls = plan_class((v + np - 1) / np); }
+        int vq[TSL_NB];
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) { vq[q] = q < B.n ? B.f[q].bhist[b] : 0; if (vq[q] > 0) tm |= 1 << q; wb += vq[q]; }
+        // frames the unit walks (tmu) / frames walked as parts (tmp): every frame's thread of the brick derives the same split
+        if (wb > unit_max) { tmp = tm; }
+        else if (wb > unit_half) {
+            int acc = 0;
+#pragma unroll
+            for (int q = 0; q < TSL_NB; ++q) if ((tm >> q) & 1) { if (2 * acc < wb) { tmu |= 1 << q; wu += vq[q]; } else tmp |= 1 << q; acc += vq[q]; }
+        } else { tmu = tm; wu = wb; }
+        if (tmu && (tmu & -tmu) == (1 << y)) ucls = plan_class(wu);                       // the first frame of the unit's frames lists the unit
+        if (((tmp >> y) & 1) && v > 0) { np = (v + psegs - 1) / psegs; pcls = plan_class((v + np - 1) / np); }
     }
     const int off = block_reserve_n(&F.counters[3], v);
     const int s0 = block_reserve_n(&B.f[0].counters[HDR_SLAB], np);                       // one slab slot per part, consecutive per (frame, brick)
@@ -559,13 +575,13 @@ __global__ void __launch_bounds__(256) k_plan(MapDev M, BatchDev B, int psegs, i
         F.bnseg[b] = v;
         const int pool = (np || ucls >= 0) ? pool_claim<false>(M, B.p[y]->slot, b) : -1;      // < 0: pool exhausted (reported through M.err), the item is skipped
         if (ucls >= 0) {
-            if (u0 < B.f[0].unit_cap) B.f[0].unit_tab[(size_t)ucls * B.f[0].unit_cap + u0] = make_int4(b, wb, pool, tm);
+            if (u0 < B.f[0].unit_cap) B.f[0].unit_tab[(size_t)ucls * B.f[0].unit_cap + u0] = make_int4(b, wu, pool, tmu);
             else for (int q = 0; q < B.n; ++q) if ((tm >> q) & 1) frame_fail(M, B.f[q], 2);
         }
         if (np && pool >= 0) {
-            if ((tm & -tm) == (1 << y)) {                                                 // the brick's first frame of the batch lists it for k_apply_slab
+            if ((tmp & -tmp) == (1 << y)) {                                               // the first of the brick's part frames lists it for k_apply_slab
                 const int hi = __hip_atomic_fetch_add(&B.f[0].counters[HDR_HEAVY], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (hi < B.f[0].max_frame_bricks) B.f[0].heavy_tab[hi] = make_int4(b, pool, tm, 0);
+                if (hi < B.f[0].max_frame_bricks) B.f[0].heavy_tab[hi] = make_int4(b, pool, tmp, 0);
                 else for (int q = 0; q < B.n; ++q) if ((tm >> q) & 1) frame_fail(M, B.f[q], 2);
             }
             if (s0 + np > F.max_frame_bricks || np >= (1 << PART_NP_BITS) || p0 + np > F.part_cap) frame_fail(M, F, 2);      // this frame is not integrated at all
@@ -1182,8 +1198,9 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     // the unit limit is quoted for a full batch; a shorter batch (one frame when something reads the map after every frame) scales it:
     // a unit is walked by one workgroup frame after frame, and with few frames a long unit is just a long serial item
     const int unit_max = m->unit_max <= 4096 ? m->unit_max : std::max(4096, (int)((long long)m->unit_max * B.n / TSL_NB));
+    const int unit_half = std::min(unit_max, m->unit_half <= 2048 ? m->unit_half : std::max(2048, (int)((long long)m->unit_half * B.n / TSL_NB)));
     prof_begin(m, TSL_K_BIN, st);
-    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max);
+    hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max, unit_half);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);
     prof_end(m, st);
     return TSL_OK;

@@ -877,7 +877,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20;      // (the middle tier is off by default: measured neutral-to-negative once the brick kernel runs on 75 % of the slots) m->batch_gen = 0;
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
@@ -1440,6 +1440,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
+    if (!std::strcmp(name, "unit_half")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit_half must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_half = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
     if (!std::strcmp(name, "adaptive")) { m->adaptive = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "ramp")) { TSL_REQUIRE(value >= 0 && value <= 16, "ramp must be 0..16 half batches"); m->ramp_batches = value; return TSL_OK; }

@@ -71,6 +71,23 @@ def test_units_and_parts_over_full_batches(hip_lib, wg, spt, unit, ramp):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} unit {unit} ramp {ramp}")
 
 
+@pytest.mark.parametrize("unit,half", [(1 << 20, 300), (3000, 100), (1 << 20, 1 << 20), (2000, 0)])
+def test_middle_tier_first_frames_as_unit_later_frames_as_parts(hip_lib, unit, half):
+    """Bricks between `unit_half` and `unit` segments per batch: their first frames are walked as a unit, their later frames as parts that
+    k_apply_slab applies on top of what the unit wrote.  Any split must give the oracle's map."""
+    from oracle import BATCHED
+    K, frames = small_stream(11)
+    g, o = make_pair(SMALL, K)
+    g.set_option("unit", unit); g.set_option("unit_half", half); g.set_option("ramp", 0)
+    so = None
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+        so = o.integrate_depth(R, T, d, mode=BATCHED)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"unit {unit} unit_half {half}")
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_arithmetic_shortcuts_hold_for_every_float(hip_lib, which):
     """The kernels round half away from zero with add+truncate and take square roots without the library's rescaling;
