@@ -731,6 +731,17 @@ static int ensure_frame_scratch(tsl_tsdf* m)
         if ((rc = own((void**)&S.Pd, sizeof(FrameParams)))) return rc;
     }
     TSL_HIP(hipStreamSynchronize(m->stream_));                  // the fills ran on the main stream; phase A uses the batch streams
+    // the runtime binds a stream to a hardware queue on its first submission (a few hundred microseconds): do that here, not in the first
+    // batch that happens to use the slot (a 20-frame burst reaches the third batch slot for the first time inside the measured region)
+    for (int bi = 0; bi < TSL_NSTREAMS; ++bi) {
+        TSL_HIP(hipMemsetAsync(m->fset[bi * TSL_NB].header, 0, 4, m->batch[bi].st));
+        TSL_HIP(hipEventRecord(m->batch[bi].a_done, m->batch[bi].st));
+    }
+    TSL_HIP(hipMemsetAsync(m->fset[0].header, 0, 4, m->copy_st));
+    for (int bi = 0; bi < TSL_NSTREAMS; ++bi) TSL_HIP(hipStreamSynchronize(m->batch[bi].st));
+    TSL_HIP(hipStreamSynchronize(m->copy_st));
+    for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventRecord(m->ring_ev[k], m->stream_));      // (events too are set up on their first record)
+    TSL_HIP(hipStreamSynchronize(m->stream_));
     m->scratch_ready = true;
     return TSL_OK;
 }
