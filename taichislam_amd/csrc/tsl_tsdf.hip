@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
     unsigned long long vkey = 0ull;
     if (jj < P.hh && ii < P.ww) {
         const int j = jj * P.step, i = ii * P.step;
-        const uint16_t d = depth[(size_t)j * P.W + i];
+        const uint16_t d = depth[(size_t)jj * P.rstride + i];
         K key = KeyOps<K>::invalid(P.pcl_bits);
         uint2 payload = make_uint2(0u, 0u);
         const float df = (float)d;
@@ -641,8 +641,10 @@ static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
     return TSL_OK;
 }
 // host buffers are copied into the staging area of the frame's working set; the host waits for the copy, so phase A needs no event
-static int stage_host(tsl_tsdf* m, int si, const void* in, size_t in_bytes, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev)
+// `in`: `rows` rows of `row_bytes` bytes, `src_pitch` bytes apart (rows == 1: one contiguous block); they are stored back to back
+static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int rows, size_t src_pitch, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev)
 {
+    const size_t in_bytes = row_bytes * (size_t)rows;
     FSet& S = m->fset[si];
     // a stream of its own for the copies: on a phase-A stream the copy (and the wait below) would queue behind phase A of an older batch
     hipStream_t sc = m->stream_;
@@ -652,7 +654,8 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t in_bytes, cons
         if (H.a_recorded) TSL_HIP(hipStreamWaitEvent(sc, H.a_done, 0));       // phase A of the slot's previous batch read this staging area
     }
     int rc = grow(&S.stage_in, &S.stage_in_bytes, in_bytes + 16); if (rc) return rc;
-    if (in_bytes) TSL_HIP(hipMemcpyAsync(S.stage_in, in, in_bytes, hipMemcpyHostToDevice, sc));
+    if (in_bytes && rows > 1 && src_pitch != row_bytes) TSL_HIP(hipMemcpy2DAsync(S.stage_in, row_bytes, in, src_pitch, row_bytes, (size_t)rows, hipMemcpyHostToDevice, sc));
+    else if (in_bytes) TSL_HIP(hipMemcpyAsync(S.stage_in, in, in_bytes, hipMemcpyHostToDevice, sc));
     *in_dev = S.stage_in; *tex_dev = nullptr;
     if (tex && tex_bytes) {
         rc = grow(&S.stage_tex, &S.stage_tex_bytes, tex_bytes); if (rc) return rc;
@@ -1146,6 +1149,7 @@ int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[
     FrameParams& P = m->P;
     P.H = h; P.W = w;
     P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);           // dense_tsdf.py:192,194
+    P.rstride = m->staged_rows ? w : P.step * w; m->staged_rows = false;
     P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0; P.tex_input = (const uint8_t*)tex_dev;
     TSL_REQUIRE(!P.tex || (th > 0 && tw > 0 && (!P.same_proj || (th >= h && tw >= w))), "integrate_depth: texture smaller than the depth image");
     m->h_stats->p_used = (int64_t)P.hh * P.ww;
@@ -1160,7 +1164,11 @@ int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], 
     int si = 0; int rc = reserve_slot(m, 0, &si); if (rc) return rc;
     const bool use_tex = tex && m->cfg.texture_enabled && th > 0 && tw > 0;
     void *ddev = nullptr, *tdev = nullptr;
-    rc = stage_host(m, si, depth, (size_t)h * w * sizeof(uint16_t), use_tex ? tex : nullptr, use_tex ? (size_t)th * tw * 3 : 0, &ddev, &tdev); if (rc) return rc;
+    // only the rows the kernel visits (every recast_step-th, dense_tsdf.py:192-195) cross the bus: half of a 640x480 image at recast_step 2
+    const int step = m->P.step, hh = (int)((float)h / (float)step);
+    rc = stage_host(m, si, depth, (size_t)w * sizeof(uint16_t), step > 1 ? hh : h, (size_t)(step > 1 ? step : 1) * w * sizeof(uint16_t),
+                    use_tex ? tex : nullptr, use_tex ? (size_t)th * tw * 3 : 0, &ddev, &tdev); if (rc) return rc;
+    m->staged_rows = step > 1;
     return tsl_tsdf_integrate_depth_dev(m, R, T, ddev, h, w, tdev, th, tw);
 }
 
@@ -1181,7 +1189,7 @@ int tsl_tsdf_integrate_points(tsl_tsdf* m, const double R[9], const double T[3],
     int si = 0; int rc = reserve_slot(m, 1, &si); if (rc) return rc;
     const bool use_tex = rgb && m->cfg.texture_enabled && n;
     void *xdev = nullptr, *cdev = nullptr;
-    rc = stage_host(m, si, xyz, (size_t)n * 3 * sizeof(float), use_tex ? rgb : nullptr, use_tex ? (size_t)n * 3 : 0, &xdev, &cdev); if (rc) return rc;
+    rc = stage_host(m, si, xyz, (size_t)n * 3 * sizeof(float), 1, 0, use_tex ? rgb : nullptr, use_tex ? (size_t)n * 3 : 0, &xdev, &cdev); if (rc) return rc;
     return tsl_tsdf_integrate_points_dev(m, R, T, xdev, cdev, n);
 }
 

@@ -17,6 +17,7 @@ struct FrameParams {
     float internal_f;                  // internal_voxels
     int   pcl_lo, pcl_ext, pcl_bits;   // sensor-centred grid: index range [lo, lo+ext), bits per axis
     int   step, hh, ww, H, W;          // recast_step, visited rows/cols, image size
+    int   rstride;                     // elements between two VISITED rows of the depth buffer: step * W for the caller's image, W for a staged host image (only its visited rows are copied)
     int   th, tw, tex, same_proj;
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
@@ -187,6 +188,7 @@ struct tsl_tsdf {
     hipStream_t producers[4]; int nproducers;   // producer streams of the queued device inputs (ordered before phase A when the batch is issued)
     hipEvent_t in_ev[8]; int in_ev_next;  // cached events ordering callers' producer streams before the input-reading stream (tsl_tsdf_input_stream)
     bool scratch_ready;                  // frame scratch allocated (first integrate call)
+    bool staged_rows;                    // the next integrate_depth_dev call reads a staged host image that holds the visited rows only
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;
     tsl::MapDev M;
