@@ -222,7 +222,8 @@ struct tsl_octo {
     std::vector<int*> tables;                 // host copy of M.tables
     std::vector<double> baseR, baseT; std::vector<float> baseRf, baseTf;
     int active; float occ_thres;
-    tsl_frame_stats* stats; tsl_frame_stats* h_stats; int64_t p_used;
+    tsl_frame_stats* stats; tsl_frame_stats* h_stats; int64_t p_used;      // stats: the CURRENT frame's slot of a ring of OCTO_STAT_RING (cleared half a ring at a time: one memset per 32 frames instead of one per frame)
+    tsl_frame_stats* stats_ring; int stat_idx;
     float *exp_xyz, *exp_rgb; int* num_particles; int64_t max_disp;
     float* pose_dev;
     void* stage; size_t stage_bytes; void* xbuf; size_t xbuf_bytes;
@@ -271,6 +272,7 @@ static int octo_leaf_scratch(tsl_octo* m, size_t n)
     return TSL_OK;
 }
 
+#define OCTO_STAT_RING 64
 extern "C" {
 
 int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
@@ -328,8 +330,9 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     m->baseRf.assign((size_t)m->nsub * 9, 0.0f); m->baseTf.assign((size_t)m->nsub * 3, 0.0f);
     for (int s = 0; s < m->nsub; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }   // identity default
     m->active = 0; m->p_used = 0;
-    TSL_HIP(hipMalloc((void**)&m->stats, sizeof(tsl_frame_stats)));
-    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    TSL_HIP(hipMalloc((void**)&m->stats_ring, sizeof(tsl_frame_stats) * OCTO_STAT_RING));
+    TSL_HIP(hipMemsetAsync(m->stats_ring, 0, sizeof(tsl_frame_stats) * OCTO_STAT_RING, m->stream));
+    m->stats = m->stats_ring; m->stat_idx = 0;
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     m->max_disp = cfg->max_disp_particles > 0 ? cfg->max_disp_particles : 1000000;
     TSL_HIP(hipMalloc((void**)&m->exp_xyz, sizeof(float) * 3 * (size_t)m->max_disp));
@@ -350,7 +353,7 @@ void tsl_octo_destroy(tsl_octo* m)
     if (!m) return;
     (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream);
     for (int* t : m->tables) if (t) (void)hipFree(t);
-    void* ptrs[] = { m->M.col, m->M.win, m->stage_tex, m->leaf_of, m->M.tables, m->M.cnt, m->M.owner_s, m->M.owner_b, m->M.pool_top, m->stats, m->exp_xyz, m->exp_rgb, m->num_particles, m->pose_dev, m->stage, m->xbuf };
+    void* ptrs[] = { m->M.col, m->M.win, m->stage_tex, m->leaf_of, m->M.tables, m->M.cnt, m->M.owner_s, m->M.owner_b, m->M.pool_top, m->stats_ring, m->exp_xyz, m->exp_rgb, m->num_particles, m->pose_dev, m->stage, m->xbuf };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
     (void)hipStreamDestroy(m->stream);
@@ -394,6 +397,16 @@ int tsl_octo_set_active_submap(tsl_octo* m, int32_t sid)
     return octo_ensure_table(m, sid);
 }
 
+// the next frame's statistics slot: zero already (half of the ring is cleared whenever the index enters it, so the slot of the frame
+// before -- the one tsl_octo_last_frame_stats reads -- is never cleared under it)
+static int octo_next_stats(tsl_octo* m)
+{
+    m->stat_idx = (m->stat_idx + 1) % OCTO_STAT_RING;
+    const int half = OCTO_STAT_RING / 2;
+    if (m->stat_idx % half == 0) TSL_HIP(hipMemsetAsync(m->stats_ring + m->stat_idx, 0, sizeof(tsl_frame_stats) * half, m->stream));
+    m->stats = m->stats_ring + m->stat_idx;
+    return TSL_OK;
+}
 static void octo_fill_pose(tsl_octo* m, const double R[9], const double T[3])
 { convert_pose(&m->baseR[(size_t)m->active * 9], &m->baseT[(size_t)m->active * 3], R, T, m->P.R, m->P.T); }
 
@@ -412,7 +425,7 @@ int tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[
         P.th = th; P.tw = tw;
         int rc = octo_leaf_scratch(m, (size_t)total); if (rc) return rc;
     }
-    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    { const int rc = octo_next_stats(m); if (rc) return rc; }
     if (total > 0) {
         hipLaunchKernelGGL(k_octo_depth, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, m->active, (const uint16_t*)depth_dev, m->stats, tex ? m->leaf_of : nullptr);
         if (tex) hipLaunchKernelGGL(k_octo_colour, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, (const uint8_t*)tex_dev, (const long long*)m->leaf_of, total, 0);
@@ -441,7 +454,7 @@ int tsl_octo_integrate_points_dev(tsl_octo* m, const double R[9], const double T
     octo_fill_pose(m, R, T);
     m->p_used = n;
     const bool use_tex = m->M.col && rgb_dev && n > 0;
-    TSL_HIP(hipMemsetAsync(m->stats, 0, sizeof(tsl_frame_stats), m->stream));
+    { const int rc = octo_next_stats(m); if (rc) return rc; }
     if (n == 0) return TSL_OK;
     if (use_tex) { int rc = octo_leaf_scratch(m, (size_t)n); if (rc) return rc; }
     hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)xyz_dev, (int)n, m->stats, use_tex ? m->leaf_of : nullptr);
