@@ -468,7 +468,9 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
                 if (j > jb) break;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) if (ev[a] == j) {
-                    cell[a] = axis_cell(axis_coord(d[a], P.T[a], P, j), hh[a], NN[a], nb[a]);
+                    // step j is the first one in another cell along this axis: the coordinate is monotone and moves by at most ~1 voxel per step
+                    // (|d| <= 1), so that cell is the neighbour in the direction of travel (-1 / nb = outside the volume) -- no evaluation needed
+                    cell[a] += d[a] > 0.0f ? 1 : -1;
                     ev[a] = next_axis_event(d[a], id[a], P.T[a], P, tv[a], j, jb, cell[a], hh[a], NN[a], nb[a]);
                 }
             }
