@@ -53,3 +53,23 @@ def test_colormap_matches_matplotlib_jet_shape():
     assert cm.shape == (1024, 3) and cm.min() >= 0 and cm.max() <= 1
     assert abs(cm[0, 2] - 0.5) < 1e-6 and cm[0, 0] == 0          # jet(0) = (0, 0, 0.5)
     assert abs(cm[1023, 0] - 0.5) < 1e-2 and cm[1023, 2] == 0    # jet(~1) = (0.5, 0, 0)
+
+
+def test_comm_and_merge_argument_errors_are_reported_not_crashed():
+    """tsl_comm_* / tsl_tsdf_allreduce_merge reject bad arguments before anything touches RCCL or a device (the multi-rank path cannot be
+    exercised on the one-GPU boxes, so its argument checking at least is)."""
+    import ctypes as C
+    from taichislam_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    buf = C.create_string_buffer(128)
+    for nranks, rank in ((0, 0), (2, 2), (2, -1)):
+        assert L.tsl_comm_create(buf, nranks, rank, 0, C.byref(h)) == -1 and not h.value
+        assert b"comm_create" in L.tsl_last_error()
+    assert L.tsl_comm_create(None, 1, 0, 0, C.byref(h)) == -1
+    assert L.tsl_comm_unique_id(None) == -1
+    assert L.tsl_comm_handle(None) is None
+    L.tsl_comm_destroy(None)                                   # a no-op
+    n = C.c_int64()
+    assert L.tsl_tsdf_allreduce_merge(None, None, None, C.byref(n)) == -1 and b"allreduce_merge" in L.tsl_last_error()
+    assert L.tsl_tsdf_merge_begin(None, None, None, 0) == -1
