@@ -250,7 +250,7 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame
                 integrated on arrival; full batches form by themselves when the producer outruns the device), 0 (default) = a batch is
                 issued when it is full -- half full for the first two batches after the pipeline ran dry -- or when anything reads the map
-     "ramp"     half batches issued after the pipeline ran dry before full ones are waited for (default 2)
+     "ramp"     short batches issued after the pipeline ran dry before full ones are waited for (default 2), "ramp_size" their length (default 4)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
      "wg"       threads per workgroup of the brick integrate kernel: 512 (default) or 256 (two workgroups per CU)
@@ -258,6 +258,7 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 <= 128 VGPRs: two 512-thread workgroups = 16 waves per CU)
      "unit"     a brick whose segments of a whole batch number at most this is walked by ONE workgroup, frame after frame, with its voxels in
                 registers; heavier bricks are split into parts that leave their sums in slab slots of their own, applied by k_apply_slab
+     "unit_floor" the unit limit is quoted for a full batch and scaled with the frames of a shorter one, but not below this (default 4096)
      "unit_half" bricks with more segments per batch than this (and at most "unit") are walked half as a unit (their first frames) and half as
                 parts (their later frames): halves the longest serial chain of a launch; >= "unit" disables the middle tier
      "chunks"   steps a part may hold (1..8, default 4)

@@ -1199,7 +1199,7 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     prof_end(m, st);
     // the unit limit is quoted for a full batch; a shorter batch (one frame when something reads the map after every frame) scales it:
     // a unit is walked by one workgroup frame after frame, and with few frames a long unit is just a long serial item
-    const int unit_max = m->unit_max <= 4096 ? m->unit_max : std::max(4096, (int)((long long)m->unit_max * B.n / TSL_NB));
+    const int unit_max = m->unit_max <= m->unit_floor ? m->unit_max : std::max(m->unit_floor, (int)((long long)m->unit_max * B.n / TSL_NB));
     const int unit_half = std::min(unit_max, m->unit_half <= 2048 ? m->unit_half : std::max(2048, (int)((long long)m->unit_half * B.n / TSL_NB)));
     prof_begin(m, TSL_K_BIN, st);
     hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max, unit_half);

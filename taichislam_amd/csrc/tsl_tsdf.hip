@@ -773,7 +773,7 @@ static int queue_frame(tsl_tsdf* m, const void* depth_dev, const void* xyz_dev, 
     m->npend++;
     // ramp-up: the first batches after the pipeline ran dry are half batches -- a burst gets its first phase A (and with it the
     // whole chain) started sooner, a steady stream is back at full batches after two of them
-    if (m->npend >= cap || (cap > 4 && m->ramp < m->ramp_batches && m->npend >= cap / 2)) return flush_pending(m);
+    if (m->npend >= cap || (cap > 4 && m->ramp < m->ramp_batches && m->npend >= m->ramp_size)) return flush_pending(m);
     // Option "adaptive": frames are only held back while the device has phase-A work to do.  When phase A of the batch issued last has
     // completed (or nothing was issued yet), the queued frames go out at once -- a 30 Hz sensor gets every frame integrated on arrival
     // -- and when the producer outruns the device the batches fill up by themselves.  One event query per queued frame.  Off by
@@ -891,7 +891,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
     // (unit_half >= unit: the middle tier of k_plan is off by default -- measured neutral-to-negative once the brick kernel runs on 75 % of the slots)
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
@@ -1460,9 +1460,11 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
+    if (!std::strcmp(name, "unit_floor")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit_floor must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_floor = value; return TSL_OK; }
     if (!std::strcmp(name, "unit_half")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit_half must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_half = value; return TSL_OK; }
     if (!std::strcmp(name, "chunks")) { TSL_REQUIRE(value >= 1 && value <= 8, "chunks must be 1..8"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->chunks = value; return TSL_OK; }
     if (!std::strcmp(name, "adaptive")) { m->adaptive = value != 0; return TSL_OK; }
+    if (!std::strcmp(name, "ramp_size")) { TSL_REQUIRE(value >= 1 && value <= TSL_NB, "ramp_size must be 1..8 frames"); m->ramp_size = value; return TSL_OK; }
     if (!std::strcmp(name, "ramp")) { TSL_REQUIRE(value >= 0 && value <= 16, "ramp must be 0..16 half batches"); m->ramp_batches = value; return TSL_OK; }
     if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 200, "bgrid must be 10..200 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
     if (!std::strcmp(name, "spt")) { TSL_REQUIRE(value == 2 || value == 4, "spt must be 2 or 4"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->spt = value; return TSL_OK; }

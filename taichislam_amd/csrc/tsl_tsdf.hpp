@@ -224,7 +224,7 @@ struct tsl_tsdf {
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
-    int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, bgrid, adaptive, ramp, ramp_batches; bool clean; uint64_t batch_gen;
+    int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;
 };
 
