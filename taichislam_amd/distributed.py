@@ -69,15 +69,39 @@ def allreduce_merge(global_map, submaps, group=None, comm=None):
     import torch
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    mask = global_map.merge_begin(submaps)                 # uint8 [bricks]: torch CUDA tensor (DenseTSDF) or numpy array (oracle adapter)
+
+    def agree(err, like):
+        """A rank that failed locally must not leave the others inside a collective: every rank runs every exchange, a failed one with
+        empty contributions, and a status word (MAX) travels next to them; the error is raised on every rank afterwards."""
+        if not multi:
+            return bool(err)
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=like.device if isinstance(like, torch.Tensor) else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        return bool(int(flag.item()))
+
+    err = None
+    try:
+        mask = global_map.merge_begin(submaps)             # uint8 [bricks]: torch CUDA tensor (DenseTSDF) or numpy array (oracle adapter)
+    except Exception as e:                                 # contribute an empty mask of the right shape
+        err = e
+        mask = global_map.empty_merge_mask() if hasattr(global_map, "empty_merge_mask") else None
+        if mask is None:
+            raise
     as_t = (lambda a: a) if isinstance(mask, torch.Tensor) else torch.from_numpy
     nbytes = 0
     if multi:
         dist.all_reduce(as_t(mask), op=dist.ReduceOp.MAX, group=group)
         nbytes += mask.size if not isinstance(mask, torch.Tensor) else mask.numel()
+    if agree(err, mask):
+        raise RuntimeError(f"allreduce_merge: {'this rank' if err else 'another rank'} failed before the exchange; nothing was merged") from err
     if isinstance(mask, torch.Tensor) and mask.is_cuda:
         torch.cuda.current_stream(mask.device).synchronize()      # the library reads the reduced mask on its own stream
-    acc, cnt = global_map.merge_pack(mask)                  # int64 [n,4096,2], int32 [n,4096] of the union bricks
+    try:
+        acc, cnt = global_map.merge_pack(mask)              # int64 [n,4096,2], int32 [n,4096] of the union bricks
+    except Exception as e:
+        err, acc, cnt = e, None, None
+    if agree(err, mask):
+        raise RuntimeError(f"allreduce_merge: {'this rank' if err else 'another rank'} failed while packing; nothing was merged") from err
     if multi and len(acc):
         dist.all_reduce(as_t(acc), op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(as_t(cnt), op=dist.ReduceOp.SUM, group=group)

@@ -338,6 +338,13 @@ class DenseTSDF(BaseMap):
         _lib.check(self.L.tsl_tsdf_merge_begin(self.h, submaps.h, C.c_void_p(mask.data_ptr()), nb.value))
         return mask
 
+    def empty_merge_mask(self):
+        """An all-zero brick mask: what a rank that could not splat its submaps contributes to the exchange (distributed.allreduce_merge)."""
+        import torch
+        nb = C.c_int64()
+        self._call("merge_mask_bytes", C.byref(nb))
+        return torch.zeros(nb.value, dtype=torch.uint8, device=f"cuda:{self.device}")
+
     def merge_pack(self, mask):
         """Step 2 (after the MAX all-reduce of the mask): packed sums of the union bricks, (int64 [n,4096,2], int32 [n,4096])."""
         import torch

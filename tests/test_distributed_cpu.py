@@ -80,6 +80,56 @@ def _global(bases):
     return _OracleGlobal(bases)
 
 
+class _FailingGlobal(_OracleGlobal):
+    """Rank-local failure injected into the step protocol."""
+
+    def __init__(self, bases, fail_in):
+        super().__init__(bases)
+        self.fail_in = fail_in
+
+    def empty_merge_mask(self):
+        return np.zeros((self.N // 16) ** 2 * (self.Nz // 16), np.uint8)
+
+    def merge_begin(self, sub):
+        if self.fail_in == "begin":
+            raise MemoryError("injected: brick pool exhausted")
+        return super().merge_begin(sub)
+
+    def merge_pack(self, mask):
+        if self.fail_in == "pack":
+            raise MemoryError("injected: no memory for the packed planes")
+        return super().merge_pack(mask)
+
+
+def _worker_failing(rank, world, port, out, fail_in):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from taichislam_amd import distributed as D
+    from taichislam_amd.utils import synthetic as syn
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sub, _ = _build_submap(rank)
+    bases = [syn.camera_pose(0, start_deg=D.stream_start_deg(r)) for r in range(world)]
+    g = _FailingGlobal(bases, fail_in if rank == 1 else None)      # only rank 1 fails
+    try:
+        D.allreduce_merge(g, sub)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out, f"fail_{fail_in}_rank{rank}.txt"), "w").write(msg)
+    dist.barrier()                                                # both ranks get here: nobody is stuck in a collective
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_in", ["begin", "pack"])
+def test_a_failing_rank_does_not_hang_the_others(tmp_path, fail_in):
+    """One rank raises inside merge_begin / merge_pack: every rank still runs every exchange and every rank raises."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_failing, args=(2, port, str(tmp_path), fail_in), nprocs=2, join=True)
+    m0 = open(tmp_path / f"fail_{fail_in}_rank0.txt").read(); m1 = open(tmp_path / f"fail_{fail_in}_rank1.txt").read()
+    assert "another rank failed" in m0 and "this rank failed" in m1, (m0, m1)
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
