@@ -49,3 +49,25 @@ def test_sequential_mode_equals_faithful_at_the_benchmark_size(hip_lib):
     e = g.export_submap()
     assert e["TSDF"].shape[0] > 1_300_000
     assert_export_equal(e, o.export_sparse(), "sequential vs FAITHFUL, C2, 12 frames")
+
+
+def test_sequential_mode_points_crowded_voxels_and_out_of_volume_rays(hip_lib):
+    """recast_pcl_to_map in sequential mode: random directions and ranges (rays that leave the volume, degenerate points at the origin)
+    plus a cluster of 3 000 points inside a few sensor voxels (the crowded-voxel replay of k_segments); two frames, FAITHFUL bit for bit."""
+    from oracle import FAITHFUL
+    rng = np.random.default_rng(11)
+    g, o = make_pair(SMALL, syn.K_DEPTH)
+    g.set_option("semantics", 1)
+    for f in range(2):
+        R, T = syn.camera_pose(2 + f)
+        d = rng.normal(size=(15000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts = (d * rng.uniform(0.2, 6.0, size=(15000, 1))).astype(np.float32)
+        pts[:5] = 0.0
+        cluster = (np.array([[0.8, 0.3, 1.1]]) + rng.uniform(-0.05, 0.05, size=(3000, 3))).astype(np.float32)
+        pts = np.concatenate([pts, cluster])
+        g.recast_pcl_to_map(R, T, pts, np.array([]))
+        so = o.integrate_points(R, T, pts, None, mode=FAITHFUL)
+        sg = g.last_frame_stats()
+        assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+        assert so["v_skipped"] >= 1 and so["steps_oob"] >= 0
+    assert_export_equal(g.export_submap(), o.export_sparse(), "sequential, point input")
