@@ -33,11 +33,6 @@ namespace tsl {
 #define EF_NODE 1
 #define EF_NEG 2
 #define EF_FIXED 4
-#define ESDF_PAD (ESDF_T * ESDF_T + ESDF_T + 1)
-#define ESDF_QCAP 256          // queue entries per wave and hand-over (four per lane)
-#ifndef ESDF_SWEEPS
-#define ESDF_SWEEPS 1
-#endif
 
 #ifdef TSL_TIMING
 // developer timing: thread 0 of every relaxation adds the clock ticks (100 MHz) of its phases to E.ctr64[k]
@@ -167,38 +162,138 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float ga
 //    point; a brick whose boundary layer improved puts the neighbours that see it on the next round's list.  Rounds are separate launches
 //    (the kernel boundary is the only synchronisation: no fences, no spinning); a launch whose list is empty returns at once.
 //
-//    LDS layout.  s_d holds the 18^3 tile with a margin of one plane + one row + one entry on both sides, so that a neighbour is entry
-//    t + (dx*18 + dy)*18 + dz without any range check.  An entry of s_d is a TARGET word: side << 31 | magnitude bits for an interior,
-//    observed, non-fixed voxel -- the only kind a push may lower -- and 0 for everything else (halo, fixed band, unobserved, margin).
-//    With that encoding the 26 neighbour tests of a push need no flags: for a source on side sb the test "same side, is a target,
-//    candidate is lower" is the single signed comparison (int)(word ^ sb) > (int)candidate (positive floats order like integers; a
-//    target of the other side and the 0 of a non-target turn negative or stay 0).  Voxels that only ever push -- the halo and the fixed
-//    band -- keep their values in s_hv / s_old (side << 31 | magnitude, 0 = unobserved); they push once, in the first pass.
-__device__ __forceinline__ int esdf_halo_index(int tx, int ty, int tz)          // position of a halo entry in s_hv (inverse of the decode below)
+//    The local relaxation is a set of six DIRECTIONAL SWEEPS, one per wave (+x, -x, +y, -y, +z, -z), all running at the same time on the
+//    one tile.  A sweep walks the 16 planes of the brick along its axis; in a plane every voxel PULLS from its nine neighbours in the plane
+//    before it (one face, four edge, four corner neighbours: min over a class, then ONE add of the class' edge cost -- fl(a + c) is
+//    monotone in a) and lowers itself with an LDS atomic min.  A wave holds a whole plane (64 lanes x 4 voxels in a row), so a sweep needs
+//    no barrier: the LDS operations of one wave execute in order.  A shortest path through free space only uses steps that advance along
+//    its dominant axis, so ONE sweep carries a value across the whole brick exactly (the push relaxation this replaces needed one pass --
+//    scan, compaction, 26 atomics per voxel, a barrier -- per voxel of distance: 17 passes, 70 us, to cross a brick); paths that bend
+//    around the other side of the surface or around unobserved space take another set.  The six waves race on the tile; every write is a
+//    monotone atomic min of a realisable path cost, so a stale read only delays an improvement, and the relaxation ends with a set in
+//    which NO wave lowered anything: in such a set every read saw the final state and the six planes-before cover all 26 neighbours,
+//    i.e. the tile is at the fixed point.
+//    A brick that is visited again (a neighbour changed its boundary layer) starts with an entry check: only the sweeps that enter through
+//    a face with a notified neighbour run, and one that lowers nothing in its first plane stops there (the rest of the tile was at its
+//    fixed point already).
+//
+//    Tile word: side << 31 | magnitude bits of an observed voxel, ES_UNOBS otherwise.  For a voxel on the positive side the unsigned
+//    minimum over raw words is the least magnitude among its positive neighbours (negative-side words and ES_UNOBS are larger than any
+//    magnitude; clamped to +inf they never win); for the negative side the signed minimum does the same.  Only interior, observed,
+//    non-band voxels ("targets", a bit mask per lane) are ever written.
+#define ES_SY 19                          // row pitch (18 entries + 1: spreads the rows of a plane over the LDS banks)
+#define ES_SX (18 * ES_SY + 1)            // plane pitch
+#define ES_TILE (18 * ES_SX)
+#define ES_UNOBS 0x7fffffffu
+#define ES_INF 0x7f800000u
+#define ES_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+// the four mask bits of a lane's voxels in plane s of a sweep along AXIS (lane = r * 4 + q: row r, voxels 4q .. 4q + 3 of the row)
+template <int AXIS> __device__ __forceinline__ uint32_t esdf_nibble(const uint32_t* bits, int s, int r, int q)
 {
-    if (tx == 0 || tx == 17) return (tx / 17) * (ESDF_T * ESDF_T) + ty * ESDF_T + tz;
-    if (ty == 0 || ty == 17) return 2 * ESDF_T * ESDF_T + (tx - 1) * (2 * ESDF_T) + (ty / 17) * ESDF_T + tz;
-    return 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T + (tx - 1) * 32 + (ty - 1) * 2 + tz / 17;
+    if (AXIS == 0) return (ES_LD(&bits[s * 8 + (r >> 1)]) >> ((r & 1) * 16 + 4 * q)) & 15u;          // voxel (s, r, 4q + j)
+    if (AXIS == 1) return (ES_LD(&bits[r * 8 + (s >> 1)]) >> ((s & 1) * 16 + 4 * q)) & 15u;          // voxel (r, s, 4q + j)
+    const uint32_t a = ES_LD(&bits[r * 8 + 2 * q]) >> s, b = ES_LD(&bits[r * 8 + 2 * q + 1]) >> s;   // voxel (r, 4q + j, s)
+    return (a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u);
 }
-__global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, float max_dist, int round)
+
+// one sweep of the calling wave.  Returns whether this lane lowered a voxel.
+template <int AXIS, int SIGN>
+__device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt, const uint32_t* s_neg, uint32_t* s_chg, const float c1, const float c2, const float c3,
+                                           const bool entry_check, int& lowered)
 {
-    constexpr int NH = ESDF_T3 - TSL_BRK3, HPER = (NH + 255) / 256;       // 1736 halo entries, 7 per thread
-    __shared__ uint32_t s_dm[ESDF_T3 + 2 * ESDF_PAD];      // target words (see above)
-    __shared__ __attribute__((aligned(16))) uint32_t s_old[TSL_BRK3];   // the brick's voxels as staged, brick order: side << 31 | magnitude, 0 = unobserved
-    __shared__ uint32_t s_hv[HPER * 256];                  // the halo's values, same encoding
-    __shared__ uint32_t s_a[(ESDF_T3 + 31) / 32 + 2];      // active bits: the entry pushes in the next pass
-    __shared__ uint16_t s_q[4 * ESDF_QCAP];                // per wave: the entries it pushes next (compacted)
-    __shared__ int s_nb[27];                       // pool index of the 27 bricks around (and including) this one, -1 = absent
+    constexpr int SD = AXIS == 0 ? ES_SX : (AXIS == 1 ? ES_SY : 1);        // along the sweep
+    constexpr int SR = AXIS == 0 ? ES_SY : ES_SX;                          // between the three rows a lane reads
+    constexpr int SJ = AXIS == 2 ? ES_SY : 1;                              // along a lane's four voxels
+    constexpr int PO = SIGN > 0 ? 0 : SD, OO = SIGN > 0 ? SD : 0;          // the plane before / the own plane, from the lower of the two
+    const int lane = (int)(threadIdx.x & 63u), q = lane & 3, r = lane >> 2;
+    unsigned long long mT = 0ull, mN = 0ull;                               // bit 4 i + j: voxel j of the i-th plane in sweep order
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int sp = SIGN > 0 ? i : 15 - i;
+        const uint32_t t = esdf_nibble<AXIS>(s_tgt, sp, r, q);
+        mT |= (unsigned long long)t << (4 * i); mN |= (unsigned long long)(t & esdf_nibble<AXIS>(s_neg, sp, r, q)) << (4 * i);
+    }
+    bool changed = false;
+    // the lower of (own plane, plane before) in tile coordinates: i for a forward sweep, 16 - i for a backward one
+    uint32_t* b = s_t + r * SR + 4 * q * SJ + (SIGN > 0 ? 0 : 16 * SD);
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i, b += SIGN * SD, mT >>= 4, mN >>= 4) {
+        const uint32_t tn = (uint32_t)mT & 15u, nn = (uint32_t)mN & 15u;
+        const bool hasP = __any((tn & ~nn) != 0u), hasN = __any(nn != 0u);
+        if (!hasP && !hasN) { if (entry_check && i == 0) return false; continue; }
+        uint32_t w[3][6], own[4];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w[rr][k] = ES_LD(b + PO + rr * SR + k * SJ);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) own[j] = ES_LD(b + OO + SR + (j + 1) * SJ);
+        float cand[4] = { __uint_as_float(ES_INF), __uint_as_float(ES_INF), __uint_as_float(ES_INF), __uint_as_float(ES_INF) };
+        if (hasP) {
+            uint32_t pr[3][4];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pr[rr][j] = min(w[rr][j], w[rr][j + 2]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t f = min(w[1][j + 1], ES_INF), e = min(min(pr[1][j], min(w[0][j + 1], w[2][j + 1])), ES_INF), c = min(min(pr[0][j], pr[2][j]), ES_INF);
+                const float v = fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3);
+                if (!((nn >> j) & 1u)) cand[j] = v;
+            }
+        }
+        if (hasN) {
+            int pr[3][4];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pr[rr][j] = min((int)w[rr][j], (int)w[rr][j + 2]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t f = min(w[1][j + 1] ^ 0x80000000u, ES_INF);
+                const uint32_t e = min((uint32_t)min(pr[1][j], min((int)w[0][j + 1], (int)w[2][j + 1])) ^ 0x80000000u, ES_INF);
+                const uint32_t c = min((uint32_t)min(pr[0][j], pr[2][j]) ^ 0x80000000u, ES_INF);
+                const float v = fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3);
+                if ((nn >> j) & 1u) cand[j] = v;
+            }
+        }
+        bool ch = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cb = __float_as_uint(cand[j]);
+            if (((tn >> j) & 1u) && cb < (own[j] & 0x7fffffffu)) {
+                __hip_atomic_fetch_min(b + OO + SR + (j + 1) * SJ, cb | (own[j] & 0x80000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int sp = SIGN > 0 ? i : 15 - i;
+                const int l = AXIS == 0 ? (sp << 8) | (r << 4) | (4 * q + j) : (AXIS == 1 ? (r << 8) | (sp << 4) | (4 * q + j) : (r << 8) | ((4 * q + j) << 4) | sp);
+                __hip_atomic_fetch_or(&s_chg[l >> 5], 1u << (l & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ch = true; ++lowered;
+            }
+        }
+        changed = changed || ch;
+        if (entry_check && i == 0 && !__any(ch)) return false;
+    }
+    return changed;
+}
+
+__global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, float max_dist, int round)
+{
+    constexpr int NH = ESDF_T3 - TSL_BRK3, HPER = (NH + 383) / 384;      // 1736 halo entries, 5 per thread
+    __shared__ uint32_t s_t[ES_TILE];                      // the tile (see above)
+    __shared__ __attribute__((aligned(4))) uint16_t s_tgt16[256], s_neg16[256];     // per interior row (x, y): bit z = target / negative side
+    __shared__ uint32_t s_chg[TSL_BRK3 / 32];              // interior voxels lowered in this visit
+    __shared__ int s_nb[27];                               // pool index of the 27 bricks around (and including) this one, -1 = absent
     __shared__ int s_notify;
-    uint32_t* const s_d = s_dm + ESDF_PAD;
+    const uint32_t* const s_tgt = reinterpret_cast<const uint32_t*>(s_tgt16);
+    const uint32_t* const s_neg = reinterpret_cast<const uint32_t*>(s_neg16);
     const int cur = round % 3, nxt = (round + 1) % 3, clr = (round + 2) % 3;
     const int n = E.ctr[2 + cur], nsnap = min(E.ctr[10], M.max_bricks);
     if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) E.ctr[7] = round + 1; }      // list (round+2) was consumed in round-1
     if (n == 0) return;
-    const float cost[4] = { 0.0f, 1.0f * vs, sqrtf(2.0f) * vs, sqrtf(3.0f) * vs };              // dense_esdf.py:286
+    const float c1 = 1.0f * vs, c2 = sqrtf(2.0f) * vs, c3 = sqrtf(3.0f) * vs;                   // dense_esdf.py:286
     const int* list = E.work + (size_t)cur * E.cap;
     int* next = E.work + (size_t)nxt * E.cap;
-    for (int i = threadIdx.x; i < ESDF_PAD; i += 256) { s_dm[i] = 0u; s_dm[ESDF_PAD + ESDF_T3 + i] = 0u; }
+    const int wave = (int)(threadIdx.x >> 6);
     for (int w = blockIdx.x; w < n; w += gridDim.x) {
 #ifdef TSL_TIMING
         long long _t = wall_clock64();
@@ -212,206 +307,117 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
             s_nb[threadIdx.x] = np < nsnap ? np : -1;                 // a brick allocated after the update's snapshot is not part of it
         }
         if (threadIdx.x == 0) s_notify = 0;
-        for (int i = threadIdx.x; i < (ESDF_T3 + 31) / 32 + 2; i += 256) s_a[i] = 0u;
-        // first relaxation in this update: the band voxels push, and so does every halo voxel; afterwards only the halo voxels of the
-        // neighbours that changed their boundary layer since (the notification mask written for this round) push again
+        if (threadIdx.x < TSL_BRK3 / 32) s_chg[threadIdx.x] = 0u;
+        // first relaxation in this update: everything is new; afterwards only the halo entries of the neighbours that changed their
+        // boundary layer since (the notification mask written for this round) are
         const bool first = E.region[p] == 1;
         uint32_t* const my_note = E.note + (size_t)(round & 1) * E.cap + p;
         const uint32_t note = first ? ~0u : *my_note;
         __syncthreads();
         ESDF_TICK(0);
         if (threadIdx.x == 0) *my_note = 0u;                        // this parity is written again in round + 1, after this launch
-        // ---- stage brick + halo as ONE batch of independent loads: thread tid owns the interior row (x, y) = (tid / 16, tid % 16) -- 16
-        //      voxels = 4 + 1 wide loads -- and <= 7 of the 1736 halo entries (loaded from a valid address unconditionally so that
-        //      nothing separates the requests) ----
+        // ---- stage brick + halo as ONE batch of independent loads: thread tid < 256 owns the interior row (x, y) = (tid / 16, tid % 16) --
+        //      16 voxels = 4 + 1 wide loads -- and every thread <= 5 of the 1736 halo entries (loaded from a valid address unconditionally
+        //      so that nothing separates the requests) ----
+        bool has_target = false;
         {
-            const size_t v0 = (size_t)p * TSL_BRK3 + (size_t)threadIdx.x * 16;
+            const int row = (int)threadIdx.x & 255;
+            const size_t v0 = (size_t)p * TSL_BRK3 + (size_t)row * 16;
             uint4 dq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) dq[q] = reinterpret_cast<const uint4*>(E.mag + v0)[q];
             const uint4 fq = *reinterpret_cast<const uint4*>(E.fl + v0);
-            int ht[HPER], hq[HPER]; uint8_t hf[HPER]; uint32_t hd[HPER]; bool hok[HPER];
+            int ht[HPER]; uint8_t hf[HPER]; uint32_t hd[HPER]; bool hok[HPER];
 #pragma unroll
             for (int q = 0; q < HPER; ++q) {
-                const int h = q * 256 + (int)threadIdx.x;
+                const int h = q * 384 + (int)threadIdx.x;
                 int tx, ty, tz;
                 if (h < 2 * ESDF_T * ESDF_T) { const int r = h % (ESDF_T * ESDF_T); tx = (h / (ESDF_T * ESDF_T)) * 17; ty = r / ESDF_T; tz = r % ESDF_T; }       // faces x = 0, 17
                 else if (h < 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T) { const int g = h - 2 * ESDF_T * ESDF_T, r = g % (2 * ESDF_T); tx = 1 + g / (2 * ESDF_T); ty = (r / ESDF_T) * 17; tz = r % ESDF_T; }   // rows y = 0, 17
                 else { const int g = h - (2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T); tx = 1 + g / 32; ty = 1 + (g % 32) / 2; tz = (g & 1) * 17; }                // entries z = 0, 17
-                ht[q] = h < NH ? (tx * ESDF_T + ty) * ESDF_T + tz : -1;
-                hq[q] = h < NH ? (((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4) : 13;     // which of the 27 bricks
-                const int np = s_nb[hq[q]];
+                ht[q] = h < NH ? tx * ES_SX + ty * ES_SY + tz : -1;
+                const int hq = h < NH ? (((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4) : 13;     // which of the 27 bricks
+                const int np = s_nb[hq];
                 hok[q] = h < NH && np >= 0;
                 const size_t v = (size_t)(np >= 0 ? np : p) * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
                 hf[q] = E.fl[v]; hd[q] = __float_as_uint(E.mag[v]);
             }
-            const uint32_t dl[16] = { dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w, dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w };
-            const uint32_t fw[4] = { fq.x, fq.y, fq.z, fq.w };
-            const int t0 = (((int)(threadIdx.x >> 4) + 1) * ESDF_T + (int)(threadIdx.x & 15) + 1) * ESDF_T + 1;
-            uint32_t am = 0u;                                        // active bits of the row
-            uint32_t enc[16];
+            if (threadIdx.x < 256) {
+                const uint32_t dl[16] = { dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w, dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w };
+                const uint32_t fw[4] = { fq.x, fq.y, fq.z, fq.w };
+                const int t0 = ((int)(threadIdx.x >> 4) + 1) * ES_SX + ((int)(threadIdx.x & 15) + 1) * ES_SY + 1;
+                uint32_t tg = 0u, ng = 0u;
 #pragma unroll
-            for (int z = 0; z < 16; ++z) {
-                const uint32_t f = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
-                enc[z] = (f & EF_NODE) ? (dl[z] | ((f & EF_NEG) ? 0x80000000u : 0u)) : 0u;
-                s_d[t0 + z] = (f & EF_FIXED) ? 0u : enc[z];
-                am |= ((f & (EF_NODE | EF_FIXED)) == (EF_NODE | EF_FIXED) ? 1u : 0u) << z;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(s_old)[threadIdx.x * 4 + q] = make_uint4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3]);
-            if (first && am) {                                       // the row's 16 bits lie in one or two words
-                atomicOr(&s_a[t0 >> 5], am << (t0 & 31));
-                if ((t0 & 31) > 16) atomicOr(&s_a[(t0 >> 5) + 1], am >> (32 - (t0 & 31)));
+                for (int z = 0; z < 16; ++z) {
+                    const uint32_t f = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
+                    s_t[t0 + z] = (f & EF_NODE) ? (dl[z] | ((f & EF_NEG) ? 0x80000000u : 0u)) : ES_UNOBS;
+                    tg |= ((f & (EF_NODE | EF_FIXED)) == EF_NODE ? 1u : 0u) << z;
+                    ng |= ((f & EF_NEG) ? 1u : 0u) << z;
+                }
+                s_tgt16[threadIdx.x] = (uint16_t)tg; s_neg16[threadIdx.x] = (uint16_t)ng;
+                has_target = tg != 0u;
             }
 #pragma unroll
             for (int q = 0; q < HPER; ++q) {
-                const int t = ht[q];
+                if (ht[q] < 0) continue;
                 const uint32_t f = hok[q] ? (uint32_t)hf[q] : 0u;
-                s_hv[q * 256 + threadIdx.x] = (f & EF_NODE) ? (hd[q] | ((f & EF_NEG) ? 0x80000000u : 0u)) : 0u;
-                if (t < 0) continue;
-                s_d[t] = 0u;
-                // a source can only improve a target whose value exceeds its own by an edge cost, and no value exceeds max_dist
-                if ((f & EF_NODE) && ((note >> hq[q]) & 1u) && __uint_as_float(hd[q]) + vs < max_dist) atomicOr(&s_a[t >> 5], 1u << (t & 31));
+                s_t[ht[q]] = (f & EF_NODE) ? (hd[q] | ((f & EF_NEG) ? 0x80000000u : 0u)) : ES_UNOBS;
             }
         }
-        __syncthreads();
+        const bool work = __syncthreads_or(has_target) != 0;       // (a brick without a target has nothing to relax)
         ESDF_TICK(1);
-        // ---- push relaxation: active entries offer value + edge cost to the targets among their 26 neighbours.
-        //      Entry t belongs to thread t mod 256 (a front -- a sheet of neighbouring voxels -- spreads over all threads).  Per pass a
-        //      thread reads the active words of its 23 entries as one batch; an active entry is cleared with a non-returning atomic AND,
-        //      then its word and the 26 neighbours' words are read as ONE batch of independent LDS loads (relaxed workgroup-scope
-        //      atomic loads: plain ds_read, but never cached in registers across passes), and non-returning atomic mins go out for the
-        //      candidates that beat what was read (a min that lost a race is a no-op and the extra activation is harmless); the active
-        //      bits of the three z-neighbours of a row are set with one OR.  LDS operations of a wave execute in order: the value read
-        //      follows the clear, the OR follows the min. ----
-        long long pushes = 0; int passes = 0;
-#define LDS_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-        for (;;) {
-            bool act = false;
-            constexpr int PER = (ESDF_T3 + 255) / 256;
-            // ESDF_SWEEPS scan + push sweeps per barrier (LDS atomics are visible to the other waves at once, the barrier is only needed to
-            // agree that nothing is active any more).  One is the default: with two or four the front loses its order, voxels are
-            // pushed 6 - 13 % more often and the update gets slower (0.84 / 1.06 ms against 0.80)
-#pragma unroll 1
-            for (int sweep = 0; sweep < ESDF_SWEEPS; ++sweep) {
-            uint32_t mine = 0u;                                    // bit q: my q-th entry is active
-            {
-                uint32_t aw[PER];
-#pragma unroll
-                for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; aw[q] = t < ESDF_T3 ? LDS_LD(&s_a[t >> 5]) : 0u; }
-#pragma unroll
-                for (int q = 0; q < PER; ++q) { const int t = q * 256 + (int)threadIdx.x; mine |= ((aw[q] >> (t & 31)) & 1u) << q; }
-            }
-            // The wave's active entries are COMPACTED before they are pushed: every lane hands up to four of its entries to the wave's
-            // queue (a prefix sum over the lanes gives the positions), then lane i pushes entries i, i + 64, ...  Without this a wave
-            // iterates as often as its busiest lane has entries (~35 % of the lanes busy on average); the push body is ~450
-            // instructions, the hand-over ~40.  LDS operations of one wave execute in order: no barrier between the queue's writes and reads.
-#pragma unroll 1
-            while (__any(mine != 0u)) {
-            const int lane = (int)(threadIdx.x & 63u);
-            uint16_t* const wq = s_q + (threadIdx.x >> 6) * ESDF_QCAP;
-            const int c = min((int)__builtin_popcount(mine), ESDF_QCAP / 64);
-            int inc = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-            const int total = __shfl(inc, 63);
-#pragma unroll
-            for (int k = 0; k < ESDF_QCAP / 64; ++k) {
-                if (k < c) {
-                    const int t = (int)__builtin_ctz(mine) * 256 + (int)threadIdx.x; mine &= mine - 1u;
-                    __hip_atomic_fetch_and(&s_a[t >> 5], ~(1u << (t & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&wq[inc - c + k], (uint16_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-            for (int qi = lane; qi < total; qi += 64) {
-                const int t = (int)__hip_atomic_load(&wq[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                uint32_t self = LDS_LD(&s_d[t]);
-                ++pushes;
-                uint32_t dn[26];
-#pragma unroll
-                for (int c = 0; c < 27; ++c) {
-                    if (c == 13) continue;
-                    dn[c < 13 ? c : c - 1] = LDS_LD(&s_d[t + ((c / 9 - 1) * ESDF_T + ((c / 3) % 3 - 1)) * ESDF_T + (c % 3 - 1)]);
-                }
-                if (self == 0u) {                                  // not a target: a halo or band voxel, its value is kept aside (first pass only)
-                    const int tz = t % ESDF_T, ty = (t / ESDF_T) % ESDF_T, tx = t / (ESDF_T * ESDF_T);
-                    const bool inner = tx >= 1 && tx <= 16 && ty >= 1 && ty <= 16 && tz >= 1 && tz <= 16;
-                    self = inner ? s_old[((tx - 1) << 8) | ((ty - 1) << 4) | (tz - 1)] : s_hv[esdf_halo_index(tx, ty, tz)];
-                }
-                const uint32_t sb = self & 0x80000000u;
-                const float dv = __uint_as_float(self & 0x7fffffffu);
-                // the three candidates (face, edge, corner neighbour) and whether a voxel that takes one could improve anything itself
-                const float cf[3] = { dv + cost[1], dv + cost[2], dv + cost[3] };
-                const uint32_t cw[3] = { sb | __float_as_uint(cf[0]), sb | __float_as_uint(cf[1]), sb | __float_as_uint(cf[2]) };
-                const uint32_t live[3] = { cf[0] + vs < max_dist ? 1u : 0u, cf[1] + vs < max_dist ? 1u : 0u, cf[2] + vs < max_dist ? 1u : 0u };
-                uint32_t any = 0u;
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {                      // the nine (dx, dy) rows of the neighbourhood, three z-neighbours each
-                    const int dx = r / 3 - 1, dy = r % 3 - 1;
-                    const int j0 = t + (dx * ESDF_T + dy) * ESDF_T - 1;
-                    uint32_t bits = 0u;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int c = r * 3 + k;
-                        if (c == 13) continue;
-                        const int e = dx * dx + dy * dy + (k - 1) * (k - 1) - 1;
-                        // same side, a target, and the candidate is lower <=> one signed comparison.  The minimum stays conditional: the
-                        // LDS atomics, not the VALU, bound this loop (26 unconditional ones per push were 30 % slower)
-                        if ((int)(dn[c < 13 ? c : c - 1] ^ sb) > (int)__float_as_uint(cf[e])) {
-                            __hip_atomic_fetch_min(&s_d[j0 + k], cw[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            bits |= live[e] << k;
-                        }
+        // ---- the sweeps ----
+        int lowered = 0, sets = 0;
+        if (work) {
+            // wave -> (axis, sign); on a later visit a sweep takes part in the entry check if a neighbour on its entry side was notified
+            const uint32_t entry_mask = wave == 0 ? 0x1ffu : wave == 1 ? 0x1ffu << 18 : wave == 2 ? 0x01c0e07u : wave == 3 ? 0x01c0e07u << 6 : wave == 4 ? 0x1249249u : 0x1249249u << 2;
+            bool full = first;
+            for (;;) {
+                bool chg = false;
+                if (full || (note & entry_mask)) {
+                    switch (wave) {
+                    case 0: chg = esdf_sweep<0, +1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
+                    case 1: chg = esdf_sweep<0, -1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
+                    case 2: chg = esdf_sweep<1, +1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
+                    case 3: chg = esdf_sweep<1, -1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
+                    case 4: chg = esdf_sweep<2, +1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
+                    default: chg = esdf_sweep<2, -1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
                     }
-                    if (bits) {
-                        const int sh = j0 & 31;
-                        __hip_atomic_fetch_or(&s_a[j0 >> 5], bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (sh > 29) __hip_atomic_fetch_or(&s_a[(j0 >> 5) + 1], bits >> (32 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    any |= bits;
                 }
-                act = act || any != 0u;
+                ++sets;
+                if (!__syncthreads_or(chg)) break;
+                full = true;
             }
-            }
-            if (!__any(act)) break;                                // nothing pushed by this wave in this sweep: wait for the others
-            }
-            ++passes;
-            if (!__syncthreads_or(act)) break;
         }
-#undef LDS_LD
 #ifdef TSL_TIMING
-        if (threadIdx.x == 0) { const long long _n = wall_clock64(); const int pb = passes < 31 ? passes : 31;
+        if (threadIdx.x == 0) { const long long _n = wall_clock64(); const int pb = sets < 31 ? sets : 31;
             atomicAdd(&E.tm[8 + pb], (unsigned long long)(_n - _t)); atomicAdd(&E.tm[40 + pb], 1ull); atomicMax(&E.tm[72], (unsigned long long)(_n - _t)); }
-        { const long long pw = wave_sum_ll(pushes); if (lane_id() == 0) atomicAdd(&E.tm[80 + (passes < 31 ? passes : 31)], (unsigned long long)pw); }
+        { const long long pw = wave_sum_ll((long long)lowered); if (lane_id() == 0) atomicAdd(&E.tm[80 + (sets < 31 ? sets : 31)], (unsigned long long)pw); }
 #endif
         ESDF_TICK(2);
-        // ---- write back the targets that changed (against the staged copy); a changed voxel of the boundary layer marks the neighbours
-        //      that hold it in their halo ----
+        // ---- write back the voxels that were lowered; one in the boundary layer marks the neighbours that hold it in their halo ----
         {
             float* gm = E.mag + (size_t)p * TSL_BRK3;
-#pragma unroll
-            for (int q = 0; q < TSL_BRK3 / 256; ++q) {
-                const int l = q * 256 + threadIdx.x;
+            for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
+                if (!((s_chg[l >> 5] >> (l & 31)) & 1u)) continue;
                 const int x = (l >> 8) + 1, y = ((l >> 4) & 15) + 1, z = (l & 15) + 1;
-                const uint32_t nv = s_d[(x * ESDF_T + y) * ESDF_T + z];
-                if (nv != 0u && nv != s_old[l]) {
-                    gm[l] = __uint_as_float(nv & 0x7fffffffu);
-                    // the neighbours (ax, ay, az) in {0, 1, 2}^3 whose halo holds this voxel: per axis the centre, plus the lower / upper
-                    // neighbour when the voxel lies in the first / last layer -- a product of three small bit sets
-                    const int sx = x == 1 ? 3 : (x == 16 ? 6 : 2), sy = y == 1 ? 3 : (y == 16 ? 6 : 2), sz = z == 1 ? 3 : (z == 16 ? 6 : 2);
-                    if ((sx | sy | sz) != 2) {
-                        const int myz = ((sy & 1) ? sz : 0) | ((sy & 2) ? sz << 3 : 0) | ((sy & 4) ? sz << 6 : 0);
-                        const int m = ((sx & 1) ? myz : 0) | ((sx & 2) ? myz << 9 : 0) | ((sx & 4) ? myz << 18 : 0);
-                        atomicOr(&s_notify, m & ~(1 << 13));
-                    }
+                gm[l] = __uint_as_float(s_t[x * ES_SX + y * ES_SY + z] & 0x7fffffffu);
+                // the neighbours (ax, ay, az) in {0, 1, 2}^3 whose halo holds this voxel: per axis the centre, plus the lower / upper
+                // neighbour when the voxel lies in the first / last layer -- a product of three small bit sets
+                const int sx = x == 1 ? 3 : (x == 16 ? 6 : 2), sy = y == 1 ? 3 : (y == 16 ? 6 : 2), sz = z == 1 ? 3 : (z == 16 ? 6 : 2);
+                if ((sx | sy | sz) != 2) {
+                    const int myz = ((sy & 1) ? sz : 0) | ((sy & 2) ? sz << 3 : 0) | ((sy & 4) ? sz << 6 : 0);
+                    const int m = ((sx & 1) ? myz : 0) | ((sx & 2) ? myz << 9 : 0) | ((sx & 4) ? myz << 18 : 0);
+                    atomicOr(&s_notify, m & ~(1 << 13));
                 }
             }
         }
         __syncthreads();
         ESDF_TICK(3);
-        pushes = wave_sum_ll(pushes);
-        if (lane_id() == 0 && pushes) __hip_atomic_fetch_add(&E.ctr[6], (int)pushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            const long long lw = wave_sum_ll((long long)lowered);
+            if (lane_id() == 0 && lw) __hip_atomic_fetch_add(&E.ctr[6], (int)lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // the neighbours that see a changed boundary voxel go on the next round's list: one lane per neighbour (the region check, the
         // stamp exchange and the list reservation are dependent device-memory round trips)
         if (threadIdx.x < 64) {
@@ -420,7 +426,7 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
             if (q < 27 && ((s_notify >> q) & 1)) {
                 np = s_nb[q];
                 if (np >= 0 && E.region[np] != 0) {                                            // present and inside this update's region
-                    // seen from the neighbour this brick is neighbour 26 - q: its halo entries from here push in the next round
+                    // seen from the neighbour this brick is neighbour 26 - q: its halo entries from here are new in the next round
                     __hip_atomic_fetch_or(E.note + (size_t)((round + 1) & 1) * E.cap + np, 1u << (26 - q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     put = __hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != round + 1;   // not listed yet
                 }
@@ -431,8 +437,8 @@ __global__ void __launch_bounds__(256, 3) k_esdf_round(MapDev M, EsdfDev E, int 
         if (threadIdx.x == 0) {
             E.region[p] = 2;
             __hip_atomic_fetch_add(&E.ctr[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&E.ctr[8], passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_max(&E.ctr[9], passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&E.ctr[8], sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&E.ctr[9], sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         ESDF_TICK(4);
@@ -573,7 +579,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     int rounds = ((full || m->esdf_rounds_seen == 0) ? 2 * reach + 8 : std::min(2 * reach + 8, std::max(reach + 3, m->esdf_rounds_seen + 3))) + extra_rounds;
     const int grid = 4 * m->ncu;
     if (m->esdf_round_cap > 0 && extra_rounds == 0 && rounds > m->esdf_round_cap) rounds = m->esdf_round_cap;      // test knob: provoke the repair path
-    for (int k = 0; k < rounds; ++k) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(256), 0, q, m->M, E, s, m->P.vs, max_dist, k);
+    for (int k = 0; k < rounds; ++k) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);
     m->prof_group = false; prof_end(m);
     TSL_HIP(hipMemcpyAsync(S.host, m->esdf_ctr, sizeof(int) * 256, hipMemcpyDeviceToHost, q));
     TSL_HIP(hipEventRecord(S.ev, q));
