@@ -33,6 +33,8 @@ namespace tsl {
 #define EF_NODE 1
 #define EF_NEG 2
 #define EF_FIXED 4
+#define ES_UNOBS 0x7fffffffu
+#define ES_INF 0x7f800000u
 
 #ifdef TSL_TIMING
 // developer timing: thread 0 of every relaxation adds the clock ticks (100 MHz) of its phases to E.ctr64[k]
@@ -41,13 +43,15 @@ namespace tsl {
 #define ESDF_TICK(k) do {} while (0)
 #endif
 struct EsdfDev {
-    float* mag;                // [max_bricks][4096] magnitude
+    float* mag;                // [max_bricks][4096] the signed distance: side << 31 | magnitude bits (a negative float on the negative side), ES_UNOBS (a NaN) where
+                               // the voxel was not observed at the last (re)initialisation -- the word the relaxation's tile holds
     uint8_t* fl;               // [max_bricks][4096] EF_* of the voxel at the last (re)initialisation
     uint8_t* region;           // [max_bricks] 1: brick is part of this update's region, 2: relaxed once already
     int* stamp;                // [max_bricks] last round the brick was put on a work list for (dedupe)
     int* dirty;                // [max_bricks] dirty list
     uint32_t* note;            // [2][max_bricks] per round parity: bit q = neighbour q (of 27) changed its boundary layer in the previous round
     int* work;                 // [3][max_bricks] work lists of rounds k, k+1, k+2 (mod 3)
+    int* nbr;                  // [max_bricks][27] pool indices of the bricks around a region brick (-1: absent), written by k_esdf_init
     int cap;                   // max_bricks
     unsigned long long* tm;    // developer timing (TSL_TIMING builds): ticks per phase, summed over relaxations
     int* ctr;                  // [0] dirty count [1] region count [2..4] work list lengths [5] brick relaxations [6] voxel pushes [7] rounds with work
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s,
                 uint32_t f; float mg;
                 esdf_inputs((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu, tv[z], gamma, max_dist, &f, &mg);
                 const uint32_t fs = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
-                changed = changed || f != fs || ((f & EF_FIXED) && __float_as_uint(mg) != mv[z]);
+                changed = changed || f != fs || ((f & EF_FIXED) && __float_as_uint(mg) != (mv[z] & 0x7fffffffu));
             }
             if (!__syncthreads_or(changed)) continue;                 // (uniform: every thread of the workgroup leaves or stays)
         }
@@ -125,12 +129,24 @@ __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s,
     }
 }
 
-// 3. (re)initialise the region's voxels; every brick of the region is on the work list of round 0
-__global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float gamma, float max_dist)
+// 3. (re)initialise the region's voxels.  Round 0 relaxes the bricks that hold a source of their own -- a band voxel -- or that touch a
+//    brick outside the region (whose values stand as boundary conditions); every other brick of the region waits until a neighbour
+//    reports values that can lower something in it (it would otherwise be relaxed from partial information and again a round later).
+__global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, int s, float gamma, float max_dist)
 {
     const int nused = min(E.ctr[10], M.max_bricks);
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         if (E.region[p] != 1) continue;
+        bool seed = false;
+        if (threadIdx.x >= 192 && threadIdx.x < 192 + 27) {      // the 27 bricks around this one (a brick allocated after the update's snapshot is not part of it)
+            const int t = (int)threadIdx.x - 192;
+            const int b = M.owner[p] - s * M.nb3;
+            const int i = b / (M.nbz * M.nbx) + t / 9 - 1, j = (b / M.nbz) % M.nbx + (t / 3) % 3 - 1, k = b % M.nbz + t % 3 - 1;
+            int np = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+            if (np >= nused) np = -1;
+            E.nbr[(size_t)p * 27 + t] = np;
+            seed = np >= 0 && E.region[np] == 0;                    // (k_esdf_dilate, the launch before this one, wrote the region marks)
+        }
         {   // a thread's 16 consecutive voxels: 1 + 4 wide loads, 1 + 4 wide stores
             const size_t v = (size_t)p * TSL_BRK3 + (size_t)threadIdx.x * 16;
             const uint4 ob = *reinterpret_cast<const uint4*>(M.obs + v);
@@ -144,15 +160,16 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float ga
             for (int z = 0; z < 16; ++z) {
                 uint32_t f; float mg;
                 esdf_inputs((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu, tv[z], gamma, max_dist, &f, &mg);
-                fo[z >> 2] |= f << ((z & 3) * 8); mo[z] = mg;
+                seed = seed || (f & EF_FIXED);
+                fo[z >> 2] |= f << ((z & 3) * 8); mo[z] = __uint_as_float((f & EF_NODE) ? (__float_as_uint(mg) | ((f & EF_NEG) ? 0x80000000u : 0u)) : ES_UNOBS);
             }
             *reinterpret_cast<uint4*>(E.fl + v) = make_uint4(fo[0], fo[1], fo[2], fo[3]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(E.mag + v)[q] = make_float4(mo[4 * q], mo[4 * q + 1], mo[4 * q + 2], mo[4 * q + 3]);
         }
+        const bool listed = __syncthreads_or(seed) != 0;
         if (threadIdx.x == 0) {
-            const int q = __hip_atomic_fetch_add(&E.ctr[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            E.work[q] = p; E.stamp[p] = 0;
+            if (listed) { const int q = __hip_atomic_fetch_add(&E.ctr[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); E.work[q] = p; E.stamp[p] = 0; }
             __hip_atomic_fetch_add(&E.ctr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -181,11 +198,13 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, float ga
 //    minimum over raw words is the least magnitude among its positive neighbours (negative-side words and ES_UNOBS are larger than any
 //    magnitude; clamped to +inf they never win); for the negative side the signed minimum does the same.  Only interior, observed,
 //    non-band voxels ("targets", a bit mask per lane) are ever written.
+#ifndef ESDF_WPE
+#define ESDF_WPE 4                        // waves per SIMD the register budget is set for: two workgroups per CU (three, with 96 registers and
+                                          // spills, or four were 7 - 25 % slower: the sweeps saturate the LDS and the VALU of a CU with two)
+#endif
 #define ES_SY 19                          // row pitch (18 entries + 1: spreads the rows of a plane over the LDS banks)
 #define ES_SX (18 * ES_SY + 1)            // plane pitch
 #define ES_TILE (18 * ES_SX)
-#define ES_UNOBS 0x7fffffffu
-#define ES_INF 0x7f800000u
 #define ES_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 // the four mask bits of a lane's voxels in plane s of a sweep along AXIS (lane = r * 4 + q: row r, voxels 4q .. 4q + 3 of the row)
@@ -197,9 +216,23 @@ template <int AXIS> __device__ __forceinline__ uint32_t esdf_nibble(const uint32
     return (a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u);
 }
 
+// the target / negative-target bits of a lane's 64 voxels in sweep order (bit 4 i + j: voxel j of the i-th plane)
+template <int AXIS, int SIGN>
+__device__ __forceinline__ void esdf_masks(const uint32_t* s_tgt, const uint32_t* s_neg, unsigned long long& mT, unsigned long long& mN)
+{
+    const int lane = (int)(threadIdx.x & 63u), q = lane & 3, r = lane >> 2;
+    mT = 0ull; mN = 0ull;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int sp = SIGN > 0 ? i : 15 - i;
+        const uint32_t t = esdf_nibble<AXIS>(s_tgt, sp, r, q);
+        mT |= (unsigned long long)t << (4 * i); mN |= (unsigned long long)(t & esdf_nibble<AXIS>(s_neg, sp, r, q)) << (4 * i);
+    }
+}
+
 // one sweep of the calling wave.  Returns whether this lane lowered a voxel.
 template <int AXIS, int SIGN>
-__device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt, const uint32_t* s_neg, uint32_t* s_chg, const float c1, const float c2, const float c3,
+__device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, uint32_t* s_chg, unsigned long long mT, unsigned long long mN, const float c1, const float c2, const float c3,
                                            const bool entry_check, int& lowered)
 {
     constexpr int SD = AXIS == 0 ? ES_SX : (AXIS == 1 ? ES_SY : 1);        // along the sweep
@@ -207,13 +240,6 @@ __device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt,
     constexpr int SJ = AXIS == 2 ? ES_SY : 1;                              // along a lane's four voxels
     constexpr int PO = SIGN > 0 ? 0 : SD, OO = SIGN > 0 ? SD : 0;          // the plane before / the own plane, from the lower of the two
     const int lane = (int)(threadIdx.x & 63u), q = lane & 3, r = lane >> 2;
-    unsigned long long mT = 0ull, mN = 0ull;                               // bit 4 i + j: voxel j of the i-th plane in sweep order
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int sp = SIGN > 0 ? i : 15 - i;
-        const uint32_t t = esdf_nibble<AXIS>(s_tgt, sp, r, q);
-        mT |= (unsigned long long)t << (4 * i); mN |= (unsigned long long)(t & esdf_nibble<AXIS>(s_neg, sp, r, q)) << (4 * i);
-    }
     bool changed = false;
     // the lower of (own plane, plane before) in tile coordinates: i for a forward sweep, 16 - i for a backward one
     uint32_t* b = s_t + r * SR + 4 * q * SJ + (SIGN > 0 ? 0 : 16 * SD);
@@ -229,8 +255,18 @@ __device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt,
             for (int k = 0; k < 6; ++k) w[rr][k] = ES_LD(b + PO + rr * SR + k * SJ);
 #pragma unroll
         for (int j = 0; j < 4; ++j) own[j] = ES_LD(b + OO + SR + (j + 1) * SJ);
-        float cand[4] = { __uint_as_float(ES_INF), __uint_as_float(ES_INF), __uint_as_float(ES_INF), __uint_as_float(ES_INF) };
-        if (hasP) {
+        uint32_t cb[4];                                            // bits of the candidate of voxel j (+inf: none)
+        if (hasP && hasN) {
+            // both sides in the plane: the words seen from the side of each voxel (the other side and unobserved turn >= +inf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t sj = ((nn >> j) & 1u) << 31;
+                const uint32_t f = min(w[1][j + 1] ^ sj, ES_INF);
+                const uint32_t e = min(min(min(w[1][j] ^ sj, w[1][j + 2] ^ sj), min(w[0][j + 1] ^ sj, w[2][j + 1] ^ sj)), ES_INF);
+                const uint32_t c = min(min(min(w[0][j] ^ sj, w[0][j + 2] ^ sj), min(w[2][j] ^ sj, w[2][j + 2] ^ sj)), ES_INF);
+                cb[j] = __float_as_uint(fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3));
+            }
+        } else if (hasP) {
             uint32_t pr[3][4];
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr)
@@ -239,11 +275,9 @@ __device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t f = min(w[1][j + 1], ES_INF), e = min(min(pr[1][j], min(w[0][j + 1], w[2][j + 1])), ES_INF), c = min(min(pr[0][j], pr[2][j]), ES_INF);
-                const float v = fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3);
-                if (!((nn >> j) & 1u)) cand[j] = v;
+                cb[j] = __float_as_uint(fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3));
             }
-        }
-        if (hasN) {
+        } else {
             int pr[3][4];
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr)
@@ -254,21 +288,26 @@ __device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt,
                 const uint32_t f = min(w[1][j + 1] ^ 0x80000000u, ES_INF);
                 const uint32_t e = min((uint32_t)min(pr[1][j], min((int)w[0][j + 1], (int)w[2][j + 1])) ^ 0x80000000u, ES_INF);
                 const uint32_t c = min((uint32_t)min(pr[0][j], pr[2][j]) ^ 0x80000000u, ES_INF);
-                const float v = fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3);
-                if ((nn >> j) & 1u) cand[j] = v;
+                cb[j] = __float_as_uint(fminf(fminf(__uint_as_float(f) + c1, __uint_as_float(e) + c2), __uint_as_float(c) + c3));
             }
         }
-        bool ch = false;
+        uint32_t cm = 0u;                                          // bit j: voxel j is a target and its candidate is lower
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t cb = __float_as_uint(cand[j]);
-            if (((tn >> j) & 1u) && cb < (own[j] & 0x7fffffffu)) {
-                __hip_atomic_fetch_min(b + OO + SR + (j + 1) * SJ, cb | (own[j] & 0x80000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int sp = SIGN > 0 ? i : 15 - i;
-                const int l = AXIS == 0 ? (sp << 8) | (r << 4) | (4 * q + j) : (AXIS == 1 ? (r << 8) | (sp << 4) | (4 * q + j) : (r << 8) | ((4 * q + j) << 4) | sp);
-                __hip_atomic_fetch_or(&s_chg[l >> 5], 1u << (l & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ch = true; ++lowered;
+        for (int j = 0; j < 4; ++j) cm |= (cb[j] < (own[j] & 0x7fffffffu) ? 1u : 0u) << j;
+        cm &= tn;
+        const bool ch = cm != 0u;
+        if (__any(ch)) {                                           // (rare once the tile has settled: a whole set without it ends the relaxation)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)                            // a minimum with ~0 changes nothing
+                __hip_atomic_fetch_min(b + OO + SR + (j + 1) * SJ, ((cm >> j) & 1u) ? (cb[j] | (own[j] & 0x80000000u)) : ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int sp = SIGN > 0 ? i : 15 - i;
+            if (AXIS == 0) __hip_atomic_fetch_or(&s_chg[sp * 8 + (r >> 1)], cm << ((r & 1) * 16 + 4 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (AXIS == 1) __hip_atomic_fetch_or(&s_chg[r * 8 + (sp >> 1)], cm << ((sp & 1) * 16 + 4 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else {
+                __hip_atomic_fetch_or(&s_chg[r * 8 + 2 * q], ((cm & 1u) | ((cm & 2u) << 15)) << sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&s_chg[r * 8 + 2 * q + 1], (((cm >> 2) & 1u) | ((cm & 8u) << 13)) << sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            lowered += __builtin_popcount(cm);
         }
         changed = changed || ch;
         if (entry_check && i == 0 && !__any(ch)) return false;
@@ -276,37 +315,52 @@ __device__ __forceinline__ bool esdf_sweep(uint32_t* s_t, const uint32_t* s_tgt,
     return changed;
 }
 
-__global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, float max_dist, int round)
+__global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev E, int s, float vs, float max_dist, int round)
 {
     constexpr int NH = ESDF_T3 - TSL_BRK3, HPER = (NH + 383) / 384;      // 1736 halo entries, 5 per thread
     __shared__ uint32_t s_t[ES_TILE];                      // the tile (see above)
     __shared__ __attribute__((aligned(4))) uint16_t s_tgt16[256], s_neg16[256];     // per interior row (x, y): bit z = target / negative side
     __shared__ uint32_t s_chg[TSL_BRK3 / 32];              // interior voxels lowered in this visit
     __shared__ int s_nb[27];                               // pool index of the 27 bricks around (and including) this one, -1 = absent
-    __shared__ int s_notify;
+    __shared__ int s_notify, s_flags;
     const uint32_t* const s_tgt = reinterpret_cast<const uint32_t*>(s_tgt16);
     const uint32_t* const s_neg = reinterpret_cast<const uint32_t*>(s_neg16);
     const int cur = round % 3, nxt = (round + 1) % 3, clr = (round + 2) % 3;
-    const int n = E.ctr[2 + cur], nsnap = min(E.ctr[10], M.max_bricks);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) E.ctr[7] = round + 1; }      // list (round+2) was consumed in round-1
+    const int n = E.ctr[2 + cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) { E.ctr[7] = round + 1; if (round < 16) E.ctr[240 + round] = n; } }      // list (round+2) was consumed in round-1
     if (n == 0) return;
     const float c1 = 1.0f * vs, c2 = sqrtf(2.0f) * vs, c3 = sqrtf(3.0f) * vs;                   // dense_esdf.py:286
     const int* list = E.work + (size_t)cur * E.cap;
     int* next = E.work + (size_t)nxt * E.cap;
     const int wave = (int)(threadIdx.x >> 6);
+    // this thread's halo entries, the same for every brick: tile index | which of the 27 bricks << 13 | voxel in that brick << 18, packed so
+    // that they cost HPER registers while the sweeps run (~0u: none)
+    uint32_t hpk[HPER], hnb[HPER];
+#pragma unroll
+    for (int q = 0; q < HPER; ++q) {
+        const int h = q * 384 + (int)threadIdx.x;
+        int tx, ty, tz;
+        if (h < 2 * ESDF_T * ESDF_T) { const int r = h % (ESDF_T * ESDF_T); tx = (h / (ESDF_T * ESDF_T)) * 17; ty = r / ESDF_T; tz = r % ESDF_T; }       // faces x = 0, 17
+        else if (h < 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T) { const int g = h - 2 * ESDF_T * ESDF_T, r = g % (2 * ESDF_T); tx = 1 + g / (2 * ESDF_T); ty = (r / ESDF_T) * 17; tz = r % ESDF_T; }   // rows y = 0, 17
+        else { const int g = h - (2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T); tx = 1 + g / 32; ty = 1 + (g % 32) / 2; tz = (g & 1) * 17; }                // entries z = 0, 17
+        const uint32_t hq = (uint32_t)((((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4));
+        const uint32_t vo = (uint32_t)((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+        hpk[q] = h < NH ? (uint32_t)(tx * ES_SX + ty * ES_SY + tz) | hq << 13 | vo << 18 : ~0u;
+        // for the notification test: the interior voxels next to the entry are base + a * su + b * sv, a, b in {-1, 0, 1}, where the axes on
+        // which the entry lies outside the brick are moved one step inwards (nf of them) and u, v are the others (stride code 0: none)
+        const int fx = tx == 0 || tx == 17, fy = ty == 0 || ty == 17, fz = tz == 0 || tz == 17;
+        const int ix = tx == 0 ? 1 : (tx == 17 ? 16 : tx), iy = ty == 0 ? 1 : (ty == 17 ? 16 : ty), iz = tz == 0 ? 1 : (tz == 17 ? 16 : tz);
+        const int ucode = !fx ? 1 : (!fy ? 2 : (!fz ? 3 : 0)), vcode = !fx ? (!fy ? 2 : (!fz ? 3 : 0)) : ((!fy && !fz) ? 3 : 0);
+        const int cu = ucode == 1 ? tx : (ucode == 2 ? ty : tz), cv = vcode == 2 ? ty : tz;
+        hnb[q] = (uint32_t)(ix * ES_SX + iy * ES_SY + iz) | (uint32_t)ucode << 13 | (uint32_t)vcode << 15 | (uint32_t)cu << 17 | (uint32_t)cv << 22 | (uint32_t)(fx + fy + fz) << 27;
+    }
     for (int w = blockIdx.x; w < n; w += gridDim.x) {
 #ifdef TSL_TIMING
         long long _t = wall_clock64();
 #endif
         const int p = list[w];
-        const int b = M.owner[p] - s * M.nb3;
-        const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
-        if (threadIdx.x < 27) {
-            const int i = bi + (int)threadIdx.x / 9 - 1, j = bj + ((int)threadIdx.x / 3) % 3 - 1, k = bk + (int)threadIdx.x % 3 - 1;
-            const int np = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
-            s_nb[threadIdx.x] = np < nsnap ? np : -1;                 // a brick allocated after the update's snapshot is not part of it
-        }
-        if (threadIdx.x == 0) s_notify = 0;
+        if (threadIdx.x < 27) s_nb[threadIdx.x] = E.nbr[(size_t)p * 27 + threadIdx.x];          // written by k_esdf_init
+        if (threadIdx.x == 0) { s_notify = 0; s_flags = 0; }
         if (threadIdx.x < TSL_BRK3 / 32) s_chg[threadIdx.x] = 0u;
         // first relaxation in this update: everything is new; afterwards only the halo entries of the neighbours that changed their
         // boundary layer since (the notification mask written for this round) are
@@ -319,7 +373,7 @@ __global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int 
         // ---- stage brick + halo as ONE batch of independent loads: thread tid < 256 owns the interior row (x, y) = (tid / 16, tid % 16) --
         //      16 voxels = 4 + 1 wide loads -- and every thread <= 5 of the 1736 halo entries (loaded from a valid address unconditionally
         //      so that nothing separates the requests) ----
-        bool has_target = false;
+        int flags = 0;                                              // 1: a target, 2: a value that can lower a neighbour (value + edge < max_dist)
         {
             const int row = (int)threadIdx.x & 255;
             const size_t v0 = (size_t)p * TSL_BRK3 + (size_t)row * 16;
@@ -327,20 +381,14 @@ __global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int 
 #pragma unroll
             for (int q = 0; q < 4; ++q) dq[q] = reinterpret_cast<const uint4*>(E.mag + v0)[q];
             const uint4 fq = *reinterpret_cast<const uint4*>(E.fl + v0);
-            int ht[HPER]; uint8_t hf[HPER]; uint32_t hd[HPER]; bool hok[HPER];
+            uint32_t hd[HPER], hk[HPER];
 #pragma unroll
             for (int q = 0; q < HPER; ++q) {
-                const int h = q * 384 + (int)threadIdx.x;
-                int tx, ty, tz;
-                if (h < 2 * ESDF_T * ESDF_T) { const int r = h % (ESDF_T * ESDF_T); tx = (h / (ESDF_T * ESDF_T)) * 17; ty = r / ESDF_T; tz = r % ESDF_T; }       // faces x = 0, 17
-                else if (h < 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T) { const int g = h - 2 * ESDF_T * ESDF_T, r = g % (2 * ESDF_T); tx = 1 + g / (2 * ESDF_T); ty = (r / ESDF_T) * 17; tz = r % ESDF_T; }   // rows y = 0, 17
-                else { const int g = h - (2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T); tx = 1 + g / 32; ty = 1 + (g % 32) / 2; tz = (g & 1) * 17; }                // entries z = 0, 17
-                ht[q] = h < NH ? tx * ES_SX + ty * ES_SY + tz : -1;
-                const int hq = h < NH ? (((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4) : 13;     // which of the 27 bricks
-                const int np = s_nb[hq];
-                hok[q] = h < NH && np >= 0;
-                const size_t v = (size_t)(np >= 0 ? np : p) * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
-                hf[q] = E.fl[v]; hd[q] = __float_as_uint(E.mag[v]);
+                hk[q] = hpk[q];
+                asm volatile("" : "+v"(hk[q]));                    // (decode here, do not keep the decoded fields across the loop)
+                const int np = hk[q] != ~0u ? s_nb[(hk[q] >> 13) & 31u] : -1;
+                if (np < 0) hk[q] = ~0u;
+                hd[q] = __float_as_uint(E.mag[(size_t)(np >= 0 ? np : p) * TSL_BRK3 + (np >= 0 ? hk[q] >> 18 : 0u)]);
             }
             if (threadIdx.x < 256) {
                 const uint32_t dl[16] = { dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w, dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w };
@@ -350,38 +398,56 @@ __global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int 
 #pragma unroll
                 for (int z = 0; z < 16; ++z) {
                     const uint32_t f = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
-                    s_t[t0 + z] = (f & EF_NODE) ? (dl[z] | ((f & EF_NEG) ? 0x80000000u : 0u)) : ES_UNOBS;
+                    s_t[t0 + z] = dl[z];
+                    if (__uint_as_float(dl[z] & 0x7fffffffu) + c1 < max_dist) flags |= 2;          // (false for the NaN of an unobserved voxel)
                     tg |= ((f & (EF_NODE | EF_FIXED)) == EF_NODE ? 1u : 0u) << z;
                     ng |= ((f & EF_NEG) ? 1u : 0u) << z;
                 }
                 s_tgt16[threadIdx.x] = (uint16_t)tg; s_neg16[threadIdx.x] = (uint16_t)ng;
-                has_target = tg != 0u;
+                if (tg != 0u) flags |= 1;
             }
 #pragma unroll
             for (int q = 0; q < HPER; ++q) {
-                if (ht[q] < 0) continue;
-                const uint32_t f = hok[q] ? (uint32_t)hf[q] : 0u;
-                s_t[ht[q]] = (f & EF_NODE) ? (hd[q] | ((f & EF_NEG) ? 0x80000000u : 0u)) : ES_UNOBS;
+                if (hpk[q] == ~0u) continue;                      // (an entry of an absent brick is written as unobserved)
+                const uint32_t hw = hk[q] != ~0u ? hd[q] : ES_UNOBS;
+                s_t[hpk[q] & 0x1fffu] = hw;
+                if (__uint_as_float(hw & 0x7fffffffu) + c1 < max_dist) flags |= 2;
             }
         }
-        const bool work = __syncthreads_or(has_target) != 0;       // (a brick without a target has nothing to relax)
+        {
+            const int f1 = __any(flags & 1) ? 1 : 0, f2 = __any(flags & 2) ? 2 : 0;
+            if ((threadIdx.x & 63u) == 0 && (f1 | f2)) atomicOr(&s_flags, f1 | f2);
+        }
+        __syncthreads();
+        // nothing to relax without a target, and nothing can be lowered if no value in the tile is an edge below max_dist (the outer
+        // bricks of the region in round 0)
+        const bool work = s_flags == 3;
         ESDF_TICK(1);
         // ---- the sweeps ----
         int lowered = 0, sets = 0;
         if (work) {
             // wave -> (axis, sign); on a later visit a sweep takes part in the entry check if a neighbour on its entry side was notified
             const uint32_t entry_mask = wave == 0 ? 0x1ffu : wave == 1 ? 0x1ffu << 18 : wave == 2 ? 0x01c0e07u : wave == 3 ? 0x01c0e07u << 6 : wave == 4 ? 0x1249249u : 0x1249249u << 2;
+            unsigned long long mT, mN;
+            switch (wave) {
+            case 0: esdf_masks<0, +1>(s_tgt, s_neg, mT, mN); break;
+            case 1: esdf_masks<0, -1>(s_tgt, s_neg, mT, mN); break;
+            case 2: esdf_masks<1, +1>(s_tgt, s_neg, mT, mN); break;
+            case 3: esdf_masks<1, -1>(s_tgt, s_neg, mT, mN); break;
+            case 4: esdf_masks<2, +1>(s_tgt, s_neg, mT, mN); break;
+            default: esdf_masks<2, -1>(s_tgt, s_neg, mT, mN); break;
+            }
             bool full = first;
             for (;;) {
                 bool chg = false;
                 if (full || (note & entry_mask)) {
                     switch (wave) {
-                    case 0: chg = esdf_sweep<0, +1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
-                    case 1: chg = esdf_sweep<0, -1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
-                    case 2: chg = esdf_sweep<1, +1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
-                    case 3: chg = esdf_sweep<1, -1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
-                    case 4: chg = esdf_sweep<2, +1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
-                    default: chg = esdf_sweep<2, -1>(s_t, s_tgt, s_neg, s_chg, c1, c2, c3, !full, lowered); break;
+                    case 0: chg = esdf_sweep<0, +1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 1: chg = esdf_sweep<0, -1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 2: chg = esdf_sweep<1, +1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 3: chg = esdf_sweep<1, -1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 4: chg = esdf_sweep<2, +1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    default: chg = esdf_sweep<2, -1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
                     }
                 }
                 ++sets;
@@ -395,22 +461,50 @@ __global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int 
         { const long long pw = wave_sum_ll((long long)lowered); if (lane_id() == 0) atomicAdd(&E.tm[80 + (sets < 31 ? sets : 31)], (unsigned long long)pw); }
 #endif
         ESDF_TICK(2);
-        // ---- write back the voxels that were lowered; one in the boundary layer marks the neighbours that hold it in their halo ----
+        // ---- write back the voxels that were lowered ----
         {
             float* gm = E.mag + (size_t)p * TSL_BRK3;
             for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
                 if (!((s_chg[l >> 5] >> (l & 31)) & 1u)) continue;
-                const int x = (l >> 8) + 1, y = ((l >> 4) & 15) + 1, z = (l & 15) + 1;
-                gm[l] = __uint_as_float(s_t[x * ES_SX + y * ES_SY + z] & 0x7fffffffu);
-                // the neighbours (ax, ay, az) in {0, 1, 2}^3 whose halo holds this voxel: per axis the centre, plus the lower / upper
-                // neighbour when the voxel lies in the first / last layer -- a product of three small bit sets
-                const int sx = x == 1 ? 3 : (x == 16 ? 6 : 2), sy = y == 1 ? 3 : (y == 16 ? 6 : 2), sz = z == 1 ? 3 : (z == 16 ? 6 : 2);
-                if ((sx | sy | sz) != 2) {
-                    const int myz = ((sy & 1) ? sz : 0) | ((sy & 2) ? sz << 3 : 0) | ((sy & 4) ? sz << 6 : 0);
-                    const int m = ((sx & 1) ? myz : 0) | ((sx & 2) ? myz << 9 : 0) | ((sx & 4) ? myz << 18 : 0);
-                    atomicOr(&s_notify, m & ~(1 << 13));
-                }
+                gm[l] = __uint_as_float(s_t[((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1]);
             }
+        }
+        // ---- which neighbours to tell: a neighbour is listed for the next round iff one of its voxels in this tile's halo could be lowered
+        //      from this brick -- the pull of the sweeps, turned outwards: for a halo entry, the least value + edge cost over the <= 9
+        //      interior voxels next to it, against the entry as it was staged.  (The entry may have been lowered by its owner since, and it
+        //      may be a band voxel, which nothing lowers: then the neighbour is told for nothing and finds nothing to do.  It is never
+        //      higher than staged.)  A brick that only took values from its inner neighbours does not call them back this way, and a brick
+        //      of the region that was never told anything is never relaxed. ----
+        if (first || __syncthreads_or(lowered != 0)) {
+            int told = 0;
+#pragma unroll
+            for (int q = 0; q < HPER; ++q) {
+                uint32_t hk = hpk[q], hn = hnb[q];
+                asm volatile("" : "+v"(hk), "+v"(hn));
+                if (hk == ~0u) continue;
+                const uint32_t hw = ES_LD(&s_t[hk & 0x1fffu]);
+                if (hw == ES_UNOBS) continue;
+                const uint32_t sb = hw & 0x80000000u;
+                const int base = (int)(hn & 0x1fffu), uc = (int)((hn >> 13) & 3u), vc = (int)((hn >> 15) & 3u), cu = (int)((hn >> 17) & 31u), cv = (int)((hn >> 22) & 31u), nf = (int)(hn >> 27);
+                const int su = uc == 1 ? ES_SX : (uc == 2 ? ES_SY : (uc == 3 ? 1 : 0)), sv = vc == 2 ? ES_SY : (vc == 3 ? 1 : 0);
+                uint32_t m[3] = { ~0u, ~0u, ~0u };                 // least same-side magnitude by the number of free axes stepped along
+#pragma unroll
+                for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                    for (int b = -1; b <= 1; ++b) {
+                        const bool ok = (a == 0 || (uc != 0 && cu + a >= 1 && cu + a <= 16)) && (b == 0 || (vc != 0 && cv + b >= 1 && cv + b <= 16));
+                        const uint32_t x = ES_LD(&s_t[base + (ok ? a * su + b * sv : 0)]) ^ sb;
+                        if (ok) m[(a != 0) + (b != 0)] = min(m[(a != 0) + (b != 0)], x);
+                    }
+                const float cc[5] = { 0.0f, c1, c2, c3, __uint_as_float(ES_INF) };
+                float best = __uint_as_float(ES_INF);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) best = fminf(best, __uint_as_float(min(m[e], ES_INF)) + cc[min(nf + e, 4)]);
+                if (__float_as_uint(best) < (hw & 0x7fffffffu)) told |= 1 << ((hk >> 13) & 31u);
+            }
+            told &= ~(1 << 13);
+            for (int d = 32; d >= 1; d >>= 1) told |= __shfl_xor(told, d);
+            if ((threadIdx.x & 63u) == 0 && told) atomicOr(&s_notify, told);
         }
         __syncthreads();
         ESDF_TICK(3);
@@ -445,7 +539,7 @@ __global__ void __launch_bounds__(384, 4) k_esdf_round(MapDev M, EsdfDev E, int 
     }
 }
 
-__global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused, const float* esdf, float gamma, int16_t* idx, float* out, long long cap, int* counter)
+__global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused, const float* esdf, float gamma, float max_dist, int16_t* idx, float* out, long long cap, int* counter)
 {
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         const int owner = M.owner[p];
@@ -461,7 +555,8 @@ __global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused,
                 idx[(size_t)o * 3] = (int16_t)(bi * 16 + (l >> 8) - M.hN); idx[(size_t)o * 3 + 1] = (int16_t)(bj * 16 + ((l >> 4) & 15) - M.hN);
                 idx[(size_t)o * 3 + 2] = (int16_t)(bk * 16 + (l & 15) - M.hNz);
                 const float t = h2f((h16)(M.tw[v] & 0xffffu));
-                out[o] = fabsf(t) < gamma ? t : (float)sgn_f(t) * esdf[v];
+                const float e = esdf[v];                                   // (a NaN: not observed yet when the ESDF was last updated)
+                out[o] = fabsf(t) < gamma ? t : (float)sgn_f(t) * (e != e ? max_dist : fabsf(e));
             }
         }
     }
@@ -470,7 +565,7 @@ __global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused,
 // cvt_ESDF_to_voxels_slice  dense_esdf.py:498-509: every observed voxel of the active submap with _index - 0.5 < k < _index + 0.5
 // (k counted from the bottom of the volume, as the legacy module does) -> export_ESDF / export_ESDF_xyz, num_export_ESDF_particles
 struct PoseE { float R[9], T[3]; };
-__global__ void __launch_bounds__(256) k_esdf_slice(MapDev M, int s, int nused, const float* esdf, float gamma, PoseE B, int is_global, float vs, float index_f,
+__global__ void __launch_bounds__(256) k_esdf_slice(MapDev M, int s, int nused, const float* esdf, float gamma, float max_dist, PoseE B, int is_global, float vs, float index_f,
                                                     float* xyz, float* val, long long cap, int* counter)
 {
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
@@ -486,7 +581,8 @@ __global__ void __launch_bounds__(256) k_esdf_slice(MapDev M, int s, int nused, 
             const int o = wave_reserve(counter, pred);                                            // :505
             if (pred && o < cap) {
                 const float t = h2f((h16)(M.tw[v] & 0xffffu));
-                val[o] = fabsf(t) < gamma ? t : (float)sgn_f(t) * esdf[v];                        // :507
+                const float e = esdf[v];
+                val[o] = fabsf(t) < gamma ? t : (float)sgn_f(t) * (e != e ? max_dist : fabsf(e));  // :507
                 const int i = bi * 16 + (l >> 8) - M.hN, j = bj * 16 + ((l >> 4) & 15) - M.hN, k = ku - M.hNz;
                 const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;           // :508  submap_i_j_k_to_xyz (mapping_common.py:221-232)
                 if (is_global) { xyz[(size_t)o * 3] = p0; xyz[(size_t)o * 3 + 1] = p1; xyz[(size_t)o * 3 + 2] = p2; }
@@ -522,6 +618,7 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         { const unsigned long long* tm = (const unsigned long long*)&h[16]; const double n = st.brick_relaxations ? st.brick_relaxations : 1;
           std::fprintf(stderr, "esdf timing: us per relaxation: setup %.2f stage %.2f relax %.2f writeback %.2f notify %.2f (%lld relaxations)\n",
                        tm[0] / n / 100.0, tm[1] / n / 100.0, tm[2] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, (long long)st.brick_relaxations);
+          std::fprintf(stderr, "esdf bricks per round:"); for (int k = 0; k < 16 && h[240 + k]; ++k) std::fprintf(stderr, " %d", h[240 + k]); std::fprintf(stderr, "\n");
           std::fprintf(stderr, "esdf relax by passes (count: mean us, mean pushes); max relax %.1f us\n", tm[72] / 100.0);
           for (int k = 0; k < 32; ++k) if (tm[40 + k]) std::fprintf(stderr, "  %2d passes: %5llu relaxations, %7.1f us, %7.0f pushes\n", k, tm[40 + k], tm[8 + k] / (double)tm[40 + k] / 100.0, tm[80 + k] / (double)tm[40 + k]); }
 #endif
@@ -541,6 +638,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
         if ((rc = dev_alloc(m, (void**)&m->esdf_list, sizeof(int) * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_note, sizeof(uint32_t) * 2 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_nbr, sizeof(int) * 27 * (size_t)nb, 0xff))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 256, 0))) return rc;
         for (int i = 0; i < TSL_ESDF_SLOTS; ++i) {
             TSL_HIP(hipEventCreateWithFlags(&m->esdf_slot[i].ev, hipEventDisableTiming));
@@ -557,7 +655,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     int reach = (int)std::ceil((double)max_dist / ((double)m->P.vs * 16.0)); if (reach < 1) reach = 1;
     const bool full = force_full || m->esdf_force_full || !m->esdf_valid || m->esdf_submap != s || m->esdf_gamma != gamma || m->esdf_maxd != max_dist ||
                       2 * reach + 1 >= m->nbx;              // the dilation would cover the grid anyway
-    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_note, m->esdf_queue, nb, (unsigned long long*)(m->esdf_ctr + 16), m->esdf_ctr };
+    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_note, m->esdf_queue, m->esdf_nbr, nb, (unsigned long long*)(m->esdf_ctr + 16), m->esdf_ctr };
     EsdfSlot& S = m->esdf_slot[(m->esdf_tail + m->esdf_npend) % TSL_ESDF_SLOTS];
     std::memset(&S.st, 0, sizeof(S.st));
     S.st.incremental = full ? 0 : 1;
@@ -571,7 +669,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     // snapshot + collect, so that every pool index below the snapshot has its owner written (launch_batch_t waits for the gate)
     TSL_HIP(hipEventRecord(m->esdf_gate, q)); m->esdf_gate_set = true;
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
-    hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, gamma, max_dist);
+    hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, s, gamma, max_dist);
     // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
     // few more (8 rounds had work at reach = 4 on the benchmark stream).
     // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards three more than the most any
@@ -660,7 +758,7 @@ static int esdf_export_stage(tsl_tsdf* m, int64_t cap, int16_t** didx, float** d
     int* counter = m->num_particles + 2;
     TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), ms(m)));
     const int s = m->cfg.is_global_map ? 0 : m->active;
-    if (nused > 0) hipLaunchKernelGGL(k_esdf_export, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, *didx, *dval, (long long)cap, counter);
+    if (nused > 0) hipLaunchKernelGGL(k_esdf_export, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, m->esdf_maxd, *didx, *dval, (long long)cap, counter);
     TSL_HIP(hipMemcpyAsync(m->h_ints, counter, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
     TSL_HIP(hipStreamSynchronize(ms(m)));
     *c = m->h_ints[0];
@@ -710,7 +808,7 @@ int tsl_esdf_slice(tsl_tsdf* m, float z, int32_t* n)
     for (int a = 0; a < 3; ++a) B.T[a] = m->baseTf[(size_t)m->active * 3 + a];
     // _index = (z + map_size_[2] / 2) / voxel_scale: Python floats at trace time (z is a ti.template()), an f32 constant in the kernel (:503)
     const float index_f = (float)(((double)z + (double)m->Nz * m->cfg.voxel_scale / 2.0) / m->cfg.voxel_scale);
-    if (nused > 0) hipLaunchKernelGGL(k_esdf_slice, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, B, m->cfg.is_global_map, m->P.vs,
+    if (nused > 0) hipLaunchKernelGGL(k_esdf_slice, dim3(nused < 8192 ? nused : 8192), dim3(256), 0, ms(m), m->M, s, nused, m->esdf, m->esdf_gamma, m->esdf_maxd, B, m->cfg.is_global_map, m->P.vs,
                                       index_f, m->esdf_exp_xyz, m->esdf_exp_val, (long long)m->max_disp, m->esdf_exp_count);
     TSL_HIP(hipMemcpyAsync(m->h_ints, m->esdf_exp_count, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
     TSL_HIP(hipStreamSynchronize(ms(m)));

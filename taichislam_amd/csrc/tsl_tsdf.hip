@@ -1005,7 +1005,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     esdf_release(m);
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
-                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_note, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_nbr, m->esdf_note, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
                      m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
