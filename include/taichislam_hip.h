@@ -265,6 +265,8 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "bgrid"    resident phase-B workgroups in percent of the slots (wg 256 only; default 100)
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
      "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)
+     "esdf_overlap" 1 (default) = an update's kernels run on one of the handle's phase-A streams: the relaxation rounds of update n overlap
+                    the integration of frame n + 1 (which waits only until the update has read the TSDF); 0 = on the handle's stream
      "esdf_round_cap" n > 0 = launch at most n relaxation rounds per update (test knob: an update that stops early must be repaired)
      "fastdiv"  0 = force IEEE division
      "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */

@@ -517,12 +517,14 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
         if (threadIdx.x < 64) {
             const int q = (int)threadIdx.x;
             bool put = false; int np = -1;
-            if (q < 27 && ((s_notify >> q) & 1)) {
-                np = s_nb[q];
-                if (np >= 0 && E.region[np] != 0) {                                            // present and inside this update's region
+            if (q < 27 && ((s_notify >> q) & 1) && (np = s_nb[q]) >= 0) {
+                // (the region mark and the stamp travel together: a stamp outside the region means nothing and is reset by the next collect)
+                const uint8_t inside = E.region[np];
+                const int seen = __hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (inside != 0) {                                                             // present and inside this update's region
                     // seen from the neighbour this brick is neighbour 26 - q: its halo entries from here are new in the next round
                     __hip_atomic_fetch_or(E.note + (size_t)((round + 1) & 1) * E.cap + np, 1u << (26 - q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    put = __hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != round + 1;   // not listed yet
+                    put = seen != round + 1;                                                   // not listed yet
                 }
             }
             const int at = wave_reserve(&E.ctr[2 + nxt], put);
@@ -645,11 +647,24 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
             TSL_HIP(hipHostMalloc((void**)&m->esdf_slot[i].host, sizeof(int) * 256, hipHostMallocDefault));
         }
         TSL_HIP(hipEventCreateWithFlags(&m->esdf_gate, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&m->esdf_in, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&m->esdf_read, hipEventDisableTiming));
         m->esdf_valid = false;
     }
     esdf_retire(m, false);
     if (m->esdf_npend == TSL_ESDF_SLOTS) { EsdfSlot& S = m->esdf_slot[m->esdf_tail]; (void)hipEventSynchronize(S.ev); esdf_retire(m, false); }
-    hipStream_t q = ms(m);                                   // issues the queued frames first
+    const hipStream_t q0 = ms(m);                            // issues the queued frames first
+    // The update runs beside the handle's stream: it starts when everything queued there so far has finished (esdf_in), and the handle's
+    // stream goes on once the update has READ the TSDF (collect, dilate, init: esdf_read) -- the relaxation rounds only touch the ESDF's
+    // own arrays, so they run beside the integration of the next frames.  The stream is the phase-A stream of the batch slot that comes
+    // into use last (the runtime maps streams onto four hardware queues: a stream of its own shared a queue with one of the phase-A
+    // streams and held every third frame back; a high-priority stream completed its kernels in ~57 us quanta); consecutive updates are
+    // on different streams and follow each other through the previous update's event.
+    const hipStream_t q = (m->esdf_overlap && m->overlap != 0) ? m->batch[(m->cur + 1) % TSL_NBATCH].st : q0;
+    if (q != q0) {
+        TSL_HIP(hipEventRecord(m->esdf_in, q0)); TSL_HIP(hipStreamWaitEvent(q, m->esdf_in, 0));
+        if (m->esdf_last) TSL_HIP(hipStreamWaitEvent(q, m->esdf_last, 0));
+    }
     const int s = m->cfg.is_global_map ? 0 : m->active;
     // a changed voxel influences voxels up to max_dist away: that many voxels = `reach` bricks in every direction
     int reach = (int)std::ceil((double)max_dist / ((double)m->P.vs * 16.0)); if (reach < 1) reach = 1;
@@ -661,7 +676,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     S.st.incremental = full ? 0 : 1;
     TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 256, q));
     TSL_HIP(hipMemcpyAsync(m->esdf_ctr + 10, m->M.pool_top, sizeof(int), hipMemcpyDeviceToDevice, q));      // the update's brick-count snapshot
-    prof_begin(m, TSL_K_ESDF);                                   // one event pair around the update's launches (collect .. last round)
+    prof_begin(m, TSL_K_ESDF, q);                                // one event pair around the update's launches (collect .. last round)
     m->prof_group = true;
     const int nbk = (nb + 255) / 256;
     hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0);
@@ -670,17 +685,18 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     TSL_HIP(hipEventRecord(m->esdf_gate, q)); m->esdf_gate_set = true;
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
     hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, s, gamma, max_dist);
+    if (q != q0) { TSL_HIP(hipEventRecord(m->esdf_read, q)); TSL_HIP(hipStreamWaitEvent(q0, m->esdf_read, 0)); }
     // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
     // few more (8 rounds had work at reach = 4 on the benchmark stream).
-    // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards three more than the most any
+    // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards two more than the most any
     // completed update of this handle needed (a round without work costs ~5 us; stopping early costs a full recompute, see esdf_finish).
-    int rounds = ((full || m->esdf_rounds_seen == 0) ? 2 * reach + 8 : std::min(2 * reach + 8, std::max(reach + 3, m->esdf_rounds_seen + 3))) + extra_rounds;
+    int rounds = ((full || m->esdf_rounds_seen == 0) ? 2 * reach + 8 : std::min(2 * reach + 8, std::max(reach + 2, m->esdf_rounds_seen + 2))) + extra_rounds;
     const int grid = 4 * m->ncu;
     if (m->esdf_round_cap > 0 && extra_rounds == 0 && rounds > m->esdf_round_cap) rounds = m->esdf_round_cap;      // test knob: provoke the repair path
     for (int k = 0; k < rounds; ++k) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);
-    m->prof_group = false; prof_end(m);
+    m->prof_group = false; prof_end(m, q);
     TSL_HIP(hipMemcpyAsync(S.host, m->esdf_ctr, sizeof(int) * 256, hipMemcpyDeviceToHost, q));
-    TSL_HIP(hipEventRecord(S.ev, q));
+    TSL_HIP(hipEventRecord(S.ev, q)); m->esdf_last = S.ev;
     TSL_HIP(hipGetLastError());
     S.rounds = rounds;
     ++m->esdf_npend;
@@ -712,6 +728,9 @@ void esdf_release(tsl_tsdf* m)
         m->esdf_slot[i].ev = nullptr; m->esdf_slot[i].host = nullptr;
     }
     if (m->esdf_gate) { (void)hipEventDestroy(m->esdf_gate); m->esdf_gate = nullptr; }
+    if (m->esdf_in) { (void)hipEventDestroy(m->esdf_in); m->esdf_in = nullptr; }
+    if (m->esdf_read) { (void)hipEventDestroy(m->esdf_read); m->esdf_read = nullptr; }
+    m->esdf_last = nullptr;
 }
 
 }  // namespace tsl

@@ -571,6 +571,10 @@ static int launch_batch_t(tsl_tsdf* m)
     if (!serial && m->esdf_gate_set) { TSL_HIP(hipStreamWaitEvent(sa, m->esdf_gate, 0)); m->esdf_gate_set = false; }      // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip)
     for (int k = 0; k < m->nproducers; ++k) {       // device inputs: phase A waits for what their producers had queued (tsl_tsdf_input_stream)
         if (m->producers[k] == sa) continue;
+        // nothing pending on the producer: no wait.  (Not only a saving: an event recorded on an idle stream still lands in the hardware
+        // queue the runtime maps that stream to -- four queues for all streams -- and completes behind whatever another stream has in
+        // that queue: phase A waited for the ESDF rounds of the previous frame that way, every third frame.)
+        if (hipStreamQuery(m->producers[k]) == hipSuccess) continue;
         if (!m->in_ev[0]) for (auto& e : m->in_ev) TSL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hipEvent_t e = m->in_ev[m->in_ev_next]; m->in_ev_next = (m->in_ev_next + 1) % 8;
         TSL_HIP(hipEventRecord(e, m->producers[k]));
@@ -899,7 +903,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_gate = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_gate = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
@@ -1459,6 +1463,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
+    if (!std::strcmp(name, "esdf_overlap")) { int rc = esdf_finish(m); if (rc) return rc; m->esdf_overlap = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }
     if (!std::strcmp(name, "unit_floor")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit_floor must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_floor = value; return TSL_OK; }
     if (!std::strcmp(name, "unit_half")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit_half must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_half = value; return TSL_OK; }
