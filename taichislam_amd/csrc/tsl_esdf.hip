@@ -33,6 +33,10 @@ namespace tsl {
 #define EF_NODE 1
 #define EF_NEG 2
 #define EF_FIXED 4
+#define ES_CTR 256               // ints of counters, followed by
+#define ES_STAT_SLOTS 64         // slots of 16 ints (one cache line each) of statistics, summed by the host: hundreds of workgroups adding to ONE
+                                 // line serialise in the L2 (~12 ns each) and hold back the list reservations that share it
+#define ES_STAT(E, k) (&(E).ctr[ES_CTR + (blockIdx.x & (ES_STAT_SLOTS - 1)) * 16 + (k)])      // [0] relaxations [1] lowered [2] sets [3] max sets [4] region [5] changed
 #define ES_UNOBS 0x7fffffffu
 #define ES_INF 0x7f800000u
 
@@ -54,7 +58,7 @@ struct EsdfDev {
     int* nbr;                  // [max_bricks][27] pool indices of the bricks around a region brick (-1: absent), written by k_esdf_init
     int cap;                   // max_bricks
     unsigned long long* tm;    // developer timing (TSL_TIMING builds): ticks per phase, summed over relaxations
-    int* ctr;                  // [0] dirty count [1] region count [2..4] work list lengths [5] brick relaxations [6] voxel pushes [7] rounds with work
+    int* ctr;                  // [0] dirty count [2..4] work list lengths [7] rounds with work [10] brick-count snapshot [240..] bricks per round; statistics: ES_STAT
 };
 
 // 1. dirty bricks of submap s (and, when `all`, every brick of it); touch marks are consumed
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(256) k_esdf_dilate(MapDev M, EsdfDev E, int s,
             }
             if (!__syncthreads_or(changed)) continue;                 // (uniform: every thread of the workgroup leaves or stays)
         }
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&E.ctr[11], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ES_STAT(E, 5), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int b = M.owner[pd] - s * M.nb3;
         const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
         for (int t = threadIdx.x; t < vol; t += 256) {
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(256) k_esdf_init(MapDev M, EsdfDev E, int s, f
         const bool listed = __syncthreads_or(seed) != 0;
         if (threadIdx.x == 0) {
             if (listed) { const int q = __hip_atomic_fetch_add(&E.ctr[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); E.work[q] = p; E.stamp[p] = 0; }
-            __hip_atomic_fetch_add(&E.ctr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ES_STAT(E, 4), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -510,7 +514,7 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
         ESDF_TICK(3);
         {
             const long long lw = wave_sum_ll((long long)lowered);
-            if (lane_id() == 0 && lw) __hip_atomic_fetch_add(&E.ctr[6], (int)lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane_id() == 0 && lw) __hip_atomic_fetch_add(ES_STAT(E, 1), (int)lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // the neighbours that see a changed boundary voxel go on the next round's list: one lane per neighbour (the region check, the
         // stamp exchange and the list reservation are dependent device-memory round trips)
@@ -532,9 +536,9 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
         }
         if (threadIdx.x == 0) {
             E.region[p] = 2;
-            __hip_atomic_fetch_add(&E.ctr[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&E.ctr[8], sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_max(&E.ctr[9], sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ES_STAT(E, 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ES_STAT(E, 2), sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(ES_STAT(E, 3), sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         ESDF_TICK(4);
@@ -609,8 +613,10 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         if (wait_all) (void)hipEventSynchronize(S.ev);
         const int* h = S.host;
         tsl_esdf_stats st = S.st;
-        st.dirty_bricks = h[0]; st.changed_bricks = h[11]; st.region_bricks = h[1]; st.brick_relaxations = h[5]; st.voxel_pushes = h[6];
-        st.rounds = h[7]; st.passes = h[8]; st.max_passes = h[9]; st.total_bricks = h[10] < m->M.max_bricks ? h[10] : m->M.max_bricks;
+        long long sum[6] = { 0, 0, 0, 0, 0, 0 };
+        for (int k = 0; k < ES_STAT_SLOTS; ++k) for (int c = 0; c < 6; ++c) { const int v = h[ES_CTR + k * 16 + c]; if (c == 3) sum[3] = v > sum[3] ? v : sum[3]; else sum[c] += v; }
+        st.dirty_bricks = h[0]; st.changed_bricks = (int)sum[5]; st.region_bricks = (int)sum[4]; st.brick_relaxations = sum[0]; st.voxel_pushes = sum[1];
+        st.rounds = h[7]; st.passes = sum[2]; st.max_passes = (int)sum[3]; st.total_bricks = h[10] < m->M.max_bricks ? h[10] : m->M.max_bricks;
         if (h[2 + S.rounds % 3] != 0) m->esdf_short = true;                  // the last launched round still had work
         if (st.incremental && st.rounds > m->esdf_rounds_seen) m->esdf_rounds_seen = st.rounds;
         m->esdf_stats = st;
@@ -641,10 +647,10 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
         if ((rc = dev_alloc(m, (void**)&m->esdf_note, sizeof(uint32_t) * 2 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_nbr, sizeof(int) * 27 * (size_t)nb, 0xff))) return rc;
-        if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 256, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * (ES_CTR + ES_STAT_SLOTS * 16), 0))) return rc;
         for (int i = 0; i < TSL_ESDF_SLOTS; ++i) {
             TSL_HIP(hipEventCreateWithFlags(&m->esdf_slot[i].ev, hipEventDisableTiming));
-            TSL_HIP(hipHostMalloc((void**)&m->esdf_slot[i].host, sizeof(int) * 256, hipHostMallocDefault));
+            TSL_HIP(hipHostMalloc((void**)&m->esdf_slot[i].host, sizeof(int) * (ES_CTR + ES_STAT_SLOTS * 16), hipHostMallocDefault));
         }
         TSL_HIP(hipEventCreateWithFlags(&m->esdf_gate, hipEventDisableTiming));
         TSL_HIP(hipEventCreateWithFlags(&m->esdf_in, hipEventDisableTiming));
@@ -674,7 +680,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     EsdfSlot& S = m->esdf_slot[(m->esdf_tail + m->esdf_npend) % TSL_ESDF_SLOTS];
     std::memset(&S.st, 0, sizeof(S.st));
     S.st.incremental = full ? 0 : 1;
-    TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * 256, q));
+    TSL_HIP(hipMemsetAsync(m->esdf_ctr, 0, sizeof(int) * (ES_CTR + ES_STAT_SLOTS * 16), q));
     TSL_HIP(hipMemcpyAsync(m->esdf_ctr + 10, m->M.pool_top, sizeof(int), hipMemcpyDeviceToDevice, q));      // the update's brick-count snapshot
     prof_begin(m, TSL_K_ESDF, q);                                // one event pair around the update's launches (collect .. last round)
     m->prof_group = true;
@@ -695,7 +701,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     if (m->esdf_round_cap > 0 && extra_rounds == 0 && rounds > m->esdf_round_cap) rounds = m->esdf_round_cap;      // test knob: provoke the repair path
     for (int k = 0; k < rounds; ++k) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);
     m->prof_group = false; prof_end(m, q);
-    TSL_HIP(hipMemcpyAsync(S.host, m->esdf_ctr, sizeof(int) * 256, hipMemcpyDeviceToHost, q));
+    TSL_HIP(hipMemcpyAsync(S.host, m->esdf_ctr, sizeof(int) * (ES_CTR + ES_STAT_SLOTS * 16), hipMemcpyDeviceToHost, q));
     TSL_HIP(hipEventRecord(S.ev, q)); m->esdf_last = S.ev;
     TSL_HIP(hipGetLastError());
     S.rounds = rounds;
