@@ -24,6 +24,7 @@
 //      (A single persistent kernel with an asynchronous brick queue was tried first: exact, but with no ordering between bricks each was
 //      relaxed ~23 times -- 5.2 ms per update at 512^3.  Rounds keep the wavefront order: ~2-3 relaxations per brick.)
 // The first update, an update after reset() / import / fusion, or one with different parameters is the same procedure with R = all bricks.
+#include <hip/hip_ext.h>
 #include "tsl_tsdf.hpp"
 
 namespace tsl {
@@ -652,9 +653,8 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
             TSL_HIP(hipEventCreateWithFlags(&m->esdf_slot[i].ev, hipEventDisableTiming));
             TSL_HIP(hipHostMalloc((void**)&m->esdf_slot[i].host, sizeof(int) * (ES_CTR + ES_STAT_SLOTS * 16), hipHostMallocDefault));
         }
-        TSL_HIP(hipEventCreateWithFlags(&m->esdf_gate, hipEventDisableTiming));
+        TSL_HIP(hipEventCreate(&m->esdf_gate)); TSL_HIP(hipEventCreate(&m->esdf_read));       // (attached to a dispatch below: plain events)
         TSL_HIP(hipEventCreateWithFlags(&m->esdf_in, hipEventDisableTiming));
-        TSL_HIP(hipEventCreateWithFlags(&m->esdf_read, hipEventDisableTiming));
         m->esdf_valid = false;
     }
     esdf_retire(m, false);
@@ -685,13 +685,16 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     prof_begin(m, TSL_K_ESDF, q);                                // one event pair around the update's launches (collect .. last round)
     m->prof_group = true;
     const int nbk = (nb + 255) / 256;
-    hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0);
     // phase A of frames queued from now on allocates bricks (pool counter, table entry, owner -- in that order): it starts after the
-    // snapshot + collect, so that every pool index below the snapshot has its owner written (launch_batch_t waits for the gate)
-    TSL_HIP(hipEventRecord(m->esdf_gate, q)); m->esdf_gate_set = true;
+    // snapshot + collect, so that every pool index below the snapshot has its owner written (launch_batch_t waits for the gate).  The gate
+    // is the collect kernel's own completion (an event recorded behind it costs a marker packet and ~6 us before the next kernel starts)
+    hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0);
+    m->esdf_gate_set = true;
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
-    hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, s, gamma, max_dist);
-    if (q != q0) { TSL_HIP(hipEventRecord(m->esdf_read, q)); TSL_HIP(hipStreamWaitEvent(q0, m->esdf_read, 0)); }
+    if (q != q0) {
+        hipExtLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, nullptr, m->esdf_read, 0, m->M, E, s, gamma, max_dist);
+        TSL_HIP(hipStreamWaitEvent(q0, m->esdf_read, 0));
+    } else hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, s, gamma, max_dist);
     // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
     // few more (8 rounds had work at reach = 4 on the benchmark stream).
     // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards two more than the most any
