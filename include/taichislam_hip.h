@@ -217,17 +217,17 @@ typedef struct {
     int32_t region_bricks;       /* bricks re-initialised and relaxed (dirty bricks dilated by max_dist) */
     int32_t total_bricks;        /* bricks of the handle */
     int64_t brick_relaxations;   /* LDS relaxations run (a brick is revisited when its surroundings change) */
-    int64_t voxel_pushes;        /* active voxels expanded */
-    int32_t rounds, max_passes;  /* relaxation rounds that had work; most LDS passes one brick relaxation needed */
+    int64_t voxel_pushes;        /* voxel values lowered by the sweeps (a voxel may be lowered more than once) */
+    int32_t rounds, max_passes;  /* relaxation rounds that had work; most sweep sets (six concurrent directional sweeps) one brick relaxation needed */
     int32_t reserved_;
-    int64_t passes;              /* LDS passes over all brick relaxations */
+    int64_t passes;              /* sweep sets over all brick relaxations */
 } tsl_esdf_stats;
 /* sums over the updates of the handle that have completed */
 typedef struct {
     int64_t updates, incremental, dirty_bricks, region_bricks, brick_relaxations, voxel_pushes, passes;
 } tsl_esdf_totals_t;
 /* n_relaxed != NULL: waits for the update and returns its brick relaxations.  n_relaxed == NULL: ASYNCHRONOUS -- the update is only
- * enqueued on the handle's stream (up to 4 may be in flight; the per-frame hook of dense_esdf.py:400-402 uses this form), nothing is
+ * enqueued (behind everything queued on the handle so far; up to 4 may be in flight; the per-frame hook of dense_esdf.py:400-402 uses this form), nothing is
  * waited for.  last_stats / totals / export wait for the outstanding updates first, so what they return is always complete. */
 int  tsl_esdf_update(tsl_tsdf* m, float gamma, float max_dist, int32_t* n_relaxed);
 int  tsl_esdf_last_stats(tsl_tsdf* m, tsl_esdf_stats* out);

@@ -10,8 +10,19 @@ for f in ("bench_default.json", "bench_driver_cmd.json", "bench_dry_rank3of8.jso
           "parity_vs_faithful.json", "box.txt"):
     if os.path.exists(os.path.join(S, f)):
         shutil.copy(os.path.join(S, f), os.path.join(D, "r03_" + f))
+# the config-4 sections were collected again after the ESDF rewrite (tools/gpu_profiles_r03_c4.sh): they replace the first set's
+S4 = os.path.join(ROOT, "gpurun_out", "r03prof_c4")
+if os.path.exists(os.path.join(S4, "pmc_summary.txt")):
+    for f in ("bench_c4.json", "bench_c4_no_overlap.json", "c4_kernel_stats.csv"):
+        if os.path.exists(os.path.join(S4, f)):
+            shutil.copy(os.path.join(S4, f), os.path.join(D, "r03_" + f))
+    keep, skip = [], False
+    for line in open(os.path.join(S, "pmc_summary.txt")):
+        if line.startswith("== "): skip = line[3:].split(":")[0].endswith("_c4")
+        if not skip: keep.append(line)
+    open(os.path.join(D, "r03_pmc_summary.txt"), "w").write("".join(keep) + open(os.path.join(S4, "pmc_summary.txt")).read())
 sec, cur = {}, None
-for line in open(os.path.join(S, "pmc_summary.txt")):
+for line in open(os.path.join(D, "r03_pmc_summary.txt")):
     if line.startswith("== "):
         cur = line[3:].split(":")[0]; sec[cur] = {"command": line.split(": ", 1)[1].strip(), "k": {}}
     elif cur and line.strip():
@@ -68,6 +79,11 @@ for c, short in ((1, "k_marching_cubes_lds"), (3, "k_octo_depth"), (4, "k_esdf_r
             upd = sec["fetch_c4"]["k"][[x for x in sec["fetch_c4"]["k"] if "k_esdf_collect" in x][0]]["FETCH_SIZE"][1]
             e["launches_per_update"] = e["launches"] / upd
             e["hbm_bytes_per_launch"] = int(e["hbm_bytes_per_launch"] * e["launches_per_update"]); e["note"] = "per ESDF update (all k_esdf_round launches of one update)"
+            if "sq_c4" in sec and "lds_c4" in sec:
+                q4, l4 = sec["sq_c4"]["k"][k[0]], sec["lds_c4"]["k"][k[0]]
+                e["sq"] = {"SQ_WAIT_ANY/SQ_WAVE_CYCLES": q4["SQ_WAIT_ANY"][0] / q4["SQ_WAVE_CYCLES"][0], "SQ_ACTIVE_INST_VALU/SQ_WAVE_CYCLES": q4["SQ_ACTIVE_INST_VALU"][0] / q4["SQ_WAVE_CYCLES"][0],
+                           "SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE": l4["SQ_LDS_BANK_CONFLICT"][0] / l4["SQ_LDS_IDX_ACTIVE"][0],
+                           "SQ_LDS_IDX_ACTIVE/SQ_BUSY_CYCLES": l4["SQ_LDS_IDX_ACTIVE"][0] / q4["SQ_BUSY_CYCLES"][0]}
         out[f"config{c}"] = e
 if "fetch_merge" in sec:
     for short in ("k_fuse_splat", "k_merge_pack", "k_merge_finish"):
