@@ -903,7 +903,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_gate = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; m->esdf_gate = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));

@@ -220,7 +220,7 @@ struct tsl_tsdf {
     hipEvent_t esdf_gate; bool esdf_gate_set;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
     hipEvent_t esdf_in, esdf_read, esdf_last;      // option "esdf_overlap": the relaxation rounds of update n run beside the integration of frame n + 1.
                                                    // esdf_in: the TSDF an update starts from; esdf_read: the update has read it; esdf_last: the latest update
-    bool esdf_overlap;
+    bool esdf_overlap; int esdf_ctr_idx;
     EsdfSlot esdf_slot[TSL_ESDF_SLOTS]; int esdf_tail, esdf_npend, esdf_rounds_seen, esdf_round_cap; bool esdf_short; tsl_esdf_totals_t esdf_tot;   // updates in flight (tsl_esdf.hip)
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;

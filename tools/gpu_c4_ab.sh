@@ -1,7 +1,7 @@
 #!/bin/bash
 # config 4 A/B of backend options (TSL_C4_OPTS), plus a kernel trace of the host probe for the first option set
 O=$GRAFT_REPO_ROOT/gpurun_out/c4; mkdir -p $O; cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-for o in "$@"; do
+for o in; do
   TSL_C4_OPTS="$o" timeout 300 python bench.py --config 4 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $O/b.json
   python -c "
 import json; j=json.load(open('$O/b.json')); print('bench config4 [$o]', round(j['value'],1), 'fps', 'esdf ms', round(j['config']['esdf_ms_per_update'],3))"
@@ -15,15 +15,15 @@ rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last three ESDF updates: from the third-last k_esdf_collect on
 idx = [i for i, r in enumerate(rows) if "k_esdf_collect" in r["Kernel_Name"]]
-i0 = idx[-8]; t0 = int(rows[i0]["Start_Timestamp"])
-rnd = 0
-for r in rows[i0:idx[-2]]:
+i0 = idx[-6]; t0 = int(rows[i0]["Start_Timestamp"])
+first = None
+for r in rows[i0:idx[-3]]:
     n = r["Kernel_Name"].split("(")[0].replace("tsl::", "").replace("void ", "")
+    st, en = (int(r['Start_Timestamp'])-t0)/1e3, (int(r['End_Timestamp'])-t0)/1e3
     if "k_esdf_round" in n:
-        rnd += 1
-        if rnd not in (1,) : continue
-    else: rnd = 0
-    if "rocclr" in n or "k_esdf_dilate" in n or "k_plan" in n or "k_scatter" in n or "k_voxelize" in n: continue
-    print(f"{n[:44]:44s} q{r.get('Queue_Id','?'):3s} start {(int(r['Start_Timestamp'])-t0)/1e3:9.1f} us  dur {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:8.1f} us")
+        if first is None: first = st
+        last = en; continue
+    if first is not None: print(f"{'  k_esdf_round x N':44s}      start {first:9.1f} us  end {last:9.1f} us"); first = None
+    print(f"{n[:44]:44s} q{r.get('Queue_Id','?'):3s} start {st:9.1f} us  end {en:9.1f} us")
 PY
 rm -rf $O/kt
