@@ -140,19 +140,42 @@ __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int
 // vertex (corner .. corner + 1, each +- 1): everything a brick's cells read lies in [-1, 17]^3 around the brick.  That 19^3 tile
 // (f16 TSDF bits + observed bits, 14.3 KiB) is gathered ONCE per brick through the 27 surrounding brick-table entries; the corner
 // reads (8 per voxel) and the normal reads (6 per vertex, up to 90 per voxel) then come from LDS instead of one table lookup +
-// one scattered 4-byte load each.  Emission is unchanged: wave-level inclusive scan of the triangle counts, one atomic per wave.
+// one scattered 4-byte load each.  Emission: the brick's triangles are counted first (pass 1), reserved with ONE atomic, then written (pass 2).
 #define MC_T 19
 #define MC_T3 (MC_T * MC_T * MC_T)
 __device__ __forceinline__ int mc_tile(int x, int y, int z) { return (x * MC_T + y) * MC_T + z; }      // tile coords = brick coords + 1
+
+#define MC_LIST 4096             // triangles listed in LDS at a time
+// the cell at brick-local index l: its case (through *cube when asked for) and how many triangles the case has; 0 when the cell's own
+// voxel is unobserved or not below the threshold (:184), or a corner is unobserved (:133-138)
+__device__ __forceinline__ int mc_cell(const uint16_t* s_t, const uint32_t* s_o, const unsigned long long* s_tri, int l, float thres, int* cube)
+{
+    const int lx = l >> 8, ly = (l >> 4) & 15, lz = l & 15;
+    const int t0 = mc_tile(lx + 1, ly + 1, lz + 1);
+    if (!(((s_o[t0 >> 5] >> (t0 & 31)) & 1u) && h2f(s_t[t0]) < thres)) return 0;
+    int c = 0;
+    for (int q = 0; q < 8; ++q) {
+        int d[3]; corner_off(q, d);
+        const int t = mc_tile(lx + 1 + d[0], ly + 1 + d[1], lz + 1 + d[2]);
+        if (!((s_o[t >> 5] >> (t & 31)) & 1u)) return 0;
+        if (h2f(s_t[t]) < 0.0f) c |= 1 << q;                                                      // :141-144
+    }
+    const unsigned long long tri = s_tri[c];
+    int n = 0;
+    for (int t = 0; t < 5; ++t) if (((tri >> (12 * t)) & 0xfull) != 0xfull) ++n;                  // :173-177 (triTable[cube][3t] != -1)
+    if (cube) *cube = c;
+    return n;
+}
 
 __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused, float thres, float vs, long long max_tri,
                                                             float* __restrict__ verts, float* __restrict__ normals, float* __restrict__ colors, int* counter)
 {
     __shared__ unsigned long long s_tri[256];
-    __shared__ float s_val[8][256];
+    __shared__ uint32_t s_list[MC_LIST];
     __shared__ uint16_t s_t[MC_T3];                    // TSDF f16 bits (0 where nothing is stored: reading an inactive cell yields 0, A7)
     __shared__ uint32_t s_o[(MC_T3 + 31) / 32];        // TSDF_observed > 0
     __shared__ int s_nb[27];
+    __shared__ int s_wtot[5], s_base;
     s_tri[threadIdx.x] = MC_TRI_PACKED[threadIdx.x];
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         const int owner = M.owner[p];
@@ -165,87 +188,105 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
         }
         for (int i = threadIdx.x; i < (MC_T3 + 31) / 32; i += 256) s_o[i] = 0u;
         __syncthreads();
-        for (int t = threadIdx.x; t < MC_T3; t += 256) {
-            const int tz = t % MC_T, ty = (t / MC_T) % MC_T, tx = t / (MC_T * MC_T);
-            const int np = s_nb[(((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4)];
-            uint16_t tv = 0;
-            if (np >= 0 && in_volume(M, bi * 16 + tx - 1 - M.hN, bj * 16 + ty - 1 - M.hN, bk * 16 + tz - 1 - M.hNz)) {
-                const size_t v = (size_t)np * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
-                tv = (uint16_t)(M.tw[v] & 0xffffu);
-                if (M.obs[v] > 0) atomicOr(&s_o[t >> 5], 1u << (t & 31));
+        // the 6 859 tile entries, 27 per thread, gathered nine at a time as ONE batch of independent loads (loaded from a valid address
+        // unconditionally so that nothing separates the requests: a loop of dependent gathers costs a memory latency per entry)
+        for (int c = 0; c < 27; c += 9) {
+            uint32_t tw[9]; int8_t ob[9]; bool ok[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const int t = (int)threadIdx.x + (c + u) * 256;
+                const int tc = t < MC_T3 ? t : 0;
+                const int tz = tc % MC_T, ty = (tc / MC_T) % MC_T, tx = tc / (MC_T * MC_T);
+                const int np = s_nb[(((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4)];
+                ok[u] = t < MC_T3 && np >= 0 && in_volume(M, bi * 16 + tx - 1 - M.hN, bj * 16 + ty - 1 - M.hN, bk * 16 + tz - 1 - M.hNz);
+                const size_t v = (size_t)(ok[u] ? np : p) * TSL_BRK3 + ((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+                tw[u] = M.tw[v]; ob[u] = M.obs[v];
             }
-            s_t[t] = tv;
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const int t = (int)threadIdx.x + (c + u) * 256;
+                if (t >= MC_T3) continue;
+                s_t[t] = ok[u] ? (uint16_t)(tw[u] & 0xffffu) : (uint16_t)0;
+                if (ok[u] && ob[u] > 0) atomicOr(&s_o[t >> 5], 1u << (t & 31));
+            }
         }
         __syncthreads();
-        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
-            const int l = l0 + threadIdx.x;
-            const int lx = l >> 8, ly = (l >> 4) & 15, lz = l & 15;
-            const int i = bi * 16 + lx - M.hN, j = bj * 16 + ly - M.hN, k = bk * 16 + lz - M.hNz;
-            const int t0 = mc_tile(lx + 1, ly + 1, lz + 1);
-            int ntri = 0, cube = 0;
-            unsigned long long tri = ~0ull;
-            if (((s_o[t0 >> 5] >> (t0 & 31)) & 1u) && h2f(s_t[t0]) < thres) {                    // :184
-                bool bad = false;
-                for (int q = 0; q < 8; ++q) {                                                     // :133-138
-                    int d[3]; corner_off(q, d);
-                    const int t = mc_tile(lx + 1 + d[0], ly + 1 + d[1], lz + 1 + d[2]);
-                    const float val = h2f(s_t[t]);
-                    s_val[q][threadIdx.x] = val;
-                    if (!((s_o[t >> 5] >> (t & 31)) & 1u)) bad = true;
-                    if (val < 0.0f) cube |= 1 << q;                                               // :141-144
-                }
-                if (!bad) {
-                    tri = s_tri[cube];
-                    for (int t = 0; t < 5; ++t) if (((tri >> (12 * t)) & 0xfull) != 0xfull) ++ntri;   // :173-177
-                }
+        // ---- pass 1: the brick's triangle count.  ONE reservation per brick (a reservation per wave and 256 cells -- the first form of
+        //      this kernel -- put ~2 000 returning atomics on one address per mesh, ~12 ns each in the L2) ----
+        int mine = 0;
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) mine += mc_cell(s_t, s_o, s_tri, l0 + threadIdx.x, thres, nullptr);
+        int incl = mine;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane_id() >= d) incl += o; }
+        if (lane_id() == 63) s_wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+            s_wtot[4] = tot;
+            s_base = tot ? __hip_atomic_fetch_add(counter, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+        __syncthreads();
+        const int total = s_wtot[4];
+        if (total == 0) continue;                                         // (uniform) nothing to emit from this brick
+        int first = incl - mine;                                          // this thread's first triangle among the brick's
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) first += s_wtot[w];
+        // ---- pass 2: the triangles as a LIST in LDS (cell | triangle of the case << 12 | case << 16, in the order of the reservation), then
+        //      one VERTEX per thread and step.  Walking the cells again and letting each thread emit its own cells' triangles (the first
+        //      form) keeps 5 - 10 % of the lanes busy -- the surface crosses few of a wave's 64 cells -- through 15 serial vertex slots of
+        //      ~600 instructions (the f16 normal arithmetic is emulated bit for bit): 148 us per mesh of a 128^3 sphere, this way 1/4. ----
+        for (int w0 = 0; w0 < total; w0 += MC_LIST) {                     // (one window unless the brick is noise: MC_LIST triangles at a time)
+            if (w0) __syncthreads();
+            int at = first;
+            for (int l0 = 0; l0 < TSL_BRK3 && mine; l0 += 256) {
+                const int l = l0 + threadIdx.x;
+                int cube = 0;
+                const int n = mc_cell(s_t, s_o, s_tri, l, thres, &cube);
+                for (int t = 0; t < n; ++t, ++at)
+                    if (at >= w0 && at < w0 + MC_LIST) s_list[at - w0] = (uint32_t)l | (uint32_t)t << 12 | (uint32_t)cube << 16;
             }
-            int inc = ntri;
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane_id() >= d) inc += o; }
-            const int wave_total = __shfl(inc, 63);
-            int base = 0;
-            if (wave_total) {
-                if (lane_id() == 63) base = __hip_atomic_fetch_add(counter, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                base = __shfl(base, 63);
-            }
-            long long idx = (long long)base + inc - ntri;
-            for (int t = 0; t < 5 && ntri; ++t) {
-                if (((tri >> (12 * t)) & 0xfull) == 0xfull) continue;
-                if (idx < max_tri) {                                                              // Q10: clamp by the returned index
-                    for (int q = 0; q < 3; ++q) {
-                        const int e = (int)((tri >> (4 * (3 * t + q))) & 0xfull);
-                        int ca, cb; edge_corners(e, &ca, &cb);
-                        int da[3], db[3]; corner_off(ca, da); corner_off(cb, db);
-                        const float v0 = s_val[ca][threadIdx.x], v1 = s_val[cb][threadIdx.x];
-                        const float p0[3] = { (float)(i + da[0]), (float)(j + da[1]), (float)(k + da[2]) };
-                        const float p1[3] = { (float)(i + db[0]), (float)(j + db[1]), (float)(k + db[2]) };
-                        float pv[3], mu = 0.0f;
-                        if (fabsf(0.0f - v0) < MC_EPS) { pv[0] = p0[0]; pv[1] = p0[1]; pv[2] = p0[2]; }            // vertexInterp :44-60
-                        else if (fabsf(0.0f - v1) < MC_EPS) { pv[0] = p1[0]; pv[1] = p1[1]; pv[2] = p1[2]; }
-                        else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
-                        if (colors) {                                                            // vertexInterp_color :62-82 (Q13); colours stay in HBM
-                            const uint2 ca2 = rd_col(M, s, i + da[0], j + da[1], k + da[2]);
-                            const uint2 cb2 = rd_col(M, s, i + db[0], j + db[1], k + db[2]);
-                            const h16 c0[3] = { (h16)(ca2.x & 0xffffu), (h16)(ca2.x >> 16), (h16)(ca2.y & 0xffffu) };
-                            const h16 c1[3] = { (h16)(cb2.x & 0xffffu), (h16)(cb2.x >> 16), (h16)(cb2.y & 0xffffu) };
-                            float vc[3] = { h2f(c0[0]), h2f(c0[1]), h2f(c0[2]) };
-                            if (h2f(c0[0]) == 0.0f) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c1[a]); }
-                            else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])); }
-                            const size_t oc = ((size_t)idx * 3 + q) * 3;
-                            for (int a = 0; a < 3; ++a) colors[oc + a] = vc[a];
-                        }
-                        // generate_normal :84-93 around the voxel nearest to the vertex: it is one of the edge's two corners
-                        const int q0 = (int)rnd_f(pv[0]) - i + lx + 1, q1 = (int)rnd_f(pv[1]) - j + ly + 1, q2 = (int)rnd_f(pv[2]) - k + lz + 1;
-                        const h16 n0 = hsub(s_t[mc_tile(q0 + 1, q1, q2)], s_t[mc_tile(q0 - 1, q1, q2)]);
-                        const h16 n1 = hsub(s_t[mc_tile(q0, q1 + 1, q2)], s_t[mc_tile(q0, q1 - 1, q2)]);
-                        const h16 n2 = hsub(s_t[mc_tile(q0, q1, q2 + 1)], s_t[mc_tile(q0, q1, q2 - 1)]);
-                        const h16 nrm = hsqrt(hadd(hadd(hmul(n0, n0), hmul(n1, n1)), hmul(n2, n2)));
-                        const h16 inv = f2h(1.0f / h2f(nrm));
-                        const size_t o = ((size_t)idx * 3 + q) * 3;
-                        verts[o] = pv[0] * vs; verts[o + 1] = pv[1] * vs; verts[o + 2] = pv[2] * vs;                  // :41-42,:97-99
-                        normals[o] = h2f(hmul(inv, n0)); normals[o + 1] = h2f(hmul(inv, n1)); normals[o + 2] = h2f(hmul(inv, n2));   // :100-102
-                    }
+            __syncthreads();
+            const int nv = 3 * min(total - w0, MC_LIST);
+            for (int v = threadIdx.x; v < nv; v += 256) {
+                const uint32_t en = s_list[v / 3];
+                const int q = v % 3, l = (int)(en & 0xfffu), t = (int)((en >> 12) & 7u);
+                const long long idx = (long long)s_base + w0 + v / 3;
+                if (idx >= max_tri) continue;                                                     // Q10: clamp by the returned index
+                const unsigned long long tri = s_tri[en >> 16];
+                // the triangles of a case are its non-empty slots in order: slot of the t-th one
+                int slot = 0;
+                for (int u = 0, seen = 0; u < 5; ++u) if (((tri >> (12 * u)) & 0xfull) != 0xfull) { if (seen == t) slot = u; ++seen; }
+                const int lx = l >> 8, ly = (l >> 4) & 15, lz = l & 15;
+                const int i = bi * 16 + lx - M.hN, j = bj * 16 + ly - M.hN, k = bk * 16 + lz - M.hNz;
+                const int e = (int)((tri >> (4 * (3 * slot + q))) & 0xfull);
+                int ca, cb; edge_corners(e, &ca, &cb);
+                int da[3], db[3]; corner_off(ca, da); corner_off(cb, db);
+                const float v0 = h2f(s_t[mc_tile(lx + 1 + da[0], ly + 1 + da[1], lz + 1 + da[2])]), v1 = h2f(s_t[mc_tile(lx + 1 + db[0], ly + 1 + db[1], lz + 1 + db[2])]);
+                const float p0[3] = { (float)(i + da[0]), (float)(j + da[1]), (float)(k + da[2]) };
+                const float p1[3] = { (float)(i + db[0]), (float)(j + db[1]), (float)(k + db[2]) };
+                float pv[3], mu = 0.0f;
+                if (fabsf(0.0f - v0) < MC_EPS) { pv[0] = p0[0]; pv[1] = p0[1]; pv[2] = p0[2]; }            // vertexInterp :44-60
+                else if (fabsf(0.0f - v1) < MC_EPS) { pv[0] = p1[0]; pv[1] = p1[1]; pv[2] = p1[2]; }
+                else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
+                if (colors) {                                                            // vertexInterp_color :62-82 (Q13); colours stay in HBM
+                    const uint2 ca2 = rd_col(M, s, i + da[0], j + da[1], k + da[2]);
+                    const uint2 cb2 = rd_col(M, s, i + db[0], j + db[1], k + db[2]);
+                    const h16 c0[3] = { (h16)(ca2.x & 0xffffu), (h16)(ca2.x >> 16), (h16)(ca2.y & 0xffffu) };
+                    const h16 c1[3] = { (h16)(cb2.x & 0xffffu), (h16)(cb2.x >> 16), (h16)(cb2.y & 0xffffu) };
+                    float vc[3] = { h2f(c0[0]), h2f(c0[1]), h2f(c0[2]) };
+                    if (h2f(c0[0]) == 0.0f) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c1[a]); }
+                    else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])); }
+                    const size_t oc = ((size_t)idx * 3 + q) * 3;
+                    for (int a = 0; a < 3; ++a) colors[oc + a] = vc[a];
                 }
-                ++idx;
+                // generate_normal :84-93 around the voxel nearest to the vertex: it is one of the edge's two corners
+                const int q0 = (int)rnd_f(pv[0]) - i + lx + 1, q1 = (int)rnd_f(pv[1]) - j + ly + 1, q2 = (int)rnd_f(pv[2]) - k + lz + 1;
+                const h16 n0 = hsub(s_t[mc_tile(q0 + 1, q1, q2)], s_t[mc_tile(q0 - 1, q1, q2)]);
+                const h16 n1 = hsub(s_t[mc_tile(q0, q1 + 1, q2)], s_t[mc_tile(q0, q1 - 1, q2)]);
+                const h16 n2 = hsub(s_t[mc_tile(q0, q1, q2 + 1)], s_t[mc_tile(q0, q1, q2 - 1)]);
+                const h16 nrm = hsqrt(hadd(hadd(hmul(n0, n0), hmul(n1, n1)), hmul(n2, n2)));
+                const h16 inv = f2h(1.0f / h2f(nrm));
+                const size_t o = ((size_t)idx * 3 + q) * 3;
+                verts[o] = pv[0] * vs; verts[o + 1] = pv[1] * vs; verts[o + 2] = pv[2] * vs;                  // :41-42,:97-99
+                normals[o] = h2f(hmul(inv, n0)); normals[o + 1] = h2f(hmul(inv, n1)); normals[o + 2] = h2f(hmul(inv, n2));   // :100-102
             }
         }
     }
