@@ -1,5 +1,5 @@
 #!/bin/bash
-# the config-4 part of the round-3 profile set again (after the ESDF rewrite): bench line, kernel stats, FETCH / WRITE / SQ / LDS counter passes.
+# the config-4 and config-1 parts of the round-3 profile set again (after the ESDF and marching-cubes rewrites): bench line, kernel stats, FETCH / WRITE / SQ / LDS counter passes.
 # Output in gpurun_out/r03prof_c4; tools/make_r03_profiles.py merges the sections into the set of tools/gpu_profiles_r03.sh.
 O=$GRAFT_REPO_ROOT/gpurun_out/r03prof_c4; mkdir -p $O; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -32,7 +32,11 @@ pmc fetch_c4 "FETCH_SIZE" $C4
 pmc write_c4 "WRITE_SIZE" $C4
 pmc sq_c4 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" $C4
 pmc lds_c4 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" $C4
+stats c1 python $R/bench.py --config 1 --steps 60 --warmup 10 --no-cpu-baseline
+pmc fetch_c1 "FETCH_SIZE" python $R/bench.py --config 1 --steps 20 --warmup 5 --no-cpu-baseline
+pmc write_c1 "WRITE_SIZE" python $R/bench.py --config 1 --steps 20 --warmup 5 --no-cpu-baseline
 cd $R
+timeout 300 python bench.py --config 1 --steps 100 --warmup 10 2>/dev/null | tail -1 > $O/bench_c1.json
 timeout 300 python bench.py --config 4 --steps 100 --warmup 10 2>/dev/null | tail -1 > $O/bench_c4.json
 TSL_C4_OPTS="esdf_overlap=0" timeout 300 python bench.py --config 4 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4_no_overlap.json
 ls $O; grep "k_esdf_round" $O/pmc_summary.txt | cut -c1-300

@@ -13,12 +13,12 @@ for f in ("bench_default.json", "bench_driver_cmd.json", "bench_dry_rank3of8.jso
 # the config-4 sections were collected again after the ESDF rewrite (tools/gpu_profiles_r03_c4.sh): they replace the first set's
 S4 = os.path.join(ROOT, "gpurun_out", "r03prof_c4")
 if os.path.exists(os.path.join(S4, "pmc_summary.txt")):
-    for f in ("bench_c4.json", "bench_c4_no_overlap.json", "c4_kernel_stats.csv"):
+    for f in ("bench_c4.json", "bench_c4_no_overlap.json", "c4_kernel_stats.csv", "bench_c1.json", "c1_kernel_stats.csv"):
         if os.path.exists(os.path.join(S4, f)):
             shutil.copy(os.path.join(S4, f), os.path.join(D, "r03_" + f))
     keep, skip = [], False
     for line in open(os.path.join(S, "pmc_summary.txt")):
-        if line.startswith("== "): skip = line[3:].split(":")[0].endswith("_c4")
+        if line.startswith("== "): skip = line[3:].split(":")[0].endswith(("_c4", "_c1"))
         if not skip: keep.append(line)
     open(os.path.join(D, "r03_pmc_summary.txt"), "w").write("".join(keep) + open(os.path.join(S4, "pmc_summary.txt")).read())
 sec, cur = {}, None
