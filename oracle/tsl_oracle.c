@@ -678,6 +678,21 @@ static void for_each_voxel(const ora_tsdf* m, int s, voxel_fn fn, void* ctx)
     }
 }
 
+/* the same cells in Taichi's struct-for order over pointer(blocks).dense(16^3): blocks by (bi, bj, bk), the cells of a block row-major
+ * (k fastest) -- the order in which tools/ti_seq executes `for s, i, j, k in TSDF` of the reference's source (A6), used where the result
+ * depends on the order (the FAITHFUL fusion: every splat is an f16 read-modify-write of the global voxel) */
+static void for_each_voxel_struct_for(const ora_tsdf* m, int s, voxel_fn fn, void* ctx)
+{
+    const submap_t* sm = &m->sub[s];
+    if (!sm->tab) return;
+    for (int bi = 0; bi < m->nbx; ++bi) for (int bj = 0; bj < m->nbx; ++bj) for (int bk = 0; bk < m->nbz; ++bk) {
+        const brick_t* b = sm->tab[((size_t)bi * m->nbx + bj) * m->nbz + bk];
+        if (!b) continue;
+        for (int l = 0; l < BRK3; ++l)
+            fn(ctx, m, s, bi * 16 + (l >> 8) - m->N / 2, bj * 16 + ((l >> 4) & 15) - m->N / 2, bk * 16 + (l & 15) - m->Nz / 2, b, l);
+    }
+}
+
 /* count_active  dense_tsdf.py:412-423 */
 static void cnt_fn(void* ctx, const ora_tsdf* m, int s, int i, int j, int k, const brick_t* b, int l)
 { (void)m; (void)s; (void)i; (void)j; (void)k; if (b->obs[l] > 0) ++*(int64_t*)ctx; }
@@ -857,7 +872,9 @@ int ora_tsdf_fuse_submaps(ora_tsdf* g, const ora_tsdf* sub, int mode)
     }
     fuse_ctx c = { g, sub, mode };
     g->ntouched = 0;
-    for (int s = 0; s < sub->nsub; ++s) for_each_voxel(sub, s, fuse_fn, &c);           /* :291 every cell of every submap */
+    for (int s = 0; s < sub->nsub; ++s) {                                              /* :291 every cell of every submap */
+        if (mode == ORA_FAITHFUL) for_each_voxel_struct_for(sub, s, fuse_fn, &c); else for_each_voxel(sub, s, fuse_fn, &c);
+    }
     if (mode == ORA_BATCHED) {
         for (int t = 0; t < g->ntouched; ++t) {
             brick_t* b = g->touched[t];

@@ -1,0 +1,156 @@
+"""Dev-box tool: golden vectors from the REFERENCE'S OWN SOURCE.
+
+/root/reference/taichi_slam/mapping/{mapping_common,dense_tsdf}.py are loaded by path, unmodified, with `import taichi` resolved to the
+sequential stand-in of tools/ti_seq (Taichi is not installable here; the stand-in's header says exactly what it does and does not model),
+driven through the reference's public API -- set_base_pose_submap, recast_depth_to_map / recast_pcl_to_map, switch_to_next_submap,
+fuse_submaps, export_submap -- on small seeded inputs, and what export_submap returns is committed, with the inputs, as
+tests/golden/ref_*.npz.  tests/test_ref_golden.py then checks, where the reference tree does not exist:
+  * oracle FAITHFUL (the reference-literal sequential replay) == these maps, bit for bit           (CPU, -m "not gpu")
+  * HIP semantics = 1 == these maps, bit for bit; the default HIP path: same voxel set, bounded deviation   (GPU)
+
+    python tools/gen_ref_golden.py            # ~3 minutes; needs /root/reference"""
+import importlib.util
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/taichi_slam/mapping"
+sys.path.insert(0, os.path.join(ROOT, "tools", "ti_seq")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def load_reference():
+    """the reference's mapping_common + dense_tsdf by path (its package __init__ pulls in modules that are not part of the path)"""
+    import taichi as ti
+    assert "ti_seq" in ti.__file__
+    pkg = types.ModuleType("taichi_slam"); pkg.__path__ = []
+    sub = types.ModuleType("taichi_slam.mapping"); sub.__path__ = [REF]; sub.__package__ = "taichi_slam.mapping"
+    sys.modules.update({"taichi_slam": pkg, "taichi_slam.mapping": sub})
+    out = {}
+    for name in ("mapping_common", "dense_tsdf"):
+        spec = importlib.util.spec_from_file_location(f"taichi_slam.mapping.{name}", os.path.join(REF, name + ".py"))
+        mod = importlib.util.module_from_spec(spec); sys.modules[spec.name] = mod; spec.loader.exec_module(mod); out[name] = mod
+    return out["dense_tsdf"].DenseTSDF
+
+
+def lin(idx):
+    i = idx.astype(np.int64)
+    return ((i[:, 0] + 32768) << 32) | ((i[:, 1] + 32768) << 16) | (i[:, 2] + 32768)
+
+
+def sorted_export(obj):
+    o = np.argsort(lin(np.asarray(obj["indices"])), kind="stable")
+    out = {"indices": np.asarray(obj["indices"])[o].astype(np.int16), "TSDF": np.asarray(obj["TSDF"], np.float16)[o].view(np.uint16),
+           "W_TSDF": np.asarray(obj["W_TSDF"], np.float16)[o].view(np.uint16), "occupy": np.asarray(obj["occupy"])[o].astype(np.int8)}
+    if np.asarray(obj["color"]).size:
+        out["color"] = np.asarray(obj["color"], np.float16)[o].view(np.uint16)
+    return out
+
+
+def scenarios():
+    from taichislam_amd.utils import synthetic as syn
+    rng = np.random.default_rng(20260926)
+    eye, zero = np.eye(3), np.zeros(3)
+    out = []
+    # 1. three frames of the sphere-room stream (the benchmark's scene, scaled down): rays of 30-45 steps, voxels hit by several rays per frame and by all frames
+    h, w = 48, 64
+    K = syn.scaled_intrinsics(h, w)
+    cfg = dict(map_scale=[10.24, 10.24], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=5.0, min_ray_length=0.3, internal_voxels=6, recast_step=2, max_submap_num=4)
+    fr = []
+    for f in range(3):
+        R, T = syn.camera_pose(4 * f)
+        fr.append(dict(kind="depth", R=R, T=T, depth=syn.sphere_room_depth(R, T, h, w, radius=3.0, K=K)))
+    out.append(("depth_stream", cfg, K, None, [dict(kind="base", sid=0, R=eye, T=zero)] + fr))
+    # 2. point clouds: random directions and ranges, a cluster inside a few sensor voxels, a point beyond max_ray_length; a rotated, shifted pose
+    cfg = dict(map_scale=[5.12, 5.12], voxel_scale=0.04, num_voxel_per_blk_axis=16, max_ray_length=2.4, min_ray_length=0.3, internal_voxels=5, recast_step=2, max_submap_num=4)
+    fr = [dict(kind="base", sid=0, R=eye, T=zero)]
+    for f in range(2):
+        d = rng.normal(size=(260, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts = d * rng.uniform(0.3, 2.2, size=(260, 1))
+        pts = np.concatenate([pts, np.array([[0.5, 0.2, 0.7]]) + rng.uniform(-0.03, 0.03, size=(40, 3)), np.array([[2.0, 2.0, 2.0]])]).astype(np.float32)
+        a = 0.3 * (f + 1)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        fr.append(dict(kind="pcl", R=R, T=np.array([0.1 * f, -0.05, 0.02]), xyz=pts))
+    out.append(("point_clouds", cfg, syn.scaled_intrinsics(30, 40), None, fr))
+    # 3. colour: depth + texture through the same projection (color_same_proj), two frames
+    h, w = 30, 40
+    K = syn.scaled_intrinsics(h, w)
+    cfg = dict(map_scale=[5.12, 5.12], voxel_scale=0.05, num_voxel_per_blk_axis=16, max_ray_length=3.0, min_ray_length=0.3, internal_voxels=5, recast_step=2, max_submap_num=4, texture_enabled=True)
+    fr = [dict(kind="base", sid=0, R=eye, T=zero)]
+    for f in range(2):
+        R, T = syn.camera_pose(6 * f, orbit=0.2)
+        depth = syn.sphere_room_depth(R, T, h, w, radius=1.6, K=K)
+        fr.append(dict(kind="depth", R=R, T=T, depth=depth, texture=rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)))
+    out.append(("textured", cfg, K, K, fr))
+    # 4. the weight clamp: a wall 0.35 m in front of a fixed camera, 14 frames -- w = 1 / z^2 = 8 per ray, W reaches Wmax = 1000 inside the run
+    h, w = 24, 32
+    K = syn.scaled_intrinsics(h, w)
+    cfg = dict(map_scale=[2.56, 2.56], voxel_scale=0.04, num_voxel_per_blk_axis=16, max_ray_length=2.0, min_ray_length=0.3, internal_voxels=4, recast_step=1, max_submap_num=4)
+    fr = [dict(kind="base", sid=0, R=eye, T=zero)]
+    for f in range(14):
+        fr.append(dict(kind="depth", R=eye, T=zero, depth=np.full((h, w), 350 + (f % 3), np.uint16)))
+    out.append(("weight_clamp", cfg, K, None, fr))
+    # 5. two submaps with their own base poses, then fuse_submaps into a global map (dense_tsdf.py:272-318)
+    h, w = 30, 40
+    K = syn.scaled_intrinsics(h, w)
+    cfg = dict(map_scale=[5.12, 5.12], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=4.0, min_ray_length=0.3, internal_voxels=5, recast_step=2, max_submap_num=4)
+    R0, T0 = syn.camera_pose(0)
+    R1, T1 = syn.camera_pose(20)
+    fr = [dict(kind="base", sid=0, R=R0, T=T0), dict(kind="depth", R=R0, T=T0, depth=syn.sphere_room_depth(R0, T0, h, w, radius=2.5, K=K)),
+          dict(kind="next_submap"), dict(kind="base", sid=1, R=R1, T=T1), dict(kind="depth", R=R1, T=T1, depth=syn.sphere_room_depth(R1, T1, h, w, radius=2.5, K=K)),
+          dict(kind="next_submap"), dict(kind="fuse", global_map_scale=[10.24, 10.24])]      # (the splat must stay inside the global volume: outside is undefined in the reference)
+    out.append(("two_submaps_fused", cfg, K, None, fr))
+    return out
+
+
+def run(DenseTSDF, name, cfg, K, Kc, steps):
+    m = DenseTSDF(**cfg, max_disp_particles=64)
+    m.set_dep_camera_intrinsic(K)
+    if Kc is not None:
+        m.set_color_camera_intrinsic(Kc)
+    g, t0 = None, time.time()
+    for s in steps:
+        if s["kind"] == "base":
+            m.set_base_pose_submap(s["sid"], np.ascontiguousarray(s["R"], dtype=np.float64), np.ascontiguousarray(s["T"], dtype=np.float64))
+        elif s["kind"] == "depth":
+            m.recast_depth_to_map(s["R"], s["T"], s["depth"], s.get("texture", np.zeros((1, 1, 3), np.uint8)))
+        elif s["kind"] == "pcl":
+            m.recast_pcl_to_map(s["R"], s["T"], s["xyz"], np.zeros((1, 3), np.uint8))
+        elif s["kind"] == "next_submap":
+            m.switch_to_next_submap()
+        elif s["kind"] == "fuse":
+            g = DenseTSDF(**{**cfg, "is_global_map": True, "map_scale": s["global_map_scale"]}, max_disp_particles=64)
+            g.set_dep_camera_intrinsic(K)
+            for b in steps:                                   # the global map needs the submaps' base poses (submap_mapping.py sets them the same way)
+                if b["kind"] == "base":
+                    g.set_base_pose_submap(b["sid"], np.ascontiguousarray(b["R"], dtype=np.float64), np.ascontiguousarray(b["T"], dtype=np.float64))
+            g.fuse_submaps(m)
+    res = sorted_export((g if g is not None else m).export_submap())
+    print(f"{name}: {res['indices'].shape[0]} voxels, {time.time() - t0:.1f} s")
+    return res
+
+
+if __name__ == "__main__":
+    assert os.path.exists(REF), "the reference tree is needed to generate the vectors"
+    DenseTSDF = load_reference()
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    only = sys.argv[1:]
+    for name, cfg, K, Kc, steps in scenarios():
+        if only and name not in only:
+            continue
+        res = run(DenseTSDF, name, cfg, K, Kc, steps)
+        arrays = {"cfg": np.array(json.dumps(cfg)), "K": np.asarray(K), "Kc": np.asarray(K if Kc is None else Kc), "has_Kc": np.array(Kc is not None),
+                  "steps": np.array(json.dumps([{k: (None if isinstance(v, np.ndarray) else v) for k, v in s.items()} for s in steps]))}
+        for n_, s in enumerate(steps):
+            for k, v in s.items():
+                if isinstance(v, np.ndarray):
+                    arrays[f"s{n_}_{k}"] = v
+        for k, v in res.items():
+            arrays["out_" + k] = v
+        path = os.path.join(ROOT, "tests", "golden", f"ref_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"  -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
