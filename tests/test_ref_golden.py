@@ -17,7 +17,8 @@ import pytest
 from util import lin
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["depth_stream", "point_clouds", "textured", "weight_clamp", "two_submaps_fused"]
+NAMES = ["depth_stream", "point_clouds", "textured", "weight_clamp", "two_submaps_fused", "aligned_submap_fused"]
+FUSED = ("two_submaps_fused", "aligned_submap_fused")
 
 
 def load(name):
@@ -146,11 +147,16 @@ def test_hip_default_path_against_the_reference_source(hip_lib, name):
     cfg, K, Kc, steps, want = load(name)
     got = replay(lambda over: _Hip({**cfg, **over}, K, Kc, 0), steps, K, Kc, {}, lambda g, m: g.m.fuse_submaps(m.m))
     assert np.array_equal(got["indices"], want["indices"]), "voxel sets differ"
-    if name != "two_submaps_fused":                      # (the fused occupancy is a sum over splat corners in both; the order-free one adds exactly the same terms)
-        assert np.array_equal(got["occupy"], want["occupy"])
+    assert np.array_equal(got["occupy"], want["occupy"])
     t_g, t_w = got["TSDF"].view(np.float16).astype(np.float64), want["TSDF"].view(np.float16).astype(np.float64)
-    d = np.abs(t_g - t_w)
+    # An axis-aligned base pose makes six of the seven splat weights exactly 0.  In the reference's fusion a voxel whose FIRST splat has weight 0 is
+    # 0 / 0 and stays NaN whatever comes later (58 % of aligned_submap_fused); the order-free sums are NaN only where EVERY splat has weight 0.
+    fin = np.isfinite(t_g) & np.isfinite(t_w)
+    assert not (np.isnan(t_g) & ~np.isnan(t_w)).any(), "a voxel that is NaN in the order-free fusion is NaN in the literal one"
+    assert fin.all() if name != "aligned_submap_fused" else (0.3 < fin.mean() < 0.6 and np.isnan(t_w).mean() > 0.5)
+    d = np.abs(t_g - t_w)[fin]
     vs = cfg["voxel_scale"]
-    assert np.percentile(d, 50) <= 0.02 * vs and np.percentile(d, 99) <= 0.6 * vs and d.max() <= 4.0 * vs, (np.percentile(d, [50, 99]), d.max())
+    assert np.percentile(d, 50) <= 0.02 * vs and np.percentile(d, 99) <= 0.6 * vs, np.percentile(d, [50, 99])
+    assert d.max() <= 4.0 * vs or name == "aligned_submap_fused", d.max()      # (there the literal fusion also divides by sums that underflow: single outliers)
     w_g, w_w = got["W_TSDF"].view(np.float16).astype(np.float64), want["W_TSDF"].view(np.float16).astype(np.float64)
-    assert np.percentile(np.abs(w_g - w_w) / np.maximum(w_w, 1e-3), 99) <= 0.02
+    assert np.percentile((np.abs(w_g - w_w) / np.maximum(w_w, 1e-3))[fin], 99) <= 0.02

@@ -98,12 +98,22 @@ def scenarios():
     h, w = 30, 40
     K = syn.scaled_intrinsics(h, w)
     cfg = dict(map_scale=[5.12, 5.12], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=4.0, min_ray_length=0.3, internal_voxels=5, recast_step=2, max_submap_num=4)
+    def tilt(R, a, b):                                   # off the lattice: with an axis-aligned base pose six of the seven splat weights are exactly 0 and the
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)      # reference's first-come 0 / 0 turns half of the fused voxels into NaN (kept in: test below)
+        return R @ np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1.0]]) @ np.array([[1.0, 0, 0], [0, cb, -sb], [0, sb, cb]])
     R0, T0 = syn.camera_pose(0)
     R1, T1 = syn.camera_pose(20)
+    R0, T0 = tilt(R0, 0.17, 0.05), T0 + np.array([0.013, 0.021, -0.037])
+    R1, T1 = tilt(R1, -0.11, 0.08), T1 + np.array([-0.027, 0.009, 0.031])
     fr = [dict(kind="base", sid=0, R=R0, T=T0), dict(kind="depth", R=R0, T=T0, depth=syn.sphere_room_depth(R0, T0, h, w, radius=2.5, K=K)),
           dict(kind="next_submap"), dict(kind="base", sid=1, R=R1, T=T1), dict(kind="depth", R=R1, T=T1, depth=syn.sphere_room_depth(R1, T1, h, w, radius=2.5, K=K)),
           dict(kind="next_submap"), dict(kind="fuse", global_map_scale=[10.24, 10.24])]      # (the splat must stay inside the global volume: outside is undefined in the reference)
     out.append(("two_submaps_fused", cfg, K, None, fr))
+    # 6. the same with ONE axis-aligned submap: the literal fusion's 0 / 0 (weights exactly 0, whichever splat comes first decides) as it is
+    Ra, Ta = syn.camera_pose(0)
+    fr = [dict(kind="base", sid=0, R=Ra, T=Ta), dict(kind="depth", R=Ra, T=Ta, depth=syn.sphere_room_depth(Ra, Ta, h, w, radius=2.5, K=K)),
+          dict(kind="next_submap"), dict(kind="fuse", global_map_scale=[10.24, 10.24])]
+    out.append(("aligned_submap_fused", cfg, K, None, fr))
     return out
 
 
