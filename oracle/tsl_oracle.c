@@ -1007,7 +1007,9 @@ static void mc_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, con
         float mu = 0.0f;
         if (fabsf(0.0f - v0) < MC_EPS) { for (int a = 0; a < 3; ++a) vert[e][a] = p0[a]; }           /* vertexInterp :44-60 */
         else if (fabsf(0.0f - v1) < MC_EPS) { for (int a = 0; a < 3; ++a) vert[e][a] = p1[a]; }
-        else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) vert[e][a] = p0[a] + mu * (p1[a] - p0[a]); }
+        /* valp2 - valp1 is a difference of two f16 values: an f16 operation, rounded to f16, before the division promotes it to f32 (found by
+         * running the reference's source on tools/ti_seq: an f32 difference moves vertices by up to 3e-5 voxels) */
+        else { mu = (0.0f - v0) / F(hsub(H(v1), H(v0))); for (int a = 0; a < 3; ++a) vert[e][a] = p0[a] + mu * (p1[a] - p0[a]); }
         if (c->col) {                                                                    /* vertexInterp_color :62-82 (Q13) */
             const f16* c0 = rd_col(m, s, a0[0], a0[1], a0[2]); const f16* c1 = rd_col(m, s, a1[0], a1[1], a1[2]);
             float c0f[3] = { F(c0[0]), F(c0[1]), F(c0[2]) }, c1f[3] = { F(c1[0]), F(c1[1]), F(c1[2]) };

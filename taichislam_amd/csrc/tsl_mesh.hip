@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int
                         float pv[3], mu = 0.0f;
                         if (fabsf(0.0f - v0) < MC_EPS) { pv[0] = p0[0]; pv[1] = p0[1]; pv[2] = p0[2]; }            // vertexInterp :44-60
                         else if (fabsf(0.0f - v1) < MC_EPS) { pv[0] = p1[0]; pv[1] = p1[1]; pv[2] = p1[2]; }
-                        else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
+                        else { mu = (0.0f - v0) / h2f(hsub(f2h(v1), f2h(v0))); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }   // (f16 - f16: an f16 operation)
                         if (colors) {                                                            // vertexInterp_color :62-82 (Q13: only channel 0 is tested)
                             const uint2 ca2 = rd_col(M, s, i + da[0] * step, j + da[1] * step, k + da[2] * step);
                             const uint2 cb2 = rd_col(M, s, i + db[0] * step, j + db[1] * step, k + db[2] * step);
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
                 float pv[3], mu = 0.0f;
                 if (fabsf(0.0f - v0) < MC_EPS) { pv[0] = p0[0]; pv[1] = p0[1]; pv[2] = p0[2]; }            // vertexInterp :44-60
                 else if (fabsf(0.0f - v1) < MC_EPS) { pv[0] = p1[0]; pv[1] = p1[1]; pv[2] = p1[2]; }
-                else { mu = (0.0f - v0) / (v1 - v0); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }
+                else { mu = (0.0f - v0) / h2f(hsub(f2h(v1), f2h(v0))); for (int a = 0; a < 3; ++a) pv[a] = p0[a] + mu * (p1[a] - p0[a]); }      // (valp2 - valp1 of two f16 values is an f16 operation)
                 if (colors) {                                                            // vertexInterp_color :62-82 (Q13); colours stay in HBM
                     const uint2 ca2 = rd_col(M, s, i + da[0], j + da[1], k + da[2]);
                     const uint2 cb2 = rd_col(M, s, i + db[0], j + db[1], k + db[2]);

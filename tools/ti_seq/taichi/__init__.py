@@ -164,6 +164,26 @@ class TV:
     def __mod__(self, o): return self._bin(o, "mod")
     def __rmod__(self, o): return self._bin(o, "mod", True)
     def __pow__(self, o): return self._bin(o, "pow")
+    def _bit(self, o, f, rev=False):
+        o = as_tv(o)
+        if o is NotImplemented:
+            return NotImplemented
+        a, b = (o, self) if rev else (self, o)
+        dt = promote(a.dt, b.dt)
+        assert not dt.is_float, "bit operation on a float"
+        return TV(f(int(a.v), int(b.v)), dt)
+
+    def __or__(self, o): return self._bit(o, lambda a, b: a | b)
+    def __ror__(self, o): return self._bit(o, lambda a, b: a | b, True)
+    def __and__(self, o): return self._bit(o, lambda a, b: a & b)
+    def __rand__(self, o): return self._bit(o, lambda a, b: a & b, True)
+    def __xor__(self, o): return self._bit(o, lambda a, b: a ^ b)
+    def __rxor__(self, o): return self._bit(o, lambda a, b: a ^ b, True)
+    def __lshift__(self, o): return self._bit(o, lambda a, b: a << b)
+    def __rlshift__(self, o): return self._bit(o, lambda a, b: a << b, True)
+    def __rshift__(self, o): return self._bit(o, lambda a, b: a >> b)
+    def __rrshift__(self, o): return self._bit(o, lambda a, b: a >> b, True)
+    def __invert__(self): return TV(~int(self.v), self.dt)
     def __neg__(self): return TV(-self.v, self.dt)
     def __pos__(self): return self
     def __abs__(self): return TV(abs(self.v), self.dt)
@@ -236,6 +256,8 @@ class Vec:
 
     def __getitem__(self, i):
         if isinstance(i, tuple):
+            if isinstance(i[1], slice):                # m[r, :]: a 1 x n matrix (the reference indexes the result as p[0, c])
+                return Vec([Vec(list(self.e[int(i[0])].e[i[1]]))])
             return self.e[int(i[0])][int(i[1])]
         return self.e[int(i)]
 
@@ -276,13 +298,18 @@ class Vec:
     def norm_sqr(self): return _sum([a * a for a in self.e])
     def norm(self, eps=0): return sqrt(self.norm_sqr() + eps) if eps else sqrt(self.norm_sqr())
     def sum(self): return _sum(list(self.e))
-    def normalized(self, eps=0): return self / self.norm(eps)
+    def normalized(self, eps=0):                    # taichi/lang/matrix.py: invlen = 1 / (self.norm() + eps); return invlen * self
+        invlen = 1 / (self.norm() + eps)
+        return invlen * self
 
     def cross(self, o):
         a, b = self.e, list(o)
         return Vec([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
 
-    def transpose(self): return Vec([Vec([self.e[r][c] for r in range(len(self.e))]) for c in range(len(self.e[0]))])
+    def transpose(self):
+        if not isinstance(self.e[0], Vec):            # a vector is a column: its transpose is a 1 x n matrix
+            return Vec([Vec(list(self.e))])
+        return Vec([Vec([self.e[r][c] for r in range(len(self.e))]) for c in range(len(self.e[0]))])
 
 
 def _sum(xs):
@@ -475,7 +502,7 @@ class SNode:
     def parent(self, n=1): return self.parent_ if n == 1 else self.parent_.parent(n - 1)
 
     def place(self, *fields, offset=None):
-        assert self.kind == "dense", "this stand-in places fields under dense nodes only"
+        # (a field placed under a pointer node, as the reference's Octomap does: the node's own cells are the storage blocks)
         chain, n = [], self
         while n is not None and n.kind != "root":
             chain.append(n)
@@ -612,6 +639,8 @@ class MatrixField(_FieldBase):
     def __setitem__(self, idx, v):
         v = v if isinstance(v, Vec) else Vec(list(v))
         a = np.array([[cast(x, self.dtype).v for x in r] for r in v.e] if isinstance(v.e[0], Vec) else [cast(x, self.dtype).v for x in v.e], self.dtype.np)
+        if a.shape != self._eshape and a.size == int(np.prod(self._eshape)):
+            a = a.reshape(self._eshape)                # (an n x 1 or 1 x n matrix into a vector field)
         assert a.shape == self._eshape, f"shape {a.shape} into a field of {self._eshape}"
         self._put(_key(idx), a)
 
@@ -733,7 +762,7 @@ class _Rewrite(ast.NodeTransformer):
     def visit_AugAssign(self, node):
         self.generic_visit(node)
         op = self.OPS.get(type(node.op))
-        if isinstance(node.target, ast.Name):
+        if isinstance(node.target, ast.Name):            # (any operator: +=, |=, <<= ...)
             val = ast.BinOp(ast.Name(node.target.id, ast.Load()), node.op, node.value)
             return ast.Assign([ast.Name(node.target.id, ast.Store())], self._wrap(node.target.id, val))
         if isinstance(node.target, ast.Subscript) and op:
