@@ -55,8 +55,15 @@ def test_marching_cubes_sphere_config1(hip_lib):
     assert np.array_equal(_tri_keys(gv, gn), _tri_keys(ov, on))
     r = np.linalg.norm(gv, axis=1)
     assert np.abs(r - radius).max() < 0.05 * 0.5            # vertices lie on the sphere to O(voxel^2)
-    # closed 2-manifold: every edge is shared by exactly two triangles (after welding equal vertices)
-    uniq, inv = np.unique(np.round(gv / 1e-5).astype(np.int64), axis=0, return_inverse=True)
+    # closed 2-manifold: every edge is shared by exactly two triangles after welding.  The two cells that share an edge walk it in opposite directions,
+    # and vertexInterp's `valp2 - valp1` is an f16 operation (relative error up to 2^-11): mu + mu' = d / fl16(d) != 1, so their two copies of the vertex
+    # are up to 5e-4 of a voxel = 2.4e-5 m apart -- the reference's own meshes have these hairline offsets.  Weld by distance, not by rounding.
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import cKDTree
+    pairs = cKDTree(gv).query_pairs(1.2e-3 * cfg["voxel_scale"], output_type="ndarray")
+    _, inv = connected_components(coo_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(gv.shape[0],) * 2), directed=False)
+    uniq = np.unique(inv)
     tri = inv.reshape(-1, 3)
     tri = tri[(tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2])]
     edges = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)

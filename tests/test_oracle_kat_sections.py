@@ -122,7 +122,7 @@ def test_marching_cubes_single_corner_by_hand():
             return pa
         if abs(f32(0) - vb) < f32(1e-6):
             return pb
-        mu = f32(f32(f32(0) - va) / f32(vb - va))
+        mu = f32(f32(f32(0) - va) / f32(f16(vb) - f16(va)))                   # valp2 - valp1: two f16 values, an f16 operation (rounded to f16)
         return np.array([f32(pa[q] + f32(mu * f32(pb[q] - pa[q]))) for q in range(3)], f32)
 
     c = [tuple(int(x) for x in i3) for i3 in idx]
