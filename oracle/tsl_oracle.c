@@ -2,7 +2,7 @@
  * tsl_oracle.c -- CPU ORACLE (test infrastructure only; see tsl_oracle.h header comment).
  *
  * Plain-C restatement of xuhao1/TaichiSLAM taichi_slam/mapping (reference paths below are
- * relative to the reference root).  PARITY UNPINNED by any reference test (none exist).
+ * relative to the reference root).  Parity: pinned to the reference's SOURCE run on tools/ti_seq (tsl_oracle.h), not to Taichi.
  *
  * Numeric model (DESIGN.md "Assumed Taichi semantics" A1-A10):
  *   h(x)   round-to-nearest-even to IEEE binary16; every f16 (op) f16 is h(f32(a) op f32(b));

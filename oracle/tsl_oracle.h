@@ -7,10 +7,16 @@
  * It is a plain-C restatement of the reference algorithm (xuhao1/TaichiSLAM,
  * taichi_slam/mapping/ *.py); every function cites the reference file:line it follows.
  *
- * PARITY UNPINNED: the reference ships no golden vectors / asserting tests for this path and
- * its execution engine (taichi, un-pinned, requirements.txt:4) is not installable here, so
- * this restatement is pinned only by its own known-answer tests (tests/test_oracle_*.py) and
- * by the numeric-semantics assumptions A1-A10 listed in DESIGN.md.
+ * PARITY PINNED TO THE REFERENCE'S SOURCE (not to Taichi): the reference ships no golden vectors or
+ * asserting tests and its execution engine (taichi, un-pinned, requirements.txt:4) is not installable
+ * here.  Its own source is: dense_tsdf.py, mapping_common.py, taichi_octomap.py and
+ * marching_cube_mesher.py are imported unmodified and RUN on a sequential stand-in for the Taichi subset
+ * they use (tools/ti_seq, tools/gen_ref_golden.py), and ORA_FAITHFUL reproduces what they produce --
+ * maps after depth / point-cloud / colour integration, the weight clamp, submap fusion, Octomap leaves,
+ * mesh vertices and normals -- bit for bit (tests/golden/ref_*.npz, tests/test_ref_golden.py).  What stays
+ * an assumption, shared by the stand-in and this file (A1-A10), is the behaviour of Taichi's own
+ * back end: f16 arithmetic through f32, ti.round half away from zero, the cast in front of an atomic add,
+ * no FMA contraction, and WHICH serialisation of a parallel struct-for a run corresponds to.
  *
  * Two update modes (DESIGN.md "Defined semantics"):
  *   ORA_FAITHFUL  sequential replay of the reference: f16 fields, per-update f16 rounding,

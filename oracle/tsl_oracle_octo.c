@@ -1,6 +1,6 @@
 /*
  * tsl_oracle_octo.c -- CPU ORACLE, Octomap hit counter (test infrastructure only).
- * Restates taichi_slam/mapping/taichi_octomap.py; PARITY UNPINNED (see tsl_oracle.h).
+ * Restates taichi_slam/mapping/taichi_octomap.py; parity pinned to the reference's source run on tools/ti_seq (tests/golden/ref_octomap.npz; see tsl_oracle.h).
  */
 #include "tsl_oracle.h"
 #include <math.h>

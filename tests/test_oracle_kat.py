@@ -1,4 +1,4 @@
-"""Known-answer tests that pin the CPU oracle itself (the reference ships none: PARITY UNPINNED).
+"""Known-answer tests that pin the CPU oracle itself (the reference ships none; the vectors made by the reference's own source are in tests/test_ref_golden.py).
 
 Each KAT is computed here independently with numpy float16/float32 arithmetic following the reference
 lines cited (taichi_slam/mapping/dense_tsdf.py:188-270, mapping_common.py:31-41,149-156,240-266)."""

@@ -1,4 +1,4 @@
-"""Known-answer tests for the oracle's fusion, marching-cubes, Octomap and ESDF sections (PARITY UNPINNED by the reference:
+"""Known-answer tests for the oracle's fusion, marching-cubes, Octomap and ESDF sections (hand-computed; the vectors from the reference's own source are in tests/test_ref_golden.py:
 these pin the restatement to hand / numpy replays written directly from the reference lines, independent of the oracle's C code).
 
   fusion          taichi_slam/mapping/dense_tsdf.py:272-307, mapping_common.py:221-232

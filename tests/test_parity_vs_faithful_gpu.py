@@ -9,7 +9,7 @@ written by tools/parity_report.py (profiles/r03_parity_vs_faithful.json, BASELIN
 consumers of the map: marching cubes (mesh of the HIP map vs mesh of the FAITHFUL map) and submap fusion (HIP fuse_submaps vs the oracle's
 sequential FAITHFUL fusion, dense_tsdf.py:272-307).  The GPU can also COMPUTE the literal semantics: tests/test_sequential_gpu.py.
 
-Parity is UNPINNED by the reference (no golden vectors, Taichi not installable): both yardsticks are restatements."""
+Both yardsticks are restatements; FAITHFUL is pinned to the reference's own source run on tools/ti_seq (tests/test_ref_golden.py), not to Taichi."""
 import numpy as np
 import pytest
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Regenerate tests/golden/*.npz from the CPU oracle (BATCHED mode).
 
-The reference ships no golden vectors and cannot be executed here (no Taichi), so these fixtures do not pin the oracle
+The reference ships no golden vectors and Taichi cannot be installed here; these fixtures are REGRESSION vectors made by the oracle and do not pin it
+(the vectors that do come from the reference's own source: tools/gen_ref_golden.py, tests/golden/ref_*.npz)
 to the reference -- they freeze the oracle's own output so that an accidental change of the restated semantics (or of the
 HIP path that is compared against the same files on the GPU box) is caught.  Inputs are the deterministic synthetic stream."""
 import os
