@@ -1015,7 +1015,7 @@ static void mc_fn(void* vctx, const ora_tsdf* m, int s, int i, int j, int k, con
             float c0f[3] = { F(c0[0]), F(c0[1]), F(c0[2]) }, c1f[3] = { F(c1[0]), F(c1[1]), F(c1[2]) };
             for (int a = 0; a < 3; ++a) vcol[e][a] = c0f[a];
             if (c0f[0] == 0.0f) { for (int a = 0; a < 3; ++a) vcol[e][a] = c1f[a]; }
-            else if (!(c1f[0] == 0.0f)) { for (int a = 0; a < 3; ++a) vcol[e][a] = c0f[a] + mu * F(hsub(c1[a], c0[a])); }   /* f16 - f16 rounds to f16 (A4) */
+            else if (!(c1f[0] == 0.0f)) { for (int a = 0; a < 3; ++a) vcol[e][a] = F(H(c0f[a] + mu * F(hsub(c1[a], c0[a])))); }   /* f16 - f16 rounds to f16 (A4); p_color was first assigned c1: an f16 variable, the f32 sum is cast to it (reference source on tools/ti_seq) */
         }
     }
     for (int t = 0; t < 5; ++t) {                                                         /* :173-177 */

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int
                             const h16 c1[3] = { (h16)(cb2.x & 0xffffu), (h16)(cb2.x >> 16), (h16)(cb2.y & 0xffffu) };
                             float vc[3] = { h2f(c0[0]), h2f(c0[1]), h2f(c0[2]) };
                             if (h2f(c0[0]) == 0.0f) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c1[a]); }
-                            else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])); }
+                            else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(f2h(h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])))); }   // (p_color is an f16 variable: first assigned c1)
                             const size_t oc = ((size_t)idx * 3 + q) * 3;
                             for (int a = 0; a < 3; ++a) colors[oc + a] = vc[a];
                         }
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
                     const h16 c1[3] = { (h16)(cb2.x & 0xffffu), (h16)(cb2.x >> 16), (h16)(cb2.y & 0xffffu) };
                     float vc[3] = { h2f(c0[0]), h2f(c0[1]), h2f(c0[2]) };
                     if (h2f(c0[0]) == 0.0f) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c1[a]); }
-                    else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])); }
+                    else if (!(h2f(c1[0]) == 0.0f)) { for (int a = 0; a < 3; ++a) vc[a] = h2f(f2h(h2f(c0[a]) + mu * h2f(hsub(c1[a], c0[a])))); }   // (p_color is an f16 variable: first assigned c1)
                     const size_t oc = ((size_t)idx * 3 + q) * 3;
                     for (int a = 0; a < 3; ++a) colors[oc + a] = vc[a];
                 }

@@ -237,3 +237,66 @@ def test_hip_mesh_reproduces_the_reference_source_bit_for_bit(hip_lib):
     v, n, _ = me.get_mesh()
     assert me.num_facelets[None] == want["mesh"].shape[0]
     assert np.array_equal(_canon(v, n).view(np.uint32), want["mesh"].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------------------------ exports, raycast, coloured mesh
+def _rows(*cols):
+    t = np.concatenate([np.asarray(c, np.float32).reshape(len(c), -1) for c in cols], axis=1).astype(np.float32)
+    return t[np.lexsort(t.view(np.uint32).T[::-1])]
+
+
+def _oracle_map(name):
+    from oracle import FAITHFUL, OracleTSDF
+    cfg, K, Kc, steps, want = load(name)
+    o = OracleTSDF(**cfg)
+    o.set_intrinsics(K, Kc if Kc is not None else K)
+    for s in steps:
+        if s["kind"] == "base":
+            o.set_base_pose_submap(s["sid"], s["R"], s["T"])
+        else:
+            o.integrate_depth(s["R"], s["T"], s["depth"], s.get("texture"), mode=FAITHFUL)
+    return cfg, o, want
+
+
+@pytest.mark.parametrize("name", ["depth_stream", "textured"])
+def test_oracle_exports_raycast_and_mesh_reproduce_the_reference_source(name):
+    """On the reference's map: cvt_TSDF_surface_to_voxels (positions + colours: the jet colour map of matplotlib, or the stored colours), cvt_TSDF_to_voxels_slice,
+    BaseMap.raycast for 24 rays, and generate_mesh(1) with vertex colours -- everything bit for bit, as sets of rows."""
+    cfg, o, want = _oracle_map(name)
+    xyz, rgb, n = o.surface_voxels()
+    assert n == want["surface"].shape[0] > 1000 and np.array_equal(_rows(xyz, rgb).view(np.uint32), want["surface"].view(np.uint32))
+    z, dz = (float(x) for x in want["slice_args"])
+    xyz, val, rgb, n = o.slice_voxels(z, dz)
+    assert n == want["slice"].shape[0] > 1000 and np.array_equal(_rows(xyz, val, rgb).view(np.uint32), want["slice"].view(np.uint32))
+    hit, end, ln = o.raycast(want["ray_pos"], want["ray_dir"], float(want["ray_max"]))
+    assert np.array_equal(hit, want["ray_hit"]) and np.array_equal(end.view(np.uint32), want["ray_end"].view(np.uint32)) and np.array_equal(ln.view(np.uint32), want["ray_len"].view(np.uint32))
+    v, nr, col, cnt = o.generate_mesh(1, float(want["mesh_thres"]), 20000)
+    cols = [v.reshape(-1, 9), nr.reshape(-1, 9)] + ([col.reshape(-1, 9)] if cfg.get("texture_enabled") else [])
+    assert cnt == want["mesh"].shape[0] > 500 and np.array_equal(_rows(*cols).view(np.uint32), want["mesh"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_exports_and_raycast_reproduce_the_reference_source(hip_lib):
+    """The HIP map of semantics = 1 is the reference's map bit for bit; so are its particle exports and ray casts."""
+    from taichislam_amd.mapping import DenseTSDF
+    cfg, K, _, steps, want = load("depth_stream")
+    m = DenseTSDF(**cfg, max_disp_particles=40000)
+    m.set_dep_camera_intrinsic(K)
+    m.set_option("semantics", 1)
+    for s in steps:
+        if s["kind"] == "base":
+            m.set_base_pose_submap(s["sid"], s["R"], s["T"])
+        else:
+            m.recast_depth_to_map(s["R"], s["T"], s["depth"], None)
+    m.cvt_TSDF_surface_to_voxels()
+    n = m.num_TSDF_particles[None]
+    xyz, rgb, _ = m._read_exports(n)
+    assert n == want["surface"].shape[0] and np.array_equal(_rows(xyz, rgb).view(np.uint32), want["surface"].view(np.uint32))
+    z, dz = (float(x) for x in want["slice_args"])
+    m.cvt_TSDF_to_voxels_slice(z, dz)
+    n = m.num_TSDF_particles[None]
+    xyz, rgb, val = m._read_exports(n)
+    assert n == want["slice"].shape[0] and np.array_equal(_rows(xyz, val, rgb).view(np.uint32), want["slice"].view(np.uint32))
+    hit, end, ln = m.raycast(want["ray_pos"], want["ray_dir"], float(want["ray_max"]))
+    assert np.array_equal(np.asarray(hit, bool), want["ray_hit"]) and np.array_equal(np.asarray(end, np.float32).view(np.uint32), want["ray_end"].view(np.uint32))
+    assert np.array_equal(np.asarray(ln, np.float32).view(np.uint32), want["ray_len"].view(np.uint32))

@@ -82,9 +82,9 @@ def scenarios():
         fr.append(dict(kind="pcl", R=R, T=np.array([0.1 * f, -0.05, 0.02]), xyz=pts))
     out.append(("point_clouds", cfg, syn.scaled_intrinsics(30, 40), None, fr))
     # 3. colour: depth + texture through the same projection (color_same_proj), two frames
-    h, w = 30, 40
+    h, w = 36, 48
     K = syn.scaled_intrinsics(h, w)
-    cfg = dict(map_scale=[5.12, 5.12], voxel_scale=0.05, num_voxel_per_blk_axis=16, max_ray_length=3.0, min_ray_length=0.3, internal_voxels=5, recast_step=2, max_submap_num=4, texture_enabled=True)
+    cfg = dict(map_scale=[5.12, 5.12], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=3.0, min_ray_length=0.3, internal_voxels=5, recast_step=1, max_submap_num=4, texture_enabled=True)
     fr = [dict(kind="base", sid=0, R=eye, T=zero)]
     for f in range(2):
         R, T = syn.camera_pose(6 * f, orbit=0.2)
@@ -122,8 +122,13 @@ def scenarios():
     return out
 
 
+def canon_rows(*cols):
+    t = np.concatenate([np.asarray(c, np.float32).reshape(len(c), -1) for c in cols], axis=1).astype(np.float32)
+    return t[np.lexsort(t.view(np.uint32).T[::-1])]
+
+
 def run(DenseTSDF, name, cfg, K, Kc, steps):
-    m = DenseTSDF(**cfg, max_disp_particles=64)
+    m = DenseTSDF(**cfg, max_disp_particles=40000 if name in ("depth_stream", "textured") else 64)
     m.set_dep_camera_intrinsic(K)
     if Kc is not None:
         m.set_color_camera_intrinsic(Kc)
@@ -146,15 +151,40 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
             g.fuse_submaps(m)
     res = sorted_export((g if g is not None else m).export_submap())
     print(f"{name}: {res['indices'].shape[0]} voxels, {time.time() - t0:.1f} s")
-    if name == "depth_stream":      # marching_cube_mesher.py on the map just built: generate_mesh(1), triangles as rows of 9 + 9 floats in a canonical order
+    if name in ("depth_stream", "textured"):      # marching_cube_mesher.py on the map just built: generate_mesh(1), triangles as rows in a canonical order
+        import taichi as ti
         t0 = time.time()
-        me = Mesher(m, max_triangles=20000, tsdf_surface_thres=5 * cfg["voxel_scale"])
+        thres = 5 * cfg["voxel_scale"]
+        me = Mesher(m, max_triangles=20000, tsdf_surface_thres=thres)
         me.generate_mesh(1)
         n = int(me.num_facelets[None])
-        tri = np.concatenate([me.mesh_vertices.to_numpy()[:n * 3].reshape(n, 9), me.mesh_normals.to_numpy()[:n * 3].reshape(n, 9)], axis=1).astype(np.float32)
-        res["mesh"] = tri[np.lexsort(tri.view(np.uint32).T[::-1])]
-        res["mesh_thres"] = np.float32(5 * cfg["voxel_scale"])
+        cols = [me.mesh_vertices.to_numpy()[:n * 3].reshape(n, 9), me.mesh_normals.to_numpy()[:n * 3].reshape(n, 9)]
+        if cfg.get("texture_enabled"):
+            cols.append(me.mesh_colors.to_numpy()[:n * 3].reshape(n, 9))
+        res["mesh"], res["mesh_thres"] = canon_rows(*cols), np.float32(thres)
         print(f"  mesh: {n} triangles, {time.time() - t0:.1f} s")
+        # the particle exports: cvt_TSDF_surface_to_voxels (dense_tsdf.py:339-366) and cvt_TSDF_to_voxels_slice (:368-391); rows in a canonical order
+        m.cvt_TSDF_surface_to_voxels()
+        ns = int(m.num_TSDF_particles[None])
+        assert ns < m.max_disp_particles
+        res["surface"] = canon_rows(m.export_TSDF_xyz.to_numpy()[:ns], m.export_color.to_numpy()[:ns])
+        m.cvt_TSDF_to_voxels_slice(0.17, 1.5)
+        nz = int(m.num_TSDF_particles[None])
+        assert nz < m.max_disp_particles
+        res["slice"] = canon_rows(m.export_TSDF_xyz.to_numpy()[:nz], m.export_TSDF.to_numpy()[:nz], m.export_color.to_numpy()[:nz])
+        res["slice_args"] = np.array([0.17, 1.5], np.float64)
+        # BaseMap.raycast (mapping_common.py:159-173), the planner's query: rays from the last camera position into the scene
+        last = [s for s in steps if s["kind"] == "depth"][-1]
+        rng = np.random.default_rng(3)
+        d = rng.normal(size=(24, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pos = np.tile(np.asarray(m.input_T[None].to_list(), dtype=np.float64).astype(np.float32), (24, 1)) + rng.uniform(-0.05, 0.05, size=(24, 3)).astype(np.float32)
+        hit, end, ln = [], [], []
+        for a, b in zip(pos, d.astype(np.float32)):
+            succ, x_, _len = m.raycast(ti.Vector([float(a[0]), float(a[1]), float(a[2])], ti.f32), ti.Vector([float(b[0]), float(b[1]), float(b[2])], ti.f32), 3.0)
+            hit.append(bool(succ)); end.append([float(e.v) for e in x_]); ln.append(float(_len.v))
+        res["ray_pos"], res["ray_dir"], res["ray_max"] = pos.astype(np.float32), d.astype(np.float32), np.float32(3.0)
+        res["ray_hit"], res["ray_end"], res["ray_len"] = np.array(hit), np.array(end, np.float32), np.array(ln, np.float32)
+        print(f"  surface {ns} particles, slice {nz}, rays hit {sum(hit)} of {len(hit)}")
     return res
 
 
