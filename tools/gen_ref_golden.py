@@ -190,7 +190,8 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
 
 def run_octomap(Octomap):
     """taichi_octomap.py: two depth frames and a point cloud into the occupancy tree; the leaves (index, count) are read from the stand-in's
-    storage (the reference's Octomap exports nothing but display particles)"""
+    storage (the reference's Octomap exports nothing but display particles).  Its fuse_submaps is not part of the vector: untextured it
+    stops with AttributeError ('Octomap' object has no attribute 'color', taichi_octomap.py:198), textured its result is a last-writer race."""
     from taichislam_amd.utils import synthetic as syn
     rng = np.random.default_rng(7)
     h, w = 30, 40
