@@ -300,3 +300,103 @@ def test_hip_exports_and_raycast_reproduce_the_reference_source(hip_lib):
     hit, end, ln = m.raycast(want["ray_pos"], want["ray_dir"], float(want["ray_max"]))
     assert np.array_equal(np.asarray(hit, bool), want["ray_hit"]) and np.array_equal(np.asarray(end, np.float32).view(np.uint32), want["ray_end"].view(np.uint32))
     assert np.array_equal(np.asarray(ln, np.float32).view(np.uint32), want["ray_len"].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------------------------ a whole session (submap_mapping.py)
+class OraMap:
+    """The oracle behind the slice of the DenseTSDF surface that SubmapMapping drives (FAITHFUL everywhere)."""
+
+    def __init__(self, **kw):
+        from oracle import OracleTSDF
+        kw = dict(kw)
+        self.max_disp_particles = kw.pop("max_disp_particles", 1 << 20)
+        self.kw = kw
+        self.o = OracleTSDF(**kw)
+        self.enable_texture = bool(kw.get("texture_enabled", False))
+        self.max_submap_num = kw.get("max_submap_num", 1024)
+        self.remote = 0
+        self.export_color = self.export_TSDF_xyz = self.num_TSDF_particles = None
+        self.clear_last_TSDF_exporting = False
+
+    def set_dep_camera_intrinsic(self, K): self.o.set_intrinsics(K, K)
+    def set_color_camera_intrinsic(self, K): pass
+    def get_active_submap_id(self): return self.o.get_active_submap()
+    def set_base_pose_submap(self, sid, R, T): self.o.set_base_pose_submap(int(sid), np.asarray(R, np.float64), np.asarray(T, np.float64))
+    def saveMap(self, filename): pass
+    def finalization_current_submap(self): pass
+
+    def switch_to_next_submap(self):
+        self.o.set_active_submap(self.o.get_active_submap() + 1)
+        return self.o.get_active_submap()
+
+    def recast_depth_to_map(self, R, T, depth, texture):
+        from oracle import FAITHFUL
+        self.o.integrate_depth(R, T, depth, None, mode=FAITHFUL)
+
+    def fuse_submaps(self, submaps):
+        from oracle import FAITHFUL
+        self.o.fuse_submaps(submaps.o, mode=FAITHFUL)
+
+    def export_submap(self):
+        e = self.o.export_sparse()
+        return {"indices": e["indices"], "TSDF": e["TSDF"], "W_TSDF": e["W_TSDF"], "color": np.array([]), "occupy": e["occupy"],
+                "map_scale": [self.kw["map_scale"][0], self.kw["map_scale"][1]], "voxel_scale": self.kw["voxel_scale"], "texture_enabled": False,
+                "num_voxel_per_blk_axis": self.kw.get("num_voxel_per_blk_axis", 16)}
+
+    def input_remote_submap(self, submap):                     # dense_tsdf.py:499-516
+        self.remote += 1
+        idx = self.max_submap_num - self.remote
+        self.o.import_sparse(idx, submap["indices"], submap["TSDF"], submap["W_TSDF"], submap["occupy"])
+        self.set_base_pose_submap(idx, *submap["pose"])
+        return idx
+
+
+def _session(map_cls, SM):
+    import submap_trace as st
+    z = np.load(os.path.join(GOLD, "ref_session.npz"))
+    p = json.loads(str(z["params"]))
+    saved = st.H, st.W, st.OPTS
+    st.H, st.W, st.OPTS = p["H"], p["W"], dict(p["OPTS"])
+    try:
+        assert (st.NFRAMES, st.KEYFRAME_STEP) == (p["NFRAMES"], p["KEYFRAME_STEP"])
+        sm, sent = st.drive(SM, map_cls)
+        smb = SM(map_cls, keyframe_step=st.KEYFRAME_STEP, sub_opts=dict(st.OPTS), global_opts=dict(st.OPTS))
+        smb.map_send_handle = smb.traj_send_handle = lambda b: None
+        for buf in sent:
+            smb.input_remote_submap(buf)
+    finally:
+        st.H, st.W, st.OPTS = saved
+    return z, sm.global_map, smb.global_map
+
+
+def test_the_reference_orchestration_on_the_reference_maps_is_reproduced_by_the_package_on_the_oracle():
+    """tests/golden/ref_session.npz: the reference's submap_mapping.py driving the reference's DenseTSDF (all of it run on tools/ti_seq) through eight frames,
+    three submaps, a pose-graph update, local_to_global, and a second agent fed from the wire.  The package's SubmapMapping on the FAITHFUL oracle ends with
+    the same two global maps, bit for bit: poses through convert_by_pgo / convert_by_base, the export -> zlib -> load_numpy path, slots from the top for
+    remote submaps, fusion in struct-for order."""
+    from taichislam_amd.mapping.submap_mapping import SubmapMapping
+    z, ga, gb = _session(OraMap, SubmapMapping)
+    for tag, g in (("A", ga), ("B", gb)):
+        got = sorted_bits(g.export_submap())
+        want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}
+        assert want["indices"].shape[0] > 20000
+        assert_bits_equal(got, want, f"agent {tag}'s global map")
+
+
+@pytest.mark.gpu
+def test_the_reference_session_on_the_hip_maps(hip_lib):
+    """The same session through the package's SubmapMapping on the HIP maps (default, order-free path): both agents' global maps hold exactly the reference's
+    voxels; values within the band of the order-free sums against the literal replay."""
+    from taichislam_amd.mapping import DenseTSDF
+    from taichislam_amd.mapping.submap_mapping import SubmapMapping
+    z, ga, gb = _session(DenseTSDF, SubmapMapping)
+    for tag, g in (("A", ga), ("B", gb)):
+        got = sorted_bits(g.export_submap())
+        want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}
+        assert np.array_equal(got["indices"], want["indices"]), f"agent {tag}: voxel sets differ"
+        assert np.array_equal(got["occupy"], want["occupy"])
+        t_g, t_w = got["TSDF"].view(np.float16).astype(np.float64), want["TSDF"].view(np.float16).astype(np.float64)
+        fin = np.isfinite(t_g) & np.isfinite(t_w)
+        assert fin.mean() > 0.999 and not (np.isnan(t_g) & ~np.isnan(t_w)).any()
+        d = np.abs(t_g - t_w)[fin]
+        assert np.percentile(d, 50) <= 0.02 * 0.08 and np.percentile(d, 99) <= 0.6 * 0.08, np.percentile(d, [50, 99])

@@ -224,6 +224,41 @@ def run_octomap(Octomap):
     return cfg, K, steps, res
 
 
+SESSION = dict(H=48, W=64, OPTS=dict(map_scale=[10.24, 10.24], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=5.0, max_submap_num=16, max_disp_particles=64))
+
+
+def run_session(DenseTSDF, Octomap):
+    """The reference's ORCHESTRATION on the reference's maps: taichi_slam/mapping/submap_mapping.py (loaded by path, unmodified; only its hard-coded
+    autosave path is turned off) drives eight depth frames through tests/submap_trace.drive -- a new submap every three keyframes, finished submaps
+    exported and put on the wire, a pose-graph update, local_to_global -- and a second agent receives the wire buffers (input_remote_submap:
+    zlib + np.load, load_numpy into a slot from the top, fuse).  Committed: both agents' global maps."""
+    import io
+    import zlib
+    import submap_trace as st
+    from test_reference_callers import load_reference_submap_mapping
+    import taichi_slam.mapping.mapping_common as mc
+    st.H, st.W, st.OPTS = SESSION["H"], SESSION["W"], dict(SESSION["OPTS"])
+    RefSM = load_reference_submap_mapping(DenseTSDF, Octomap, mc.BaseMap)
+    t0 = time.time()
+    sm, sent = st.drive(RefSM, DenseTSDF)
+    a = sorted_export(sm.global_map.export_submap())
+    print(f"session: agent A global map {a['indices'].shape[0]} voxels, {len(sent)} submaps sent, {time.time() - t0:.1f} s")
+    smb = RefSM(DenseTSDF, keyframe_step=st.KEYFRAME_STEP, sub_opts=dict(st.OPTS), global_opts=dict(st.OPTS))
+    smb.map_send_handle = lambda b: None
+    smb.traj_send_handle = lambda b: None
+    smb.saveMap = lambda filename: None
+    for buf in sent:
+        smb.input_remote_submap(buf)
+    b = sorted_export(smb.global_map.export_submap())
+    print(f"session: agent B (received {len(sent)} submaps) global map {b['indices'].shape[0]} voxels, {time.time() - t0:.1f} s")
+    res = {"A_" + k: v for k, v in a.items()}
+    res.update({"B_" + k: v for k, v in b.items()})
+    res["params"] = np.array(json.dumps({"H": st.H, "W": st.W, "OPTS": st.OPTS, "NFRAMES": st.NFRAMES, "KEYFRAME_STEP": st.KEYFRAME_STEP}))
+    path = os.path.join(ROOT, "tests", "golden", "ref_session.npz")
+    np.savez_compressed(path, **res)
+    print(f"  -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def save(name, cfg, K, Kc, steps, res):
     arrays = {"cfg": np.array(json.dumps(cfg)), "K": np.asarray(K), "Kc": np.asarray(K if Kc is None else Kc), "has_Kc": np.array(Kc is not None),
               "steps": np.array(json.dumps([{k: (None if isinstance(v, np.ndarray) else v) for k, v in s.items()} for s in steps]))}
@@ -250,3 +285,5 @@ if __name__ == "__main__":
     if not only or "octomap" in only:
         cfg, K, steps, res = run_octomap(Octomap)
         save("octomap", cfg, K, None, steps, res)
+    if not only or "session" in only:
+        run_session(DenseTSDF, Octomap)
