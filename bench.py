@@ -177,6 +177,25 @@ def sequential_leg(dev, frames, oracle_map):
                     "(dense_tsdf.py:264-267) -- a legal schedule of the racy reference, equal to the sequential CPU replay on every TSDF / W bit"}
 
 
+def reference_source_leg(dev):
+    """tests/golden/ref_*.npz -- what the reference's OWN source produces when run on the sequential Taichi stand-in of tools/ti_seq (generated on the dev
+    box by tools/gen_ref_golden.py; the reference tree is not needed here).  Checked live: the oracle's FAITHFUL mode and the HIP path with semantics = 1
+    against the three untextured integration vectors, bit for bit.  (The whole set, fusion / Octomap / mesh / exports / session included: tests/test_ref_golden.py.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import test_ref_golden as tr
+    from oracle import FAITHFUL
+    names, ora_ok, hip_ok, voxels = ["depth_stream", "point_clouds", "weight_clamp"], [], [], 0
+    for name in names:
+        cfg, K, Kc, steps, want = tr.load(name)
+        keys = ("indices", "TSDF", "W_TSDF", "occupy")
+        same = lambda got: all(got[k].shape == want[k].shape and np.array_equal(got[k], want[k]) for k in keys)
+        ora_ok.append(bool(same(tr.replay(lambda over: tr._Ora({**cfg, **over}, K, Kc), steps, K, Kc, {"mode": FAITHFUL}, None))))
+        hip_ok.append(bool(same(tr.replay(lambda over: tr._Hip({**cfg, **over, "device": dev}, K, Kc, 1), steps, K, Kc, {}, None))))
+        voxels += int(want["indices"].shape[0])
+    return {"vectors": names, "voxels": voxels, "oracle_FAITHFUL_bit_exact": all(ora_ok), "hip_semantics_1_bit_exact": all(hip_ok),
+            "note": "golden maps made by the reference's dense_tsdf.py + mapping_common.py, imported unmodified and run on tools/ti_seq (not by Taichi itself)"}
+
+
 def relaunch(args):
     """--gpus N > 1 from a bare shell: one rank per GPU under torch.distributed.run on this node."""
     import socket
@@ -483,6 +502,10 @@ def main():
                 out["value_sequential"] = sequential_leg(dev, sample[:n_done], omap)
             except Exception as e:
                 out["value_sequential"] = {"error": repr(e)[:200]}
+            try:
+                out["reference_source_vectors"] = reference_source_leg(dev)
+            except Exception as e:
+                out["reference_source_vectors"] = {"error": repr(e)[:200]}
         emit(out)
     if merge_timed_out:
         sys.stderr.write("bench.py: merge leg timed out; leaving without further collectives\n"); real_stdout.flush()
