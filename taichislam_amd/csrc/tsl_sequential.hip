@@ -12,7 +12,9 @@
 //     k_seq_order   rays -> (struct-for key, ray id), radix sort (rocPRIM)            => rank of every ray
 //     k_seq_expand  every (ray, step) -> tuple  key = brick pool index | voxel | rank | step,  value = { w, signed distance } (f32 bits)
 //     radix sort of the tuples (rocPRIM)                                              => per voxel: its updates in replay order
-//     k_seq_apply   one thread per voxel run: the updates applied one after the other in f16, exactly :264-267
+//     k_seq_apply   one thread per voxel run: the updates applied one after the other in f16, exactly :264-267; on a textured map the
+//                   voxel takes the colour of the LAST ray of its run (:268-269: every step stores its ray's colour) -- the tuple then
+//                   carries the ray id instead of the weight, which is read back from the ray record
 //   Updates of different voxels commute, so sorting by voxel first and by replay order inside a voxel reproduces the sequential map.
 //   The chain of the voxel next to the sensor (every ray of the frame passes through it) is what bounds a frame: ~27 k dependent updates.
 #include "tsl_tsdf.hpp"
@@ -33,6 +35,7 @@ __global__ void __launch_bounds__(256) k_seq_order(FrameDev F, unsigned long lon
 }
 
 // one thread per ray, in replay order: its steps become tuples (dense_tsdf.py:251-260, the arithmetic of step_voxel / step_term)
+template <bool TEX>
 __global__ void __launch_bounds__(256) k_seq_expand(MapDev M, FrameDev F, const FrameParams* __restrict__ Pp, const uint32_t* __restrict__ ray_of_rank,
                                                     unsigned long long* tkeys, unsigned long long* tvals, long long cap, unsigned long long* counter)
 {
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(256) k_seq_expand(MapDev M, FrameDev F, const 
                 const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
                 const float sd = dist * (float)sgn_f(dot);                                                              // :260
                 key = ((unsigned long long)cur_p << SEQ_POOL_SHIFT) | ((unsigned long long)l << SEQ_VOX_SHIFT) | ((unsigned long long)i << SEQ_RANK_SHIFT) | (unsigned long long)j;
-                val = ((unsigned long long)__float_as_uint(w) << 32) | (unsigned long long)__float_as_uint(sd);
+                val = ((unsigned long long)(TEX ? (uint32_t)r : __float_as_uint(w)) << 32) | (unsigned long long)__float_as_uint(sd);
             }
         }
         tkeys[base + (unsigned long long)(j - 1)] = key;
@@ -81,6 +84,7 @@ __global__ void __launch_bounds__(256) k_seq_pad(unsigned long long* tkeys, cons
 }
 
 // one thread per tuple; the head of a voxel's run applies the whole run in order  (dense_tsdf.py:264-267)
+template <bool TEX>
 __global__ void __launch_bounds__(256) k_seq_apply(MapDev M, FrameDev F, const unsigned long long* __restrict__ tkeys, const unsigned long long* __restrict__ tvals,
                                                    const unsigned long long* __restrict__ counter, long long cap)
 {
@@ -95,16 +99,19 @@ __global__ void __launch_bounds__(256) k_seq_apply(MapDev M, FrameDev F, const u
             const size_t v = (size_t)(k >> SEQ_POOL_SHIFT) * TSL_BRK3 + (size_t)((k >> SEQ_VOX_SHIFT) & 4095ull);
             const uint32_t old = M.tw[v];
             h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
+            uint32_t last_ray = 0u;
             for (long long q = i; q < total; ++q) {
                 if ((tkeys[q] >> SEQ_VOX_SHIFT) != run) break;
                 const unsigned long long tv = tvals[q];
-                const float w = __uint_as_float((uint32_t)(tv >> 32)), sd = __uint_as_float((uint32_t)tv);
+                if (TEX) last_ray = (uint32_t)(tv >> 32);
+                const float w = __uint_as_float(TEX ? F.rayA[last_ray].w : (uint32_t)(tv >> 32)), sd = __uint_as_float((uint32_t)tv);
                 const h16 Tn = f2h((h2f(hmul(T0, W0)) + w * sd) / (h2f(W0) + w));                                       // :264
                 float wn = h2f(W0) + w; if (TSL_WMAX < wn) wn = TSL_WMAX;                                               // :267
                 T0 = Tn; W0 = f2h(wn);
             }
             M.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16);
             M.obs[v] = 1;                                                                                               // :265
+            if (TEX) reinterpret_cast<uint2*>(M.col)[v] = F.colpix[F.rayFirst[last_ray]];                               // :268-269, the run's last writer
             M.touch[k >> SEQ_POOL_SHIFT] = 1;
         }
     }
@@ -123,7 +130,7 @@ __global__ void __launch_bounds__(256) k_seq_cleanup(FrameDev F)
 // phase B of one frame, sequential semantics; enqueued on the main stream behind the frame's phase A
 int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P)
 {
-    TSL_REQUIRE(B.n == 1 && P.group && P.variant == 2 && !P.tex, "sequential semantics: one untextured frame at a time on the hash-grouped brick path");
+    TSL_REQUIRE(B.n == 1 && P.group && P.variant == 2, "sequential semantics: one frame at a time on the hash-grouped brick path");
     const FrameDev& F = B.f[0];
     hipStream_t q = m->stream_;
     const size_t np = (size_t)m->F.max_points;
@@ -152,7 +159,8 @@ int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P
     TSL_HIP(rocprim::radix_sort_pairs(m->seq_temp, tb, rk, rk_s, rv, rv_s, np, 0u, 64u, q));
     // 2. tuples, 3. their replay order per voxel, 4. apply
     TSL_HIP(hipMemsetAsync(m->seq_ctr, 0, 64, q));
-    hipLaunchKernelGGL(k_seq_expand, dim3(blocks), dim3(256), 0, q, m->M, F, B.p[0], (const uint32_t*)rv_s, m->seq_keys[0], m->seq_vals[0], m->seq_cap, m->seq_ctr);
+    if (P.tex) hipLaunchKernelGGL(k_seq_expand<true>, dim3(blocks), dim3(256), 0, q, m->M, F, B.p[0], (const uint32_t*)rv_s, m->seq_keys[0], m->seq_vals[0], m->seq_cap, m->seq_ctr);
+    else hipLaunchKernelGGL(k_seq_expand<false>, dim3(blocks), dim3(256), 0, q, m->M, F, B.p[0], (const uint32_t*)rv_s, m->seq_keys[0], m->seq_vals[0], m->seq_cap, m->seq_ctr);
     // the tuple count is on the device as well: sort what the frame could have produced at most -- bounded by the frame's own statistics
     // on the host side is not possible without a round trip, so the sort length is fixed by a cheap upper bound: rays <= visited pixels,
     // steps per ray <= max_steps; unused entries keep the key ~0 from the previous fill and sort to the end
@@ -162,8 +170,10 @@ int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P
     hipLaunchKernelGGL(k_seq_pad, dim3(1024), dim3(256), 0, q, m->seq_keys[0], m->seq_ctr, bound);
     tb = m->seq_temp_bytes;
     TSL_HIP(rocprim::radix_sort_pairs(m->seq_temp, tb, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], (size_t)bound, 0u, 64u, q));
-    hipLaunchKernelGGL(k_seq_apply, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, q, m->M, F, (const unsigned long long*)m->seq_keys[1], (const unsigned long long*)m->seq_vals[1],
-                       (const unsigned long long*)m->seq_ctr, bound);
+    if (P.tex) hipLaunchKernelGGL(k_seq_apply<true>, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, q, m->M, F, (const unsigned long long*)m->seq_keys[1], (const unsigned long long*)m->seq_vals[1],
+                                  (const unsigned long long*)m->seq_ctr, bound);
+    else hipLaunchKernelGGL(k_seq_apply<false>, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, q, m->M, F, (const unsigned long long*)m->seq_keys[1], (const unsigned long long*)m->seq_vals[1],
+                            (const unsigned long long*)m->seq_ctr, bound);
     hipLaunchKernelGGL(k_seq_cleanup, dim3(16), dim3(256), 0, q, F);
     TSL_HIP(hipGetLastError());
     return TSL_OK;

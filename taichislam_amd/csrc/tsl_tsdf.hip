@@ -1455,7 +1455,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "semantics")) {
         TSL_REQUIRE(value == 0 || value == 1, "semantics must be 0 (batched exact sums) or 1 (sequential replay of the reference)");
-        TSL_REQUIRE(value == 0 || (!m->cfg.texture_enabled && m->M.max_bricks <= (1 << 17)), "sequential semantics: untextured maps with at most 2^17 bricks");
+        TSL_REQUIRE(value == 0 || m->M.max_bricks <= (1 << 17), "sequential semantics: maps with at most 2^17 bricks");
         int rc = tsl_tsdf_sync(m); if (rc) return rc;
         m->semantics = value; m->P.seq = value; return TSL_OK;
     }

@@ -132,7 +132,7 @@ class _Hip:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["depth_stream", "point_clouds", "weight_clamp"])
+@pytest.mark.parametrize("name", ["depth_stream", "point_clouds", "weight_clamp", "textured"])
 def test_hip_sequential_mode_reproduces_the_reference_source_bit_for_bit(hip_lib, name):
     cfg, K, Kc, steps, want = load(name)
     got = replay(lambda over: _Hip({**cfg, **over}, K, Kc, 1), steps, K, Kc, {}, None)
@@ -220,23 +220,32 @@ def test_oracle_mesh_reproduces_the_reference_source_bit_for_bit():
     assert np.array_equal(_canon(v, n).view(np.uint32), want["mesh"].view(np.uint32))
 
 
-@pytest.mark.gpu
-def test_hip_mesh_reproduces_the_reference_source_bit_for_bit(hip_lib):
-    from taichislam_amd.mapping import DenseTSDF, MarchingCubeMesher
-    cfg, K, _, steps, want = load("depth_stream")
-    m = DenseTSDF(**cfg)
+def _hip_map(name, **extra):
+    from taichislam_amd.mapping import DenseTSDF
+    cfg, K, Kc, steps, want = load(name)
+    m = DenseTSDF(**cfg, **extra)
     m.set_dep_camera_intrinsic(K)
+    m.set_color_camera_intrinsic(Kc if Kc is not None else K)
     m.set_option("semantics", 1)
     for s in steps:
         if s["kind"] == "base":
             m.set_base_pose_submap(s["sid"], s["R"], s["T"])
         else:
-            m.recast_depth_to_map(s["R"], s["T"], s["depth"], None)
+            m.recast_depth_to_map(s["R"], s["T"], s["depth"], s.get("texture"))
+    return cfg, m, want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["depth_stream", "textured"])
+def test_hip_mesh_reproduces_the_reference_source_bit_for_bit(hip_lib, name):
+    from taichislam_amd.mapping import MarchingCubeMesher
+    cfg, m, want = _hip_map(name)
     me = MarchingCubeMesher(m, 20000, tsdf_surface_thres=float(want["mesh_thres"]))
     me.generate_mesh(1)
-    v, n, _ = me.get_mesh()
+    v, n, c = me.get_mesh()
     assert me.num_facelets[None] == want["mesh"].shape[0]
-    assert np.array_equal(_canon(v, n).view(np.uint32), want["mesh"].view(np.uint32))
+    cols = [v.reshape(-1, 9), n.reshape(-1, 9)] + ([c.reshape(-1, 9)] if cfg.get("texture_enabled") else [])
+    assert np.array_equal(_rows(*cols).view(np.uint32), want["mesh"].view(np.uint32))
 
 
 # ------------------------------------------------------------------------------------------------------------------ exports, raycast, coloured mesh
@@ -276,18 +285,10 @@ def test_oracle_exports_raycast_and_mesh_reproduce_the_reference_source(name):
 
 
 @pytest.mark.gpu
-def test_hip_exports_and_raycast_reproduce_the_reference_source(hip_lib):
-    """The HIP map of semantics = 1 is the reference's map bit for bit; so are its particle exports and ray casts."""
-    from taichislam_amd.mapping import DenseTSDF
-    cfg, K, _, steps, want = load("depth_stream")
-    m = DenseTSDF(**cfg, max_disp_particles=40000)
-    m.set_dep_camera_intrinsic(K)
-    m.set_option("semantics", 1)
-    for s in steps:
-        if s["kind"] == "base":
-            m.set_base_pose_submap(s["sid"], s["R"], s["T"])
-        else:
-            m.recast_depth_to_map(s["R"], s["T"], s["depth"], None)
+@pytest.mark.parametrize("name", ["depth_stream", "textured"])
+def test_hip_exports_and_raycast_reproduce_the_reference_source(hip_lib, name):
+    """The HIP map of semantics = 1 is the reference's map bit for bit (colours included); so are its particle exports and ray casts."""
+    cfg, m, want = _hip_map(name, max_disp_particles=40000)
     m.cvt_TSDF_surface_to_voxels()
     n = m.num_TSDF_particles[None]
     xyz, rgb, _ = m._read_exports(n)
