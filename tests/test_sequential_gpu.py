@@ -71,3 +71,29 @@ def test_sequential_mode_points_crowded_voxels_and_out_of_volume_rays(hip_lib):
         assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
         assert so["v_skipped"] >= 1 and so["steps_oob"] >= 0
     assert_export_equal(g.export_submap(), o.export_sparse(), "sequential, point input")
+
+
+def test_sequential_mode_textured_equals_faithful(hip_lib):
+    """Colour under the sequential semantics: every ray step stores its ray's colour (dense_tsdf.py:268-269), so a voxel ends a frame with the colour of
+    the last ray of its replay run.  Four 120 x 160 frames with random textures, the point-cloud form with colours as well: map and colours == FAITHFUL."""
+    from oracle import FAITHFUL
+    rng = np.random.default_rng(5)
+    cfg = dict(SMALL, texture_enabled=True)
+    K, frames = small_stream(4)
+    g, o = make_pair(cfg, K)
+    g.set_option("semantics", 1)
+    for R, T, d in frames:
+        tex = rng.integers(0, 256, size=d.shape + (3,), dtype=np.uint8)
+        g.recast_depth_to_map(R, T, d, tex)
+        so = o.integrate_depth(R, T, d, tex, mode=FAITHFUL)
+        sg = g.last_frame_stats()
+        assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    R, T = syn.camera_pose(3)
+    dd = rng.normal(size=(4000, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    pts = (dd * rng.uniform(0.3, 4.0, size=(4000, 1))).astype(np.float32)
+    rgb = rng.integers(0, 256, size=(4000, 3), dtype=np.uint8)
+    g.recast_pcl_to_map(R, T, pts, rgb)
+    o.integrate_points(R, T, pts, rgb, mode=FAITHFUL)
+    e = g.export_submap()
+    assert e["color"].shape[0] == e["TSDF"].shape[0] > 100000 and (np.asarray(e["color"]).view(np.uint16) != 0).any()
+    assert_export_equal(e, o.export_sparse(), "sequential, textured")
