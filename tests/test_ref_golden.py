@@ -403,3 +403,19 @@ def test_the_reference_session_on_the_hip_maps(hip_lib):
         assert fin.mean() > 0.6 and (np.isnan(t_g) & ~np.isnan(t_w)).sum() <= 1e-4 * t_g.size
         d = np.abs(t_g - t_w)[fin]
         assert np.percentile(d, 50) <= 0.02 * 0.08 and np.percentile(d, 99) <= 0.6 * 0.08, np.percentile(d, [50, 99])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/taichi_slam/mapping/submap_mapping.py"), reason="needs the reference tree (dev box)")
+def test_the_reference_orchestration_itself_on_the_oracle_maps():
+    """The third side of the triangle, where the reference tree exists: the REFERENCE's submap_mapping.py (loaded by path, unmodified) driving the oracle-backed
+    maps ends with the same two global maps as the reference's orchestration on the reference's maps (the vector) and as the package's orchestration on the
+    oracle (the test above)."""
+    from test_reference_callers import load_reference_submap_mapping
+
+    class _Base:            # (the reference module imports BaseMap only for annotations)
+        pass
+    RefSM = load_reference_submap_mapping(OraMap, type("NoOcto", (), {}), _Base)
+    z, ga, gb = _session(OraMap, RefSM)
+    for tag, g in (("A", ga), ("B", gb)):
+        want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}
+        assert_bits_equal(sorted_bits(g.export_submap()), want, f"reference orchestration on the oracle, agent {tag}")
