@@ -419,3 +419,31 @@ def test_the_reference_orchestration_itself_on_the_oracle_maps():
     for tag, g in (("A", ga), ("B", gb)):
         want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}
         assert_bits_equal(sorted_bits(g.export_submap()), want, f"reference orchestration on the oracle, agent {tag}")
+
+
+def _octo_textured(o, z, depth_fn, export):
+    o.set_base_pose_submap(0, np.eye(3), np.zeros(3))
+    depth_fn(z["out_tex_R"], z["out_tex_T"], z["out_tex_depth"], z["out_tex_texture"])
+    idx, cnt, rgb = export()
+    order = np.argsort(lin(idx), kind="stable")
+    assert np.array_equal(idx[order].astype(np.int16), z["out_tex_indices"]) and np.array_equal(cnt[order].astype(np.float32).view(np.uint32), z["out_tex_occupy"].view(np.uint32))
+    assert np.array_equal(rgb[order].astype(np.float32).view(np.uint32), z["out_tex_color"].view(np.uint32)), "leaf colours (last writer, BGR -> RGB, / 255)"
+
+
+def test_oracle_textured_octomap_reproduces_the_reference_source():
+    from oracle import OracleOctomap
+    cfg, K, _, _, _ = load("octomap")
+    z = np.load(os.path.join(GOLD, "ref_octomap.npz"))
+    o = OracleOctomap(**{**cfg, "texture_enabled": True})
+    o.set_intrinsics(K, K)
+    _octo_textured(o, z, lambda R, T, d, t: o.integrate_depth(R, T, d, t), lambda: o.export_leaves(with_color=True))
+
+
+@pytest.mark.gpu
+def test_hip_textured_octomap_reproduces_the_reference_source(hip_lib):
+    from taichislam_amd.mapping import Octomap
+    cfg, K, _, _, _ = load("octomap")
+    z = np.load(os.path.join(GOLD, "ref_octomap.npz"))
+    o = Octomap(**{**cfg, "texture_enabled": True})
+    o.set_dep_camera_intrinsic(K); o.set_color_camera_intrinsic(K)
+    _octo_textured(o, z, lambda R, T, d, t: o.recast_depth_to_map(R, T, d, t), lambda: o.export_leaves(with_color=True))

@@ -211,15 +211,30 @@ def run_octomap(Octomap):
     Rp = np.array([[0.0, -1.0, 0], [1.0, 0, 0], [0, 0, 1.0]]); Tp = np.array([0.05, 0.1, -0.02])
     m.recast_pcl_to_map(Rp, Tp, pts, np.zeros((1, 3), np.uint8), pts.shape[0])
     steps.append(dict(kind="pcl", R=Rp, T=Tp, xyz=pts))
-    cells = []
-    for b, blk in m.B.blocks.items():
-        a = blk[id(m.occupy)]
-        for c in np.argwhere(a != 0):
-            idx = [bb * s_ + o + cc for bb, s_, o, cc in zip(b, m.B.blk, m.B.offset, c)]
-            assert idx[0] == 0
-            cells.append((idx[1], idx[2], idx[3], float(a[tuple(c)])))
-    cells.sort()
+    def leaves(o, colour=False):
+        cells = []
+        for b, blk in o.B.blocks.items():
+            a = blk[id(o.occupy)]
+            for c in np.argwhere(a != 0):
+                idx = [bb * s_ + off + cc for bb, s_, off, cc in zip(b, o.B.blk, o.B.offset, c)]
+                assert idx[0] == 0
+                cells.append((idx[1], idx[2], idx[3], float(a[tuple(c)])) + (tuple(float(x) for x in blk[id(o.color)][tuple(c)]) if colour else ()))
+        cells.sort()
+        return cells
+    cells = leaves(m)
     res = {"indices": np.array([c[:3] for c in cells], np.int16), "occupy": np.array([c[3] for c in cells], np.float32)}
+    # the textured tree: colours are stored per point, last writer, channels swapped (taichi_octomap.py:118-121); one frame, so that the
+    # last writer of a leaf is the last pixel in raster order whichever way the tree is walked
+    mt = Octomap(**{**cfg, "texture_enabled": True}, max_disp_particles=64)
+    mt.set_dep_camera_intrinsic(K); mt.set_color_camera_intrinsic(K)
+    mt.set_base_pose_submap(0, np.eye(3), np.zeros(3))
+    R, T = syn.camera_pose(2, orbit=0.2)
+    depth = syn.sphere_room_depth(R, T, h, w, radius=1.6, K=K)
+    tex = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    mt.recast_depth_to_map(R, T, depth, tex)
+    ct = leaves(mt, True)
+    res.update({"tex_R": R, "tex_T": T, "tex_depth": depth, "tex_texture": tex, "tex_indices": np.array([c[:3] for c in ct], np.int16),
+                "tex_occupy": np.array([c[3] for c in ct], np.float32), "tex_color": np.array([c[4:] for c in ct], np.float32)})
     print(f"octomap: {len(cells)} leaves, {time.time() - t0:.1f} s")
     return cfg, K, steps, res
 
