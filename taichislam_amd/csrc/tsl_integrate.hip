@@ -1083,8 +1083,12 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
 // part to arrive (round 2's ticket scheme: 25-33 us per brick on the critical path of the persistent kernel, plus an L2 atomic pair per
 // voxel and part).
 // =====================================================================================================
+#ifndef APPLY_SPLIT
 #define APPLY_SPLIT 8
+#endif
+#ifndef APPLY_ROUND
 #define APPLY_ROUND 2
+#endif
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_apply_slab(MapDev M, BatchDev B)
 {
