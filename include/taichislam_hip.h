@@ -254,7 +254,7 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame
                 integrated on arrival; full batches form by themselves when the producer outruns the device), 0 (default) = a batch is
                 issued when it is full -- half full for the first two batches after the pipeline ran dry -- or when anything reads the map
-     "ramp"     short batches issued after the pipeline ran dry before full ones are waited for (default 1: a 20-frame burst runs as 4 + 8 + 8; 18.5 k against 18.3 k frames/s with 2), "ramp_size" their length (default 4)
+     "ramp"     short batches issued after the pipeline ran dry before full ones are waited for (default 2; with 1 a 20-frame burst runs as 4 + 8 + 8: 18.5 k against 18.3 k frames/s in an A/B, inside the box-to-box spread, while the launches of the burst get longer per frame), "ramp_size" their length (default 4)
      "group"    1 (default) = hash grouping of the pixels of a sensor voxel, 0 = stable radix sort
      "split"    lanes per ray (divides 64; the brick-binned path uses at most 8), default 2
      "wg"       threads per workgroup of the brick integrate kernel: 512 (default) or 256 (two workgroups per CU)

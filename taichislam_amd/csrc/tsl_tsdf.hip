@@ -895,7 +895,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 1; m->ramp_size = 4; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
     // (unit_half >= unit: the middle tier of k_plan is off by default -- measured neutral-to-negative once the brick kernel runs on 75 % of the slots)
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
