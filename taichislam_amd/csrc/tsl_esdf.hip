@@ -696,7 +696,10 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     // phase A of frames queued from now on allocates bricks (pool counter, table entry, owner -- in that order): it starts after the
     // snapshot + collect, so that every pool index below the snapshot has its owner written (launch_batch_t waits for the gate).  The gate
     // is the collect kernel's own completion (an event recorded behind it costs a marker packet and ~6 us before the next kernel starts)
-    hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0);
+    // Beside the next frame (q != q0) ONE event serves both purposes, the completion of the init kernel: phase A has slack there -- the update is
+    // the longer chain -- and every event attached to a dispatch costs the update ~5 us before its next kernel starts.
+    if (q == q0) { hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_gate; }
+    else { hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_read; }
     m->esdf_gate_set = true;
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
     if (q != q0) {

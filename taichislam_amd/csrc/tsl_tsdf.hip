@@ -568,7 +568,7 @@ static int launch_batch_t(tsl_tsdf* m)
         if (m->ring_upto[ring] > m->frames_consumed) m->frames_consumed = m->ring_upto[ring];
     }
     if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
-    if (!serial && m->esdf_gate_set) { TSL_HIP(hipStreamWaitEvent(sa, m->esdf_gate, 0)); m->esdf_gate_set = false; }      // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip)
+    if (!serial && m->esdf_gate_set) { TSL_HIP(hipStreamWaitEvent(sa, m->esdf_gate_ev, 0)); m->esdf_gate_set = false; }      // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip)
     for (int k = 0; k < m->nproducers; ++k) {       // device inputs: phase A waits for what their producers had queued (tsl_tsdf_input_stream)
         if (m->producers[k] == sa) continue;
         // nothing pending on the producer: no wait.  (Not only a saving: an event recorded on an idle stream still lands in the hardware
@@ -903,7 +903,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; m->esdf_gate = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));

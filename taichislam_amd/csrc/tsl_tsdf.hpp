@@ -217,7 +217,7 @@ struct tsl_tsdf {
     float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq, *esdf_nbr; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
     float *esdf_exp_xyz, *esdf_exp_val; int* esdf_exp_count; int esdf_exp_n;      // export_ESDF_xyz / export_ESDF / num_export_ESDF_particles (dense_esdf.py:498-509), allocated by the first slice
     bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
-    hipEvent_t esdf_gate; bool esdf_gate_set;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
+    hipEvent_t esdf_gate, esdf_gate_ev; bool esdf_gate_set;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
     hipEvent_t esdf_in, esdf_read, esdf_last;      // option "esdf_overlap": the relaxation rounds of update n run beside the integration of frame n + 1.
                                                    // esdf_in: the TSDF an update starts from; esdf_read: the update has read it; esdf_last: the latest update
     bool esdf_overlap; int esdf_ctr_idx;
