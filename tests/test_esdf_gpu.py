@@ -158,3 +158,31 @@ def test_updates_beside_the_next_frames_integration_equal_serial_full_recomputes
     # and the TSDF itself is untouched by the overlap
     from util import assert_export_equal
     assert_export_equal(inc.export_submap(), ref.export_submap(), "TSDF beside overlapped ESDF updates")
+
+
+def test_updates_follow_the_active_submap(hip_lib):
+    """The ESDF belongs to the active submap: after switch_to_next_submap the next update recomputes everything for the new submap (enqueued-only
+    updates of the old one still in flight beside the frames), and equals what a handle that only ever saw the new submap's frames computes."""
+    from taichislam_amd.mapping import DenseTSDF
+    K, frames = small_stream(6)
+    a = DenseTSDF(**SMALL); b = DenseTSDF(**SMALL)
+    for m in (a, b):
+        m.set_dep_camera_intrinsic(K)
+    eye, zero = np.eye(3), np.zeros(3)
+    a.set_base_pose_submap(0, eye, zero)
+    for R, T, d in frames[:3]:
+        a.recast_depth_to_map(R, T, d, None)
+        assert a.update_esdf(max_dist=0.5, wait=False) is None
+    a.switch_to_next_submap()
+    a.set_base_pose_submap(1, eye, zero)
+    b.switch_to_next_submap()
+    b.set_base_pose_submap(1, eye, zero)
+    for R, T, d in frames[3:]:
+        a.recast_depth_to_map(R, T, d, None)
+        assert a.update_esdf(max_dist=0.5, wait=False) is None
+        b.recast_depth_to_map(R, T, d, None)
+        b.update_esdf(max_dist=0.5)
+    (ai, ae), (bi, be) = _esdf_sorted(a), _esdf_sorted(b)
+    assert ai.shape[0] > 10000 and np.array_equal(ai, bi) and np.array_equal(ae, be)
+    ta = a.esdf_totals()
+    assert ta["updates"] == 6 and ta["incremental"] == 4          # the first update of each submap is a full one
