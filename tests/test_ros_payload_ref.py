@@ -60,3 +60,15 @@ def test_pointcloud2_payload_equals_the_reference_helper(has_rgb):
         (mine["height"], mine["width"], mine["is_dense"], mine["is_bigendian"], mine["point_step"], mine["row_step"])
     assert [(f.name, f.offset, f.datatype, f.count) for f in msg.fields] == [(f["name"], f["offset"], f["datatype"], f["count"]) for f in mine["fields"]]
     assert bytes(msg.data) == mine["data"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scripts/taichislam_node.py"), reason="needs the reference tree (dev box)")
+def test_every_name_the_reference_node_uses_on_the_maps_exists_in_the_shims():
+    """scripts/taichislam_node.py drives the map, the mesher and the submap orchestration through these attributes / methods; a drop-in must have them all."""
+    import re
+    src = open("/root/reference/scripts/taichislam_node.py").read()
+    used = set(re.findall(r"(?:self\.mapping|mapping|self\.mesher|mesher)\.([A-Za-z_][A-Za-z0-9_]*)", src))
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "taichislam_amd", "mapping")
+    mine = "".join(open(os.path.join(root, f)).read() for f in os.listdir(root) if f.endswith(".py"))
+    missing = [n for n in sorted(used) if not re.search(r"\b" + re.escape(n) + r"\b", mine)]
+    assert len(used) >= 20 and not missing, missing
