@@ -17,7 +17,7 @@ import pytest
 from util import lin
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["depth_stream", "point_clouds", "textured", "weight_clamp", "two_submaps_fused", "aligned_submap_fused"]
+NAMES = ["depth_stream", "point_clouds", "textured", "textured_points", "weight_clamp", "two_submaps_fused", "aligned_submap_fused"]
 FUSED = ("two_submaps_fused", "aligned_submap_fused")
 
 
@@ -87,7 +87,7 @@ class _Ora:
         if kind == "depth":
             self.o.integrate_depth(s["R"], s["T"], s["depth"], s.get("texture"), mode=mode)
         else:
-            self.o.integrate_points(s["R"], s["T"], s["xyz"], None, mode=mode)
+            self.o.integrate_points(s["R"], s["T"], s["xyz"], s.get("rgb"), mode=mode)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -128,11 +128,11 @@ class _Hip:
         if kind == "depth":
             self.m.recast_depth_to_map(s["R"], s["T"], s["depth"], s.get("texture"))
         else:
-            self.m.recast_pcl_to_map(s["R"], s["T"], s["xyz"], np.array([]))
+            self.m.recast_pcl_to_map(s["R"], s["T"], s["xyz"], s["rgb"] if s.get("rgb") is not None else np.array([]))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["depth_stream", "point_clouds", "weight_clamp", "textured"])
+@pytest.mark.parametrize("name", ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points"])
 def test_hip_sequential_mode_reproduces_the_reference_source_bit_for_bit(hip_lib, name):
     cfg, K, Kc, steps, want = load(name)
     got = replay(lambda over: _Hip({**cfg, **over}, K, Kc, 1), steps, K, Kc, {}, None)

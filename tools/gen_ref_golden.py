@@ -91,6 +91,14 @@ def scenarios():
         depth = syn.sphere_room_depth(R, T, h, w, radius=1.6, K=K)
         fr.append(dict(kind="depth", R=R, T=T, depth=depth, texture=rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)))
     out.append(("textured", cfg, K, K, fr))
+    # 3b. coloured point clouds (recast_pcl_to_map with rgb_array: the colours are cast to f16 before they are summed, dense_tsdf.py:176-181)
+    cfgp = dict(map_scale=[5.12, 5.12], voxel_scale=0.05, num_voxel_per_blk_axis=16, max_ray_length=2.4, min_ray_length=0.3, internal_voxels=5, recast_step=2, max_submap_num=4, texture_enabled=True)
+    frp = [dict(kind="base", sid=0, R=eye, T=zero)]
+    for f in range(2):
+        d = rng.normal(size=(220, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts = np.concatenate([d * rng.uniform(0.3, 2.2, size=(220, 1)), np.array([[0.4, -0.3, 0.6]]) + rng.uniform(-0.04, 0.04, size=(60, 3))]).astype(np.float32)
+        frp.append(dict(kind="pcl", R=eye, T=np.array([0.02 * f, 0.01, 0.0]), xyz=pts, rgb=rng.integers(0, 256, size=(pts.shape[0], 3), dtype=np.uint8)))
+    out.append(("textured_points", cfgp, syn.scaled_intrinsics(30, 40), syn.scaled_intrinsics(30, 40), frp))
     # 4. the weight clamp: a wall 0.35 m in front of a fixed camera, 14 frames -- w = 1 / z^2 = 8 per ray, W reaches Wmax = 1000 inside the run
     h, w = 24, 32
     K = syn.scaled_intrinsics(h, w)
@@ -139,7 +147,7 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
         elif s["kind"] == "depth":
             m.recast_depth_to_map(s["R"], s["T"], s["depth"], s.get("texture", np.zeros((1, 1, 3), np.uint8)))
         elif s["kind"] == "pcl":
-            m.recast_pcl_to_map(s["R"], s["T"], s["xyz"], np.zeros((1, 3), np.uint8))
+            m.recast_pcl_to_map(s["R"], s["T"], s["xyz"], s.get("rgb", np.zeros((1, 3), np.uint8)))
         elif s["kind"] == "next_submap":
             m.switch_to_next_submap()
         elif s["kind"] == "fuse":
