@@ -247,8 +247,10 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "variant"  0|1: one global int64 atomic pair per ray step, 2 (default): brick-binned LDS accumulation
      "semantics" 0 (default): a frame's contributions to a voxel are summed exactly and applied once (order-free, oracle mode BATCHED);
                 1: the reference-literal SEQUENTIAL replay of dense_tsdf.py:236-270 -- rays in Taichi's struct-for order, every ray step an f16
-                read-modify-write with the W clamp, colours by last writer -- bit-exact with oracle FAITHFUL and with the maps the reference's own
-                source produces on tools/ti_seq (tests/golden/ref_*.npz); one frame per batch, ~180 frames/s at 512^3; maps of at most 2^17 bricks
+                read-modify-write with the W clamp, colours by last writer; on a GLOBAL map: tsl_tsdf_fuse_submaps replays fuse_submaps_kernel
+                (dense_tsdf.py:272-318) the same way, submap cells in struct-for order, corners in loop order -- bit-exact with oracle FAITHFUL and
+                with the maps the reference's own source produces on tools/ti_seq (tests/golden/ref_*.npz); one frame per batch, ~180 frames/s at
+                512^3; maps of at most 2^17 bricks
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 8; three batch slots: phase A of up to two
                 batches is in flight beside phase B of a third)
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame

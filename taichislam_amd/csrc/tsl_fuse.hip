@@ -6,7 +6,8 @@
 // weighted running average voxel by voxel in a racy read-modify-write; here the contributions {w*t, w} are summed in
 // exact 2^-24 fixed point (int64 atomics) plus a contribution/occupancy count, and the average is formed once per
 // voxel -- order-free, so N GPUs that each splat their own submaps and all-reduce(sum) the three arrays produce the
-// same bits as one GPU fusing everything (tsl_tsdf_fuse_accumulate_dev / _finalize_dev).
+// same bits as one GPU fusing everything (tsl_tsdf_fuse_accumulate_dev / _finalize_dev).  With option "semantics" = 1 on the global map
+// tsl_tsdf_fuse_submaps instead replays the reference's running average literally, splat by splat (tsl_sequential.hip).
 #include "tsl_tsdf.hpp"
 
 namespace tsl {
@@ -153,6 +154,14 @@ int tsl_tsdf_fuse_submaps(tsl_tsdf* g, tsl_tsdf* sub)
     TSL_REQUIRE(g->device == sub->device, "fuse_submaps: maps live on different devices");
     TSL_HIP(hipSetDevice(g->device));
     int ndst = 0;
+    if (g->semantics == 1) {      // the reference-literal sequential fusion (tsl_sequential.hip): same reset, same pose table, then tuples instead of sums
+        int rc = tsl_tsdf_sync(sub); if (rc) return rc;
+        rc = tsl_tsdf_reset(g); if (rc && rc != TSL_ERR_CAPACITY) return rc;
+        if ((rc = upload_poses(g, sub))) return rc;
+        int nsrc = 0; if ((rc = used_bricks(sub, &nsrc))) return rc;
+        if (nsrc > 0 && (rc = fuse_submaps_sequential(g, sub, g->pose_dev, nsrc))) return rc;
+        return tsl_tsdf_sync(g);
+    }
     int rc = fuse_splat_into_global(g, sub, &ndst, true); if (rc) return rc;
     unsigned long long* cacc = (g->M.col && sub->M.col) ? (unsigned long long*)g->fuse_cacc : nullptr;
     if (ndst > 0) hipLaunchKernelGGL(k_fuse_finalize, dim3(ndst < 8192 ? ndst : 8192), dim3(256), 0, ms(g), g->M, ndst,

@@ -179,4 +179,169 @@ int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P
     return TSL_OK;
 }
 
+// =====================================================================================================================================
+// Option "semantics" = 1 on a GLOBAL map: the reference-literal SEQUENTIAL fusion, fuse_submaps_kernel / fuse_with_interploation
+// (dense_tsdf.py:272-318).  The reference walks every cell of every submap and, for seven of the eight surrounding global voxels, does an
+// unsynchronised f16 read-modify-write of the running weighted average (:274-280); splats race.  The sequential schedule -- submap cells in
+// struct-for order (submap, brick lexicographic, cell row-major), the seven corners in loop order -- is what the CPU checker's FAITHFUL fusion
+// and tools/ti_seq execute.  Here: every splat becomes a tuple  key = global brick | global voxel | sequence number (rank of the source brick
+// among the submaps' bricks by owner, cell, corner),  value = { w_tsdf, tsdf, occupancy };  radix sort;  one thread per global voxel applies
+// its run in order.  (The default fusion, tsl_fuse.hip, sums the same terms exactly and divides once: order-free, the multi-GPU merge rests on it.)
+// =====================================================================================================================================
+struct PoseTabS { const float* p; };
+#define FSEQ_GP_SHIFT 44          // key: global pool brick (17 bits) | voxel (12) | source brick rank (17) | source cell (12) | corner (3)
+#define FSEQ_GL_SHIFT 32
+
+__global__ void __launch_bounds__(256) k_fseq_order(MapDev S, int nused, unsigned long long* keys, uint32_t* vals)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < nused) { keys[p] = (unsigned long long)(uint32_t)S.owner[p]; vals[p] = (uint32_t)p; }
+}
+
+__global__ void __launch_bounds__(256) k_fseq_expand(MapDev S, MapDev G, PoseTabS poses, float vs, int nused, int npose, const uint32_t* __restrict__ brick_of_rank,
+                                                     unsigned long long* tkeys, unsigned long long* tvals, unsigned long long cap, unsigned long long* counter)
+{
+    for (int r = blockIdx.x; r < nused; r += gridDim.x) {
+        const int p = (int)brick_of_rank[r];
+        const int owner = S.owner[p];
+        const int s = owner / S.nb3, b = owner - s * S.nb3;
+        if (s >= npose) continue;
+        const float* Rp = poses.p + (size_t)s * 12;
+        float R[9], T[3];
+        for (int a = 0; a < 9; ++a) R[a] = Rp[a];
+        for (int a = 0; a < 3; ++a) T[a] = Rp[9 + a];
+        const int bk = b % S.nbz, bj = (b / S.nbz) % S.nbx, bi = b / (S.nbz * S.nbx);
+        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
+            const int l = l0 + (int)threadIdx.x;
+            const size_t v = (size_t)p * TSL_BRK3 + l;
+            const bool on = S.obs[v] > 0;                                                       // :292
+            unsigned long long key[7], val[7]; int n = 0;
+            if (on) {
+                const int i = bi * 16 + (l >> 8) - S.hN, j = bj * 16 + ((l >> 4) & 15) - S.hN, k = bk * 16 + (l & 15) - S.hNz;
+                const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;
+                float f[3]; int lo[3];
+                for (int a = 0; a < 3; ++a) {
+                    const float x = ((R[a * 3] * p0 + R[a * 3 + 1] * p1) + R[a * 3 + 2] * p2) + T[a];      // :293
+                    f[a] = x / vs; lo[a] = (int)floorf(f[a]);                                     // :294-296
+                }
+                const uint32_t tw = S.tw[v];
+                const float wsrc = h2f((h16)(tw >> 16));
+                const uint32_t occ = (uint32_t)(uint8_t)S.occ[v];
+                for (int c = 1; c < 8; ++c) {                                                    // :297-300 (corner 0 skipped), di, dj, dk in loop order
+                    const int ci = lo[0] + ((c >> 2) & 1), cj = lo[1] + ((c >> 1) & 1), ck = lo[2] + (c & 1);
+                    const float wt = ((1.0f - fabsf((float)ci - f[0])) * (1.0f - fabsf((float)cj - f[1]))) * (1.0f - fabsf((float)ck - f[2]));   // :303
+                    const float w_tsdf = wsrc * wt;                                              // :307
+                    if (!in_volume(G, ci, cj, ck)) continue;
+                    int gl; const int gb = brick_of(G, ci, cj, ck, &gl);
+                    const int gp = pool_claim<false>(G, 0, gb);
+                    if (gp < 0) continue;
+                    key[n] = ((unsigned long long)gp << FSEQ_GP_SHIFT) | ((unsigned long long)gl << FSEQ_GL_SHIFT) | ((unsigned long long)r << 15) | ((unsigned long long)l << 3) | (unsigned long long)c;
+                    val[n] = ((unsigned long long)__float_as_uint(w_tsdf) << 32) | ((unsigned long long)(tw & 0xffffu) << 8) | (unsigned long long)occ;
+                    ++n;
+                }
+            }
+            // wave-aggregated append (the order of the tuples in memory does not matter: the sort puts them in replay order)
+            int inc = n;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane_id() >= d) inc += o; }
+            const int tot = __shfl(inc, 63);
+            unsigned long long base = 0ull;
+            if (tot) {
+                if (lane_id() == 63) base = __hip_atomic_fetch_add(counter, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = __shfl(base, 63);
+            }
+            const unsigned long long at = base + (unsigned long long)(inc - n);
+            for (int t = 0; t < n; ++t) if (at + t < cap) { tkeys[at + t] = key[t]; tvals[at + t] = val[t]; }
+        }
+    }
+}
+
+// one thread per tuple; the head of a global voxel's run applies the whole run in order  (fuse_with_interploation :272-280)
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_fseq_apply(MapDev S, MapDev G, const unsigned long long* __restrict__ tkeys, const unsigned long long* __restrict__ tvals,
+                                                    const uint32_t* __restrict__ brick_of_rank, long long total)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const unsigned long long k = tkeys[i];
+    if (i != 0 && (tkeys[i - 1] >> FSEQ_GL_SHIFT) == (k >> FSEQ_GL_SHIFT)) return;
+    const unsigned long long run = k >> FSEQ_GL_SHIFT;
+    const size_t v = (size_t)(k >> FSEQ_GP_SHIFT) * TSL_BRK3 + (size_t)((k >> FSEQ_GL_SHIFT) & 4095ull);
+    const uint32_t old = G.tw[v];
+    h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
+    int8_t occ = G.occ[v];
+    h16 col[3] = { 0, 0, 0 };
+    if (TEX) { const uint2 c = reinterpret_cast<const uint2*>(G.col)[v]; col[0] = (h16)(c.x & 0xffffu); col[1] = (h16)(c.x >> 16); col[2] = (h16)(c.y & 0xffffu); }
+    for (long long q = i; q < total; ++q) {
+        const unsigned long long kq = tkeys[q];
+        if ((kq >> FSEQ_GL_SHIFT) != run) break;
+        const unsigned long long tv = tvals[q];
+        const float w_tsdf = __uint_as_float((uint32_t)(tv >> 32)), tsdf = h2f((h16)((tv >> 8) & 0xffffull));
+        const float w_new = w_tsdf + h2f(W0);                                                                              // :273
+        if (TEX) {                                                                                                          // :276-277 (with the old W)
+            const size_t sv = (size_t)brick_of_rank[(kq >> 15) & 0x1ffffull] * TSL_BRK3 + (size_t)((kq >> 3) & 4095ull);
+            const uint2 sc = reinterpret_cast<const uint2*>(S.col)[sv];
+            const h16 c1[3] = { (h16)(sc.x & 0xffffu), (h16)(sc.x >> 16), (h16)(sc.y & 0xffffu) };
+            for (int a = 0; a < 3; ++a) col[a] = f2h((h2f(hmul(W0, col[a])) + w_tsdf * h2f(c1[a])) / w_new);
+        }
+        T0 = f2h((h2f(hmul(W0, T0)) + w_tsdf * tsdf) / w_new);                                                             // :274
+        W0 = f2h(w_new);                                                                                                    // :278
+        occ = (int8_t)(occ + (int8_t)(tv & 0xffull));                                                                       // :280
+    }
+    G.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16);
+    G.obs[v] = 1;                                                                                                           // :279
+    G.occ[v] = occ;
+    if (TEX) reinterpret_cast<uint2*>(G.col)[v] = make_uint2((uint32_t)col[0] | ((uint32_t)col[1] << 16), (uint32_t)col[2]);
+    G.touch[k >> FSEQ_GP_SHIFT] = 1;
+}
+
+// tsl_tsdf_fuse_submaps with semantics = 1 on the global map (called after the reset and the pose upload)
+int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, int nsrc)
+{
+    TSL_REQUIRE(nsrc <= (1 << 17) && g->M.max_bricks <= (1 << 17), "sequential fusion: at most 2^17 bricks on either side");
+    hipStream_t q = ms(g);
+    int rc;
+    const unsigned long long cap = (unsigned long long)nsrc * TSL_BRK3 * 7ull;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = grow(&g->fseq_keys[k], &g->fseq_bytes[k], 8 * (size_t)cap + 8 * (size_t)nsrc + 64))) return rc;
+        if ((rc = grow(&g->fseq_vals[k], &g->fseq_vbytes[k], 8 * (size_t)cap + 8 * (size_t)nsrc + 64))) return rc;
+    }
+    size_t ta = 0, tb = 0;
+    TSL_HIP(rocprim::radix_sort_pairs(nullptr, ta, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)cap, 0u, 64u, q));
+    TSL_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)nsrc, 0u, 32u, q));
+    if ((rc = grow(&g->fseq_temp, &g->fseq_tbytes, (ta > tb ? ta : tb) + 256))) return rc;
+    if (!g->fseq_ctr) { if ((rc = dev_alloc(g, (void**)&g->fseq_ctr, 64, 0))) return rc; }
+    // 1. the submaps' bricks in struct-for order: by owner = submap * bricks per submap + brick index
+    unsigned long long* bk = (unsigned long long*)g->fseq_keys[0]; unsigned long long* bk_s = (unsigned long long*)g->fseq_keys[1];
+    uint32_t* bv = (uint32_t*)g->fseq_vals[0]; uint32_t* bv_s = (uint32_t*)g->fseq_vals[1];
+    hipLaunchKernelGGL(k_fseq_order, dim3((nsrc + 255) / 256), dim3(256), 0, q, sub->M, nsrc, bk, bv);
+    size_t tmp = g->fseq_tbytes;
+    TSL_HIP(rocprim::radix_sort_pairs(g->fseq_temp, tmp, bk, bk_s, bv, bv_s, (size_t)nsrc, 0u, 32u, q));
+    // the rank -> brick table must outlive the tuple buffers it shares memory with: it is kept behind them
+    uint32_t* rank_tab = (uint32_t*)((char*)g->fseq_vals[0] + 8 * (size_t)cap);
+    TSL_HIP(hipMemcpyAsync(rank_tab, bv_s, 4 * (size_t)nsrc, hipMemcpyDeviceToDevice, q));
+    // 2. every splat as a tuple, 3. replay order per global voxel, 4. apply
+    TSL_HIP(hipMemsetAsync(g->fseq_ctr, 0, 64, q));
+    PoseTabS pt = { pose_dev };
+    prof_begin(g, TSL_K_FUSE);
+    hipLaunchKernelGGL(k_fseq_expand, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, q, sub->M, g->M, pt, g->P.vs, nsrc, g->npose, (const uint32_t*)rank_tab,
+                       (unsigned long long*)g->fseq_keys[0], (unsigned long long*)g->fseq_vals[0], cap, (unsigned long long*)g->fseq_ctr);
+    unsigned long long count = 0;
+    TSL_HIP(hipMemcpyAsync(&count, g->fseq_ctr, 8, hipMemcpyDeviceToHost, q));
+    TSL_HIP(hipStreamSynchronize(q));
+    TSL_REQUIRE(count <= cap, "sequential fusion: tuple buffer overflow");
+    if (count) {
+        tmp = g->fseq_tbytes;
+        TSL_HIP(rocprim::radix_sort_pairs(g->fseq_temp, tmp, (unsigned long long*)g->fseq_keys[0], (unsigned long long*)g->fseq_keys[1], (unsigned long long*)g->fseq_vals[0],
+                                          (unsigned long long*)g->fseq_vals[1], (size_t)count, 0u, 64u, q));
+        const unsigned blocks = (unsigned)((count + 255) / 256);
+        if (g->M.col && sub->M.col) hipLaunchKernelGGL(k_fseq_apply<true>, dim3(blocks), dim3(256), 0, q, sub->M, g->M, (const unsigned long long*)g->fseq_keys[1],
+                                                        (const unsigned long long*)g->fseq_vals[1], (const uint32_t*)rank_tab, (long long)count);
+        else hipLaunchKernelGGL(k_fseq_apply<false>, dim3(blocks), dim3(256), 0, q, sub->M, g->M, (const unsigned long long*)g->fseq_keys[1],
+                                (const unsigned long long*)g->fseq_vals[1], (const uint32_t*)rank_tab, (long long)count);
+    }
+    prof_end(g);
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+
 }  // namespace tsl

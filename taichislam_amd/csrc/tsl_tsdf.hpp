@@ -169,6 +169,7 @@ struct SetPtrs { FrameParams* p[TSL_NB]; int* header[TSL_NB]; };        // k_set
 struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending, a_recorded; };
 #define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
+int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, int nsrc);      // tsl_sequential.hip
 int esdf_finish(tsl_tsdf* m);            // tsl_esdf.hip: wait for the ESDF updates in flight (repairing one that stopped early)
 void esdf_release(tsl_tsdf* m);
 }  // namespace tsl
@@ -221,6 +222,7 @@ struct tsl_tsdf {
     hipEvent_t esdf_in, esdf_read, esdf_last;      // option "esdf_overlap": the relaxation rounds of update n run beside the integration of frame n + 1.
                                                    // esdf_in: the TSDF an update starts from; esdf_read: the update has read it; esdf_last: the latest update
     bool esdf_overlap; int esdf_ctr_idx;
+    void *fseq_keys[2], *fseq_vals[2], *fseq_temp; size_t fseq_bytes[2], fseq_vbytes[2], fseq_tbytes; void* fseq_ctr;      // sequential fusion (tsl_sequential.hip)
     EsdfSlot esdf_slot[TSL_ESDF_SLOTS]; int esdf_tail, esdf_npend, esdf_rounds_seen, esdf_round_cap; bool esdf_short; tsl_esdf_totals_t esdf_tot;   // updates in flight (tsl_esdf.hip)
     // profiling
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;

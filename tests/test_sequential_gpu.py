@@ -97,3 +97,40 @@ def test_sequential_mode_textured_equals_faithful(hip_lib):
     e = g.export_submap()
     assert e["color"].shape[0] == e["TSDF"].shape[0] > 100000 and (np.asarray(e["color"]).view(np.uint16) != 0).any()
     assert_export_equal(e, o.export_sparse(), "sequential, textured")
+
+
+def test_sequential_fusion_textured_equals_faithful(hip_lib):
+    """semantics = 1 on a global map: fuse_submaps replays the reference's racy running average sequentially (submap cells in struct-for order, the seven
+    corners in loop order, colours before TSDF with the old weight).  Two textured 120 x 160 submaps with tilted base poses: the fused map, colours included,
+    == the FAITHFUL fusion of the FAITHFUL submaps, bit for bit (NaN bit patterns included); fusing twice gives the same map."""
+    from oracle import FAITHFUL, OracleTSDF
+    from taichislam_amd.mapping import DenseTSDF
+    from util import sort_export
+    rng = np.random.default_rng(9)
+    cfg = dict(SMALL, texture_enabled=True, max_submap_num=8)
+    K, frames = small_stream(4)
+    g, o = make_pair(cfg, K)
+    g.set_option("semantics", 1)
+
+    def tilt(R, a):
+        return R @ np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    bases = [(tilt(frames[0][0], 0.13), frames[0][1] + np.array([0.011, -0.007, 0.003])), (tilt(frames[2][0], -0.21), frames[2][1] + np.array([-0.02, 0.013, 0.017]))]
+    for sid, fr in ((0, frames[:2]), (1, frames[2:])):
+        g.set_base_pose_submap(sid, *bases[sid]); o.set_base_pose_submap(sid, *bases[sid])
+        for R, T, d in fr:
+            tex = rng.integers(0, 256, size=d.shape + (3,), dtype=np.uint8)
+            g.recast_depth_to_map(R, T, d, tex); o.integrate_depth(R, T, d, tex, mode=FAITHFUL)
+        g.switch_to_next_submap(); o.set_active_submap(sid + 1)
+    gcfg = dict(cfg, is_global_map=True)
+    gg, og = DenseTSDF(**gcfg), OracleTSDF(**gcfg)
+    gg.set_option("semantics", 1)
+    for sid in (0, 1):
+        gg.set_base_pose_submap(sid, *bases[sid]); og.set_base_pose_submap(sid, *bases[sid])
+    og.fuse_submaps(o, mode=FAITHFUL)
+    eo = sort_export(og.export_sparse())
+    for _ in range(2):
+        gg.fuse_submaps(g)
+        eg = sort_export(gg.export_submap())
+        assert eg["indices"].shape[0] > 50000 and np.array_equal(eg["indices"], eo["indices"])
+        for k in ("TSDF", "W_TSDF", "occupy", "color"):
+            assert np.array_equal(eg[k], eo[k]), k
