@@ -180,17 +180,18 @@ def sequential_leg(dev, frames, oracle_map):
 def reference_source_leg(dev):
     """tests/golden/ref_*.npz -- what the reference's OWN source produces when run on the sequential Taichi stand-in of tools/ti_seq (generated on the dev
     box by tools/gen_ref_golden.py; the reference tree is not needed here).  Checked live: the oracle's FAITHFUL mode and the HIP path with semantics = 1
-    against the five integration vectors (depth stream, point clouds, weight clamp, depth + colour, coloured point clouds), bit for bit.  (The whole set, fusion / Octomap / mesh / exports / session included: tests/test_ref_golden.py.)"""
+    against the five integration vectors (depth stream, point clouds, weight clamp, depth + colour, coloured point clouds) and the two fused global maps
+    (tilted and axis-aligned base poses), bit for bit.  (The whole set, fusion / Octomap / mesh / exports / session included: tests/test_ref_golden.py.)"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
     import test_ref_golden as tr
     from oracle import FAITHFUL
-    names, ora_ok, hip_ok, voxels = ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points"], [], [], 0
+    names, ora_ok, hip_ok, voxels = ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points", "two_submaps_fused", "aligned_submap_fused"], [], [], 0
     for name in names:
         cfg, K, Kc, steps, want = tr.load(name)
         keys = ("indices", "TSDF", "W_TSDF", "occupy") + (("color",) if "color" in want else ())
         same = lambda got: all(got[k].shape == want[k].shape and np.array_equal(got[k], want[k]) for k in keys)
-        ora_ok.append(bool(same(tr.replay(lambda over: tr._Ora({**cfg, **over}, K, Kc), steps, K, Kc, {"mode": FAITHFUL}, None))))
-        hip_ok.append(bool(same(tr.replay(lambda over: tr._Hip({**cfg, **over, "device": dev}, K, Kc, 1), steps, K, Kc, {}, None))))
+        ora_ok.append(bool(same(tr.replay(lambda over: tr._Ora({**cfg, **over}, K, Kc), steps, K, Kc, {"mode": FAITHFUL}, lambda g, m: g.o.fuse_submaps(m.o, mode=FAITHFUL)))))
+        hip_ok.append(bool(same(tr.replay(lambda over: tr._Hip({**cfg, **over, "device": dev}, K, Kc, 1), steps, K, Kc, {}, lambda g, m: g.m.fuse_submaps(m.m)))))
         voxels += int(want["indices"].shape[0])
     return {"vectors": names, "voxels": voxels, "oracle_FAITHFUL_bit_exact": all(ora_ok), "hip_semantics_1_bit_exact": all(hip_ok),
             "note": "golden maps made by the reference's dense_tsdf.py + mapping_common.py, imported unmodified and run on tools/ti_seq (not by Taichi itself)"}
