@@ -475,3 +475,34 @@ def test_the_reference_session_on_the_hip_maps_with_the_literal_semantics(hip_li
     for tag, g in (("A", ga), ("B", gb)):
         want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}
         assert_bits_equal(sorted_bits(g.export_submap()), want, f"agent {tag}'s global map, literal semantics on the GPU")
+
+
+# ------------------------------------------------------------------------------------------------------------------ provenance of the vectors
+@pytest.mark.skipif(not os.path.exists("/root/reference/taichi_slam/mapping/dense_tsdf.py"), reason="needs the reference tree (dev box)")
+def test_committed_vectors_regenerate_from_the_reference_source():
+    """Where the reference tree exists (the dev box, the driver's CPU tier): run the generator again for two of the vectors -- the reference's dense_tsdf.py /
+    taichi_octomap.py imported unmodified and executed on tools/ti_seq, ~12 s -- and compare with the committed files.  The vectors are what that source produces."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(root, 'tools')!r})\n"
+        "import gen_ref_golden as G\n"
+        "D, O = G.load_reference()\n"
+        "name, cfg, K, Kc, steps = [x for x in G.scenarios() if x[0] == 'weight_clamp'][0]\n"
+        "res = G.run(D, name, cfg, K, Kc, steps)\n"
+        "_, _, _, oc = G.run_octomap(O)\n"
+        "np.savez(sys.argv[1], **{'w_' + k: v for k, v in res.items()}, **{'o_' + k: v for k, v in oc.items()})\n")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "regen.npz")
+        r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, timeout=600)          # a process of its own: `import taichi` must not leak
+        assert r.returncode == 0, r.stderr[-2000:]
+        z = np.load(out)
+        w = np.load(os.path.join(GOLD, "ref_weight_clamp.npz"))
+        o = np.load(os.path.join(GOLD, "ref_octomap.npz"))
+        for k in ("indices", "TSDF", "W_TSDF", "occupy"):
+            assert np.array_equal(z["w_" + k], w["out_" + k]), k
+        for k in ("indices", "occupy", "tex_indices", "tex_occupy", "tex_color"):
+            assert np.array_equal(z["o_" + k], o["out_" + k]), k
