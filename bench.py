@@ -490,7 +490,7 @@ def main():
         if dry:
             out["dry_run"] = {"as_rank": rank, "of": world, "note": "single-process dry run of the multi-rank branch: this rank's stream offset, submap id and pose table, "
                               "merge leg without a communicator; `value` is this rank's rate alone, n_gpus is the simulated world size"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # the CPU legs: rank 0 at N = 1 only (the other ranks of a multi-GPU run would wait at the barrier)
             sample = [(R, T, d) for R, T, d in host[: max(8, min(len(host), 200))]]
             one, allc, omap, n_done = cpu_baselines(sample)
             out["cpu_baseline"] = one
