@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     __shared__ int s_bin[64];
     __shared__ int s_claim[2];
     __shared__ int s_uq[TSL_NB];                                // distinct voxels this workgroup updated, per frame of the batch
-    __shared__ int s_cum[NRANGE + 1];                           // first rank of every range of the work list (class-major: units, frame 0, 1, ...)
+    __shared__ int s_cum[NRANGE + 1];                           // first rank of every range of the work list (units by class, then parts by class and frame)
     __shared__ int s_it[3][IT_WORDS];
     uint32_t okmask = 0u;
 #pragma unroll
@@ -767,10 +767,19 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     if (threadIdx.x < TSL_NB) s_uq[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         int acc = 0, k = 0;
+#ifdef TSL_CLASS_MAJOR        // developer A/B: the first order of the list
         for (int c = 0; c < PLAN_NCLS; ++c) {
             s_cum[k++] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap);
             for (int q = 0; q < TSL_NB; ++q) { s_cum[k++] = acc; if ((okmask >> q) & 1u) acc += min(B.f[q].counters[HDR_PARTS + c], B.f[q].part_cap); }
         }
+#else
+        // ALL units first (long to short), then all parts (long to short): a unit is a chain of up to eight frame steps with ~4 us of fixed cost
+        // each -- a unit of 600 segments takes 45 us, a part of 3 000 segments 26 -- so ranking the items by segments alone left the light units
+        // for the end of the launch, where each of them added its whole chain to the span
+        for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[k++] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
+        for (int c = 0; c < PLAN_NCLS; ++c)
+            for (int q = 0; q < TSL_NB; ++q) { s_cum[k++] = acc; if ((okmask >> q) & 1u) acc += min(B.f[q].counters[HDR_PARTS + c], B.f[q].part_cap); }
+#endif
         s_cum[NRANGE] = acc;
         s_claim[0] = __hip_atomic_fetch_add(&B.f[0].counters[HDR_CLAIM], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -782,7 +791,11 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
         int k = 0;
 #pragma unroll
         for (int j = 1; j < NRANGE; ++j) k += r >= uni(s_cum[j]) ? 1 : 0;
+#ifdef TSL_CLASS_MAJOR
         const int local = r - uni(s_cum[k]), cls = k / (TSL_NB + 1), sub = k - cls * (TSL_NB + 1);
+#else
+        const int local = r - uni(s_cum[k]), cls = k < PLAN_NCLS ? k : (k - PLAN_NCLS) / TSL_NB, sub = k < PLAN_NCLS ? 0 : 1 + (k - PLAN_NCLS) % TSL_NB;
+#endif
         *kq = sub - 1;
         if (sub == 0) return B.f[0].unit_tab[(size_t)cls * B.f[0].unit_cap + local];
         const FrameDev& Fq = B.f[sub - 1];
