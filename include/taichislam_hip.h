@@ -268,7 +268,13 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "unit_half" bricks with more segments per batch than this (and at most "unit") are walked half as a unit (their first frames) and half as
                 parts (their later frames): halves the longest serial chain of a launch; >= "unit" disables the middle tier
      "chunks"   steps a part may hold (1..8, default 4)
-     "bgrid"    resident phase-B workgroups in percent of the slots (wg 256 only; default 100)
+     "bgrid"    resident workgroups of the brick kernel in percent of the slots (default 75: the rest is left to phase A of the next batch)
+     "split_launch" 1 = full batches of the overlapped pipeline launch the brick kernel twice: the PARTS of the heavy bricks (they read
+                their frame's rays and write slab slots of their own, never the map) on the batch's phase-A stream, beside the previous
+                batch's phase B, and the UNITS + k_apply_slab on the handle's stream; 0 (default) = one launch over the whole work list.
+                Measured slower (27 k against 30 k frames/s): the brick kernel is bound by the SIMDs' issue rate, two launches side by side
+                slow each other by more than the shorter chain saves
+     "ugrid" / "pgrid" resident workgroups of the units / parts launch in percent of the slots (defaults 75 / 25)
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
      "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)
      "esdf_overlap" 1 (default) = an update's kernels run on one of the handle's phase-A streams: the relaxation rounds of update n overlap

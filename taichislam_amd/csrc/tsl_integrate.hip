@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 #define HDR_HEAVY 14           //   batch: heavy bricks listed
 #define HDR_PARTS 16           //   [16..19] parts per class
 #define HDR_UNITS 20           //   batch: [20..23] units per class
+#define HDR_CLAIM2 24          //   batch: next rank to claim of the parts-only launch (split launches)
 __device__ __forceinline__ int plan_class(int w) { return w >= 2560 ? 0 : (w >= 1280 ? 1 : (w >= 512 ? 2 : 3)); }
 // Three tiers by the brick's segments of the whole batch (wb):
 //   wb <= unit_half            UNIT over all its frames;
@@ -737,8 +738,10 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 #define NRANGE (PLAN_NCLS * (TSL_NB + 1))
 
 template <bool TEX, bool FASTDIV, int NT, int SPT, int WPE>
-__global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev B)
+__global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev B, int kind)
 {
+    // kind: 0 = the whole work list; split launches: 1 = the UNITS only (main stream, behind the previous batch's phase B: they read and write
+    // the map), 2 = the PARTS only (the batch's phase-A stream: a part reads its frame's rays and writes its own slab slot, never the map)
     // NT threads walk a step of up to CSEGS = SPT * NT segments (SPT per thread), WPE = waves per SIMD the register budget allows.
     //   NT 256, SPT 4, WPE 2: two workgroups per CU (74 KiB of LDS each), 8 waves per CU;
     //   NT 512, SPT 4, WPE 2: one workgroup per CU (82 KiB), 8 waves on one brick: half the walk latency per brick, half as many bricks in flight;
@@ -776,16 +779,16 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
         // ALL units first (long to short), then all parts (long to short): a unit is a chain of up to eight frame steps with ~4 us of fixed cost
         // each -- a unit of 600 segments takes 45 us, a part of 3 000 segments 26 -- so ranking the items by segments alone left the light units
         // for the end of the launch, where each of them added its whole chain to the span
-        for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[k++] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
+        for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[k++] = acc; if (kind != 2) acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
         for (int c = 0; c < PLAN_NCLS; ++c)
-            for (int q = 0; q < TSL_NB; ++q) { s_cum[k++] = acc; if ((okmask >> q) & 1u) acc += min(B.f[q].counters[HDR_PARTS + c], B.f[q].part_cap); }
+            for (int q = 0; q < TSL_NB; ++q) { s_cum[k++] = acc; if (kind != 1 && ((okmask >> q) & 1u)) acc += min(B.f[q].counters[HDR_PARTS + c], B.f[q].part_cap); }
 #endif
         s_cum[NRANGE] = acc;
-        s_claim[0] = __hip_atomic_fetch_add(&B.f[0].counters[HDR_CLAIM], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_claim[0] = __hip_atomic_fetch_add(&B.f[0].counters[kind == 2 ? HDR_CLAIM2 : HDR_CLAIM], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const int total = uni(s_cum[NRANGE]);
-    int* const claim = &B.f[0].counters[HDR_CLAIM];
+    int* const claim = &B.f[0].counters[kind == 2 ? HDR_CLAIM2 : HDR_CLAIM];
     // rank -> table entry; *kq = -1 for a unit, else the frame of the part
     auto entry_of = [&](int r, int* kq) -> int4 {
         int k = 0;
@@ -1225,28 +1228,39 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     return TSL_OK;
 }
 
-// phase B of a batch on the main stream: one launch of the brick kernel (variant 2), or per frame the global-atomics kernels (variants 0/1)
-int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start, hipEvent_t stop)
+// phase B of a batch, variant 2: the brick kernel.  kind 0 = one launch over the whole work list on the main stream; split launches:
+// kind 2 = the parts on the batch's phase-A stream `st` (grid: `pgrid` percent of the slots), kind 1 = the units on the main stream.
+int launch_brick(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int kind, hipStream_t st, hipEvent_t start, hipEvent_t stop)
 {
     // resident workgroups: one 512-thread one per CU (82 KiB of LDS, textured 98 KiB), or two 256-thread ones (74 KiB each; textured 90 KiB: one).
     // With start / stop events the launch goes through hipExtLaunchKernelGGL, which records them in the dispatch itself.
     // A batch of one or two frames (the per-frame ESDF hook flushes after every frame) has ~500 items: half the grid, one workgroup per CU,
     // leaves LDS for what runs beside it (the ESDF rounds of the frame before: +2 % in bench.py --config 4) and costs the batch nothing.
-    const int bg = B.n <= 2 ? (m->bgrid + 1) / 2 : m->bgrid;
+    const int bg = kind == 2 ? m->pgrid : (B.n <= 2 ? (m->bgrid + 1) / 2 : (kind == 1 ? m->ugrid : m->bgrid));
 #define TSL_LAUNCH_IB(TEXV, FD) do { \
-        if (m->wg == 512 && m->spt == 2 && !TEXV) hipExtLaunchKernelGGL((k_integrate_batch<false, FD, 512, 2, 4>), dim3((2 * m->ncu * bg + 99) / 100), dim3(512), 0, m->stream_, start, stop, 0, m->M, B); \
-        else if (m->wg == 512) hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512, 4, 2>), dim3((m->ncu * bg + 99) / 100), dim3(512), 0, m->stream_, start, stop, 0, m->M, B); \
-        else hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256, 4, (TEXV ? 1 : 2)>), dim3(((TEXV ? 1 : 2) * m->ncu * bg + 99) / 100), dim3(256), 0, m->stream_, start, stop, 0, m->M, B); } while (0)
+        if (m->wg == 512 && m->spt == 2 && !TEXV) hipExtLaunchKernelGGL((k_integrate_batch<false, FD, 512, 2, 4>), dim3((2 * m->ncu * bg + 99) / 100), dim3(512), 0, st, start, stop, 0, m->M, B, kind); \
+        else if (m->wg == 512) hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 512, 4, 2>), dim3((m->ncu * bg + 99) / 100), dim3(512), 0, st, start, stop, 0, m->M, B, kind); \
+        else hipExtLaunchKernelGGL((k_integrate_batch<TEXV, FD, 256, 4, (TEXV ? 1 : 2)>), dim3(((TEXV ? 1 : 2) * m->ncu * bg + 99) / 100), dim3(256), 0, st, start, stop, 0, m->M, B, kind); } while (0)
     if (P.tex) { if (P.fastdiv) TSL_LAUNCH_IB(true, true); else TSL_LAUNCH_IB(true, false); }
     else { if (P.fastdiv) TSL_LAUNCH_IB(false, true); else TSL_LAUNCH_IB(false, false); }
 #undef TSL_LAUNCH_IB
-    // the batch's heavy bricks: parts -> map (the count lives on the device: the grid covers what a batch can list, idle workgroups leave at once)
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+// the batch's heavy bricks: parts -> map (the count lives on the device: the grid covers what a batch can list, idle workgroups leave at once)
+int launch_slab_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P)
+{
     prof_begin(m, TSL_K_FINALIZE);
     if (P.tex) hipLaunchKernelGGL(k_apply_slab<true>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
     else hipLaunchKernelGGL(k_apply_slab<false>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B);
     prof_end(m);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
+}
+int launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start, hipEvent_t stop)
+{
+    const int rc = launch_brick(m, B, P, 0, m->stream_, start, stop);
+    return rc ? rc : launch_slab_apply(m, B, P);
 }
 
 int launch_apply(tsl_tsdf* m, FSet& S, int total)

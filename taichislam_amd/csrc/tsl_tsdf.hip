@@ -594,16 +594,35 @@ static int launch_batch_t(tsl_tsdf* m)
         TSL_HIP(hipEventRecord(H.a_done, sa)); H.a_recorded = true;
         TSL_HIP(hipStreamWaitEvent(m->stream_, H.a_done, 0));
     }
+    // Split launches (option "split_launch", off by default; full batches of the overlapped pipeline): the brick kernel runs twice.  The PARTS
+    // of the heavy bricks depend on the batch's phase A only -- a part reads its frame's rays and writes a slab slot of its own -- so they
+    // are launched here, on the phase-A stream, and run beside the previous batch's phase B; the UNITS (they read and write the map) and
+    // k_apply_slab follow on the main stream, whose chain is shorter by the parts.  Bit-exact, and measured SLOWER (26.9 k against 30.3 k
+    // frames/s, the two launches take 377 us together against 214 us for one): the brick kernel is bound by the SIMDs' issue rate, not by
+    // the length of the chain, and two launches side by side slow each other by more than the overlap saves.
+    bool any = false; for (int q = 0; q < n; ++q) any = any || m->pend[q].total > 0;
+    const bool split = !serial && m->split_launch && (m->phases & 2) && m->pend[0].variant == 2 && !m->pend[0].seq && n > 2 && any;
+    if (split) {
+        hipEvent_t pa = nullptr, pb = nullptr;
+        const bool timed = prof_slot(m, TSL_K_INTEGRATE, 0, &pa, &pb);       // counted with the units launch: one "launch" of the batch in the statistics
+        int rc = launch_brick(m, B, m->pend[0], 2, sa, timed ? pa : nullptr, timed ? pb : nullptr);
+        if (rc) return rc;
+        TSL_HIP(hipEventRecord(H.p_done, sa));
+    }
     // ---- phase B: apply to the map on the main stream: the brick kernel takes the whole batch in one launch (frame order is kept per
     //      brick inside it); the global-atomics variants run frame by frame ----
     if (m->phases & 2) {
         int rc = TSL_OK;
         if (m->pend[0].variant == 2) {
-            bool any = false; for (int q = 0; q < n; ++q) any = any || m->pend[q].total > 0;
             if (any) {
                 hipEvent_t ea = nullptr, eb = nullptr;
                 const bool timed = prof_slot(m, TSL_K_INTEGRATE, 1, &ea, &eb);
                 if (m->pend[0].seq) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_apply_sequential(m, B, m->pend[0]); prof_end(m); }
+                else if (split) {
+                    rc = launch_brick(m, B, m->pend[0], 1, m->stream_, timed ? ea : nullptr, timed ? eb : nullptr);
+                    TSL_HIP(hipStreamWaitEvent(m->stream_, H.p_done, 0));
+                    if (!rc) rc = launch_slab_apply(m, B, m->pend[0]);
+                }
                 else rc = launch_apply_batch(m, B, m->pend[0], timed ? ea : nullptr, timed ? eb : nullptr);
             }
         } else {
@@ -850,7 +869,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
     m->overlap = TSL_NB; m->last_set = 0;
     for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; }
-    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.b_pending = false; H.a_recorded = false; }
+    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.p_done = nullptr; H.b_pending = false; H.a_recorded = false; }
     m->frames_issued = 0; m->frames_consumed = 0; m->batch_seq = 0;
     for (int k = 0; k < TSL_INFLIGHT; ++k) { m->ring_ev[k] = nullptr; m->ring_upto[k] = 0; }
     m->cur = 0; m->npend = 0; m->pend_points = 0; m->deferred_rc = 0;
@@ -895,7 +914,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
+    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->ugrid = 75; m->pgrid = 25; m->split_launch = 0; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
     // (unit_half >= unit: the middle tier of k_plan is off by default -- measured neutral-to-negative once the brick kernel runs on 75 % of the slots)
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     m->active = 0; m->variant = 2; m->split = 2;
@@ -942,6 +961,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
         // the stream of slot bi - TSL_NSTREAMS (its phase A is ordered behind that slot's, which is two or three batches older)
         if (bi < TSL_NSTREAMS) TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking)); else H.st = m->batch[bi % TSL_NSTREAMS].st;
         TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&H.p_done, hipEventDisableTiming));
     }
     for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], hipEventDisableTiming));
     TSL_HIP(hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking));
@@ -998,6 +1018,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         BatchHost& H = m->batch[bi];
         if (H.st && bi < TSL_NSTREAMS) (void)hipStreamDestroy(H.st);
         if (H.a_done) (void)hipEventDestroy(H.a_done);
+        if (H.p_done) (void)hipEventDestroy(H.p_done);
     }
     for (auto& S : m->fset) {
 
@@ -1471,6 +1492,8 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "adaptive")) { m->adaptive = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "ramp_size")) { TSL_REQUIRE(value >= 1 && value <= TSL_NB, "ramp_size must be 1..8 frames"); m->ramp_size = value; return TSL_OK; }
     if (!std::strcmp(name, "ramp")) { TSL_REQUIRE(value >= 0 && value <= 16, "ramp must be 0..16 half batches"); m->ramp_batches = value; return TSL_OK; }
+    if (!std::strcmp(name, "ugrid") || !std::strcmp(name, "pgrid")) { TSL_REQUIRE(value >= 5 && value <= 200, "ugrid / pgrid must be 5..200 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } (name[0] == 'u' ? m->ugrid : m->pgrid) = value; return TSL_OK; }
+    if (!std::strcmp(name, "split_launch")) { TSL_REQUIRE(value == 0 || value == 1, "split_launch must be 0 or 1"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->split_launch = value; return TSL_OK; }
     if (!std::strcmp(name, "bgrid")) { TSL_REQUIRE(value >= 10 && value <= 200, "bgrid must be 10..200 (percent of the resident workgroup slots)"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->bgrid = value; return TSL_OK; }
     if (!std::strcmp(name, "spt")) { TSL_REQUIRE(value == 2 || value == 4, "spt must be 2 or 4"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->spt = value; return TSL_OK; }
     if (!std::strcmp(name, "wg")) { TSL_REQUIRE(value == 256 || value == 512, "wg must be 256 or 512"); { int rc = tsl_tsdf_sync(m); if (rc) return rc; } m->wg = value; return TSL_OK; }

@@ -166,7 +166,7 @@ struct FSet {
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
 struct ParamPack { FrameParams p[TSL_NB]; };
 struct SetPtrs { FrameParams* p[TSL_NB]; int* header[TSL_NB]; };        // k_set_params: where the parameters go, the headers to clear
-struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done; bool b_pending, a_recorded; };
+struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done, p_done; bool b_pending, a_recorded; };      // p_done: the batch's parts-only brick launch (split launches)
 #define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
 int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, int nsrc);      // tsl_sequential.hip
@@ -229,7 +229,7 @@ struct tsl_tsdf {
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
-    int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
+    int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;
 };
 
@@ -246,5 +246,7 @@ int  check_variant2(tsl_tsdf* m);
 int  launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int total, hipStream_t st);      // phase A tail: rays -> brick-sorted segments
 int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // phase B, variants 0/1: apply one frame to the map
 int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+int  launch_brick(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int kind, hipStream_t st, hipEvent_t start, hipEvent_t stop);
+int  launch_slab_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);
 int  launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // tsl_sequential.hip: phase B of one frame, sequential semantics      // phase B, variant 2: apply a batch of frames (one launch)
 }

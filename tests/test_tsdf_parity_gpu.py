@@ -56,29 +56,31 @@ def test_integrate_workgroup_and_part_sizes(hip_lib, wg, spt, chunks):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} chunks {chunks}")
 
 
-@pytest.mark.parametrize("wg,spt,unit,ramp", [(512, 4, 0, 0), (256, 4, 0, 0), (512, 4, 200, 2), (256, 4, 1 << 20, 0), (512, 2, 0, 0), (512, 2, 200, 2), (512, 2, 1 << 20, 0)])
-def test_units_and_parts_over_full_batches(hip_lib, wg, spt, unit, ramp):
+@pytest.mark.parametrize("wg,spt,unit,ramp,split", [(512, 4, 0, 0, 0), (256, 4, 0, 0, 0), (512, 4, 200, 2, 0), (256, 4, 1 << 20, 0, 0), (512, 2, 0, 0, 0), (512, 2, 200, 2, 0),
+                                                       (512, 2, 1 << 20, 0, 0), (512, 2, 200, 0, 1), (512, 2, 0, 0, 1), (256, 4, 200, 2, 1)])
+def test_units_and_parts_over_full_batches(hip_lib, wg, spt, unit, ramp, split):
     """Eleven frames with nothing read in between (a full batch of eight + three, or half batches first): with the unit limit at 0
     every brick is split into parts and merged through the per-(frame, brick) slab slots, with a huge limit every brick is a unit
-    walked by one workgroup over all frames of the batch; any mix in between must give the same map."""
+    walked by one workgroup over all frames of the batch; any mix in between must give the same map -- also when the parts are walked
+    by a launch of their own on the batch's phase-A stream (split_launch)."""
     from oracle import BATCHED
     K, frames = small_stream(11)
     g, o = make_pair(SMALL, K)
-    g.set_option("wg", wg); g.set_option("spt", spt); g.set_option("unit", unit); g.set_option("ramp", ramp)
+    g.set_option("wg", wg); g.set_option("spt", spt); g.set_option("unit", unit); g.set_option("ramp", ramp); g.set_option("split_launch", split)
     for R, T, d in frames:
         g.recast_depth_to_map(R, T, d, None)
         o.integrate_depth(R, T, d, mode=BATCHED)
-    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} unit {unit} ramp {ramp}")
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} unit {unit} ramp {ramp} split_launch {split}")
 
 
-@pytest.mark.parametrize("unit,half", [(1 << 20, 300), (3000, 100), (1 << 20, 1 << 20), (2000, 0)])
-def test_middle_tier_first_frames_as_unit_later_frames_as_parts(hip_lib, unit, half):
+@pytest.mark.parametrize("unit,half,split", [(1 << 20, 300, 0), (3000, 100, 0), (1 << 20, 1 << 20, 0), (2000, 0, 0), (3000, 100, 1)])
+def test_middle_tier_first_frames_as_unit_later_frames_as_parts(hip_lib, unit, half, split):
     """Bricks between `unit_half` and `unit` segments per batch: their first frames are walked as a unit, their later frames as parts that
     k_apply_slab applies on top of what the unit wrote.  Any split must give the oracle's map."""
     from oracle import BATCHED
     K, frames = small_stream(11)
     g, o = make_pair(SMALL, K)
-    g.set_option("unit", unit); g.set_option("unit_half", half); g.set_option("ramp", 0)
+    g.set_option("unit", unit); g.set_option("unit_half", half); g.set_option("ramp", 0); g.set_option("split_launch", split)
     so = None
     for R, T, d in frames:
         g.recast_depth_to_map(R, T, d, None)
@@ -135,13 +137,15 @@ def test_full_size_full_batches_bit_exact(hip_lib):
     g, o = make_pair(C2, syn.K_DEPTH)
     g.set_option("ramp", 0)
     h = DenseTSDF(**C2); h.set_dep_camera_intrinsic(syn.K_DEPTH)
+    s = DenseTSDF(**C2); s.set_dep_camera_intrinsic(syn.K_DEPTH); s.set_option("split_launch", 1)
     so = None
     for R, T, d in frames:
         g.recast_depth_to_map(R, T, d, None)
         h.recast_depth_to_map(R, T, d, None)
+        s.recast_depth_to_map(R, T, d, None)
         so = o.integrate_depth(R, T, d, mode=BATCHED)
     want = o.export_sparse()
-    for m, what in ((g, "[8][8][4]"), (h, "[4][4][8][4]")):
+    for m, what in ((g, "[8][8][4]"), (h, "[4][4][8][4]"), (s, "[4][4][8][4], the parts in a launch of their own")):
         sg = m.last_frame_stats()
         assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}, what
         assert_export_equal(m.export_submap(), want, f"C2, 20 frames as {what}")
