@@ -705,23 +705,24 @@ __device__ __forceinline__ void apply_chunk(const uint32_t* old, const long long
 // =====================================================================================================
 // k_integrate_batch: phase B of a whole batch of frames (up to TSL_NB) as ONE persistent, software-pipelined launch.
 //
-// The work list (k_plan) is class-major: for each of PLAN_NCLS length classes the batch's UNITS, then the PARTS of frame 0, 1, ...
-// The resident workgroups claim items from it in rank order through one counter, two items ahead of the one they walk.
+// The work list (k_plan's tables, PLAN_NCLS length classes each): all UNITS of the batch, long to short, then all PARTS, long to short
+// (by class, frame 0, 1, ... inside a class).  The resident workgroups claim items from it in rank order through one counter, two
+// items ahead of the one they walk.
 //   UNIT  a brick whose whole batch fits one workgroup: its frames are walked in order, the brick's voxels stay in registers in
 //         between (each frame's sums are applied to them exactly as a per-frame launch would apply them to memory), the brick is
 //         read once and written once per batch and nothing has to be ordered against other workgroups.
 //   PART  (a slice of) one frame's segments in a heavier brick.  A part's walk depends only on its frame's rays, never on the map, so
-//         the parts of all frames of the batch are walked side by side, in any order; each adds its sums into the (frame, brick)'s slot
-//         of the batch's merge slab in HBM (L2 atomics) and takes an arrival ticket of the brick.  The workgroup that arrives last --
-//         over all parts of all frames -- reads the brick once, applies the frames' sums in frame order exactly as per-frame launches
-//         would, writes it once and leaves the slots zeroed.  Nobody ever waits for another workgroup.
+//         the parts of all frames of the batch are walked side by side, in any order; each stores its 4096 {num, den} sums into a
+//         slot of its own in the batch's merge slab in HBM (plain coalesced stores: no atomics, no tickets, nothing to clear).
+//         k_apply_slab, the next launch on the stream, adds the parts of every (frame, brick) and applies the frames in frame order
+//         exactly as per-frame launches would; the brick is read once and written once.  Nobody ever waits for another workgroup.
 //
 // Inside a workgroup the pipeline is the one of round 2's per-frame kernel, over "steps" (one chunk of CSEGS segments of one frame of
 // one item): while a step is walked, the keys of the next step -- next chunk, next frame of the unit, or the first step of the next
 // claimed item -- are in flight; after the walk they are length-sorted in their own 8 KiB of LDS and their ray records requested,
 // and only then the finished frame is applied.  The items' descriptions live in a three-slot LDS ring (current, next, being fetched).
 // One launch per batch removes three of four kernel tails (half of the workgroups of a per-frame launch were idle for the second
-// half of it), and with longest-first dynamic claims over a four-frame work list the heavy bricks next to the sensor no longer
+// half of it), and with longest-first dynamic claims over an eight-frame work list the heavy bricks next to the sensor no longer
 // set the length of every frame.
 // =====================================================================================================
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane holds (read from LDS): keep it in an SGPR
