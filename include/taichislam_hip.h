@@ -250,7 +250,9 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 read-modify-write with the W clamp, colours by last writer; on a GLOBAL map: tsl_tsdf_fuse_submaps replays fuse_submaps_kernel
                 (dense_tsdf.py:272-318) the same way, submap cells in struct-for order, corners in loop order -- bit-exact with oracle FAITHFUL and
                 with the maps the reference's own source produces on tools/ti_seq (tests/golden/ref_*.npz); one frame per batch, ~180 frames/s at
-                512^3; maps of at most 2^17 bricks
+                512^3; maps of at most 2^17 bricks.  The integration follows the struct-for order for any num_voxel_per_blk_axis; the fusion
+                walks the submaps in 16^3-brick order, which is the reference's struct-for order when num_voxel_per_blk_axis is 16 and
+                another sequential schedule of the same racy kernel otherwise
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 8; three batch slots: phase A of up to two
                 batches is in flight beside phase B of a third)
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame

@@ -678,13 +678,39 @@ static void for_each_voxel(const ora_tsdf* m, int s, voxel_fn fn, void* ctx)
     }
 }
 
-/* the same cells in Taichi's struct-for order over pointer(blocks).dense(16^3): blocks by (bi, bj, bk), the cells of a block row-major
- * (k fastest) -- the order in which tools/ti_seq executes `for s, i, j, k in TSDF` of the reference's source (A6), used where the result
- * depends on the order (the FAITHFUL fusion: every splat is an f16 read-modify-write of the global voxel) */
+/* the same cells in Taichi's struct-for order over pointer(blocks).dense(blk^3), blk = num_voxel_per_blk_axis (dense_tsdf.py:44-52):
+ * blocks by (bi, bj, bk), the cells of a block row-major (k fastest) -- the order in which tools/ti_seq executes `for s, i, j, k in TSDF`
+ * of the reference's source (A6), used where the result depends on the order (the FAITHFUL fusion: every splat is an f16
+ * read-modify-write of the global voxel).  The maps here are stored in 16^3 bricks whatever blk is: with blk = 16 the bricks ARE the
+ * reference's blocks; otherwise (the reference's own configuration uses 10) the cells are put into the reference's order by a sort. */
+typedef struct { uint64_t key; const brick_t* b; int i, j, k, l; } sf_cell;
+static int sf_cmp(const void* a, const void* b) { uint64_t x = ((const sf_cell*)a)->key, y = ((const sf_cell*)b)->key; return x < y ? -1 : (x > y ? 1 : 0); }
 static void for_each_voxel_struct_for(const ora_tsdf* m, int s, voxel_fn fn, void* ctx)
 {
     const submap_t* sm = &m->sub[s];
     if (!sm->tab) return;
+    const int blk = m->cfg.num_voxel_per_blk_axis;
+    if (blk != 16) {
+        size_t nb = 0, n = 0;
+        for (size_t t = 0; t < (size_t)m->nbx * m->nbx * m->nbz; ++t) if (sm->tab[t]) ++nb;
+        sf_cell* c = (sf_cell*)malloc((nb ? nb : 1) * BRK3 * sizeof(sf_cell));
+        const uint64_t nrz = (uint64_t)(m->Nz / blk), nr = (uint64_t)(m->N / blk), b3 = (uint64_t)blk * blk * blk;
+        for (int bi = 0; bi < m->nbx; ++bi) for (int bj = 0; bj < m->nbx; ++bj) for (int bk = 0; bk < m->nbz; ++bk) {
+            const brick_t* b = sm->tab[((size_t)bi * m->nbx + bj) * m->nbz + bk];
+            if (!b) continue;
+            for (int l = 0; l < BRK3; ++l) {
+                const int u = bi * 16 + (l >> 8), v = bj * 16 + ((l >> 4) & 15), w = bk * 16 + (l & 15);      /* 0-based cell of the field */
+                if (u >= m->N || v >= m->N || w >= m->Nz) continue;                                           /* beyond the field (N is a multiple of blk, not of 16) */
+                const uint64_t block = (((uint64_t)(u / blk)) * nr + (uint64_t)(v / blk)) * nrz + (uint64_t)(w / blk);
+                const uint64_t cell = (((uint64_t)(u % blk)) * blk + (uint64_t)(v % blk)) * blk + (uint64_t)(w % blk);
+                c[n].key = block * b3 + cell; c[n].b = b; c[n].i = u - m->N / 2; c[n].j = v - m->N / 2; c[n].k = w - m->Nz / 2; c[n].l = l; ++n;
+            }
+        }
+        qsort(c, n, sizeof(sf_cell), sf_cmp);
+        for (size_t t = 0; t < n; ++t) fn(ctx, m, s, c[t].i, c[t].j, c[t].k, c[t].b, c[t].l);
+        free(c);
+        return;
+    }
     for (int bi = 0; bi < m->nbx; ++bi) for (int bj = 0; bj < m->nbx; ++bj) for (int bk = 0; bk < m->nbz; ++bk) {
         const brick_t* b = sm->tab[((size_t)bi * m->nbx + bj) * m->nbz + bk];
         if (!b) continue;

@@ -19,6 +19,9 @@ from util import lin
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NAMES = ["depth_stream", "point_clouds", "textured", "textured_points", "weight_clamp", "two_submaps_fused", "aligned_submap_fused"]
 FUSED = ("two_submaps_fused", "aligned_submap_fused")
+# the same two submaps with num_voxel_per_blk_axis = 10, the block size of the reference's own configuration: volumes of 70 / 130 voxels per axis (not
+# multiples of the 16^3 storage bricks), a sensor grid of 10^3 blocks (another ray order), a struct-for over 10^3 blocks in fuse_submaps (another splat order)
+BLK10 = ["blk10_two_submaps", "blk10_two_submaps_fused"]
 
 
 def load(name):
@@ -55,6 +58,8 @@ def replay(make, steps, K, Kc, mode_kw, fuse):
             m.integrate("pcl", s, **mode_kw)
         elif s["kind"] == "next_submap":
             m.next_submap()
+        elif s["kind"] == "select":
+            m.select(s["sid"])
         elif s["kind"] == "fuse":
             g = make({"is_global_map": True, "map_scale": s["global_map_scale"]})
             for b in steps:
@@ -81,6 +86,7 @@ class _Ora:
 
     def set_base_pose_submap(self, sid, R, T): self.o.set_base_pose_submap(sid, R, T)
     def next_submap(self): self.o.set_active_submap(self.o.get_active_submap() + 1)
+    def select(self, sid): self.o.set_active_submap(sid)
     def export(self): return self.o.export_sparse()
 
     def integrate(self, kind, s, mode):
@@ -90,7 +96,7 @@ class _Ora:
             self.o.integrate_points(s["R"], s["T"], s["xyz"], s.get("rgb"), mode=mode)
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES + BLK10)
 def test_oracle_faithful_reproduces_the_reference_source_bit_for_bit(name):
     from oracle import FAITHFUL
     cfg, K, Kc, steps, want = load(name)
@@ -107,7 +113,7 @@ def test_the_vectors_cover_what_they_claim():
     assert "color" in t and (t["color"] != 0).any()
     _, _, _, steps, p = load("point_clouds")
     assert p["indices"].shape[0] > 10000 and sum(s["kind"] == "pcl" for s in steps) == 2
-    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + ["octomap", "session"])
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + ["octomap", "session"])
 
 
 # ------------------------------------------------------------------------------------------------------------------ HIP (GPU)
@@ -122,6 +128,7 @@ class _Hip:
 
     def set_base_pose_submap(self, sid, R, T): self.m.set_base_pose_submap(sid, R, T)
     def next_submap(self): self.m.switch_to_next_submap()
+    def select(self, sid): self.m.active_submap_id[None] = sid
     def export(self): return self.m.export_submap()
 
     def integrate(self, kind, s):
@@ -132,7 +139,7 @@ class _Hip:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points"])
+@pytest.mark.parametrize("name", ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points", "blk10_two_submaps"])
 def test_hip_sequential_mode_reproduces_the_reference_source_bit_for_bit(hip_lib, name):
     cfg, K, Kc, steps, want = load(name)
     got = replay(lambda over: _Hip({**cfg, **over}, K, Kc, 1), steps, K, Kc, {}, None)

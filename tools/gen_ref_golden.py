@@ -127,6 +127,13 @@ def scenarios():
     fr = [dict(kind="base", sid=0, R=Ra, T=Ta), dict(kind="depth", R=Ra, T=Ta, depth=syn.sphere_room_depth(Ra, Ta, h, w, radius=2.5, K=K)),
           dict(kind="next_submap"), dict(kind="fuse", global_map_scale=[10.24, 10.24])]
     out.append(("aligned_submap_fused", cfg, K, None, fr))
+    # 7. blocks of 10 voxels per axis, the block size of the reference's own configuration (submap_mapping.py:33-36, taichislam_node.py): the volume is
+    #    rounded up to whole blocks (N = 70 and 130 here, not a multiple of 16), the sensor grid is made of 10^3 blocks (another ray order) and
+    #    fuse_submaps walks the submaps' 10^3 blocks lexicographically (another splat order) -- none of which may change with the 16^3 bricks the maps are stored in
+    cfg10 = {**cfg, "num_voxel_per_blk_axis": 10}
+    tilted = [s for s in out[-2][4]]
+    out.append(("blk10_two_submaps_fused", cfg10, K, None, tilted))
+    out.append(("blk10_two_submaps", cfg10, K, None, [s for s in tilted if s["kind"] != "fuse"] + [dict(kind="select", sid=1)]))
     return out
 
 
@@ -150,6 +157,8 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
             m.recast_pcl_to_map(s["R"], s["T"], s["xyz"], s.get("rgb", np.zeros((1, 3), np.uint8)))
         elif s["kind"] == "next_submap":
             m.switch_to_next_submap()
+        elif s["kind"] == "select":                       # export_submap() writes the ACTIVE submap: go back to an earlier one
+            m.active_submap_id[None] = s["sid"]
         elif s["kind"] == "fuse":
             g = DenseTSDF(**{**cfg, "is_global_map": True, "map_scale": s["global_map_scale"]}, max_disp_particles=64)
             g.set_dep_camera_intrinsic(K)
