@@ -180,12 +180,12 @@ def sequential_leg(dev, frames, oracle_map):
 def reference_source_leg(dev):
     """tests/golden/ref_*.npz -- what the reference's OWN source produces when run on the sequential Taichi stand-in of tools/ti_seq (generated on the dev
     box by tools/gen_ref_golden.py; the reference tree is not needed here).  Checked live: the oracle's FAITHFUL mode and the HIP path with semantics = 1
-    against the five integration vectors (depth stream, point clouds, weight clamp, depth + colour, coloured point clouds) and the two fused global maps
-    (tilted and axis-aligned base poses), bit for bit.  (The whole set, fusion / Octomap / mesh / exports / session included: tests/test_ref_golden.py.)"""
+    against the six integration vectors (depth stream, point clouds, weight clamp, depth + colour, coloured point clouds, two submaps made of 10^3 blocks) and
+    the two fused global maps (tilted and axis-aligned base poses), bit for bit.  (The whole set, fusion / Octomap / mesh / exports / session included: tests/test_ref_golden.py.)"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
     import test_ref_golden as tr
     from oracle import FAITHFUL
-    names, ora_ok, hip_ok, voxels = ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points", "two_submaps_fused", "aligned_submap_fused"], [], [], 0
+    names, ora_ok, hip_ok, voxels = ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points", "blk10_two_submaps", "two_submaps_fused", "aligned_submap_fused"], [], [], 0
     for name in names:
         cfg, K, Kc, steps, want = tr.load(name)
         keys = ("indices", "TSDF", "W_TSDF", "occupy") + (("color",) if "color" in want else ())
