@@ -255,6 +255,23 @@ def test_hip_mesh_reproduces_the_reference_source_bit_for_bit(hip_lib, name):
     assert np.array_equal(_rows(*cols).view(np.uint32), want["mesh"].view(np.uint32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["depth_stream", "textured"])
+def test_hip_coarse_mesh_and_the_gather_kernel_reproduce_the_reference_source(hip_lib, name):
+    """generate_mesh(2) -- cubes of edge 2 anchored at every voxel, corners up to two voxels beyond the brick: every value is read through the brick
+    table (k_marching_cubes) -- and the same kernel at step 1 (option mesh_gather) against the reference's own meshes."""
+    from taichislam_amd.mapping import MarchingCubeMesher
+    cfg, m, want = _hip_map(name)
+    for step, gather, key in ((2, 0, "mesh_step2"), (1, 1, "mesh")):
+        m.set_option("mesh_gather", gather)
+        me = MarchingCubeMesher(m, 60000, tsdf_surface_thres=float(want["mesh_thres"]))
+        me.generate_mesh(step)
+        v, n, c = me.get_mesh()
+        assert me.num_facelets[None] == want[key].shape[0], (step, gather)
+        cols = [v.reshape(-1, 9), n.reshape(-1, 9)] + ([c.reshape(-1, 9)] if cfg.get("texture_enabled") else [])
+        assert np.array_equal(_rows(*cols).view(np.uint32), want[key].view(np.uint32)), (step, gather)
+
+
 # ------------------------------------------------------------------------------------------------------------------ exports, raycast, coloured mesh
 def _rows(*cols):
     t = np.concatenate([np.asarray(c, np.float32).reshape(len(c), -1) for c in cols], axis=1).astype(np.float32)
@@ -289,6 +306,10 @@ def test_oracle_exports_raycast_and_mesh_reproduce_the_reference_source(name):
     v, nr, col, cnt = o.generate_mesh(1, float(want["mesh_thres"]), 20000)
     cols = [v.reshape(-1, 9), nr.reshape(-1, 9)] + ([col.reshape(-1, 9)] if cfg.get("texture_enabled") else [])
     assert cnt == want["mesh"].shape[0] > 500 and np.array_equal(_rows(*cols).view(np.uint32), want["mesh"].view(np.uint32))
+    # generate_mesh(2): every voxel below the threshold anchors a cube of edge 2 (the anchors are not thinned out: overlapping cubes, more triangles than at step 1)
+    v, nr, col, cnt = o.generate_mesh(2, float(want["mesh_thres"]), 60000)
+    cols = [v.reshape(-1, 9), nr.reshape(-1, 9)] + ([col.reshape(-1, 9)] if cfg.get("texture_enabled") else [])
+    assert cnt == want["mesh_step2"].shape[0] > want["mesh"].shape[0] and np.array_equal(_rows(*cols).view(np.uint32), want["mesh_step2"].view(np.uint32))
 
 
 @pytest.mark.gpu

@@ -180,6 +180,18 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
             cols.append(me.mesh_colors.to_numpy()[:n * 3].reshape(n, 9))
         res["mesh"], res["mesh_thres"] = canon_rows(*cols), np.float32(thres)
         print(f"  mesh: {n} triangles, {time.time() - t0:.1f} s")
+        # generate_mesh(2): EVERY voxel below the threshold anchors a cube of edge 2 (marching_cube_mesher.py:133-136,:156-159: the corner offsets are
+        # multiplied by `step`, the anchors are not thinned out), so the cubes overlap and reach two voxels beyond the anchor's block
+        t0 = time.time()
+        me2 = Mesher(m, max_triangles=60000, tsdf_surface_thres=thres)
+        me2.generate_mesh(2)
+        n2 = int(me2.num_facelets[None])
+        assert n2 < 60000
+        cols2 = [me2.mesh_vertices.to_numpy()[:n2 * 3].reshape(n2, 9), me2.mesh_normals.to_numpy()[:n2 * 3].reshape(n2, 9)]
+        if cfg.get("texture_enabled"):
+            cols2.append(me2.mesh_colors.to_numpy()[:n2 * 3].reshape(n2, 9))
+        res["mesh_step2"] = canon_rows(*cols2)
+        print(f"  mesh, step 2: {n2} triangles, {time.time() - t0:.1f} s")
         # the particle exports: cvt_TSDF_surface_to_voxels (dense_tsdf.py:339-366) and cvt_TSDF_to_voxels_slice (:368-391); rows in a canonical order
         m.cvt_TSDF_surface_to_voxels()
         ns = int(m.num_TSDF_particles[None])
