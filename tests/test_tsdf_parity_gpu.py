@@ -73,6 +73,25 @@ def test_units_and_parts_over_full_batches(hip_lib, wg, spt, unit, ramp, split):
     assert_export_equal(g.export_submap(), o.export_sparse(), f"wg {wg} spt {spt} unit {unit} ramp {ramp} split_launch {split}")
 
 
+@pytest.mark.parametrize("opts", [{"adaptive": 1}, {"adaptive": 1, "ramp": 0}, {"bgrid": 100}, {"bgrid": 20}, {"ramp_size": 2}, {"ramp_size": 6, "ramp": 3}, {"unit_floor": 0, "unit": 300},
+                                  {"split_launch": 1, "ugrid": 40, "pgrid": 60}])
+def test_scheduling_options_do_not_show_in_the_map(hip_lib, opts):
+    """How the queued frames are issued (adaptive: as soon as phase A of the previous batch is done; the length and number of the short batches
+    after the pipeline ran dry) and how many workgroups the brick kernel is given are scheduling choices: the map must not depend on them."""
+    from oracle import BATCHED
+    K, frames = small_stream(13)
+    g, o = make_pair(SMALL, K)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    so = None
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+        so = o.integrate_depth(R, T, d, mode=BATCHED)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}, opts
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"options {opts}")
+
+
 @pytest.mark.parametrize("unit,half,split", [(1 << 20, 300, 0), (3000, 100, 0), (1 << 20, 1 << 20, 0), (2000, 0, 0), (3000, 100, 1)])
 def test_middle_tier_first_frames_as_unit_later_frames_as_parts(hip_lib, unit, half, split):
     """Bricks between `unit_half` and `unit` segments per batch: their first frames are walked as a unit, their later frames as parts that
