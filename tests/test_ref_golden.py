@@ -22,6 +22,9 @@ FUSED = ("two_submaps_fused", "aligned_submap_fused")
 # the same two submaps with num_voxel_per_blk_axis = 10, the block size of the reference's own configuration: volumes of 70 / 130 voxels per axis (not
 # multiples of the 16^3 storage bricks), a sensor grid of 10^3 blocks (another ray order), a struct-for over 10^3 blocks in fuse_submaps (another splat order)
 BLK10 = ["blk10_two_submaps", "blk10_two_submaps_fused"]
+# a submap with a tilted base pose, a display window, recast_step = 3 on an image of 61 rows, internal_voxels = 3, voxels of 12 cm: map, particle exports
+# (positions through the submap's pose), ray casts, meshes at step 1 and 2
+POSED = ["posed_exports"]
 
 
 def load(name):
@@ -96,7 +99,7 @@ class _Ora:
             self.o.integrate_points(s["R"], s["T"], s["xyz"], s.get("rgb"), mode=mode)
 
 
-@pytest.mark.parametrize("name", NAMES + BLK10)
+@pytest.mark.parametrize("name", NAMES + BLK10 + POSED)
 def test_oracle_faithful_reproduces_the_reference_source_bit_for_bit(name):
     from oracle import FAITHFUL
     cfg, K, Kc, steps, want = load(name)
@@ -113,7 +116,7 @@ def test_the_vectors_cover_what_they_claim():
     assert "color" in t and (t["color"] != 0).any()
     _, _, _, steps, p = load("point_clouds")
     assert p["indices"].shape[0] > 10000 and sum(s["kind"] == "pcl" for s in steps) == 2
-    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + ["octomap", "session"])
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + POSED + ["octomap", "session"])
 
 
 # ------------------------------------------------------------------------------------------------------------------ HIP (GPU)
@@ -291,7 +294,7 @@ def _oracle_map(name):
     return cfg, o, want
 
 
-@pytest.mark.parametrize("name", ["depth_stream", "textured"])
+@pytest.mark.parametrize("name", ["depth_stream", "textured"] + POSED)
 def test_oracle_exports_raycast_and_mesh_reproduce_the_reference_source(name):
     """On the reference's map: cvt_TSDF_surface_to_voxels (positions + colours: the jet colour map of matplotlib, or the stored colours), cvt_TSDF_to_voxels_slice,
     BaseMap.raycast for 24 rays, and generate_mesh(1) with vertex colours -- everything bit for bit, as sets of rows."""
@@ -300,7 +303,7 @@ def test_oracle_exports_raycast_and_mesh_reproduce_the_reference_source(name):
     assert n == want["surface"].shape[0] > 1000 and np.array_equal(_rows(xyz, rgb).view(np.uint32), want["surface"].view(np.uint32))
     z, dz = (float(x) for x in want["slice_args"])
     xyz, val, rgb, n = o.slice_voxels(z, dz)
-    assert n == want["slice"].shape[0] > 1000 and np.array_equal(_rows(xyz, val, rgb).view(np.uint32), want["slice"].view(np.uint32))
+    assert n == want["slice"].shape[0] > 20 and np.array_equal(_rows(xyz, val, rgb).view(np.uint32), want["slice"].view(np.uint32))
     hit, end, ln = o.raycast(want["ray_pos"], want["ray_dir"], float(want["ray_max"]))
     assert np.array_equal(hit, want["ray_hit"]) and np.array_equal(end.view(np.uint32), want["ray_end"].view(np.uint32)) and np.array_equal(ln.view(np.uint32), want["ray_len"].view(np.uint32))
     v, nr, col, cnt = o.generate_mesh(1, float(want["mesh_thres"]), 20000)

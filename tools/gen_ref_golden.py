@@ -132,6 +132,15 @@ def scenarios():
     #    fuse_submaps walks the submaps' 10^3 blocks lexicographically (another splat order) -- none of which may change with the 16^3 bricks the maps are stored in
     cfg10 = {**cfg, "num_voxel_per_blk_axis": 10}
     tilted = [s for s in out[-2][4]]
+    # 8. exports of a submap with a tilted base pose, a display window (disp_floor / disp_ceiling) and recast_step = 3 on an image whose height it does not
+    #    divide: the particle positions go through the submap's pose (dense_tsdf.py:352-355,:379-382), the mesh stays in the map's own frame
+    h3, w3 = 61, 80
+    K3 = syn.scaled_intrinsics(h3, w3)
+    cfg3 = dict(map_scale=[5.12, 5.12], voxel_scale=0.12, num_voxel_per_blk_axis=16, max_ray_length=4.0, min_ray_length=0.3, internal_voxels=3, recast_step=3, max_submap_num=4,
+                disp_floor=-0.6, disp_ceiling=0.9)
+    fr3 = [dict(kind="base", sid=0, R=R0, T=T0), dict(kind="depth", R=R0, T=T0, depth=syn.sphere_room_depth(R0, T0, h3, w3, radius=2.5, K=K3)),
+           dict(kind="depth", R=R0, T=T0 + np.array([0.04, -0.02, 0.03]), depth=syn.sphere_room_depth(R0, T0 + np.array([0.04, -0.02, 0.03]), h3, w3, radius=2.5, K=K3))]
+    out.append(("posed_exports", cfg3, K3, None, fr3))
     out.append(("blk10_two_submaps_fused", cfg10, K, None, tilted))
     out.append(("blk10_two_submaps", cfg10, K, None, [s for s in tilted if s["kind"] != "fuse"] + [dict(kind="select", sid=1)]))
     return out
@@ -142,8 +151,11 @@ def canon_rows(*cols):
     return t[np.lexsort(t.view(np.uint32).T[::-1])]
 
 
+WITH_EXPORTS = ("depth_stream", "textured", "posed_exports")
+
+
 def run(DenseTSDF, name, cfg, K, Kc, steps):
-    m = DenseTSDF(**cfg, max_disp_particles=40000 if name in ("depth_stream", "textured") else 64)
+    m = DenseTSDF(**cfg, max_disp_particles=40000 if name in WITH_EXPORTS else 64)
     m.set_dep_camera_intrinsic(K)
     if Kc is not None:
         m.set_color_camera_intrinsic(Kc)
@@ -168,7 +180,7 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
             g.fuse_submaps(m)
     res = sorted_export((g if g is not None else m).export_submap())
     print(f"{name}: {res['indices'].shape[0]} voxels, {time.time() - t0:.1f} s")
-    if name in ("depth_stream", "textured"):      # marching_cube_mesher.py on the map just built: generate_mesh(1), triangles as rows in a canonical order
+    if name in WITH_EXPORTS:      # marching_cube_mesher.py on the map just built: generate_mesh(1), triangles as rows in a canonical order
         import taichi as ti
         t0 = time.time()
         thres = 5 * cfg["voxel_scale"]
