@@ -196,6 +196,28 @@ def test_oracle_octomap_reproduces_the_reference_source_bit_for_bit():
     assert np.array_equal(idx, want["indices"]) and np.array_equal(cnt.view(np.uint32), want["occupy"].view(np.uint32))
 
 
+@pytest.mark.parametrize("textured", [False, True])
+def test_oracle_octomap_exports_reproduce_the_reference_source(textured):
+    """cvt_occupy_to_voxels(level) of the reference (taichi_octomap.py:90-102; the node calls it with level 0) on a submap with a tilted base pose: the leaves above
+    min_occupy_thres, positions through the pose, colours of the textured tree -- the same rows, bit for bit, at level 0 and 1."""
+    from oracle import OracleOctomap
+    cfg, K, _, steps, want = load("octomap")
+    o = OracleOctomap(**{**cfg, "texture_enabled": textured})
+    o.set_intrinsics(K, K)
+    o.set_base_pose_submap(0, want["posed_R"], want["posed_T"])
+    for s in steps[1:3]:
+        o.integrate_depth(s["R"], s["T"], s["depth"], want["tex_texture"] if textured else None)
+    for level in (0, 1):
+        if textured:
+            xyz, rgb, n = o.occupied_voxels(level, with_color=True)
+            got = _rows(xyz, rgb)
+        else:
+            xyz, n = o.occupied_voxels(level)
+            got = _rows(xyz)
+        w = want[("posedtex" if textured else "posed") + f"_export{level}"]
+        assert n == w.shape[0] > 500 and np.array_equal(got.view(np.uint32), w.view(np.uint32)), level
+
+
 @pytest.mark.gpu
 def test_hip_octomap_reproduces_the_reference_source_bit_for_bit(hip_lib):
     from taichislam_amd.mapping import Octomap

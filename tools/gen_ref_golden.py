@@ -276,6 +276,24 @@ def run_octomap(Octomap):
     ct = leaves(mt, True)
     res.update({"tex_R": R, "tex_T": T, "tex_depth": depth, "tex_texture": tex, "tex_indices": np.array([c[:3] for c in ct], np.int16),
                 "tex_occupy": np.array([c[3] for c in ct], np.float32), "tex_color": np.array([c[4:] for c in ct], np.float32)})
+    # cvt_occupy_to_voxels(level) (taichi_octomap.py:90-102; the node calls it with level 0): the leaves above min_occupy_thres, positions through the
+    # submap's base pose (a tilted one here) -- as rows in a canonical order, untextured and textured
+    ca, sa = np.cos(0.23), np.sin(0.23)
+    Rb, Tb = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1.0]]) @ np.array([[1.0, 0, 0], [0, np.cos(0.1), -np.sin(0.1)], [0, np.sin(0.1), np.cos(0.1)]]), np.array([0.21, -0.13, 0.07])
+    for tag, textured in (("posed", False), ("posedtex", True)):
+        mp = Octomap(**{**cfg, "texture_enabled": textured}, max_disp_particles=40000)
+        mp.set_dep_camera_intrinsic(K); mp.set_color_camera_intrinsic(K)
+        mp.set_base_pose_submap(0, Rb, Tb)
+        for s_ in steps[1:3]:
+            mp.recast_depth_to_map(s_["R"], s_["T"], s_["depth"], tex if textured else np.zeros((1, 1, 3), np.uint8))
+        for level in (0, 1):
+            mp.cvt_occupy_to_voxels(level)
+            n_ = int(mp.num_export_particles[None])
+            assert 100 < n_ < 40000
+            cols = [mp.export_x.to_numpy()[:n_]] + ([mp.export_color.to_numpy()[:n_]] if textured else [])
+            res[f"{tag}_export{level}"] = canon_rows(*cols)
+        print(f"  {tag}: {n_} particles above the threshold")
+    res["posed_R"], res["posed_T"] = Rb, Tb
     print(f"octomap: {len(cells)} leaves, {time.time() - t0:.1f} s")
     return cfg, K, steps, res
 

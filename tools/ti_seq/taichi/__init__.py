@@ -554,6 +554,9 @@ class SNode:
                 out.append(tuple(x + y for x, y in zip(base, c)))
         return out
 
+    def __iter__(self):                            # struct-for over the node the fields are placed in: its cells
+        return iter(self._cells())
+
     def deactivate_all(self):
         self.blocks.clear()
         for c in self.children:
@@ -579,7 +582,12 @@ class _FieldBase:
         self.snode = node
         self.shape = node.shape
 
-    def parent(self, n=1): return self.snode if n == 1 else self.snode.parent(n - 1)
+    def parent(self, n=1):
+        # n = 0: the field's own place node, n = 1: the node it is placed in -- both walk the field's cells.  (A struct-for over a COARSER level of a
+        # pointer tree is not restated here: the reference's callers use level 0, scripts/taichislam_node.py:37.)
+        if n in (0, 1):
+            return self if n == 0 else self.snode
+        raise NotImplementedError("struct-for over an ancestor above the field's own node")
 
     def _get(self, key):
         if self.arr is not None:
