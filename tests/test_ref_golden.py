@@ -331,6 +331,10 @@ def test_oracle_exports_raycast_and_mesh_reproduce_the_reference_source(name):
     v, nr, col, cnt = o.generate_mesh(1, float(want["mesh_thres"]), 20000)
     cols = [v.reshape(-1, 9), nr.reshape(-1, 9)] + ([col.reshape(-1, 9)] if cfg.get("texture_enabled") else [])
     assert cnt == want["mesh"].shape[0] > 500 and np.array_equal(_rows(*cols).view(np.uint32), want["mesh"].view(np.uint32))
+    # the planner's point queries: is_pos_occupy, is_pos_unobserved, is_near_pos_occupy(xyz, 2) for 200 points (mapping_common.py:178-201)
+    qp = want["q_pos"]
+    assert 50 < want["q_occ"].sum() < 190 and 30 < want["q_unobs"].sum() < 150
+    assert np.array_equal(o.query_points(0, qp), want["q_occ"]) and np.array_equal(o.query_points(1, qp), want["q_unobs"]) and np.array_equal(o.query_points(2, qp, 2), want["q_near2"])
     # generate_mesh(2): every voxel below the threshold anchors a cube of edge 2 (the anchors are not thinned out: overlapping cubes, more triangles than at step 1)
     v, nr, col, cnt = o.generate_mesh(2, float(want["mesh_thres"]), 60000)
     cols = [v.reshape(-1, 9), nr.reshape(-1, 9)] + ([col.reshape(-1, 9)] if cfg.get("texture_enabled") else [])

@@ -225,7 +225,16 @@ def run(DenseTSDF, name, cfg, K, Kc, steps):
             hit.append(bool(succ)); end.append([float(e.v) for e in x_]); ln.append(float(_len.v))
         res["ray_pos"], res["ray_dir"], res["ray_max"] = pos.astype(np.float32), d.astype(np.float32), np.float32(3.0)
         res["ray_hit"], res["ray_end"], res["ray_len"] = np.array(hit), np.array(end, np.float32), np.array(ln, np.float32)
-        print(f"  surface {ns} particles, slice {nz}, rays hit {sum(hit)} of {len(hit)}")
+        # the planner's point queries (mapping_common.py:178-201 with dense_tsdf.py:148-155): is_pos_occupy, is_pos_unobserved, is_near_pos_occupy(xyz, 2)
+        # for points scattered through the observed part of the map and around it
+        obs_idx = res["indices"][rng.integers(0, res["indices"].shape[0], size=160)].astype(np.float32) * np.float32(cfg["voxel_scale"])
+        qp = np.concatenate([obs_idx + rng.uniform(-0.3, 0.3, size=obs_idx.shape).astype(np.float32), rng.uniform(-1.0, 1.0, size=(40, 3)).astype(np.float32)]).astype(np.float32)
+        qo, qu, qn = [], [], []
+        for a in qp:
+            v = ti.Vector([float(a[0]), float(a[1]), float(a[2])], ti.f32)
+            qo.append(bool(m.is_pos_occupy(v))); qu.append(bool(m.is_pos_unobserved(v))); qn.append(bool(m.is_near_pos_occupy(v, 2)))
+        res["q_pos"], res["q_occ"], res["q_unobs"], res["q_near2"] = qp, np.array(qo), np.array(qu), np.array(qn)
+        print(f"  surface {ns} particles, slice {nz}, rays hit {sum(hit)} of {len(hit)}; of {len(qp)} query points {sum(qo)} occupied, {sum(qu)} unobserved, {sum(qn)} near an occupied voxel")
     return res
 
 
