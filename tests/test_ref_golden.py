@@ -116,7 +116,7 @@ def test_the_vectors_cover_what_they_claim():
     assert "color" in t and (t["color"] != 0).any()
     _, _, _, steps, p = load("point_clouds")
     assert p["indices"].shape[0] > 10000 and sum(s["kind"] == "pcl" for s in steps) == 2
-    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + POSED + ["octomap", "session"])
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + POSED + ["octomap", "session", "session_blk10"])
 
 
 # ------------------------------------------------------------------------------------------------------------------ HIP (GPU)
@@ -409,9 +409,9 @@ class OraMap:
         return idx
 
 
-def _session(map_cls, SM):
+def _session(map_cls, SM, name="session"):
     import submap_trace as st
-    z = np.load(os.path.join(GOLD, "ref_session.npz"))
+    z = np.load(os.path.join(GOLD, f"ref_{name}.npz"))
     p = json.loads(str(z["params"]))
     saved = st.H, st.W, st.OPTS
     st.H, st.W, st.OPTS = p["H"], p["W"], dict(p["OPTS"])
@@ -427,13 +427,14 @@ def _session(map_cls, SM):
     return z, sm.global_map, smb.global_map
 
 
-def test_the_reference_orchestration_on_the_reference_maps_is_reproduced_by_the_package_on_the_oracle():
-    """tests/golden/ref_session.npz: the reference's submap_mapping.py driving the reference's DenseTSDF (all of it run on tools/ti_seq) through eight frames,
+@pytest.mark.parametrize("name", ["session", "session_blk10"])
+def test_the_reference_orchestration_on_the_reference_maps_is_reproduced_by_the_package_on_the_oracle(name):
+    """tests/golden/ref_session.npz (and ref_session_blk10.npz: the same with blocks of 10 voxels, the reference's own configuration): the reference's submap_mapping.py driving the reference's DenseTSDF (all of it run on tools/ti_seq) through eight frames,
     three submaps, a pose-graph update, local_to_global, and a second agent fed from the wire.  The package's SubmapMapping on the FAITHFUL oracle ends with
     the same two global maps, bit for bit: poses through convert_by_pgo / convert_by_base, the export -> zlib -> load_numpy path, slots from the top for
     remote submaps, fusion in struct-for order."""
     from taichislam_amd.mapping.submap_mapping import SubmapMapping
-    z, ga, gb = _session(OraMap, SubmapMapping)
+    z, ga, gb = _session(OraMap, SubmapMapping, name)
     for tag, g in (("A", ga), ("B", gb)):
         got = sorted_bits(g.export_submap())
         want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}

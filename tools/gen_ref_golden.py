@@ -310,7 +310,7 @@ def run_octomap(Octomap):
 SESSION = dict(H=48, W=64, OPTS=dict(map_scale=[10.24, 10.24], voxel_scale=0.08, num_voxel_per_blk_axis=16, max_ray_length=5.0, max_submap_num=16, max_disp_particles=64))
 
 
-def run_session(DenseTSDF, Octomap):
+def run_session(DenseTSDF, Octomap, name="session", opts=None):
     """The reference's ORCHESTRATION on the reference's maps: taichi_slam/mapping/submap_mapping.py (loaded by path, unmodified; only its hard-coded
     autosave path is turned off) drives eight depth frames through tests/submap_trace.drive -- a new submap every three keyframes, finished submaps
     exported and put on the wire, a pose-graph update, local_to_global -- and a second agent receives the wire buffers (input_remote_submap:
@@ -320,7 +320,7 @@ def run_session(DenseTSDF, Octomap):
     import submap_trace as st
     from test_reference_callers import load_reference_submap_mapping
     import taichi_slam.mapping.mapping_common as mc
-    st.H, st.W, st.OPTS = SESSION["H"], SESSION["W"], dict(SESSION["OPTS"])
+    st.H, st.W, st.OPTS = SESSION["H"], SESSION["W"], {**SESSION["OPTS"], **(opts or {})}
     RefSM = load_reference_submap_mapping(DenseTSDF, Octomap, mc.BaseMap)
     t0 = time.time()
     sm, sent = st.drive(RefSM, DenseTSDF)
@@ -337,7 +337,7 @@ def run_session(DenseTSDF, Octomap):
     res = {"A_" + k: v for k, v in a.items()}
     res.update({"B_" + k: v for k, v in b.items()})
     res["params"] = np.array(json.dumps({"H": st.H, "W": st.W, "OPTS": st.OPTS, "NFRAMES": st.NFRAMES, "KEYFRAME_STEP": st.KEYFRAME_STEP}))
-    path = os.path.join(ROOT, "tests", "golden", "ref_session.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"ref_{name}.npz")
     np.savez_compressed(path, **res)
     print(f"  -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
@@ -370,3 +370,5 @@ if __name__ == "__main__":
         save("octomap", cfg, K, None, steps, res)
     if not only or "session" in only:
         run_session(DenseTSDF, Octomap)
+    if not only or "session_blk10" in only:     # the same session with the block size of the reference's own configuration (submap_mapping.py:33-36)
+        run_session(DenseTSDF, Octomap, "session_blk10", dict(num_voxel_per_blk_axis=10))
