@@ -109,5 +109,11 @@ def test_sparse_field_semantics_and_struct_for_order():
     first = cells[:4]
     assert first == [(-3, 1), (-3, 2), (-2, 1), (-2, 2)]
     assert [int(k.sp[c]) for c in cells if int(k.sp[c])] == [5, 6, 7]
+    # a struct-for over the field's own node (parent(0)) or the node it is placed in (parent(1)) walks the same cells (the reference's Octomap export,
+    # taichi_octomap.py:94 with level 0 / 1); a coarser ancestor is not restated
+    assert [tuple(int(x) for x in c) for c in ti.grouped(k.sp.parent(0))] == cells == [tuple(int(x) for x in c) for c in ti.grouped(k.sp.parent(1))]
+    import pytest
+    with pytest.raises(NotImplementedError):
+        k.sp.parent(2)
     k.node.parent().deactivate_all()
     assert list(k.sp) == []
