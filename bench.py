@@ -92,7 +92,7 @@ def parity_vs_faithful(dev, frames, oracle_map):
     out = parity.short_summary(rep)
     out["frames"] = len(frames)
     out["note"] = ("HIP == oracle BATCHED bit for bit (tests); this is HIP vs the reference-literal sequential f16 replay (oracle FAITHFUL). "
-                   "Parity unpinned by the reference (no golden vectors, Taichi not installable). Histogram, growth with the stream length, fusion and mesh deviation: profiles/r03_parity_vs_faithful.json")
+                   "FAITHFUL itself is pinned to the reference's own source run on tools/ti_seq (reference_source_vectors; Taichi is not installable). Histogram, growth with the stream length, fusion and mesh deviation: profiles/r03_parity_vs_faithful.json")
     return out
 
 
