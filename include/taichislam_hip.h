@@ -285,7 +285,9 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "fastdiv"  0 = force IEEE division
      "phases"   developer timing aid: 1 = phase A only, 2 = phase B only (the map contents are then meaningless), 3 = both */
 int  tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value);
-int  tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value);   /* also "fastdiv": 1 when the device verified the fma-refined division */
+int  tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value);   /* also "fastdiv": 1 when the device verified the fma-refined division;
+                                                                           read-only: "last_heavy_bricks" / "last_slab_slots" = bricks walked in parts and
+                                                                           merge-slab slots handed out by the batch issued last (synchronises) */
 
 /* ---- profiling: HIP-event timing of the per-frame kernels on the handle's stream ----------------- */
 int  tsl_tsdf_prof_enable(tsl_tsdf* m, int on);   /* 0 off, 1 every kernel, 2*mask: only the kernel ids whose bit is set in mask */

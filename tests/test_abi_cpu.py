@@ -28,6 +28,17 @@ def test_library_exports_every_declared_symbol():
     assert L.tsl_version().startswith(b"taichislam_hip")
 
 
+def test_every_backend_option_is_documented_in_the_header():
+    """tsl_tsdf_set_option / tsl_tsdf_get_option take their names as strings: every name the library compares against must be described in include/taichislam_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "taichislam_hip.h")).read()
+    names = set()
+    for f in ("tsl_tsdf.hip", "tsl_esdf.hip", "tsl_octo.hip"):
+        names |= set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', open(os.path.join(ROOT, "taichislam_amd", "csrc", f)).read()))
+    assert len(names) > 20
+    missing = sorted(n for n in names if f'"{n}"' not in hdr)
+    assert not missing, f"options without a line in the header: {missing}"
+
+
 def test_no_silent_cpu_fallback():
     from taichislam_amd import _lib
     from taichislam_amd.mapping import DenseTSDF
