@@ -249,10 +249,17 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 1: the reference-literal SEQUENTIAL replay of dense_tsdf.py:236-270 -- rays in Taichi's struct-for order, every ray step an f16
                 read-modify-write with the W clamp, colours by last writer; on a GLOBAL map: tsl_tsdf_fuse_submaps replays fuse_submaps_kernel
                 (dense_tsdf.py:272-318) the same way, submap cells in struct-for order, corners in loop order -- bit-exact with oracle FAITHFUL and
-                with the maps the reference's own source produces on tools/ti_seq (tests/golden/ref_*.npz); one frame per batch, ~180 frames/s at
-                512^3; maps of at most 2^17 bricks.  The integration follows the struct-for order for any num_voxel_per_blk_axis; the fusion
+                with the maps the reference's own source produces on tools/ti_seq (tests/golden/ref_*.npz); needs variant 2 and group 1, at
+                most 2^21 points per frame and maps of at most 2^17 bricks.  The integration follows the struct-for order for any num_voxel_per_blk_axis; the fusion
                 walks the submaps in 16^3-brick order, which is the reference's struct-for order when num_voxel_per_blk_axis is 16 and
                 another sequential schedule of the same racy kernel otherwise
+     "seq_impl" how semantics 1 integrates.  1 (default): on the brick pipeline, whole batches -- behind phase A every (frame, brick) gets its
+                ray steps as 8-byte tuples, stably grouped by voxel in replay order (k_seq_group: LDS sort of the brick's segments by ray rank,
+                LDS counting sort of the steps by voxel), phase B is one thread per voxel applying its runs frame after frame (k_seq_replay);
+                memory: 2 x 8 bytes x "seq_tuple_cap" + 16 KiB x max_frame_bricks per working set, 24 working sets, allocated by the first
+                sequential frame.  0: round 3's form -- every ray step a 16-byte tuple, two global radix sorts, one frame per batch
+     "seq_tuple_cap" ray steps one frame may produce under seq_impl 1 (default 2^24; a frame beyond it is dropped with TSL_ERR_CAPACITY);
+                set before the first sequential frame
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 8; three batch slots: phase A of up to two
                 batches is in flight beside phase B of a third)
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame

@@ -37,12 +37,7 @@ namespace tsl {
 #define TSL_TICK(F, k) do {} while (0)
 #endif
 
-// segment key (variants 0/1 staging): [0,6) step count  [6,18) first step  [18,42) ray id  [42,58) frame slot of the brick
-#define SEG_CNT_BITS 6
-#define SEG_J_BITS   12
-#define SEG_RAY_BITS 24
-#define SEG_SLOT_SHIFT (SEG_CNT_BITS + SEG_J_BITS + SEG_RAY_BITS)
-#define SEG_MAX_CNT 63
+// (the segment key layout, the header words and the work-list classes are in tsl_tsdf.hpp: tsl_sequential.hip reads the same tables)
 #define SCATTER_TILE 4096
 
 struct RayRegs { float pf0, pf1, pf2, d0, d1, d2, P0, P1, P2, w; long long qden; int n; };
@@ -277,11 +272,9 @@ __device__ __forceinline__ int lh_slot(int* keys, int b)         // find-or-inse
 // dense renumbering of the frame's bricks is the order in which they are listed); per-brick counts are kept in an LDS hash and flushed
 // once per block.
 // segment: [0,6) count [6,18) first step [18,40) ray [40,64) brick id
-#define STG_RAY_BITS 22
 #define SEG_RAY_SLOTS 16        // private segment slots per ray (split evenly over its lanes); further segments are appended behind them
 #define SEG_LH_LOG2 9
 #define SEG_LH (1 << SEG_LH_LOG2)
-#define STG_B_SHIFT (SEG_CNT_BITS + SEG_J_BITS + STG_RAY_BITS)
 // FUSED: the rays are built here as well -- lane 0 of every ray replays the pixels of its sensor voxel in raster order
 // (dense_tsdf.py:230-249; crowded voxels by the whole wave) and hands the ray to the other lanes; ray id = position of the
 // sensor voxel in the frame's list.
@@ -522,16 +515,6 @@ __global__ void __launch_bounds__(256) k_segments(MapDev M, BatchDev B)
 // unit  = { brick id, segments of the batch, pool index (claimed here, on the brick's first touch ever), frames of the batch with segments }
 // part  = { first segment, segments | parts of the (frame, brick) << 16, pool index, slab slot }
 // heavy = { brick id, pool index, frames of the batch with segments, - }
-#define PART_NP_BITS 12
-#define SLAB_SLOT_BITS 20         // bslab word: first slot | parts << 20
-#define PLAN_NCLS 4
-#define HDR_FAIL 11            // header words (FrameDev.counters): frame overflow bits
-#define HDR_CLAIM 12           //   batch (first frame's header): next rank to claim
-#define HDR_SLAB 13            //   batch: merge-slab slots handed out
-#define HDR_HEAVY 14           //   batch: heavy bricks listed
-#define HDR_PARTS 16           //   [16..19] parts per class
-#define HDR_UNITS 20           //   batch: [20..23] units per class
-#define HDR_CLAIM2 24          //   batch: next rank to claim of the parts-only launch (split launches)
 __device__ __forceinline__ int plan_class(int w) { return w >= 2560 ? 0 : (w >= 1280 ? 1 : (w >= 512 ? 2 : 3)); }
 // Three tiers by the brick's segments of the whole batch (wb):
 //   wb <= unit_half            UNIT over all its frames;
@@ -1220,8 +1203,9 @@ int launch_segments(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int t
     prof_end(m, st);
     // the unit limit is quoted for a full batch; a shorter batch (one frame when something reads the map after every frame) scales it:
     // a unit is walked by one workgroup frame after frame, and with few frames a long unit is just a long serial item
-    const int unit_max = m->unit_max <= m->unit_floor ? m->unit_max : std::max(m->unit_floor, (int)((long long)m->unit_max * B.n / TSL_NB));
-    const int unit_half = std::min(unit_max, m->unit_half <= 2048 ? m->unit_half : std::max(2048, (int)((long long)m->unit_half * B.n / TSL_NB)));
+    int unit_max = m->unit_max <= m->unit_floor ? m->unit_max : std::max(m->unit_floor, (int)((long long)m->unit_max * B.n / TSL_NB));
+    int unit_half = std::min(unit_max, m->unit_half <= 2048 ? m->unit_half : std::max(2048, (int)((long long)m->unit_half * B.n / TSL_NB)));
+    if (P.seq && m->seq_impl) unit_max = unit_half = 1 << 30;      // sequential semantics: every brick of the batch is listed once, as a unit (k_seq_replay walks that list); no parts, no slab
     prof_begin(m, TSL_K_BIN, st);
     hipLaunchKernelGGL(k_plan, dim3((B.f[0].max_frame_bricks + 255) / 256, B.n), dim3(256), 0, st, m->M, B, m->chunks * m->wg * m->spt, unit_max, unit_half);
     hipLaunchKernelGGL(k_scatter, dim3(256, B.n), dim3(256), 0, st, B);

@@ -180,6 +180,417 @@ int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P
 }
 
 // =====================================================================================================================================
+// Round 4: the same sequential map built on the brick pipeline (option "seq_impl" = 1, the default) -- no global sort of ray steps.
+//
+// Updates of different voxels commute, so the sequential map is fixed by the ORDER OF THE UPDATES OF EACH VOXEL: (ray rank in struct-for
+// order, step along the ray).  Phase A already delivers, per frame, the ray segments of every 16^3 brick (k_segments / k_plan / k_scatter).
+// Added behind it on the batch's phase-A stream (nothing here reads the map, so it runs beside phase B of the batch before):
+//   k_seq_keys + ONE radix sort per batch + k_seq_ranks   struct-for rank of every ray of every frame of the batch (keys = frame | struct-for key)
+//   k_seq_group   one workgroup per (frame, brick): the brick's segments are put in (rank, first step) order in LDS (bitonic sort, <= 2048
+//                 at a time; a brick with more is first cut by rank into chunks that fit), walked -- every step becomes an 8-byte tuple
+//                 { signed distance | voxel | z^2 } written at its replay position -- and counted per voxel; a stable counting sort by voxel
+//                 (offsets by an LDS scan; position of a tuple = its voxel's cursor + the tuples of the same voxel before it in a 256-tuple
+//                 block: 12 ballots inside a wave, one packed LDS word per voxel across the four waves) leaves every voxel's run contiguous
+//                 and in replay order, with the 4097 run offsets of the brick beside it.
+// Phase B (main stream, batches in order): k_seq_replay, one thread per voxel of every brick the batch touches: the voxel's runs of the batch's
+// frames, frame after frame, applied exactly as dense_tsdf.py:264-267 -- no LDS, no barrier, no atomics; the voxel next to the sensor
+// (every ray of a frame passes through it) is one long chain in one lane, everything else finishes around it.
+// =====================================================================================================================================
+#define SQ_NT 256
+#define SQ_SORTCAP 2048           // segments sorted in LDS at a time
+#define SQ_BSHIFT 8               // rank bucket of a heavy brick = rank >> 8: 256 rays, at most 8 segments per ray and brick (lanes per ray) = SQ_SORTCAP
+#define SQ_NBK_MAX 8192           // rank buckets (aliases the 32 KiB of the packed counters): 2 M rays per frame
+#define SQ_TUP_L_SHIFT 32
+#define SQ_TUP_Z_SHIFT 44
+
+__device__ __forceinline__ void seq_update(h16& T0, h16& W0, float w, float sd)
+{
+    const h16 Tn = f2h((h2f(hmul(T0, W0)) + w * sd) / (h2f(W0) + w));                                                   // dense_tsdf.py:264
+    float wn = h2f(W0) + w; if (TSL_WMAX < wn) wn = TSL_WMAX;                                                           // :267
+    T0 = Tn; W0 = f2h(wn);
+}
+// a ray's weight is 1 / (an f16 value), clamped (finish_ray): 16 bits describe it.  z^2 = RN16(1 / w) exactly (the reciprocal of the
+// reciprocal is within 2^-23 of the f16 value, an f16 rounding boundary is 2^-12 away), and a clamped weight maps to 2^-16 -> 65536.
+__device__ __forceinline__ h16 seq_w_code(float w) { return f2h(1.0f / w); }
+__device__ __forceinline__ float seq_w_of(h16 zz) { float w = 1.0f / h2f(zz); if (w > TSL_W_CLAMP) w = TSL_W_CLAMP; return w; }
+
+// exclusive prefix sums of a[0, C * SQ_NT) in LDS, in place; returns the total.  Every thread of the workgroup calls it with the data in
+// place and visible (a barrier before); two barriers inside, the result is visible on return.
+template <int C>
+__device__ __forceinline__ uint32_t sq_scan_excl(uint32_t* a, uint32_t* s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t v[C]; uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < C; ++q) { v[q] = a[tid * C + q]; sum += v[q]; }
+    uint32_t inc = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    uint32_t base = inc - sum;
+    for (int w = 0; w < wid; ++w) base += s_w[w];
+    const uint32_t total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+#pragma unroll
+    for (int q = 0; q < C; ++q) { a[tid * C + q] = base; base += v[q]; }
+    __syncthreads();
+    return total;
+}
+
+// the rays of all frames of a batch, keyed (frame | struct-for key of the sensor voxel, left by k_segments); unused entries sort last
+__global__ void __launch_bounds__(256) k_seq_keys(BatchDev B, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int stride, int keybits)
+{
+    const int q = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B.n || i >= stride) return;
+    const FrameDev& F = B.f[q];
+    const bool on = i < F.counters[6];
+    const size_t at = (size_t)q * stride + i;
+    keys[at] = on ? (((unsigned long long)q << keybits) | reinterpret_cast<const unsigned long long*>(F.keys)[i]) : ~0ull;      // (frame 15 = all ones: behind every frame)
+    vals[at] = on ? (((uint32_t)q << 24) | (uint32_t)i) : 0xffffffffu;
+}
+// position in the sorted array - rays of the frames before = the ray's rank in its frame's struct-for order (left in the set's `vals`)
+__global__ void __launch_bounds__(256) k_seq_ranks(BatchDev B, const uint32_t* __restrict__ vals_sorted, int total)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t v = vals_sorted[p];
+    if (v == 0xffffffffu) return;
+    const int q = (int)(v >> 24), ray = (int)(v & 0xffffffu);
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < TSL_NB; ++k) if (k < q) base += B.f[k].counters[6];
+    B.f[q].vals[ray] = (uint32_t)(p - base);
+}
+
+template <bool TEX>
+__global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+{
+    const int q = blockIdx.y;
+    if (q >= B.n) return;
+    const FrameDev& F = B.f[q];
+    const FrameParams& P = *B.p[q];
+    const SeqDev S = SD[q];
+    __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: segments of the chunk being sorted: rank 22 | first step 12 | steps 6 | ray 22
+    __shared__ uint32_t s_pre[SQ_SORTCAP];                       //  8 KiB: replay position of a sorted segment's first step inside the chunk
+    __shared__ uint32_t s_hist[TSL_BRK3];                        // 16 KiB: tuples per voxel -> run offsets -> run cursors
+    __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, tuples of each of the four waves in the current 256-tuple block (16 bits each);
+                                                                 //         before that, for a heavy brick: segments per rank bucket (u32[SQ_NBK_MAX])
+    __shared__ uint32_t s_w[4];
+    __shared__ unsigned long long s_rb;
+    __shared__ uint32_t s_red[2];
+    uint32_t* const s_bk = reinterpret_cast<uint32_t*>(s_pack);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nrays = F.counters[6];
+    const bool failed = F.counters[HDR_FAIL] != 0 || nrays > (SQ_NBK_MAX << SQ_BSHIFT);
+    if (nrays > (SQ_NBK_MAX << SQ_BSHIFT) && blockIdx.x == 0 && tid == 0) frame_fail(M, F, 4);
+    const int nact = min(F.counters[1], F.max_frame_bricks);
+    const uint32_t* __restrict__ rank_of_ray = F.vals;
+    for (int bi = blockIdx.x; bi < nact; bi += gridDim.x) {
+        const int b = F.act_b[bi];
+        const int n = F.bnseg[b], off = F.boffset[b];
+        if (tid == 0) { F.bhist[b] = 0; F.bcursor[b] = 0; F.bslab[b] = bi; }        // the set's per-brick words are zero between frames; the brick's slot of this frame
+        if (failed || n <= 0) continue;                                               // (uniform) nothing of a frame that overflowed its scratch is integrated
+        uint32_t* const csr = S.csr + (size_t)bi * SQ_CSR_STRIDE;
+        const unsigned long long* const segs = F.seg_sorted + off;
+        // ---- clear the counters, count the brick's steps, reserve its part of the frame's tuple arrays ----
+        for (int i = tid; i < TSL_BRK3; i += SQ_NT) { s_hist[i] = 0u; s_pack[i] = 0ull; }
+        if (tid < 2) s_red[tid] = 0u;
+        __syncthreads();
+        {
+            uint32_t ts = 0u;
+            for (int k = tid; k < n; k += SQ_NT) ts += (uint32_t)(segs[k] & 63ull);
+            for (int d = 32; d > 0; d >>= 1) ts += (uint32_t)__shfl_xor((int)ts, d);
+            if (lane == 0) atomicAdd(&s_red[0], ts);
+        }
+        __syncthreads();
+        const uint32_t T = s_red[0];
+        if (tid == 0) s_rb = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&F.counters[HDR_SEQ_TUPLES]), (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned long long rb = s_rb;
+        if ((long long)(rb + T) > S.cap) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
+        unsigned long long* const stash = S.stash + rb;
+        // ---- a heavy brick: its segments cut by rank into buckets of 256 rays (counting sort into the frame's spare segment array) ----
+        const bool heavy = n > SQ_SORTCAP;
+        const int nbk = heavy ? (nrays + (1 << SQ_BSHIFT) - 1) >> SQ_BSHIFT : 1;
+        unsigned long long* const temp = F.seg + off;                 // (k_scatter has consumed the raw segments; [off, off + n) belongs to this brick)
+        if (heavy) {
+            for (int k = tid; k < n; k += SQ_NT) {
+                const int ray = (int)((segs[k] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
+                atomicAdd(&s_bk[rank_of_ray[ray] >> SQ_BSHIFT], 1u);
+            }
+            __syncthreads();
+            (void)sq_scan_excl<SQ_NBK_MAX / SQ_NT>(s_bk, s_w);
+            for (int k = tid; k < n; k += SQ_NT) {
+                const unsigned long long sg = segs[k];
+                const int ray = (int)((sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
+                temp[atomicAdd(&s_bk[rank_of_ray[ray] >> SQ_BSHIFT], 1u)] = sg;      // afterwards s_bk[k] = END of bucket k
+            }
+            __syncthreads();
+        }
+        // ---- chunks of <= SQ_SORTCAP segments in rank order: sort, walk, stash the tuples at their replay positions, count per voxel ----
+        uint32_t Tb = 0u;                                              // tuples of the chunks before this one
+        int s0 = 0, k0 = 0;                                            // first segment / first bucket of the chunk
+        bool bad = false;
+        while (s0 < n) {
+            int m;
+            if (!heavy) m = n;
+            else {      // the longest run of buckets k0 .. e that fits (every thread searches the same LDS words)
+                int lo = k0, hi = nbk - 1;
+                if (s_bk[k0] > (uint32_t)(s0 + SQ_SORTCAP)) { bad = true; break; }      // one bucket beyond the sort buffer: more than 8 segments per ray and brick
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_bk[mid] <= (uint32_t)(s0 + SQ_SORTCAP)) lo = mid; else hi = mid - 1; }
+                m = (int)s_bk[lo] - s0; k0 = lo + 1;
+            }
+            int P2 = 1; while (P2 < m) P2 <<= 1;
+            const unsigned long long* const src = heavy ? temp + s0 : segs;
+            for (int k = tid; k < P2; k += SQ_NT) {
+                unsigned long long key = ~0ull;
+                if (k < m) {
+                    const unsigned long long sg = src[k];
+                    const unsigned long long ray = (sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1);
+                    key = ((unsigned long long)rank_of_ray[ray] << 40) | (((sg >> SEG_CNT_BITS) & 0xfffull) << 28) | ((sg & 63ull) << 22) | ray;
+                }
+                s_seg[k] = key;
+            }
+            __syncthreads();
+            for (int kk = 2; kk <= P2; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (P2 >> 1); t += SQ_NT) {
+                        const int i = 2 * t - (t & (j - 1)), ix = i + j;
+                        const unsigned long long a = s_seg[i], c = s_seg[ix];
+                        const bool up = (i & kk) == 0;
+                        if ((a > c) == up) { s_seg[i] = c; s_seg[ix] = a; }
+                    }
+                    __syncthreads();
+                }
+            for (int k = tid; k < SQ_SORTCAP; k += SQ_NT) s_pre[k] = k < m ? (uint32_t)((s_seg[k] >> 22) & 63ull) : 0u;
+            __syncthreads();
+            const uint32_t Tc = sq_scan_excl<SQ_SORTCAP / SQ_NT>(s_pre, s_w);
+            for (int k = tid; k < m; k += SQ_NT) {
+                const unsigned long long sk = s_seg[k];
+                const int ray = (int)(sk & 0x3fffffull), cnt = (int)((sk >> 22) & 63ull), j0 = (int)((sk >> 28) & 0xfffull);
+                const uint4 rec = F.rayA[ray];
+                const float pf0 = h2f((h16)(rec.x & 0xffffu)), pf1 = h2f((h16)(rec.x >> 16)), pf2 = h2f((h16)(rec.y & 0xffffu));
+                const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
+                const unsigned long long zz = (unsigned long long)seq_w_code(__uint_as_float(rec.w)) << SQ_TUP_Z_SHIFT;
+                const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                     // :246
+                const size_t at = (size_t)Tb + s_pre[k];
+                for (int s = 0; s < cnt; ++s) {
+                    const float jf = (float)(j0 + s);
+                    const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
+                    const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));   // :254
+                    const int l = (((i0 + M.hN) & 15) << 8) | (((i1 + M.hN) & 15) << 4) | ((i2 + M.hNz) & 15);            // the segment lies inside this brick
+                    const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2f - x2;                                                 // :258
+                    const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
+                    const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);                      // :259  (2^-96: below it sqrtf rescales)
+                    const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
+                    const float sd = dist * (float)sgn_f(dot);                                                              // :260
+                    stash[at + s] = zz | ((unsigned long long)l << SQ_TUP_L_SHIFT) | (unsigned long long)__float_as_uint(sd);
+                    if (TEX) S.stash_ray[rb + at + s] = (uint32_t)ray;
+                    atomicAdd(&s_hist[l], 1u);
+                }
+            }
+            Tb += Tc; s0 += m;
+            __syncthreads();
+        }
+        if (bad) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
+        if (heavy) { for (int i = tid; i < TSL_BRK3; i += SQ_NT) s_pack[i] = 0ull; }      // the bucket ends lived in the packed counters
+        // ---- run offsets of the brick's voxels; distinct voxels updated = non-empty runs ----
+        {
+            uint32_t nz = 0u;
+            for (int i = tid; i < TSL_BRK3; i += SQ_NT) nz += s_hist[i] != 0u ? 1u : 0u;
+            for (int d = 32; d > 0; d >>= 1) nz += (uint32_t)__shfl_xor((int)nz, d);
+            if (lane == 0) atomicAdd(&s_red[1], nz);
+        }
+        __syncthreads();
+        (void)sq_scan_excl<TSL_BRK3 / SQ_NT>(s_hist, s_w);
+        for (int i = tid; i < TSL_BRK3; i += SQ_NT) csr[i] = s_hist[i];
+        if (tid == 0) { csr[TSL_BRK3] = T; csr[TSL_BRK3 + 1] = (uint32_t)rb; if (s_red[1]) atomic_add_i64(&F.stats->unique, (long long)s_red[1]); }
+        // ---- stable counting sort by voxel: blocks of 256 tuples in replay order ----
+        unsigned long long* const tup = S.tup + rb;
+        uint32_t* const lastray = TEX ? S.lastray + (size_t)bi * TSL_BRK3 : nullptr;
+        for (uint32_t t0 = 0u; t0 < T; t0 += SQ_NT) {
+            const uint32_t t = t0 + (uint32_t)tid;
+            const bool valid = t < T;
+            const unsigned long long x = valid ? stash[t] : 0ull;
+            const int l = (int)((x >> SQ_TUP_L_SHIFT) & 4095ull);
+            unsigned long long mk = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 12; ++bit) { const bool on = (l >> bit) & 1; const unsigned long long bm = __ballot(on); mk &= on ? bm : ~bm; }
+            const int my = rank_below(mk), gs = popc64(mk);                       // tuples of my voxel before me in this wave / in this wave
+            if (valid && my == 0) atomicAdd(&s_pack[l], (unsigned long long)gs << (16 * wid));
+            __syncthreads();
+            bool lastw = false; uint32_t tot = 0u;
+            if (valid) {
+                const unsigned long long v = s_pack[l];
+                const uint32_t f0 = (uint32_t)(v & 0xffffull), f1 = (uint32_t)((v >> 16) & 0xffffull), f2 = (uint32_t)((v >> 32) & 0xffffull), f3 = (uint32_t)(v >> 48);
+                const uint32_t before = (wid > 0 ? f0 : 0u) + (wid > 1 ? f1 : 0u) + (wid > 2 ? f2 : 0u);
+                tot = f0 + f1 + f2 + f3;
+                lastw = (wid == 3) || (wid == 2 ? f3 == 0u : (wid == 1 ? (f2 | f3) == 0u : (f1 | f2 | f3) == 0u));      // no later wave holds this voxel
+                tup[s_hist[l] + before + (uint32_t)my] = x;
+                if (TEX && lastw && my == gs - 1) lastray[l] = S.stash_ray[rb + t];      // the latest tuple of the voxel so far (later blocks overwrite)
+            }
+            __syncthreads();
+            if (valid && my == 0 && lastw) { s_hist[l] += tot; s_pack[l] = 0ull; }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+// phase B: one thread per voxel of every brick the batch integrates into (k_plan's unit tables with every brick a unit: brick id, pool index,
+// frames of the batch with segments in it); sixteen 256-voxel slices per brick
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+{
+    __shared__ int s_cum[PLAN_NCLS + 1];
+    uint32_t okmask = 0u;
+#pragma unroll
+    for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[c] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
+        s_cum[PLAN_NCLS] = acc;
+    }
+    __syncthreads();
+    const int total = s_cum[PLAN_NCLS] * 16;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int u = item >> 4, l = ((item & 15) << 8) | (int)threadIdx.x;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < PLAN_NCLS; ++j) c += u >= s_cum[j] ? 1 : 0;
+        const int4 e = B.f[0].unit_tab[(size_t)c * B.f[0].unit_cap + (u - s_cum[c])];
+        const int b = e.x, pool = e.z;
+        const uint32_t tm = (uint32_t)e.w & okmask;
+        if (pool < 0 || tm == 0u) continue;
+        // the run of this voxel in every frame of the batch: all offsets are requested before the first run is walked
+        uint32_t o0[TSL_NB], o1[TSL_NB], rb[TSL_NB], slot[TSL_NB];
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {
+            o0[q] = o1[q] = rb[q] = slot[q] = 0u;
+            if ((tm >> q) & 1u) {
+                slot[q] = (uint32_t)B.f[q].bslab[b];
+                const uint32_t* csr = SD[q].csr + (size_t)slot[q] * SQ_CSR_STRIDE;
+                o0[q] = csr[l]; o1[q] = csr[l + 1]; rb[q] = csr[TSL_BRK3 + 1];
+            }
+        }
+        const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
+        const uint32_t old = M.tw[v];
+        h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
+        bool touched = false;
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {
+            if (o1[q] <= o0[q]) continue;
+            touched = true;
+            const unsigned long long* const tp = SD[q].tup + rb[q];
+            const uint32_t end = o1[q];
+            uint32_t t = o0[q];
+            unsigned long long x[4], y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = tp[min(t + k, end - 1u)];
+            while (t < end) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = tp[min(t + 4u + k, end - 1u)];       // the next four ride under this four's chain
+                float w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = seq_w_of((h16)(x[k] >> SQ_TUP_Z_SHIFT));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (t + k < end) seq_update(T0, W0, w[k], __uint_as_float((uint32_t)x[k]));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = y[k];
+                t += 4u;
+            }
+            if (TEX) {                                                                                                    // :268-269: every step stores its ray's colour, the run's last ray stays
+                const uint32_t ray = SD[q].lastray[(size_t)slot[q] * TSL_BRK3 + l];
+                reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[ray]];
+            }
+        }
+        if (touched) { M.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16); M.obs[v] = 1; }                                     // :265
+        if (__any(touched) && lane_id() == 0) M.touch[pool] = 1;
+    }
+}
+
+static int seq_ensure(tsl_tsdf* m)
+{
+    if (m->seq_ready) return TSL_OK;
+    int rc;
+    const size_t np = (size_t)m->F.max_points;
+    if (m->seq_tuple_cap <= 0) m->seq_tuple_cap = 1ll << 24;          // a frame yields at most rays x steps tuples; 2^24 covers 640 x 480 at recast_step 2 four times over (a frame beyond it fails loudly)
+    const bool tex = m->cfg.texture_enabled != 0;
+    for (int si = 0; si < TSL_NSETS; ++si) {
+        SeqDev& S = m->seq_h[si];
+        S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.lastray = nullptr;
+        if ((rc = dev_alloc(m, (void**)&S.stash, 8 * (size_t)S.cap, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&S.tup, 8 * (size_t)S.cap, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&S.csr, 4 * (size_t)m->F.max_frame_bricks * SQ_CSR_STRIDE, 0))) return rc;
+        if (tex) {
+            if ((rc = dev_alloc(m, (void**)&S.stash_ray, 4 * (size_t)S.cap, 0))) return rc;
+            if ((rc = dev_alloc(m, (void**)&S.lastray, 4 * (size_t)m->F.max_frame_bricks * TSL_BRK3, 0))) return rc;
+        }
+    }
+    if ((rc = dev_alloc(m, (void**)&m->seq_d, sizeof(SeqDev) * TSL_NSETS, 0))) return rc;
+    TSL_HIP(hipMemcpyAsync(m->seq_d, m->seq_h, sizeof(SeqDev) * TSL_NSETS, hipMemcpyHostToDevice, m->stream_));
+    size_t tb = 0;
+    TSL_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, np * TSL_NB, 0u, 64u, m->stream_));
+    m->seqb_temp_bytes = tb + 256;
+    for (int bi = 0; bi < TSL_NBATCH; ++bi) {
+        for (int k = 0; k < 2; ++k) {
+            if ((rc = dev_alloc(m, &m->seqb_keys[bi][k], 8 * np * TSL_NB, 0))) return rc;
+            if ((rc = dev_alloc(m, &m->seqb_vals[bi][k], 4 * np * TSL_NB, 0))) return rc;
+        }
+        if ((rc = dev_alloc(m, &m->seqb_temp[bi], m->seqb_temp_bytes, 0))) return rc;
+    }
+    TSL_HIP(hipStreamSynchronize(m->stream_));          // the fills ran on the main stream; the kernels below use the batch streams
+    m->seq_ready = true;
+    return TSL_OK;
+}
+void seq_release(tsl_tsdf* m)
+{
+    for (auto& S : m->seq_h) { void* p[] = { S.stash, S.tup, S.csr, S.stash_ray, S.lastray }; for (void* x : p) if (x) (void)hipFree(x); S = SeqDev(); }
+    if (m->seq_d) (void)hipFree(m->seq_d);
+    m->seq_d = nullptr;
+    for (int bi = 0; bi < TSL_NBATCH; ++bi) {
+        for (int k = 0; k < 2; ++k) { if (m->seqb_keys[bi][k]) (void)hipFree(m->seqb_keys[bi][k]); if (m->seqb_vals[bi][k]) (void)hipFree(m->seqb_vals[bi][k]); m->seqb_keys[bi][k] = m->seqb_vals[bi][k] = nullptr; }
+        if (m->seqb_temp[bi]) (void)hipFree(m->seqb_temp[bi]);
+        m->seqb_temp[bi] = nullptr;
+    }
+    m->seq_ready = false;
+}
+
+// behind phase A of a batch, on its stream: struct-for ranks of the batch's rays (one sort), then every (frame, brick)'s replay runs
+int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int bi, hipStream_t st)
+{
+    TSL_REQUIRE(hp[0].group && hp[0].variant == 2, "sequential semantics: the hash-grouped brick path (variant 2, group 1)");
+    int rc = seq_ensure(m); if (rc) return rc;
+    int stride = 0;
+    for (int q = 0; q < B.n; ++q) stride = hp[q].total > stride ? hp[q].total : stride;
+    if (stride <= 0) return TSL_OK;
+    const int keybits = 3 * m->pcl_bits;                     // the struct-for key counts the cells of the sensor grid: < ext^3 <= 2^(3 bits)
+    TSL_REQUIRE(keybits + 4 <= 64, "sequential semantics: sensor grid too large for the rank key");
+    const int total = B.n * stride;
+    unsigned long long* k0 = (unsigned long long*)m->seqb_keys[bi][0]; unsigned long long* k1 = (unsigned long long*)m->seqb_keys[bi][1];
+    uint32_t* v0 = (uint32_t*)m->seqb_vals[bi][0]; uint32_t* v1 = (uint32_t*)m->seqb_vals[bi][1];
+    prof_begin(m, TSL_K_SORT, st);
+    hipLaunchKernelGGL(k_seq_keys, dim3((stride + 255) / 256, B.n), dim3(256), 0, st, B, k0, v0, stride, keybits);
+    size_t tb = m->seqb_temp_bytes;
+    TSL_HIP(rocprim::radix_sort_pairs(m->seqb_temp[bi], tb, k0, k1, v0, v1, (size_t)total, 0u, (unsigned)(keybits + 4), st));
+    hipLaunchKernelGGL(k_seq_ranks, dim3((total + 255) / 256), dim3(256), 0, st, B, (const uint32_t*)v1, total);
+    prof_end(m, st);
+    prof_begin(m, TSL_K_RAYS, st);
+    const int gx = m->F.max_frame_bricks < 2048 ? m->F.max_frame_bricks : 2048;
+    if (hp[0].tex) hipLaunchKernelGGL(k_seq_group<true>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    else hipLaunchKernelGGL(k_seq_group<false>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    prof_end(m, st);
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi)
+{
+    if (P.tex) hipLaunchKernelGGL(k_seq_replay<true>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    else hipLaunchKernelGGL(k_seq_replay<false>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    TSL_HIP(hipGetLastError());
+    return TSL_OK;
+}
+
+// =====================================================================================================================================
 // Option "semantics" = 1 on a GLOBAL map: the reference-literal SEQUENTIAL fusion, fuse_submaps_kernel / fuse_with_interploation
 // (dense_tsdf.py:272-318).  The reference walks every cell of every submap and, for seven of the eight surrounding global voxels, does an
 // unsynchronised f16 read-modify-write of the running weighted average (:274-280); splats race.  The sequential schedule -- submap cells in

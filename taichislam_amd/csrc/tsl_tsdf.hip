@@ -589,6 +589,8 @@ static int launch_batch_t(tsl_tsdf* m)
     for (int q = 0; q < TSL_NB; ++q) { SP.p[q] = const_cast<FrameParams*>(B.p[q]); SP.header[q] = reinterpret_cast<int*>(B.f[q].stats); }
     hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, SP);
     if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
+    const bool seq_bricks = m->pend[0].seq && m->seq_impl && m->pend[0].variant == 2;
+    if (seq_bricks && (m->phases & 1)) { int rc = launch_seq_group(m, B, m->pend, bi, sa); if (rc) return rc; }      // sequential semantics: replay runs per (frame, brick), still map-independent
     m->frames_issued += n;
     if (!serial) {
         TSL_HIP(hipEventRecord(H.a_done, sa)); H.a_recorded = true;
@@ -617,7 +619,8 @@ static int launch_batch_t(tsl_tsdf* m)
             if (any) {
                 hipEvent_t ea = nullptr, eb = nullptr;
                 const bool timed = prof_slot(m, TSL_K_INTEGRATE, 1, &ea, &eb);
-                if (m->pend[0].seq) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_apply_sequential(m, B, m->pend[0]); prof_end(m); }
+                if (seq_bricks) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_seq_apply(m, B, m->pend[0], bi); prof_end(m); }
+                else if (m->pend[0].seq) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_apply_sequential(m, B, m->pend[0]); prof_end(m); }
                 else if (split) {
                     rc = launch_brick(m, B, m->pend[0], 1, m->stream_, timed ? ea : nullptr, timed ? eb : nullptr);
                     TSL_HIP(hipStreamWaitEvent(m->stream_, H.p_done, 0));
@@ -654,7 +657,7 @@ int flush_pending(tsl_tsdf* m)
 hipStream_t ms(tsl_tsdf* m) { m->clean = false; (void)flush_pending(m); return m->stream_; }
 
 static int batch_cap(const tsl_tsdf* m)
-{ return (m->overlap > 0 && m->variant == 2 && m->P.group && !m->semantics) ? (m->overlap < TSL_NB ? m->overlap : TSL_NB) : 1; }
+{ return (m->overlap > 0 && m->variant == 2 && m->P.group && (!m->semantics || m->seq_impl)) ? (m->overlap < TSL_NB ? m->overlap : TSL_NB) : 1; }
 // working set the next queued frame will use; issues the queued frames first when the new one cannot join them
 static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
 {
@@ -917,7 +920,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->ugrid = 75; m->pgrid = 25; m->split_launch = 0; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
     // (unit_half >= unit: the middle tier of k_plan is off by default -- measured neutral-to-negative once the brick kernel runs on 75 % of the slots)
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    m->active = 0; m->variant = 2; m->split = 2;
+    m->active = 0; m->variant = 2; m->split = 2; m->semantics = 0; m->seq_impl = 1; m->seq_ready = false; m->seq_d = nullptr; m->seq_tuple_cap = 0;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
@@ -1028,6 +1031,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
 
     }
     esdf_release(m);
+    seq_release(m);
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_nbr, m->esdf_note, m->fseq_keys[0], m->fseq_keys[1], m->fseq_vals[0], m->fseq_vals[1], m->fseq_temp, m->fseq_ctr, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
@@ -1098,6 +1102,7 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
     TSL_REQUIRE(m && name && value, "null");
     if (!std::strcmp(name, "group")) { *value = m->P.group; return TSL_OK; }
     if (!std::strcmp(name, "semantics")) { *value = m->semantics; return TSL_OK; }
+    if (!std::strcmp(name, "seq_impl")) { *value = m->seq_impl; return TSL_OK; }
     if (!std::strcmp(name, "last_heavy_bricks") || !std::strcmp(name, "last_slab_slots")) {
         // developer statistics of the batch issued last: bricks walked in parts / slab slots (= parts) they used
         TSL_REQUIRE(m->scratch_ready, "nothing integrated yet");
@@ -1464,6 +1469,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     TSL_REQUIRE(m && name, "null");
     if (!std::strcmp(name, "variant")) {
         TSL_REQUIRE(value >= 0 && value <= 2, "variant must be 0, 1 or 2");
+        TSL_REQUIRE(value == 2 || !m->semantics, "variant: the sequential semantics run on variant 2 only (set semantics 0 first)");
         if (value != 2 && m->variant == 2 && m->scratch_ready) {
             // the global-atomics variants expect their brick scratch to be zero between launches; the brick-binned path leaves the
             // parts' sums of its last batches in the same buffers
@@ -1473,12 +1479,25 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
         }
         m->variant = value; return TSL_OK;
     }
-    if (!std::strcmp(name, "group")) { int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
+    if (!std::strcmp(name, "group")) { TSL_REQUIRE(value != 0 || !m->semantics, "group: the sequential semantics need the hash grouping (set semantics 0 first)"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->P.group = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "semantics")) {
         TSL_REQUIRE(value == 0 || value == 1, "semantics must be 0 (batched exact sums) or 1 (sequential replay of the reference)");
         TSL_REQUIRE(value == 0 || m->M.max_bricks <= (1 << 17), "sequential semantics: maps with at most 2^17 bricks");
+        // the sequential replay lives on the hash-grouped brick path only: with another variant / grouping the frames would be
+        // integrated with the batched sums while get_option reported semantics = 1
+        TSL_REQUIRE(value == 0 || (m->variant == 2 && m->P.group), "sequential semantics needs variant 2 and the hash grouping (group 1)");
+        TSL_REQUIRE(value == 0 || m->F.max_points <= (1 << 21), "sequential semantics: at most 2^21 points per frame");
         int rc = tsl_tsdf_sync(m); if (rc) return rc;
         m->semantics = value; m->P.seq = value; return TSL_OK;
+    }
+    if (!std::strcmp(name, "seq_impl")) {
+        TSL_REQUIRE(value == 0 || value == 1, "seq_impl must be 1 (per-brick replay runs) or 0 (round 3's global sorts)");
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        m->seq_impl = value; return TSL_OK;
+    }
+    if (!std::strcmp(name, "seq_tuple_cap")) {
+        TSL_REQUIRE(value >= (1 << 16) && !m->seq_ready, "seq_tuple_cap: at least 2^16 ray steps per frame, set before the first sequential frame");
+        m->seq_tuple_cap = value; return TSL_OK;
     }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }

@@ -67,6 +67,27 @@ struct FrameDev {
     int    max_points;
 };
 
+// ray segment (k_segments -> k_scatter -> brick kernels): [0,6) step count  [6,18) first step  [18,40) ray id  [40,64) brick id
+// (variants 0/1 staging: [18,42) ray id  [42,58) frame slot of the brick)
+#define SEG_CNT_BITS 6
+#define SEG_J_BITS   12
+#define SEG_RAY_BITS 24
+#define SEG_SLOT_SHIFT (SEG_CNT_BITS + SEG_J_BITS + SEG_RAY_BITS)
+#define SEG_MAX_CNT 63
+#define STG_RAY_BITS 22
+#define STG_B_SHIFT (SEG_CNT_BITS + SEG_J_BITS + STG_RAY_BITS)
+#define PART_NP_BITS 12
+#define SLAB_SLOT_BITS 20         // bslab word: first slot | parts << 20
+#define PLAN_NCLS 4
+#define HDR_FAIL 11            // header words (FrameDev.counters): frame overflow bits
+#define HDR_CLAIM 12           //   batch (first frame's header): next rank to claim
+#define HDR_SLAB 13            //   batch: merge-slab slots handed out
+#define HDR_HEAVY 14           //   batch: heavy bricks listed
+#define HDR_PARTS 16           //   [16..19] parts per class
+#define HDR_UNITS 20           //   batch: [20..23] units per class
+#define HDR_CLAIM2 24          //   batch: next rank to claim of the parts-only launch (split launches)
+#define HDR_SEQ_TUPLES 26      //   [26..27] sequential semantics: ray-step tuples reserved in the frame's tuple arrays (one 64-bit counter)
+
 // A frame that runs out of its own scratch (bit 1: frame bricks / parts, bit 2: ray segments) is not integrated at all: the flag
 // lives in the frame's header (counters[11], cleared by the frame's prologue), so it cannot leak into other frames, and it is
 // mirrored into the handle's sticky word, which the host reports (TSL_ERR_CAPACITY) from the next call that synchronises.
@@ -148,6 +169,19 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 }
 
 
+// Sequential semantics on the brick pipeline (tsl_sequential.hip): per frame working set, the ray steps of every (frame, brick) as 8-byte
+// tuples { signed distance f32 | voxel 12 | z^2 f16 } -- first in replay order (stash), then stably grouped by voxel (tup) with the run offsets
+// of the brick's 4096 voxels (csr).  Lives in device memory (the batch's working sets already fill the 4 KiB of kernel arguments).
+#define SQ_CSR_STRIDE 4104            // words per (frame, brick): 4097 run offsets | [4097] first tuple of the brick's region
+struct SeqDev {
+    unsigned long long* stash;        // [cap]
+    unsigned long long* tup;          // [cap]
+    uint32_t* csr;                    // [max_frame_bricks][SQ_CSR_STRIDE]
+    uint32_t* stash_ray;              // textured maps: [cap] ray of every stashed tuple
+    uint32_t* lastray;                // textured maps: [max_frame_bricks][4096] ray of the last tuple of every voxel run
+    long long cap;
+};
+
 struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 
 // Frames are queued and processed TSL_NB at a time: phase A of a whole batch runs as one sequence of launches (grid.y = frame)
@@ -228,6 +262,9 @@ struct tsl_tsdf {
     bool prof_on, prof_open, prof_group; unsigned prof_mask; std::vector<tsl::ProfSlot> prof; std::vector<hipEvent_t> prof_free;
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
+    int seq_impl;                        // 1: per-brick replay runs built on the brick pipeline (default), 0: round 3's two global radix sorts (one frame per batch; kept as a cross-check)
+    bool seq_ready; tsl::SeqDev seq_h[TSL_NSETS]; tsl::SeqDev* seq_d;      // seq_impl 1: tuple arrays of every working set (allocated by the first sequential batch)
+    void *seqb_keys[TSL_NBATCH][2], *seqb_vals[TSL_NBATCH][2], *seqb_temp[TSL_NBATCH]; size_t seqb_temp_bytes; long long seq_tuple_cap;      // per batch slot: the rays' struct-for keys of all its frames, sorted in one call
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;
@@ -248,5 +285,8 @@ int  launch_apply(tsl_tsdf* m, FSet& S, int total);                          // 
 int  launch_apply_batch(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 int  launch_brick(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int kind, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 int  launch_slab_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);
+int  launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int bi, hipStream_t st);      // tsl_sequential.hip, phase A tail: replay ranks of the rays, per-brick replay runs
+int  launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi);                       // tsl_sequential.hip, phase B of a batch: every voxel's runs applied in frame order
+void seq_release(tsl_tsdf* m);
 int  launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // tsl_sequential.hip: phase B of one frame, sequential semantics      // phase B, variant 2: apply a batch of frames (one launch)
 }
