@@ -71,7 +71,9 @@ const char* tsl_last_error(void);
 int  tsl_device_count(int* n);
 /* Exhaustive device check (all 2^32 float patterns) of an arithmetic shortcut the kernels rely on for bit-exactness:
    which = 0: three-instruction round-half-away == ti.round (mapping_common.py:263-266, dense_tsdf.py:254);
-   which = 1: rescale-free correctly rounded sqrt == sqrtf on [2^-96, inf).  *mismatches must come back 0. */
+   which = 1: rescale-free correctly rounded sqrt == sqrtf on [2^-96, inf);
+   which = 2 (2^32 pseudo-random operand pairs, not exhaustive): the division-free quotient of the sequential replay's saturated voxels
+              (reciprocal product + two FMA residual corrections) == IEEE division.  *mismatches must come back 0. */
 int  tsl_selftest(int which, int64_t* mismatches);
 
 /* ---- lifecycle -------------------------------------------------------------------------- */

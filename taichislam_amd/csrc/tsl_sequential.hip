@@ -214,6 +214,34 @@ __device__ __forceinline__ void seq_update(h16& T0, h16& W0, float w, float sd)
 __device__ __forceinline__ h16 seq_w_code(float w) { return f2h(1.0f / w); }
 __device__ __forceinline__ float seq_w_of(h16 zz) { float w = 1.0f / h2f(zz); if (w > TSL_W_CLAMP) w = TSL_W_CLAMP; return w; }
 
+// One update of a voxel whose weight has reached Wmax (W = 1000 stays 1000: dense_tsdf.py:267), the state of every long replay run:
+//   T' = RN16( RN32( RN16(T * 1000) + c ) / D ),   c = RN32(w * sd),  D = RN32(1000 + w),  with r = RN32(1 / D) from the tuple.
+// The quotient is formed without the division: q0 = RN(n r), then two residual corrections q <- RN(q + RN(n - q D) r).  With r the correctly
+// rounded reciprocal, q0 is within 2 ulp, the first correction leaves a faithful quotient and the second the correctly rounded one
+// (Markstein's theorem; the residuals are exact under FMA) -- valid while nothing overflows or underflows, which k_seq_group guarantees per
+// (frame, brick) (|sd| <= 60, no tiny products: SQ_CSR_UNSAFE) and the caller per run (|T| <= 60: the update is a convex combination, so T
+// stays there).  tsl_selftest(2) compares it with IEEE division on 2^32 operand pairs; every parity test of the sequential mode runs through it.
+__device__ __forceinline__ float seq_div_sat(float n, float D, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-q, D, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-q, D, n);
+    return __builtin_fmaf(e, r, q);
+}
+// { a = RN16(T * W), n = RN32(a + c), q = n / D, T' = RN16(q) } with D and r = RN32(1 / D) given; W as f16 (1000 once saturated)
+__device__ __forceinline__ _Float16 seq_update_fast(_Float16 T, _Float16 W, float c, float D, float r)
+{
+    const _Float16 a = T * W;                                  // RN16(T * W): one v_mul_f16 (f16 denormals are kept)
+    const float n = __builtin_fmaf((float)a, 1.0f, c);         // = a + c, one rounding (v_fma_mix_f32: the f16 operand is read as it is)
+    return (_Float16)seq_div_sat(n, D, r);
+}
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: keep it in an SGPR
+#define SQ_W_SAT 0x63d0u          // 1000 as f16 bits
+#define SQ_LONG 64                // a voxel with a run of at least this many updates in some frame of the batch gets a wave of its own (k_seq_replay_long)
+#define SQ_LCHUNK 256             // updates staged in LDS at a time there
+#define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to k_seq_replay_long (beyond: they stay with their lane)
+
 // exclusive prefix sums of a[0, C * SQ_NT) in LDS, in place; returns the total.  Every thread of the workgroup calls it with the data in
 // place and visible (a barrier before); two barriers inside, the result is visible on return.
 template <int C>
@@ -403,10 +431,10 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
         __syncthreads();
         (void)sq_scan_excl<TSL_BRK3 / SQ_NT>(s_hist, s_w);
         for (int i = tid; i < TSL_BRK3; i += SQ_NT) csr[i] = s_hist[i];
-        if (tid == 0) { csr[TSL_BRK3] = T; csr[TSL_BRK3 + 1] = (uint32_t)rb; if (s_red[1]) atomic_add_i64(&F.stats->unique, (long long)s_red[1]); }
+        if (tid == 0) { csr[TSL_BRK3] = T; csr[SQ_CSR_BASE] = (uint32_t)rb; csr[SQ_CSR_UNSAFE] = 0u; if (s_red[1]) atomic_add_i64(&F.stats->unique, (long long)s_red[1]); }
         // ---- stable counting sort by voxel: blocks of 256 tuples in replay order ----
-        unsigned long long* const tup = S.tup + rb;
-        uint32_t* const lastray = TEX ? S.lastray + (size_t)bi * TSL_BRK3 : nullptr;
+        float4* const tup = S.tup + rb;
+        bool unsafe = false;
         for (uint32_t t0 = 0u; t0 < T; t0 += SQ_NT) {
             const uint32_t t = t0 + (uint32_t)tid;
             const bool valid = t < T;
@@ -425,21 +453,30 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
                 const uint32_t before = (wid > 0 ? f0 : 0u) + (wid > 1 ? f1 : 0u) + (wid > 2 ? f2 : 0u);
                 tot = f0 + f1 + f2 + f3;
                 lastw = (wid == 3) || (wid == 2 ? f3 == 0u : (wid == 1 ? (f2 | f3) == 0u : (f1 | f2 | f3) == 0u));      // no later wave holds this voxel
-                tup[s_hist[l] + before + (uint32_t)my] = x;
-                if (TEX && lastw && my == gs - 1) lastray[l] = S.stash_ray[rb + t];      // the latest tuple of the voxel so far (later blocks overwrite)
+                // the replay tuple: everything an update needs that does not depend on the voxel -- w, c = w * sd (:264), 1 / (Wmax + w), Wmax + w
+                const float sd = __uint_as_float((uint32_t)x), w = seq_w_of((h16)(x >> SQ_TUP_Z_SHIFT)), c = w * sd;
+                const float D = TSL_WMAX + w;
+                const uint32_t pos = s_hist[l] + before + (uint32_t)my;
+                tup[pos] = make_float4(w, c, 1.0f / D, D);
+                if (TEX) S.tup_ray[rb + pos] = S.stash_ray[rb + t];
+                unsafe = unsafe || !(fabsf(sd) <= 60.0f) || (c != 0.0f && fabsf(c) < 8.67e-19f);      // 2^-60: the residuals of the division-free quotient stay representable
             }
             __syncthreads();
             if (valid && my == 0 && lastw) { s_hist[l] += tot; s_pack[l] = 0ull; }
             __syncthreads();
         }
+        if (unsafe) csr[SQ_CSR_UNSAFE] = 1u;          // (csr[SQ_CSR_UNSAFE] was cleared with the offsets; whoever sees an odd tuple sets it)
         __syncthreads();
     }
 }
 
 // phase B: one thread per voxel of every brick the batch integrates into (k_plan's unit tables with every brick a unit: brick id, pool index,
-// frames of the batch with segments in it); sixteen 256-voxel slices per brick
+// frames of the batch with segments in it); sixteen 256-voxel slices per brick.  A voxel whose longest run of the batch has fewer than SQ_LONG
+// updates is replayed by its lane, frame after frame (literal expression while the weight is below Wmax, the division-free form from then
+// on); the others -- a few thousand voxels around the sensor, among them the one every ray of a frame passes through -- are only LISTED
+// here and replayed by k_seq_replay_long, a wave each.
 template <bool TEX>
-__global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+__global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, int4* __restrict__ long_list)
 {
     __shared__ int s_cum[PLAN_NCLS + 1];
     uint32_t okmask = 0u;
@@ -462,14 +499,25 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
         const uint32_t tm = (uint32_t)e.w & okmask;
         if (pool < 0 || tm == 0u) continue;
         // the run of this voxel in every frame of the batch: all offsets are requested before the first run is walked
-        uint32_t o0[TSL_NB], o1[TSL_NB], rb[TSL_NB], slot[TSL_NB];
+        uint32_t o0[TSL_NB], o1[TSL_NB], rb[TSL_NB], unsafe[TSL_NB];
+        bool is_long = false;
 #pragma unroll
         for (int q = 0; q < TSL_NB; ++q) {
-            o0[q] = o1[q] = rb[q] = slot[q] = 0u;
+            o0[q] = o1[q] = rb[q] = unsafe[q] = 0u;
             if ((tm >> q) & 1u) {
-                slot[q] = (uint32_t)B.f[q].bslab[b];
-                const uint32_t* csr = SD[q].csr + (size_t)slot[q] * SQ_CSR_STRIDE;
-                o0[q] = csr[l]; o1[q] = csr[l + 1]; rb[q] = csr[TSL_BRK3 + 1];
+                const uint32_t* csr = SD[q].csr + (size_t)B.f[q].bslab[b] * SQ_CSR_STRIDE;
+                o0[q] = csr[l]; o1[q] = csr[l + 1]; rb[q] = csr[SQ_CSR_BASE]; unsafe[q] = csr[SQ_CSR_UNSAFE];
+                is_long = is_long || o1[q] - o0[q] >= (uint32_t)SQ_LONG;
+            }
+        }
+        {   // hand the long ones over (one reservation per wave); a voxel that does not fit the list stays here
+            const unsigned long long lm = __ballot(is_long);
+            if (lm) {
+                int base = 0;
+                if (lane_id() == (int)__builtin_ctzll(lm)) base = __hip_atomic_fetch_add(&B.f[0].counters[HDR_SEQ_LONG], popc64(lm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = __shfl(base, (int)__builtin_ctzll(lm));
+                const int pos = base + rank_below(lm);
+                if (is_long) { if (pos < SQ_LONG_CAP) long_list[pos] = make_int4(pool, b, l, (int)tm); else is_long = false; }
             }
         }
         const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
@@ -478,52 +526,181 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
         bool touched = false;
 #pragma unroll
         for (int q = 0; q < TSL_NB; ++q) {
-            if (o1[q] <= o0[q]) continue;
+            if (is_long || o1[q] <= o0[q]) continue;
             touched = true;
-            const unsigned long long* const tp = SD[q].tup + rb[q];
+            const float4* const tp = SD[q].tup + rb[q];
             const uint32_t end = o1[q];
             uint32_t t = o0[q];
-            unsigned long long x[4], y[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = tp[min(t + k, end - 1u)];
-            while (t < end) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = tp[min(t + 4u + k, end - 1u)];       // the next four ride under this four's chain
-                float w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = seq_w_of((h16)(x[k] >> SQ_TUP_Z_SHIFT));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (t + k < end) seq_update(T0, W0, w[k], __uint_as_float((uint32_t)x[k]));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = y[k];
-                t += 4u;
+            // literal updates until the weight sits at Wmax (for good: w > 0) and the value is where the division-free form is exact
+            const bool can_sat = unsafe[q] == 0u;
+            while (t < end && !(can_sat && W0 == (h16)SQ_W_SAT && fabsf(h2f(T0)) <= 60.0f)) {
+                const float4 x = tp[t];
+                const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                          // dense_tsdf.py:264
+                float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                               // :267
+                T0 = Tn; W0 = f2h(wn);
+                ++t;
             }
-            if (TEX) {                                                                                                    // :268-269: every step stores its ray's colour, the run's last ray stays
-                const uint32_t ray = SD[q].lastray[(size_t)slot[q] * TSL_BRK3 + l];
-                reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[ray]];
+            if (t < end) {
+                _Float16 Th = __builtin_bit_cast(_Float16, T0);
+                for (; t < end; ++t) { const float4 z = tp[t]; Th = seq_update_fast(Th, (_Float16)1000.0f, z.y, z.w, z.z); }
+                T0 = __builtin_bit_cast(h16, Th);
             }
+            if (TEX) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[rb[q] + end - 1u]]];        // :268-269: every step stores its ray's colour, the run's last ray stays
         }
         if (touched) { M.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16); M.obs[v] = 1; }                                     // :265
         if (__any(touched) && lane_id() == 0) M.touch[pool] = 1;
     }
 }
 
+// The long runs: ONE WAVE PER VOXEL, wave-uniform.  A wave issues one instruction per four cycles however many lanes are active, so what a long
+// chain costs is instructions per update -- and the latency of whatever it waits for.  Here the wave's 64 lanes move a chunk of 256 replay
+// tuples from HBM into LDS with four coalesced loads (the next chunk is requested before the current one is replayed: the chain never waits
+// for memory), and the chain itself reads { c, D, 1 / D, W } from LDS -- eight instructions per update: ds_read_b128, v_mul_f16, v_fma_mix_f32,
+// v_mul_f32, three v_fma_f32, v_fma_mixlo_f16.  While the voxel's weight is still below Wmax the chunk's W sequence (four dependent
+// instructions per update, independent of the values) is run first, then D = W + w and 1 / D are formed by the 64 lanes side by side.
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list)
+{
+    __shared__ float4 s_t[4][SQ_LCHUNK];             // per wave: { c, D, 1 / D, W bits before the update } of the chunk's updates
+    __shared__ float s_wv[4][SQ_LCHUNK];             // w
+    __shared__ uint32_t s_wp[4][SQ_LCHUNK];          // W (f16 bits) before update k, while unsaturated
+    const int wid = threadIdx.x >> 6, lane = lane_id();
+    float4* const st = s_t[wid]; float* const sw = s_wv[wid]; uint32_t* const swp = s_wp[wid];
+    uint32_t okmask = 0u;
+#pragma unroll
+    for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
+    const int n = min(B.f[0].counters[HDR_SEQ_LONG], SQ_LONG_CAP);
+    for (int i = blockIdx.x * 4 + wid; i < n; i += gridDim.x * 4) {
+        const int4 e = long_list[i];
+        const int pool = uni_i(e.x), b = uni_i(e.y), l = uni_i(e.z);
+        const uint32_t tm = (uint32_t)uni_i(e.w) & okmask;
+        const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
+        const uint32_t old = (uint32_t)uni_i((int)M.tw[v]);
+        uint32_t Tb = old & 0xffffu, Wb = old >> 16;
+        for (int q = 0; q < TSL_NB; ++q) {
+            if (!((tm >> q) & 1u)) continue;
+            const uint32_t* csr = SD[q].csr + (size_t)B.f[q].bslab[b] * SQ_CSR_STRIDE;
+            const uint32_t o0 = (uint32_t)uni_i((int)csr[l]), o1 = (uint32_t)uni_i((int)csr[l + 1]), rbq = (uint32_t)uni_i((int)csr[SQ_CSR_BASE]), unsafe = (uint32_t)uni_i((int)csr[SQ_CSR_UNSAFE]);
+            if (o1 <= o0) continue;
+            const float4* const tp = SD[q].tup + rbq;
+            uint32_t t = o0;
+            if (unsafe != 0u || !(fabsf(h2f((h16)Tb)) <= 60.0f)) {        // outside the division-free form's range: the literal expression (never seen in practice)
+                h16 T0 = (h16)Tb, W0 = (h16)Wb;
+                for (; t < o1; ++t) {
+                    const float4 x = tp[t];
+                    const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                      // dense_tsdf.py:264
+                    float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                           // :267
+                    T0 = Tn; W0 = f2h(wn);
+                }
+                Tb = (uint32_t)uni_i((int)T0); Wb = (uint32_t)uni_i((int)W0);
+            } else {
+                float4 nx[SQ_LCHUNK / 64];
+#pragma unroll
+                for (int j = 0; j < SQ_LCHUNK / 64; ++j) { const uint32_t idx = t + (uint32_t)(j * 64 + lane); nx[j] = idx < o1 ? tp[idx] : make_float4(0.f, 0.f, 0.f, 0.f); }
+                while (t < o1) {
+                    const int m = (int)min(o1 - t, (uint32_t)SQ_LCHUNK);
+#pragma unroll
+                    for (int j = 0; j < SQ_LCHUNK / 64; ++j) {
+                        const int k = j * 64 + lane;
+                        st[k] = make_float4(nx[j].y, nx[j].w, nx[j].z, __uint_as_float(SQ_W_SAT)); sw[k] = nx[j].x;
+                    }
+                    {   // the next chunk rides under this one's chain (volatile: the request stays HERE, it is not sunk to its use behind the chain)
+                        const uint32_t tn = t + (uint32_t)m;
+#pragma unroll
+                        for (int j = 0; j < SQ_LCHUNK / 64; ++j) {
+                            const uint32_t idx = tn + (uint32_t)(j * 64 + lane);
+                            const volatile float4* src = tp + (idx < o1 ? idx : o1 - 1u);
+                            nx[j].x = src->x; nx[j].y = src->y; nx[j].z = src->z; nx[j].w = src->w;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (Wb != SQ_W_SAT) {
+                        float Wf = h2f((h16)Wb);
+                        for (int k = 0; k < m; ++k) {
+                            swp[k] = (uint32_t)f2h(Wf);
+                            float d = Wf + sw[k]; if (TSL_WMAX < d) d = TSL_WMAX;                                         // :267
+                            Wf = h2f(f2h(d));
+                        }
+                        Wb = (uint32_t)uni_i((int)f2h(Wf));
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int j = 0; j < SQ_LCHUNK / 64; ++j) {
+                            const int k = j * 64 + lane;
+                            if (k < m) { const float D = h2f((h16)swp[k]) + sw[k]; const float4 x = st[k]; st[k] = make_float4(x.x, D, 1.0f / D, __uint_as_float(swp[k])); }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    _Float16 Th = __builtin_bit_cast(_Float16, (h16)Tb);
+                    int k = 0;
+                    for (; k + 16 <= m; k += 16) {      // sixteen updates per trip: all sixteen LDS reads are issued in front of the chain (the LDS answers in
+                        float4 x[16];                   // order, so the chain waits for the first one only: ~100 cycles per 16 updates; the scheduling barrier keeps
+#pragma unroll                                          // the reads there -- left alone the scheduler moves each read next to its use and the chain waits every time)
+                        for (int j = 0; j < 16; ++j) x[j] = st[k + j];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) Th = seq_update_fast(Th, __builtin_bit_cast(_Float16, (h16)__float_as_uint(x[j].w)), x[j].x, x[j].y, x[j].z);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    for (; k < m; ++k) {
+                        const float4 x = st[k];
+                        Th = seq_update_fast(Th, __builtin_bit_cast(_Float16, (h16)__float_as_uint(x.w)), x.x, x.y, x.z);
+                    }
+                    Tb = (uint32_t)uni_i((int)__builtin_bit_cast(h16, Th));
+                    __builtin_amdgcn_wave_barrier();
+                    t += (uint32_t)m;
+                }
+            }
+            if (TEX && lane == 0) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[rbq + o1 - 1u]]];      // :268-269
+        }
+        if (lane == 0) { M.tw[v] = Tb | (Wb << 16); M.obs[v] = 1; M.touch[pool] = 1; }                                    // :265
+    }
+}
+
+// tsl_selftest(2): the division-free quotient against IEEE division, 2^32 operand pairs drawn from what a saturated voxel sees
+// (n = an f16-valued product + c over a wide range of magnitudes and signs, D = 1000 + w for every weight class)
+__global__ void __launch_bounds__(256) k_selftest_seqdiv(unsigned long long* bad)
+{
+    unsigned long long st = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    long long nbad = 0;
+    for (int it = 0; it < 2048; ++it) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const uint32_t a = (uint32_t)(st >> 32), bq = (uint32_t)st;
+        // w: any positive finite f16 z^2 code (as the tuples carry it); T: any f16 value up to 60 in magnitude; sd: a float of up to 60 in
+        // magnitude with a random exponent over 32 binades, either sign
+        uint32_t zc = a & 0x7fffu; if (zc == 0u) zc = 1u; if (zc >= 0x7c00u) zc = 0x3c00u;
+        const float w = seq_w_of((h16)zc);
+        uint32_t tb = a >> 16; if (!(fabsf(h2f((h16)tb)) <= 60.0f)) tb &= 0xbfffu;
+        const float T = h2f((h16)tb);
+        float sd = __uint_as_float((bq & 0x80000000u) | ((132u - ((bq >> 23) & 31u)) << 23) | (bq & 0x7fffffu));
+        if (fabsf(sd) > 60.0f) sd *= 0.5f;
+        const float c = w * sd;
+        if (c != 0.0f && fabsf(c) < 1e-30f) continue;
+        const _Float16 Th = (_Float16)T;
+        const float n = (float)(Th * (_Float16)1000.0f) + c, D = TSL_WMAX + w;
+        const float want = n / D, got = seq_div_sat(n, D, 1.0f / D);
+        if (__float_as_uint(want) != __float_as_uint(got)) ++nbad;
+    }
+    nbad = wave_sum_ll(nbad);
+    if (lane_id() == 0 && nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+int selftest_seqdiv(unsigned long long* bad_dev) { hipLaunchKernelGGL(k_selftest_seqdiv, dim3(8192), dim3(256), 0, 0, bad_dev); return TSL_OK; }
+
 static int seq_ensure(tsl_tsdf* m)
 {
     if (m->seq_ready) return TSL_OK;
     int rc;
     const size_t np = (size_t)m->F.max_points;
-    if (m->seq_tuple_cap <= 0) m->seq_tuple_cap = 1ll << 24;          // a frame yields at most rays x steps tuples; 2^24 covers 640 x 480 at recast_step 2 four times over (a frame beyond it fails loudly)
+    if (m->seq_tuple_cap <= 0) m->seq_tuple_cap = 1ll << 23;          // a frame yields at most rays x steps tuples; 2^23 is 640 x 480 at recast_step 2 twice over (a frame beyond it fails loudly; option "seq_tuple_cap")
     const bool tex = m->cfg.texture_enabled != 0;
     for (int si = 0; si < TSL_NSETS; ++si) {
         SeqDev& S = m->seq_h[si];
-        S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.lastray = nullptr;
+        S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.tup_ray = nullptr;
         if ((rc = dev_alloc(m, (void**)&S.stash, 8 * (size_t)S.cap, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&S.tup, 8 * (size_t)S.cap, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&S.tup, 16 * ((size_t)S.cap + 16), 0))) return rc;          // + spare tuples: the replay requests four ahead
         if ((rc = dev_alloc(m, (void**)&S.csr, 4 * (size_t)m->F.max_frame_bricks * SQ_CSR_STRIDE, 0))) return rc;
         if (tex) {
             if ((rc = dev_alloc(m, (void**)&S.stash_ray, 4 * (size_t)S.cap, 0))) return rc;
-            if ((rc = dev_alloc(m, (void**)&S.lastray, 4 * (size_t)m->F.max_frame_bricks * TSL_BRK3, 0))) return rc;
+            if ((rc = dev_alloc(m, (void**)&S.tup_ray, 4 * (size_t)S.cap, 0))) return rc;
         }
     }
     if ((rc = dev_alloc(m, (void**)&m->seq_d, sizeof(SeqDev) * TSL_NSETS, 0))) return rc;
@@ -537,6 +714,7 @@ static int seq_ensure(tsl_tsdf* m)
             if ((rc = dev_alloc(m, &m->seqb_vals[bi][k], 4 * np * TSL_NB, 0))) return rc;
         }
         if ((rc = dev_alloc(m, &m->seqb_temp[bi], m->seqb_temp_bytes, 0))) return rc;
+        if ((rc = dev_alloc(m, &m->seqb_long[bi], sizeof(int4) * (size_t)SQ_LONG_CAP, 0))) return rc;
     }
     TSL_HIP(hipStreamSynchronize(m->stream_));          // the fills ran on the main stream; the kernels below use the batch streams
     m->seq_ready = true;
@@ -544,13 +722,14 @@ static int seq_ensure(tsl_tsdf* m)
 }
 void seq_release(tsl_tsdf* m)
 {
-    for (auto& S : m->seq_h) { void* p[] = { S.stash, S.tup, S.csr, S.stash_ray, S.lastray }; for (void* x : p) if (x) (void)hipFree(x); S = SeqDev(); }
+    for (auto& S : m->seq_h) { void* p[] = { S.stash, S.tup, S.csr, S.stash_ray, S.tup_ray }; for (void* x : p) if (x) (void)hipFree(x); S = SeqDev(); }
     if (m->seq_d) (void)hipFree(m->seq_d);
     m->seq_d = nullptr;
     for (int bi = 0; bi < TSL_NBATCH; ++bi) {
         for (int k = 0; k < 2; ++k) { if (m->seqb_keys[bi][k]) (void)hipFree(m->seqb_keys[bi][k]); if (m->seqb_vals[bi][k]) (void)hipFree(m->seqb_vals[bi][k]); m->seqb_keys[bi][k] = m->seqb_vals[bi][k] = nullptr; }
         if (m->seqb_temp[bi]) (void)hipFree(m->seqb_temp[bi]);
-        m->seqb_temp[bi] = nullptr;
+        if (m->seqb_long[bi]) (void)hipFree(m->seqb_long[bi]);
+        m->seqb_temp[bi] = nullptr; m->seqb_long[bi] = nullptr;
     }
     m->seq_ready = false;
 }
@@ -584,8 +763,15 @@ int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int 
 }
 int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi)
 {
-    if (P.tex) hipLaunchKernelGGL(k_seq_replay<true>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
-    else hipLaunchKernelGGL(k_seq_replay<false>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    const SeqDev* sd = m->seq_d + bi * TSL_NB;
+    int4* ll = static_cast<int4*>(m->seqb_long[bi]);
+    if (P.tex) {
+        hipLaunchKernelGGL(k_seq_replay<true>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, ll);
+        hipLaunchKernelGGL(k_seq_replay_long<true>, dim3(4 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, (const int4*)ll);
+    } else {
+        hipLaunchKernelGGL(k_seq_replay<false>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, ll);
+        hipLaunchKernelGGL(k_seq_replay_long<false>, dim3(4 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, (const int4*)ll);
+    }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }

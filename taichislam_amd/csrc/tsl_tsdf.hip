@@ -845,11 +845,12 @@ const char* tsl_version(void) { return "taichislam_hip 0.1 (gfx950)"; }
 const char* tsl_last_error(void) { return g_err.c_str(); }
 int tsl_selftest(int which, int64_t* mismatches)
 {
-    TSL_REQUIRE(mismatches && (which == 0 || which == 1), "tsl_selftest: bad argument");
+    TSL_REQUIRE(mismatches && which >= 0 && which <= 2, "tsl_selftest: bad argument");
     unsigned long long* bad = nullptr;
     TSL_HIP(hipMalloc((void**)&bad, sizeof(unsigned long long)));
     TSL_HIP(hipMemset(bad, 0, sizeof(unsigned long long)));
-    hipLaunchKernelGGL(k_selftest, dim3(8192), dim3(256), 0, 0, which, bad);
+    if (which == 2) (void)selftest_seqdiv(bad);
+    else hipLaunchKernelGGL(k_selftest, dim3(8192), dim3(256), 0, 0, which, bad);
     unsigned long long h = ~0ull;
     hipError_t e = hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(bad);

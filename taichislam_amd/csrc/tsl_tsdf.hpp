@@ -87,6 +87,7 @@ struct FrameDev {
 #define HDR_UNITS 20           //   batch: [20..23] units per class
 #define HDR_CLAIM2 24          //   batch: next rank to claim of the parts-only launch (split launches)
 #define HDR_SEQ_TUPLES 26      //   [26..27] sequential semantics: ray-step tuples reserved in the frame's tuple arrays (one 64-bit counter)
+#define HDR_SEQ_LONG 28        //   batch: sequential semantics: voxels listed for k_seq_replay_long
 
 // A frame that runs out of its own scratch (bit 1: frame bricks / parts, bit 2: ray segments) is not integrated at all: the flag
 // lives in the frame's header (counters[11], cleared by the frame's prologue), so it cannot leak into other frames, and it is
@@ -169,16 +170,19 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 }
 
 
-// Sequential semantics on the brick pipeline (tsl_sequential.hip): per frame working set, the ray steps of every (frame, brick) as 8-byte
-// tuples { signed distance f32 | voxel 12 | z^2 f16 } -- first in replay order (stash), then stably grouped by voxel (tup) with the run offsets
-// of the brick's 4096 voxels (csr).  Lives in device memory (the batch's working sets already fill the 4 KiB of kernel arguments).
-#define SQ_CSR_STRIDE 4104            // words per (frame, brick): 4097 run offsets | [4097] first tuple of the brick's region
+// Sequential semantics on the brick pipeline (tsl_sequential.hip): per frame working set, the ray steps of every (frame, brick) -- first as
+// 8-byte tuples { signed distance f32 | voxel 12 | z^2 f16 } in replay order (stash), then stably grouped by voxel as 16-byte replay tuples
+// { w, w * sd, 1 / (Wmax + w), Wmax + w } (tup) with the run offsets of the brick's 4096 voxels (csr).  Lives in device memory (the batch's working
+// sets already fill the 4 KiB of kernel arguments).
+#define SQ_CSR_STRIDE 4104            // words per (frame, brick): 4097 run offsets | first tuple of the brick's region | "a tuple outside the fast path's range"
+#define SQ_CSR_BASE 4097
+#define SQ_CSR_UNSAFE 4098
 struct SeqDev {
     unsigned long long* stash;        // [cap]
-    unsigned long long* tup;          // [cap]
+    float4* tup;                      // [cap + 16]
     uint32_t* csr;                    // [max_frame_bricks][SQ_CSR_STRIDE]
     uint32_t* stash_ray;              // textured maps: [cap] ray of every stashed tuple
-    uint32_t* lastray;                // textured maps: [max_frame_bricks][4096] ray of the last tuple of every voxel run
+    uint32_t* tup_ray;                // textured maps: [cap] ray of every replay tuple (a run's last one colours the voxel)
     long long cap;
 };
 
@@ -264,7 +268,7 @@ struct tsl_tsdf {
     int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
     int seq_impl;                        // 1: per-brick replay runs built on the brick pipeline (default), 0: round 3's two global radix sorts (one frame per batch; kept as a cross-check)
     bool seq_ready; tsl::SeqDev seq_h[TSL_NSETS]; tsl::SeqDev* seq_d;      // seq_impl 1: tuple arrays of every working set (allocated by the first sequential batch)
-    void *seqb_keys[TSL_NBATCH][2], *seqb_vals[TSL_NBATCH][2], *seqb_temp[TSL_NBATCH]; size_t seqb_temp_bytes; long long seq_tuple_cap;      // per batch slot: the rays' struct-for keys of all its frames, sorted in one call
+    void *seqb_keys[TSL_NBATCH][2], *seqb_vals[TSL_NBATCH][2], *seqb_temp[TSL_NBATCH], *seqb_long[TSL_NBATCH]; size_t seqb_temp_bytes; long long seq_tuple_cap;      // per batch slot: the rays' struct-for keys of all its frames, sorted in one call
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;
@@ -288,5 +292,6 @@ int  launch_slab_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);
 int  launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int bi, hipStream_t st);      // tsl_sequential.hip, phase A tail: replay ranks of the rays, per-brick replay runs
 int  launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi);                       // tsl_sequential.hip, phase B of a batch: every voxel's runs applied in frame order
 void seq_release(tsl_tsdf* m);
+int  selftest_seqdiv(unsigned long long* bad_dev);
 int  launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // tsl_sequential.hip: phase B of one frame, sequential semantics      // phase B, variant 2: apply a batch of frames (one launch)
 }

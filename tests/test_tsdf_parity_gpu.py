@@ -109,10 +109,11 @@ def test_middle_tier_first_frames_as_unit_later_frames_as_parts(hip_lib, unit, h
     assert_export_equal(g.export_submap(), o.export_sparse(), f"unit {unit} unit_half {half}")
 
 
-@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("which", [0, 1, 2])
 def test_arithmetic_shortcuts_hold_for_every_float(hip_lib, which):
     """The kernels round half away from zero with add+truncate and take square roots without the library's rescaling;
-    both must agree with the plain forms (ti.round, sqrtf) for all 2^32 float patterns."""
+    both must agree with the plain forms (ti.round, sqrtf) for all 2^32 float patterns.  2: the sequential replay divides by Wmax + w
+    through a reciprocal product with two FMA corrections once a voxel's weight is saturated -- against IEEE division on 2^32 operand pairs."""
     import ctypes
     from taichislam_amd import _lib
     bad = ctypes.c_int64(-1)
