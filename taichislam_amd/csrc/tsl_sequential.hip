@@ -233,8 +233,14 @@ __device__ __forceinline__ float seq_div_sat(float n, float D, float r)
 __device__ __forceinline__ _Float16 seq_update_fast(_Float16 T, _Float16 W, float c, float D, float r)
 {
     const _Float16 a = T * W;                                  // RN16(T * W): one v_mul_f16 (f16 denormals are kept)
-    const float n = __builtin_fmaf((float)a, 1.0f, c);         // = a + c, one rounding (v_fma_mix_f32: the f16 operand is read as it is)
-    return (_Float16)seq_div_sat(n, D, r);
+    const float n = (float)a + c;
+    float q = seq_div_sat(n, D, r);
+    // the quotient is an f32 value that is THEN rounded to f16 (two roundings, as dense_tsdf.py:264 stores an f32 expression into an f16 field).
+    // Left to itself the compiler folds the last FMA and the conversion into one v_fma_mixlo_f16, which rounds the exact FMA result to f16
+    // once -- a different value whenever the f32 rounding lands on an f16 tie (seen: 14 of 1.4 M voxels after 12 frames).  The empty asm hides
+    // the FMA from the conversion.
+    asm("" : "+v"(q));
+    return (_Float16)q;
 }
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: keep it in an SGPR
 #define SQ_W_SAT 0x63d0u          // 1000 as f16 bits
@@ -656,8 +662,8 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
     }
 }
 
-// tsl_selftest(2): the division-free quotient against IEEE division, 2^32 operand pairs drawn from what a saturated voxel sees
-// (n = an f16-valued product + c over a wide range of magnitudes and signs, D = 1000 + w for every weight class)
+// tsl_selftest(2): the division-free update against the literal expression, 2^32 operand tuples drawn from what the replay sees (any f16 value
+// up to 60 in magnitude, any weight code, signed distances over 32 binades, the state's weight at Wmax or anywhere below it)
 __global__ void __launch_bounds__(256) k_selftest_seqdiv(unsigned long long* bad)
 {
     unsigned long long st = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x1234567ull;
@@ -670,15 +676,16 @@ __global__ void __launch_bounds__(256) k_selftest_seqdiv(unsigned long long* bad
         uint32_t zc = a & 0x7fffu; if (zc == 0u) zc = 1u; if (zc >= 0x7c00u) zc = 0x3c00u;
         const float w = seq_w_of((h16)zc);
         uint32_t tb = a >> 16; if (!(fabsf(h2f((h16)tb)) <= 60.0f)) tb &= 0xbfffu;
-        const float T = h2f((h16)tb);
         float sd = __uint_as_float((bq & 0x80000000u) | ((132u - ((bq >> 23) & 31u)) << 23) | (bq & 0x7fffffu));
         if (fabsf(sd) > 60.0f) sd *= 0.5f;
         const float c = w * sd;
-        if (c != 0.0f && fabsf(c) < 1e-30f) continue;
-        const _Float16 Th = (_Float16)T;
-        const float n = (float)(Th * (_Float16)1000.0f) + c, D = TSL_WMAX + w;
-        const float want = n / D, got = seq_div_sat(n, D, 1.0f / D);
-        if (__float_as_uint(want) != __float_as_uint(got)) ++nbad;
+        if (c != 0.0f && fabsf(c) < 8.67e-19f) continue;
+        // the state's weight: Wmax, or any f16 value below it
+        const uint32_t wb = (it & 1) ? SQ_W_SAT : (uint32_t)(((bq >> 8) ^ a) & 0x7fffu) % (SQ_W_SAT + 1u);
+        const float D = h2f((h16)wb) + w;
+        const h16 want = f2h((h2f(hmul((h16)tb, (h16)wb)) + c) / D);                                                      // the literal expression, dense_tsdf.py:264
+        const _Float16 got = seq_update_fast(__builtin_bit_cast(_Float16, (h16)tb), __builtin_bit_cast(_Float16, (h16)wb), c, D, 1.0f / D);
+        if (want != __builtin_bit_cast(h16, got)) ++nbad;
     }
     nbad = wave_sum_ll(nbad);
     if (lane_id() == 0 && nbad) atomicAdd(bad, (unsigned long long)nbad);
