@@ -63,6 +63,7 @@ def lib():
         L.ora_tsdf_integrate_depth.argtypes = [vp, C.c_int, dp, dp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                                C.POINTER(FrameStats)]
         L.ora_tsdf_integrate_points.argtypes = [vp, C.c_int, dp, dp, vp, vp, i64, C.POINTER(FrameStats)]
+        L.ora_tsdf_set_schedule.argtypes = [vp, C.c_int, C.c_int, C.c_uint64]
         L.ora_tsdf_integrate_depth_mt.argtypes = [vp, dp, dp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FrameStats)]
         L.ora_tsdf_count_active.restype = i64
         L.ora_tsdf_count_active.argtypes = [vp]
@@ -151,6 +152,11 @@ class OracleTSDF:
         _, r = _d(R, 9)
         _, t = _d(T, 3)
         self.L.ora_tsdf_set_base_pose_submap(self.h, sid, r, t)
+
+    def set_schedule(self, kind=0, param=0, seed=0):
+        """Which legal serialisation of the reference's racy ray loop FAITHFUL / IDEAL replay: 0 struct-for order (default), 1 random ray
+        order (seed), 2 `param` threads over contiguous shares of the struct-for order, one step per turn."""
+        self.L.ora_tsdf_set_schedule(self.h, int(kind), int(param), int(seed))
 
     def set_active_submap(self, sid):
         self.L.ora_tsdf_set_active_submap(self.h, sid)

@@ -130,6 +130,8 @@ struct ora_tsdf {
     float   colormap[1024][3];
     /* frame scratch */
     brick_t** touched; int ntouched, captouched;
+    /* which legal serialisation of the racy ray loop FAITHFUL / IDEAL replay (ora_tsdf_set_schedule; default 0: struct-for order) */
+    int sched_kind, sched_param; uint64_t sched_seed;
 };
 
 static int ceil_div_blk(double scale, double voxel, int blk)
@@ -356,6 +358,62 @@ static int cmp_pcl_order(const void* a, const void* b)
 /* ------------------------------------------------------------------------------------------ */
 /* process_new_pcl  dense_tsdf.py:236-270                                                      */
 /* ------------------------------------------------------------------------------------------ */
+/* The reference's ray loop (:239) is a PARALLEL struct-for whose body updates TSDF / W with an unsynchronised read-modify-write per step
+ * (:264-267): any interleaving of the rays' step sequences is a legal outcome (whole updates are kept atomic here; a real run may lose some).
+ * sched_kind 0 (default): rays one after the other in struct-for order -- the serialisation tools/ti_seq executes and the GPU's literal mode
+ *                         reproduces;
+ *            1: rays one after the other in a random order (seed);
+ *            2: `param` threads, each with a contiguous share of the struct-for order (how a CPU back end splits a struct-for), advancing
+ *               one ray step per turn, round robin.
+ * Only FAITHFUL / IDEAL depend on it; the BATCHED sums and every statistic are order-free.  Used by tools/parity_envelope.py to measure
+ * how far two legal schedules of the reference are from each other. */
+void ora_tsdf_set_schedule(ora_tsdf* m, int kind, int param, uint64_t seed) { m->sched_kind = kind; m->sched_param = param; m->sched_seed = seed; }
+
+typedef struct { float pf[3], dirf[3], P[3], w; int n; int64_t qden; f16 col[3]; int first; } ray_t;
+
+static inline void ray_step(ora_tsdf* m, int s, int mode, int tex, const ray_t* r, int jj, ora_frame_stats* st)
+{
+    const float vs = m->vs;
+    const float jf = (float)(jj + 1);                                                  /* :251-252 (the reference adds 1 per step: exact below 2^24) */
+    float x[3]; int xi[3];
+    for (int a = 0; a < 3; ++a) { x[a] = (r->dirf[a] * jf) * vs + m->inT[a]; xi[a] = rnd_i(x[a] / vs); }   /* :253-254 */
+    if (!in_volume(m, xi[0], xi[1], xi[2])) { st->steps_oob++; return; }
+    float v[3] = { r->P[0] - x[0], r->P[1] - x[1], r->P[2] - x[2] };                    /* :258 */
+    float dist = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);                    /* :259 */
+    float dot = (v[0] * r->pf[0] + v[1] * r->pf[1]) + v[2] * r->pf[2];
+    float sd = dist * (float)sgn_f(dot);                                               /* :260 */
+    const float w = r->w;
+    int l; brick_t* b = get_brick(m, s, xi[0], xi[1], xi[2], 1, &l);
+    touch_brick(m, b);
+    st->steps++;
+    b->num[l] += to_fix(w * sd);
+    b->den[l] += r->qden;
+    if (mode == ORA_FAITHFUL) {
+        f16 T0 = b->tsdf[l], W0 = b->w[l];
+        b->tsdf[l] = H((F(hmul(T0, W0)) + w * sd) / (F(W0) + w));             /* :264 */
+        b->obs[l] = 1;                                                         /* :265 */
+        float wn = F(W0) + w; if (WMAX < wn) wn = WMAX;
+        b->w[l] = H(wn);                                                       /* :267 */
+        if (tex) for (int a = 0; a < 3; ++a) b->col[l][a] = r->col[a];          /* :268-269 */
+    } else if (mode == ORA_IDEAL) {
+        /* the same sequence of updates as FAITHFUL with the map state kept in float64: no f16 rounding of TSDF / W
+         * between updates (what the reference computes up to its storage format).  Measurement aid for the parity
+         * statement -- how far FAITHFUL and BATCHED each are from it -- never a target of its own. */
+        if (!b->ideal) b->ideal = (double (*)[2])calloc(BRK3, sizeof(double[2]));
+        const double T0 = b->ideal[l][0], W0 = b->ideal[l][1];
+        b->ideal[l][0] = (T0 * W0 + (double)w * (double)sd) / (W0 + (double)w);
+        b->ideal[l][1] = (W0 + (double)w) > (double)WMAX ? (double)WMAX : (W0 + (double)w);
+        b->tsdf[l] = H((float)b->ideal[l][0]); b->w[l] = H((float)b->ideal[l][1]); b->obs[l] = 1;
+    } else if (tex && (uint32_t)r->first + 1u > b->win[l]) {
+        /* BATCHED colour: of the rays that reach a voxel in this frame, the one whose sensor cell was opened by the
+         * latest pixel wins -- an order-free stand-in for the reference's "last writer" race (:268-269) */
+        b->win[l] = (uint32_t)r->first + 1u;
+        for (int a = 0; a < 3; ++a) b->col[l][a] = r->col[a];
+    }
+}
+
+static inline uint64_t sched_rand(uint64_t* st) { uint64_t x = *st; x ^= x << 13; x ^= x >> 7; x ^= x << 17; *st = x; return x; }
+
 static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats* st)
 {
     const int tex = m->cfg.texture_enabled;
@@ -364,6 +422,9 @@ static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats*
     qsort(g->cells, (size_t)g->n, sizeof(pcl_cell), cmp_pcl_order);
     const float vs = m->vs;
     m->ntouched = 0;
+    /* the rays, in struct-for order: everything of :242-249 that does not touch TSDF / W */
+    ray_t* rays = (ray_t*)malloc(sizeof(ray_t) * (size_t)(g->n > 0 ? g->n : 1));
+    int nr = 0;
     for (int r = 0; r < g->n; ++r) {
         pcl_cell* cell = &g->cells[r];
         st->v_pcl++;
@@ -375,59 +436,54 @@ static void process_new_pcl(ora_tsdf* m, pcl_grid* g, int mode, ora_frame_stats*
         float lenf = F(len), zzf = F(zz);
         if (!(lenf > 0.0f) || !isfinite(lenf) || !(zzf > 0.0f) || !isfinite(zzf)) { st->v_skipped++; continue; }   /* degenerate ray: NaN/inf in the reference; skipped */
         f16 dir[3]; for (int a = 0; a < 3; ++a) dir[a] = hdiv(p[a], len);            /* :245 */
-        float pf[3], dirf[3], P[3];
-        for (int a = 0; a < 3; ++a) { pf[a] = F(p[a]); dirf[a] = F(dir[a]); P[a] = pf[a] + m->inT[a]; }   /* :246 */
+        ray_t* R = &rays[nr++];
+        for (int a = 0; a < 3; ++a) { R->pf[a] = F(p[a]); R->dirf[a] = F(dir[a]); R->P[a] = R->pf[a] + m->inT[a]; }   /* :246 */
         {   /* :248  occupy[sxyz_to_ijk(submap_id, pos_p)] = 1 */
-            int oi = rnd_i(P[0] / vs), oj = rnd_i(P[1] / vs), ok = rnd_i(P[2] / vs);
+            int oi = rnd_i(R->P[0] / vs), oj = rnd_i(R->P[1] / vs), ok = rnd_i(R->P[2] / vs);
             if (in_volume(m, oi, oj, ok)) { int l; brick_t* b = get_brick(m, s, oi, oj, ok, 1, &l); b->occ[l] = 1; }
         }
         float nf = lenf / vs + m->internal_f;                                        /* :249 */
         if (m->max_steps_f < nf) nf = m->max_steps_f;
-        int n = (int)nf;
+        R->n = (int)nf;
         float w = 1.0f / zzf;                                                        /* w_x_p :216-225 with d>=0 (Q3) */
         if (w > W_CLAMP) w = W_CLAMP;
-        int64_t qden = to_fix(w);
-        f16 col[3] = {0, 0, 0};
-        if (tex) for (int a = 0; a < 3; ++a) col[a] = H(F(hdiv(cell->csum[a], c)) / 255.0f);   /* :269 */
-        float jf = 0.0f;
-        for (int jj = 0; jj < n; ++jj) {                                              /* :251-269 */
-            jf += 1.0f;
-            float x[3]; int xi[3];
-            for (int a = 0; a < 3; ++a) { x[a] = (dirf[a] * jf) * vs + m->inT[a]; xi[a] = rnd_i(x[a] / vs); }   /* :253-254 */
-            if (!in_volume(m, xi[0], xi[1], xi[2])) { st->steps_oob++; continue; }
-            float v[3] = { P[0] - x[0], P[1] - x[1], P[2] - x[2] };                    /* :258 */
-            float dist = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);            /* :259 */
-            float dot = (v[0] * pf[0] + v[1] * pf[1]) + v[2] * pf[2];
-            float sd = dist * (float)sgn_f(dot);                                       /* :260 */
-            int l; brick_t* b = get_brick(m, s, xi[0], xi[1], xi[2], 1, &l);
-            touch_brick(m, b);
-            st->steps++;
-            b->num[l] += to_fix(w * sd);
-            b->den[l] += qden;
-            if (mode == ORA_FAITHFUL) {
-                f16 T0 = b->tsdf[l], W0 = b->w[l];
-                b->tsdf[l] = H((F(hmul(T0, W0)) + w * sd) / (F(W0) + w));             /* :264 */
-                b->obs[l] = 1;                                                         /* :265 */
-                float wn = F(W0) + w; if (WMAX < wn) wn = WMAX;
-                b->w[l] = H(wn);                                                       /* :267 */
-                if (tex) for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];             /* :268-269 */
-            } else if (mode == ORA_IDEAL) {
-                /* the same sequence of updates as FAITHFUL with the map state kept in float64: no f16 rounding of TSDF / W
-                 * between updates (what the reference computes up to its storage format).  Measurement aid for the parity
-                 * statement -- how far FAITHFUL and BATCHED each are from it -- never a target of its own. */
-                if (!b->ideal) b->ideal = (double (*)[2])calloc(BRK3, sizeof(double[2]));
-                const double T0 = b->ideal[l][0], W0 = b->ideal[l][1];
-                b->ideal[l][0] = (T0 * W0 + (double)w * (double)sd) / (W0 + (double)w);
-                b->ideal[l][1] = (W0 + (double)w) > (double)WMAX ? (double)WMAX : (W0 + (double)w);
-                b->tsdf[l] = H((float)b->ideal[l][0]); b->w[l] = H((float)b->ideal[l][1]); b->obs[l] = 1;
-            } else if (tex && (uint32_t)cell->first + 1u > b->win[l]) {
-                /* BATCHED colour: of the rays that reach a voxel in this frame, the one whose sensor cell was opened by the
-                 * latest pixel wins -- an order-free stand-in for the reference's "last writer" race (:268-269) */
-                b->win[l] = (uint32_t)cell->first + 1u;
-                for (int a = 0; a < 3; ++a) b->col[l][a] = col[a];
+        R->w = w; R->qden = to_fix(w); R->first = cell->first;
+        for (int a = 0; a < 3; ++a) R->col[a] = 0;
+        if (tex) for (int a = 0; a < 3; ++a) R->col[a] = H(F(hdiv(cell->csum[a], c)) / 255.0f);   /* :269 */
+    }
+    if (m->sched_kind == 2 && m->sched_param > 1 && nr > 0) {
+        /* `param` threads over contiguous shares of the struct-for order, one ray step per turn */
+        const int P = m->sched_param < nr ? m->sched_param : nr;
+        int* cur = (int*)malloc(sizeof(int) * (size_t)P * 3);      /* current ray, its end, next step */
+        for (int t = 0; t < P; ++t) { cur[3 * t] = (int)((int64_t)nr * t / P); cur[3 * t + 1] = (int)((int64_t)nr * (t + 1) / P); cur[3 * t + 2] = 0; }
+        int live = P;
+        while (live > 0) {
+            live = 0;
+            for (int t = 0; t < P; ++t) {
+                int* c = &cur[3 * t];
+                while (c[0] < c[1] && c[2] >= rays[c[0]].n) { c[0]++; c[2] = 0; }      /* rays without steps (n <= 0) */
+                if (c[0] >= c[1]) continue;
+                ray_step(m, s, mode, tex, &rays[c[0]], c[2]++, st);
+                live++;
             }
         }
+        free(cur);
+    } else {
+        int* order = NULL;
+        if (m->sched_kind == 1 && nr > 1) {
+            order = (int*)malloc(sizeof(int) * (size_t)nr);
+            for (int i = 0; i < nr; ++i) order[i] = i;
+            uint64_t rs = m->sched_seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull; if (!rs) rs = 1;
+            for (int i = nr - 1; i > 0; --i) { int j = (int)(sched_rand(&rs) % (uint64_t)(i + 1)); int t = order[i]; order[i] = order[j]; order[j] = t; }
+            m->sched_seed = rs;                                                     /* the next frame draws another order */
+        }
+        for (int i = 0; i < nr; ++i) {
+            const ray_t* R = &rays[order ? order[i] : i];
+            for (int jj = 0; jj < R->n; ++jj) ray_step(m, s, mode, tex, R, jj, st);   /* :251-269 */
+        }
+        free(order);
     }
+    free(rays);
     /* finalize: apply the per-frame sums once per touched voxel (BATCHED) and clear scratch */
     st->bricks += m->ntouched;
     for (int t = 0; t < m->ntouched; ++t) {

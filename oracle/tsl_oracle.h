@@ -81,6 +81,9 @@ int ora_tsdf_integrate_depth(ora_tsdf* m, int mode, const double R[9], const dou
 /* all-core "port" of the BATCHED semantics (brick-binned like the GPU path; bit-identical map), for bench.py's cpu_baseline_allcore */
 int ora_tsdf_integrate_depth_mt(ora_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
                                 int nthreads, ora_frame_stats* st);
+/* which legal serialisation of the reference's racy ray loop FAITHFUL / IDEAL replay: kind 0 struct-for order (default), 1 random ray
+ * order (seed), 2 `param` threads over contiguous shares of the struct-for order, one step per turn (tsl_oracle.c, process_new_pcl) */
+void ora_tsdf_set_schedule(ora_tsdf* m, int kind, int param, uint64_t seed);
 int ora_tsdf_integrate_points(ora_tsdf* m, int mode, const double R[9], const double T[3],
                               const float* xyz, const uint8_t* rgb, int64_t n, ora_frame_stats* st);
 
