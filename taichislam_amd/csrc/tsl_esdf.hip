@@ -700,7 +700,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     // the longer chain -- and every event attached to a dispatch costs the update ~5 us before its next kernel starts.
     if (q == q0) { hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_gate; }
     else { hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_read; }
-    m->esdf_gate_set = true;
+    m->esdf_gate_set = true; m->esdf_gate_mask = 0;
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
     if (q != q0) {
         hipExtLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, nullptr, m->esdf_read, 0, m->M, E, s, gamma, max_dist);

@@ -787,26 +787,63 @@ int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int b
 // Option "semantics" = 1 on a GLOBAL map: the reference-literal SEQUENTIAL fusion, fuse_submaps_kernel / fuse_with_interploation
 // (dense_tsdf.py:272-318).  The reference walks every cell of every submap and, for seven of the eight surrounding global voxels, does an
 // unsynchronised f16 read-modify-write of the running weighted average (:274-280); splats race.  The sequential schedule -- submap cells in
-// struct-for order (submap, brick lexicographic, cell row-major), the seven corners in loop order -- is what the CPU checker's FAITHFUL fusion
-// and tools/ti_seq execute.  Here: every splat becomes a tuple  key = global brick | global voxel | sequence number (rank of the source brick
-// among the submaps' bricks by owner, cell, corner),  value = { w_tsdf, tsdf, occupancy };  radix sort;  one thread per global voxel applies
-// its run in order.  (The default fusion, tsl_fuse.hip, sums the same terms exactly and divides once: order-free, the multi-GPU merge rests on it.)
+// struct-for order (submap, block of num_voxel_per_blk_axis^3 cells lexicographic, cell row-major inside the block), the seven corners in loop
+// order -- is what the CPU checker's FAITHFUL fusion and tools/ti_seq execute.  Here: every splat becomes a tuple
+//   key = global brick | global voxel | place of the source cell in that order | corner,   value = { w_tsdf, tsdf, occupancy };
+// radix sort; one thread per global voxel applies its run in order.  (The default fusion, tsl_fuse.hip, sums the same terms exactly and
+// divides once: order-free, the multi-GPU merge rests on it.)
+// The place of a source cell: the map is stored in 16^3 bricks whatever num_voxel_per_blk_axis is (the reference's own configuration uses 10),
+// so the struct-for blocks a brick overlaps are listed for every brick (at most (15 / blk + 2)^3 of them), the list is sorted, and a cell's
+// place is (position of its block in the sorted list, cell inside the block) -- positions in a sorted superset of the active blocks order the
+// cells exactly as the active blocks would.  For blocks of 16 this is the brick order by owner.
 // =====================================================================================================================================
 struct PoseTabS { const float* p; };
-#define FSEQ_GP_SHIFT 44          // key: global pool brick (17 bits) | voxel (12) | source brick rank (17) | source cell (12) | corner (3)
+#define FSEQ_GP_SHIFT 44          // key: global pool brick (17 bits) | voxel (12) | block place and cell (29) | corner (3)
 #define FSEQ_GL_SHIFT 32
+struct FseqGeo { int blk, nca, cand, cellbits, nrx, nrz; };      // block edge, candidate blocks per axis and per brick, bits of a cell inside a block, blocks per axis of the field
 
-__global__ void __launch_bounds__(256) k_fseq_order(MapDev S, int nused, unsigned long long* keys, uint32_t* vals)
+__device__ __forceinline__ unsigned long long fseq_block_key(const FseqGeo& Q, int s, int ub, int vb, int wb)
+{ return (((unsigned long long)s * Q.nrx + ub) * Q.nrx + vb) * Q.nrz + wb; }
+
+// the struct-for blocks every source brick overlaps (~0 where the candidate lies beyond the brick or the field)
+__global__ void __launch_bounds__(128) k_fseq_cand(MapDev S, FseqGeo Q, int nused, unsigned long long* __restrict__ cand)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < nused) { keys[p] = (unsigned long long)(uint32_t)S.owner[p]; vals[p] = (uint32_t)p; }
+    const int p = blockIdx.x;
+    if (p >= nused) return;
+    const int owner = S.owner[p];
+    const int s = owner / S.nb3, b = owner - s * S.nb3;
+    const int bk = b % S.nbz, bj = (b / S.nbz) % S.nbx, bi = b / (S.nbz * S.nbx);
+    for (int t = threadIdx.x; t < Q.cand; t += 128) {
+        const int cc = t % Q.nca, cb = (t / Q.nca) % Q.nca, ca = t / (Q.nca * Q.nca);
+        const int ub = (bi * 16) / Q.blk + ca, vb = (bj * 16) / Q.blk + cb, wb = (bk * 16) / Q.blk + cc;
+        const bool on = ub * Q.blk <= bi * 16 + 15 && vb * Q.blk <= bj * 16 + 15 && wb * Q.blk <= bk * 16 + 15 && ub < Q.nrx && vb < Q.nrx && wb < Q.nrz;
+        cand[(size_t)p * Q.cand + t] = on ? fseq_block_key(Q, s, ub, vb, wb) : ~0ull;
+    }
+}
+__device__ __forceinline__ int fseq_lower_bound(const unsigned long long* __restrict__ a, int n, unsigned long long key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// observed cells of the source bricks: sizes the tuple arrays (seven splats each at most)
+__global__ void __launch_bounds__(256) k_fseq_count(MapDev S, int nused, unsigned long long* __restrict__ counter)
+{
+    long long n = 0;
+    const uint32_t* o32 = reinterpret_cast<const uint32_t*>(S.obs);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)nused * (TSL_BRK3 / 4); i += (size_t)gridDim.x * 256) {
+        const uint32_t v = o32[i];
+        n += ((int8_t)v > 0) + ((int8_t)(v >> 8) > 0) + ((int8_t)(v >> 16) > 0) + ((int8_t)(v >> 24) > 0);
+    }
+    n = wave_sum_ll(n);
+    if (lane_id() == 0 && n) __hip_atomic_fetch_add(counter + 1, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void __launch_bounds__(256) k_fseq_expand(MapDev S, MapDev G, PoseTabS poses, float vs, int nused, int npose, const uint32_t* __restrict__ brick_of_rank,
+__global__ void __launch_bounds__(256) k_fseq_expand(MapDev S, MapDev G, PoseTabS poses, float vs, int nused, int npose, FseqGeo Q, const unsigned long long* __restrict__ csort, int ncand,
                                                      unsigned long long* tkeys, unsigned long long* tvals, unsigned long long cap, unsigned long long* counter)
 {
-    for (int r = blockIdx.x; r < nused; r += gridDim.x) {
-        const int p = (int)brick_of_rank[r];
+    __shared__ int s_place[125];
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
         const int owner = S.owner[p];
         const int s = owner / S.nb3, b = owner - s * S.nb3;
         if (s >= npose) continue;
@@ -815,13 +852,24 @@ __global__ void __launch_bounds__(256) k_fseq_expand(MapDev S, MapDev G, PoseTab
         for (int a = 0; a < 9; ++a) R[a] = Rp[a];
         for (int a = 0; a < 3; ++a) T[a] = Rp[9 + a];
         const int bk = b % S.nbz, bj = (b / S.nbz) % S.nbx, bi = b / (S.nbz * S.nbx);
+        const int ub0 = (bi * 16) / Q.blk, vb0 = (bj * 16) / Q.blk, wb0 = (bk * 16) / Q.blk;
+        __syncthreads();
+        for (int t = threadIdx.x; t < Q.cand; t += 256) {
+            const int cc = t % Q.nca, cb = (t / Q.nca) % Q.nca, ca = t / (Q.nca * Q.nca);
+            s_place[t] = fseq_lower_bound(csort, ncand, fseq_block_key(Q, s, ub0 + ca, vb0 + cb, wb0 + cc));
+        }
+        __syncthreads();
         for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) {
             const int l = l0 + (int)threadIdx.x;
             const size_t v = (size_t)p * TSL_BRK3 + l;
             const bool on = S.obs[v] > 0;                                                       // :292
             unsigned long long key[7], val[7]; int n = 0;
             if (on) {
-                const int i = bi * 16 + (l >> 8) - S.hN, j = bj * 16 + ((l >> 4) & 15) - S.hN, k = bk * 16 + (l & 15) - S.hNz;
+                const int u = bi * 16 + (l >> 8), vv = bj * 16 + ((l >> 4) & 15), w = bk * 16 + (l & 15);      // 0-based cell of the field
+                const int i = u - S.hN, j = vv - S.hN, k = w - S.hNz;
+                const int ub = u / Q.blk, vb = vv / Q.blk, wb = w / Q.blk;
+                const unsigned long long cell = (unsigned long long)(((u - ub * Q.blk) * Q.blk + (vv - vb * Q.blk)) * Q.blk + (w - wb * Q.blk));
+                const unsigned long long place = ((unsigned long long)s_place[((ub - ub0) * Q.nca + (vb - vb0)) * Q.nca + (wb - wb0)] << Q.cellbits) | cell;
                 const float p0 = (float)i * vs, p1 = (float)j * vs, p2 = (float)k * vs;
                 float f[3]; int lo[3];
                 for (int a = 0; a < 3; ++a) {
@@ -839,7 +887,7 @@ __global__ void __launch_bounds__(256) k_fseq_expand(MapDev S, MapDev G, PoseTab
                     int gl; const int gb = brick_of(G, ci, cj, ck, &gl);
                     const int gp = pool_claim<false>(G, 0, gb);
                     if (gp < 0) continue;
-                    key[n] = ((unsigned long long)gp << FSEQ_GP_SHIFT) | ((unsigned long long)gl << FSEQ_GL_SHIFT) | ((unsigned long long)r << 15) | ((unsigned long long)l << 3) | (unsigned long long)c;
+                    key[n] = ((unsigned long long)gp << FSEQ_GP_SHIFT) | ((unsigned long long)gl << FSEQ_GL_SHIFT) | (place << 3) | (unsigned long long)c;
                     val[n] = ((unsigned long long)__float_as_uint(w_tsdf) << 32) | ((unsigned long long)(tw & 0xffffu) << 8) | (unsigned long long)occ;
                     ++n;
                 }
@@ -862,7 +910,7 @@ __global__ void __launch_bounds__(256) k_fseq_expand(MapDev S, MapDev G, PoseTab
 // one thread per tuple; the head of a global voxel's run applies the whole run in order  (fuse_with_interploation :272-280)
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_fseq_apply(MapDev S, MapDev G, const unsigned long long* __restrict__ tkeys, const unsigned long long* __restrict__ tvals,
-                                                    const uint32_t* __restrict__ brick_of_rank, long long total)
+                                                    FseqGeo Q, const unsigned long long* __restrict__ csort, long long total)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -882,7 +930,16 @@ __global__ void __launch_bounds__(256) k_fseq_apply(MapDev S, MapDev G, const un
         const float w_tsdf = __uint_as_float((uint32_t)(tv >> 32)), tsdf = h2f((h16)((tv >> 8) & 0xffffull));
         const float w_new = w_tsdf + h2f(W0);                                                                              // :273
         if (TEX) {                                                                                                          // :276-277 (with the old W)
-            const size_t sv = (size_t)brick_of_rank[(kq >> 15) & 0x1ffffull] * TSL_BRK3 + (size_t)((kq >> 3) & 4095ull);
+            // the source cell, back from its place: block -> (submap, block coordinates), cell -> coordinates inside the block
+            const unsigned long long place = (kq >> 3) & ((1ull << 29) - 1ull);
+            unsigned long long bkey = csort[place >> Q.cellbits];
+            const int cell = (int)(place & ((1ull << Q.cellbits) - 1ull));
+            const int wb = (int)(bkey % Q.nrz); bkey /= Q.nrz;
+            const int vb = (int)(bkey % Q.nrx); bkey /= Q.nrx;
+            const int ub = (int)(bkey % Q.nrx); const int s = (int)(bkey / Q.nrx);
+            const int u = ub * Q.blk + cell / (Q.blk * Q.blk), vv = vb * Q.blk + (cell / Q.blk) % Q.blk, w = wb * Q.blk + cell % Q.blk;
+            const int sp = pool_lookup_ro(S, s, ((u >> 4) * S.nbx + (vv >> 4)) * S.nbz + (w >> 4));
+            const size_t sv = (size_t)sp * TSL_BRK3 + (size_t)(((u & 15) << 8) | ((vv & 15) << 4) | (w & 15));
             const uint2 sc = reinterpret_cast<const uint2*>(S.col)[sv];
             const h16 c1[3] = { (h16)(sc.x & 0xffffu), (h16)(sc.x >> 16), (h16)(sc.y & 0xffffu) };
             for (int a = 0; a < 3; ++a) col[a] = f2h((h2f(hmul(W0, col[a])) + w_tsdf * h2f(c1[a])) / w_new);
@@ -902,32 +959,44 @@ __global__ void __launch_bounds__(256) k_fseq_apply(MapDev S, MapDev G, const un
 int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, int nsrc)
 {
     TSL_REQUIRE(nsrc <= (1 << 17) && g->M.max_bricks <= (1 << 17), "sequential fusion: at most 2^17 bricks on either side");
+    FseqGeo Q;
+    Q.blk = sub->cfg.num_voxel_per_blk_axis;
+    TSL_REQUIRE(Q.blk >= 4 && Q.blk <= 32, "sequential fusion: num_voxel_per_blk_axis of the submaps must be 4..32");
+    Q.nca = 15 / Q.blk + 2; Q.cand = Q.nca * Q.nca * Q.nca;
+    Q.cellbits = 0; while ((1 << Q.cellbits) < Q.blk * Q.blk * Q.blk) ++Q.cellbits;
+    Q.nrx = sub->N / Q.blk; Q.nrz = sub->Nz / Q.blk;
+    const long long ncand = (long long)nsrc * Q.cand;
+    TSL_REQUIRE(ncand < (1ll << (29 - Q.cellbits)), "sequential fusion: too many source bricks for the replay key at this num_voxel_per_blk_axis");
     hipStream_t q = ms(g);
     int rc;
-    const unsigned long long cap = (unsigned long long)nsrc * TSL_BRK3 * 7ull;
+    if (!g->fseq_ctr) { if ((rc = dev_alloc(g, (void**)&g->fseq_ctr, 64, 0))) return rc; }
+    // 0. how many cells splat: sizes the tuple arrays (a worst-case allocation was ~0.9 GB per 1000 source bricks: ADVICE r3)
+    TSL_HIP(hipMemsetAsync(g->fseq_ctr, 0, 64, q));
+    hipLaunchKernelGGL(k_fseq_count, dim3(1024), dim3(256), 0, q, sub->M, nsrc, (unsigned long long*)g->fseq_ctr);
+    unsigned long long nobs = 0;
+    TSL_HIP(hipMemcpyAsync(&nobs, (unsigned long long*)g->fseq_ctr + 1, 8, hipMemcpyDeviceToHost, q));
+    TSL_HIP(hipStreamSynchronize(q));
+    const unsigned long long cap = nobs * 7ull;
+    const size_t cbytes = 8 * (size_t)ncand + 64;
     for (int k = 0; k < 2; ++k) {
-        if ((rc = grow(&g->fseq_keys[k], &g->fseq_bytes[k], 8 * (size_t)cap + 8 * (size_t)nsrc + 64))) return rc;
-        if ((rc = grow(&g->fseq_vals[k], &g->fseq_vbytes[k], 8 * (size_t)cap + 8 * (size_t)nsrc + 64))) return rc;
+        if ((rc = grow(&g->fseq_keys[k], &g->fseq_bytes[k], 8 * (size_t)cap + cbytes))) return rc;
+        if ((rc = grow(&g->fseq_vals[k], &g->fseq_vbytes[k], 8 * (size_t)cap + cbytes))) return rc;
     }
     size_t ta = 0, tb = 0;
-    TSL_HIP(rocprim::radix_sort_pairs(nullptr, ta, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)cap, 0u, 64u, q));
-    TSL_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)nsrc, 0u, 32u, q));
+    TSL_HIP(rocprim::radix_sort_pairs(nullptr, ta, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)(cap ? cap : 1), 0u, 64u, q));
+    TSL_HIP(rocprim::radix_sort_keys(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)ncand, 0u, 64u, q));
     if ((rc = grow(&g->fseq_temp, &g->fseq_tbytes, (ta > tb ? ta : tb) + 256))) return rc;
-    if (!g->fseq_ctr) { if ((rc = dev_alloc(g, (void**)&g->fseq_ctr, 64, 0))) return rc; }
-    // 1. the submaps' bricks in struct-for order: by owner = submap * bricks per submap + brick index
-    unsigned long long* bk = (unsigned long long*)g->fseq_keys[0]; unsigned long long* bk_s = (unsigned long long*)g->fseq_keys[1];
-    uint32_t* bv = (uint32_t*)g->fseq_vals[0]; uint32_t* bv_s = (uint32_t*)g->fseq_vals[1];
-    hipLaunchKernelGGL(k_fseq_order, dim3((nsrc + 255) / 256), dim3(256), 0, q, sub->M, nsrc, bk, bv);
+    // 1. the struct-for blocks the source bricks overlap, sorted: a block's position in the list is its place in the replay order.  The
+    //    list must outlive the tuple buffers it shares memory with: it is kept behind them
+    unsigned long long* cin = (unsigned long long*)((char*)g->fseq_keys[0] + 8 * (size_t)cap);
+    unsigned long long* csort = (unsigned long long*)((char*)g->fseq_vals[0] + 8 * (size_t)cap);
+    hipLaunchKernelGGL(k_fseq_cand, dim3(nsrc), dim3(128), 0, q, sub->M, Q, nsrc, cin);
     size_t tmp = g->fseq_tbytes;
-    TSL_HIP(rocprim::radix_sort_pairs(g->fseq_temp, tmp, bk, bk_s, bv, bv_s, (size_t)nsrc, 0u, 32u, q));
-    // the rank -> brick table must outlive the tuple buffers it shares memory with: it is kept behind them
-    uint32_t* rank_tab = (uint32_t*)((char*)g->fseq_vals[0] + 8 * (size_t)cap);
-    TSL_HIP(hipMemcpyAsync(rank_tab, bv_s, 4 * (size_t)nsrc, hipMemcpyDeviceToDevice, q));
+    TSL_HIP(rocprim::radix_sort_keys(g->fseq_temp, tmp, cin, csort, (size_t)ncand, 0u, 64u, q));
     // 2. every splat as a tuple, 3. replay order per global voxel, 4. apply
-    TSL_HIP(hipMemsetAsync(g->fseq_ctr, 0, 64, q));
     PoseTabS pt = { pose_dev };
     prof_begin(g, TSL_K_FUSE);
-    hipLaunchKernelGGL(k_fseq_expand, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, q, sub->M, g->M, pt, g->P.vs, nsrc, g->npose, (const uint32_t*)rank_tab,
+    hipLaunchKernelGGL(k_fseq_expand, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, q, sub->M, g->M, pt, g->P.vs, nsrc, g->npose, Q, (const unsigned long long*)csort, (int)ncand,
                        (unsigned long long*)g->fseq_keys[0], (unsigned long long*)g->fseq_vals[0], cap, (unsigned long long*)g->fseq_ctr);
     unsigned long long count = 0;
     TSL_HIP(hipMemcpyAsync(&count, g->fseq_ctr, 8, hipMemcpyDeviceToHost, q));
@@ -939,9 +1008,9 @@ int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, i
                                           (unsigned long long*)g->fseq_vals[1], (size_t)count, 0u, 64u, q));
         const unsigned blocks = (unsigned)((count + 255) / 256);
         if (g->M.col && sub->M.col) hipLaunchKernelGGL(k_fseq_apply<true>, dim3(blocks), dim3(256), 0, q, sub->M, g->M, (const unsigned long long*)g->fseq_keys[1],
-                                                        (const unsigned long long*)g->fseq_vals[1], (const uint32_t*)rank_tab, (long long)count);
+                                                        (const unsigned long long*)g->fseq_vals[1], Q, (const unsigned long long*)csort, (long long)count);
         else hipLaunchKernelGGL(k_fseq_apply<false>, dim3(blocks), dim3(256), 0, q, sub->M, g->M, (const unsigned long long*)g->fseq_keys[1],
-                                (const unsigned long long*)g->fseq_vals[1], (const uint32_t*)rank_tab, (long long)count);
+                                (const unsigned long long*)g->fseq_vals[1], Q, (const unsigned long long*)csort, (long long)count);
     }
     prof_end(g);
     TSL_HIP(hipGetLastError());

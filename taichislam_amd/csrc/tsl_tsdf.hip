@@ -568,7 +568,13 @@ static int launch_batch_t(tsl_tsdf* m)
         if (m->ring_upto[ring] > m->frames_consumed) m->frames_consumed = m->ring_upto[ring];
     }
     if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
-    if (!serial && m->esdf_gate_set) { TSL_HIP(hipStreamWaitEvent(sa, m->esdf_gate_ev, 0)); m->esdf_gate_set = false; }      // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip)
+    if (!serial && m->esdf_gate_set) {
+        // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip).  The gate stays armed until every phase-A stream has waited for
+        // it: the batch after next uses a third stream, which is ordered behind neither the update's stream nor the first waiter
+        TSL_HIP(hipStreamWaitEvent(sa, m->esdf_gate_ev, 0));
+        m->esdf_gate_mask |= 1u << (bi % TSL_NSTREAMS);
+        if (m->esdf_gate_mask == (1u << TSL_NSTREAMS) - 1u) m->esdf_gate_set = false;
+    }
     for (int k = 0; k < m->nproducers; ++k) {       // device inputs: phase A waits for what their producers had queued (tsl_tsdf_input_stream)
         if (m->producers[k] == sa) continue;
         // nothing pending on the producer: no wait.  (Not only a saving: an event recorded on an idle stream still lands in the hardware
@@ -926,7 +932,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_gate_mask = 0; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
@@ -1168,8 +1174,10 @@ int tsl_tsdf_set_colormap(tsl_tsdf* m, const float* rgb)
     return TSL_OK;
 }
 
-int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
-                                 const void* tex_dev, int th, int tw)
+// rstride: elements between two VISITED rows of the buffer -- recast_step * w for a caller's full image, w for a staged host image that holds
+// the visited rows only (a parameter, not a flag on the handle: a call that fails half way cannot leave it behind for the next one -- ADVICE r3)
+static int integrate_depth_dev_impl(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
+                                    const void* tex_dev, int th, int tw, bool rows_only)
 {
     TSL_REQUIRE(m && R && T && depth_dev, "integrate_depth: null argument");
     TSL_REQUIRE(h > 0 && w > 0, "integrate_depth: bad image size");
@@ -1180,12 +1188,15 @@ int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[
     FrameParams& P = m->P;
     P.H = h; P.W = w;
     P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);           // dense_tsdf.py:192,194
-    P.rstride = m->staged_rows ? w : P.step * w; m->staged_rows = false;
+    P.rstride = rows_only ? w : P.step * w;
     P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0; P.tex_input = (const uint8_t*)tex_dev;
     TSL_REQUIRE(!P.tex || (th > 0 && tw > 0 && (!P.same_proj || (th >= h && tw >= w))), "integrate_depth: texture smaller than the depth image");
     m->h_stats->p_used = (int64_t)P.hh * P.ww;
     return queue_frame(m, depth_dev, nullptr, 0);
 }
+int tsl_tsdf_integrate_depth_dev(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
+                                 const void* tex_dev, int th, int tw)
+{ return integrate_depth_dev_impl(m, R, T, depth_dev, h, w, tex_dev, th, tw, false); }
 
 int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
                              const uint8_t* tex, int th, int tw)
@@ -1199,8 +1210,7 @@ int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], 
     const int step = m->P.step, hh = (int)((float)h / (float)step);
     rc = stage_host(m, si, depth, (size_t)w * sizeof(uint16_t), step > 1 ? hh : h, (size_t)(step > 1 ? step : 1) * w * sizeof(uint16_t),
                     use_tex ? tex : nullptr, use_tex ? (size_t)th * tw * 3 : 0, &ddev, &tdev); if (rc) return rc;
-    m->staged_rows = step > 1;
-    return tsl_tsdf_integrate_depth_dev(m, R, T, ddev, h, w, tdev, th, tw);
+    return integrate_depth_dev_impl(m, R, T, ddev, h, w, tdev, th, tw, step > 1);
 }
 
 int tsl_tsdf_integrate_points_dev(tsl_tsdf* m, const double R[9], const double T[3], const void* xyz_dev, const void* rgb_dev, int64_t n)

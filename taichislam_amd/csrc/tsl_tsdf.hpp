@@ -227,7 +227,6 @@ struct tsl_tsdf {
     hipStream_t producers[4]; int nproducers;   // producer streams of the queued device inputs (ordered before phase A when the batch is issued)
     hipEvent_t in_ev[8]; int in_ev_next;  // cached events ordering callers' producer streams before the input-reading stream (tsl_tsdf_input_stream)
     bool scratch_ready;                  // frame scratch allocated (first integrate call)
-    bool staged_rows;                    // the next integrate_depth_dev call reads a staged host image that holds the visited rows only
     int N, Nz, nbx, nbz, nb3, nsub, npose;
     int pcl_lo, pcl_ext, pcl_bits;
     tsl::MapDev M;
@@ -256,7 +255,8 @@ struct tsl_tsdf {
     float* esdf; uint8_t *esdf_fl, *esdf_region; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq, *esdf_nbr; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
     float *esdf_exp_xyz, *esdf_exp_val; int* esdf_exp_count; int esdf_exp_n;      // export_ESDF_xyz / export_ESDF / num_export_ESDF_particles (dense_esdf.py:498-509), allocated by the first slice
     bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
-    hipEvent_t esdf_gate, esdf_gate_ev; bool esdf_gate_set;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
+    hipEvent_t esdf_gate, esdf_gate_ev; bool esdf_gate_set; unsigned esdf_gate_mask;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
+                                                                                           // -- on EVERY phase-A stream (mask: the streams that have waited since the update was queued)
     hipEvent_t esdf_in, esdf_read, esdf_last;      // option "esdf_overlap": the relaxation rounds of update n run beside the integration of frame n + 1.
                                                    // esdf_in: the TSDF an update starts from; esdf_read: the update has read it; esdf_last: the latest update
     bool esdf_overlap; int esdf_ctr_idx;

@@ -535,6 +535,7 @@ class DenseTSDF(BaseMap):
         g = self.voxel_scale if gamma is None else gamma                 # dense_esdf.py:40 gamma = voxel_scale
         md = self.max_ray_length if max_dist is None else max_dist       # dense_esdf.py:265 sign * max_ray_length
         self._esdf_ever = True
+        self._esdf_gamma, self._esdf_max_dist = g, md
         if not wait:
             _lib.check(self.L.tsl_esdf_update(self.h, float(g), float(md), None))
             return None
@@ -555,9 +556,10 @@ class DenseTSDF(BaseMap):
 
     def cvt_ESDF_to_voxels_slice(self, z):
         """dense_esdf.py:498-509: ESDF values of the voxel layer at height z -> export_ESDF / export_ESDF_xyz (device-resident;
-        `.to_numpy()` / `.to_torch()`), count in num_export_ESDF_particles[None].  The ESDF is brought up to date first."""
-        if not getattr(self, "_esdf_ever", False):
-            self.update_esdf()
+        `.to_numpy()` / `.to_torch()`), count in num_export_ESDF_particles[None].  The ESDF is brought up to date first -- the reference updates it
+        inside every recast (dense_esdf.py:400-402), so its slice is always current: an incremental update is queued here (it finds nothing to do when
+        no frame was integrated since the last one; tsl_esdf_slice waits for it), with the parameters of the last update."""
+        self.update_esdf(gamma=getattr(self, "_esdf_gamma", None), max_dist=getattr(self, "_esdf_max_dist", None), wait=False)
         n = C.c_int32()
         _lib.check(self.L.tsl_esdf_slice(self.h, float(z), C.byref(n)))
         self._esdf_slice_n = n.value

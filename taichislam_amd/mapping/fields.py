@@ -38,7 +38,10 @@ class _DevicePointer:
 def device_view(ptr, shape, typestr="<f4", keep=None, device=0):
     """torch tensor over `shape` elements at device pointer `ptr` (zero-copy; the buffer belongs to the handle `keep`)."""
     import torch
-    if not ptr or any(int(x) == 0 for x in shape):
+    empty = any(int(x) == 0 for x in shape)
+    if not ptr and not empty:       # e.g. mesh_colors / export_color of an untextured map: there is no such buffer (an uninitialised tensor would pass for one)
+        raise ValueError("device_view: the handle has no buffer for this field (texture disabled?)")
+    if empty:
         dt = {"<f4": torch.float32, "<i2": torch.int16, "|u1": torch.uint8}[typestr]
         return torch.empty(tuple(int(x) for x in shape), dtype=dt, device=f"cuda:{device}")
     return torch.as_tensor(_DevicePointer(ptr, shape, typestr, keep), device=f"cuda:{device}")

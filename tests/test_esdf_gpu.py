@@ -186,3 +186,31 @@ def test_updates_follow_the_active_submap(hip_lib):
     assert ai.shape[0] > 10000 and np.array_equal(ai, bi) and np.array_equal(ae, be)
     ta = a.esdf_totals()
     assert ta["updates"] == 6 and ta["incremental"] == 4          # the first update of each submap is a full one
+
+
+def test_async_update_followed_by_many_batches_on_every_phase_a_stream(hip_lib):
+    """an asynchronous update takes a snapshot of the brick pool; phase A of LATER frames (it allocates bricks) must start behind it on
+    every one of the three phase-A streams, not only on the first that issues a batch.  One update(wait=False), then 40 frames (five full batches:
+    each stream issues at least one) without a sync, repeated; the ESDF at the end must equal the full recompute of the final map, and the slice
+    export must be current without an explicit update (the reference updates inside every recast, dense_esdf.py:400-402)."""
+    from taichislam_amd.mapping import DenseTSDF
+    K, frames = small_stream(44, start_deg=10.0)
+    inc, full = DenseTSDF(**SMALL), DenseTSDF(**SMALL)
+    for m in (inc, full):
+        m.set_dep_camera_intrinsic(K)
+    full.set_option("esdf_full", 1)
+    md = 0.5
+    for f, (R, T, d) in enumerate(frames):
+        inc.recast_depth_to_map(R, T, d, None)
+        full.recast_depth_to_map(R, T, d, None)
+        if f in (1, 3):
+            inc.update_esdf(max_dist=md, wait=False)          # enqueued; the next frames pile up behind it
+    z = 0.2
+    pi, vi = inc.get_voxels_ESDF_slice(z)                      # brings the ESDF up to date first (the last update saw frame 3)
+    full.update_esdf(max_dist=md)
+    pf, vf = full.get_voxels_ESDF_slice(z)
+    assert pi.shape[0] == pf.shape[0] > 500
+    oi, of = np.lexsort(pi.T[::-1]), np.lexsort(pf.T[::-1])
+    assert np.array_equal(pi[oi], pf[of]) and np.array_equal(vi[oi], vf[of])
+    (ii, ie), (fi, fe) = _esdf_sorted(inc), _esdf_sorted(full)
+    assert np.array_equal(ii, fi) and np.array_equal(ie, fe), f"incremental != full at {(ie != fe).sum()} voxels"

@@ -509,19 +509,22 @@ def test_hip_textured_octomap_reproduces_the_reference_source(hip_lib):
 
 # ------------------------------------------------------------------------------------------------------------------ the literal fusion on the GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", list(FUSED))
+@pytest.mark.parametrize("name", list(FUSED) + ["blk10_two_submaps_fused"])
 def test_hip_sequential_fusion_reproduces_the_reference_source_bit_for_bit(hip_lib, name):
     """semantics = 1 on the submaps AND on the global map: integration and fusion both replay the reference literally (csrc/tsl_sequential.hip) -- the fused
-    global maps of the reference's own source, NaNs of the axis-aligned case included, bit for bit."""
+    global maps of the reference's own source, NaNs of the axis-aligned case included, bit for bit.  blk10: blocks of 10 voxels, the reference's own
+    configuration (submap_mapping.py:21,:67) -- fuse_submaps' struct-for walks 10^3 blocks while the map is stored in 16^3 bricks (round 4: the replay key
+    carries the source cell's place in the reference's block order)."""
     cfg, K, Kc, steps, want = load(name)
     got = replay(lambda over: _Hip({**cfg, **over}, K, Kc, 1), steps, K, Kc, {}, lambda g, m: g.m.fuse_submaps(m.m))
     assert_bits_equal(got, want, f"HIP semantics = 1 (integration + fusion) vs reference source, {name}")
 
 
 @pytest.mark.gpu
-def test_the_reference_session_on_the_hip_maps_with_the_literal_semantics(hip_lib):
+@pytest.mark.parametrize("name", ["session", "session_blk10"])
+def test_the_reference_session_on_the_hip_maps_with_the_literal_semantics(hip_lib, name):
     """The whole session (eight frames, three submaps, pose-graph update, fusion, a second agent fed from the wire) on HIP maps with semantics = 1:
-    both agents' global maps equal the reference's, bit for bit."""
+    both agents' global maps equal the reference's, bit for bit -- with blocks of 16 and with blocks of 10 voxels (the reference's own configuration)."""
     from taichislam_amd.mapping import DenseTSDF
     from taichislam_amd.mapping.submap_mapping import SubmapMapping
 
@@ -529,10 +532,10 @@ def test_the_reference_session_on_the_hip_maps_with_the_literal_semantics(hip_li
         def __init__(self, *a, **kw):
             super().__init__(*a, **kw)
             self.set_option("semantics", 1)
-    z, ga, gb = _session(SeqTSDF, SubmapMapping)
+    z, ga, gb = _session(SeqTSDF, SubmapMapping, name)
     for tag, g in (("A", ga), ("B", gb)):
         want = {k[2:]: z[k] for k in z.files if k.startswith(tag + "_")}
-        assert_bits_equal(sorted_bits(g.export_submap()), want, f"agent {tag}'s global map, literal semantics on the GPU")
+        assert_bits_equal(sorted_bits(g.export_submap()), want, f"agent {tag}'s global map, literal semantics on the GPU, {name}")
 
 
 # ------------------------------------------------------------------------------------------------------------------ provenance of the vectors
