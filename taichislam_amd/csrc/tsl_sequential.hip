@@ -295,24 +295,24 @@ __global__ void __launch_bounds__(256) k_seq_ranks(BatchDev B, const uint32_t* _
     B.f[q].vals[ray] = (uint32_t)(p - base);
 }
 
-template <bool TEX>
-__global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+// work items of k_seq_group: one per (frame, brick) -- or, for a brick with more than SQ_SORTCAP segments (the few next to the sensor: every ray
+// of the frame crosses them), one per CHUNK of its segments: the segments are first cut by ray rank into buckets of 256 rays (counting sort
+// into the frame's spare segment array), consecutive buckets are grouped while they fit the LDS sort.  Every item gets a slot (run offsets) of
+// its own; the brick's word holds first slot | items << 20, and the replay walks a voxel's runs slot after slot: chunks are in rank order, so
+// that IS the replay order.  (One workgroup per heavy brick took ~0.9 ms for the brick around the sensor; its chunks now run side by side.)
+#define SQ_SLOT_BITS 20
+#define SQ_CHUNK_MAX 1024
+__global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
 {
     const int q = blockIdx.y;
     if (q >= B.n) return;
     const FrameDev& F = B.f[q];
-    const FrameParams& P = *B.p[q];
     const SeqDev S = SD[q];
-    __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: segments of the chunk being sorted: rank 22 | first step 12 | steps 6 | ray 22
-    __shared__ uint32_t s_pre[SQ_SORTCAP];                       //  8 KiB: replay position of a sorted segment's first step inside the chunk
-    __shared__ uint32_t s_hist[TSL_BRK3];                        // 16 KiB: tuples per voxel -> run offsets -> run cursors
-    __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, tuples of each of the four waves in the current 256-tuple block (16 bits each);
-                                                                 //         before that, for a heavy brick: segments per rank bucket (u32[SQ_NBK_MAX])
+    __shared__ uint32_t s_bk[SQ_NBK_MAX];                        // segments per rank bucket -> bucket ends
+    __shared__ uint32_t s_ch[SQ_CHUNK_MAX + 1];                  // chunk boundaries (segment index inside the brick)
     __shared__ uint32_t s_w[4];
-    __shared__ unsigned long long s_rb;
-    __shared__ uint32_t s_red[2];
-    uint32_t* const s_bk = reinterpret_cast<uint32_t*>(s_pack);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ int s_n[3];
+    const int tid = threadIdx.x;
     const int nrays = F.counters[6];
     const bool failed = F.counters[HDR_FAIL] != 0 || nrays > (SQ_NBK_MAX << SQ_BSHIFT);
     if (nrays > (SQ_NBK_MAX << SQ_BSHIFT) && blockIdx.x == 0 && tid == 0) frame_fail(M, F, 4);
@@ -321,123 +321,147 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
     for (int bi = blockIdx.x; bi < nact; bi += gridDim.x) {
         const int b = F.act_b[bi];
         const int n = F.bnseg[b], off = F.boffset[b];
-        if (tid == 0) { F.bhist[b] = 0; F.bcursor[b] = 0; F.bslab[b] = bi; }        // the set's per-brick words are zero between frames; the brick's slot of this frame
-        if (failed || n <= 0) continue;                                               // (uniform) nothing of a frame that overflowed its scratch is integrated
-        uint32_t* const csr = S.csr + (size_t)bi * SQ_CSR_STRIDE;
+        if (tid == 0) { F.bhist[b] = 0; F.bcursor[b] = 0; }                            // the set's per-brick words are zero between frames
+        if (failed || n <= 0) { if (tid == 0) F.bslab[b] = 0; continue; }               // (uniform) nothing of a frame that overflowed its scratch is integrated
+        if (n <= SQ_SORTCAP) {
+            if (tid == 0) {
+                const int slot = __hip_atomic_fetch_add(&F.counters[HDR_SEQ_SLOTS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot >= S.slot_cap) { frame_fail(M, F, 4); F.bslab[b] = 0; }
+                else { S.items[slot] = make_int4(off, n, slot, 0); F.bslab[b] = slot | (1 << SQ_SLOT_BITS); }
+            }
+            continue;
+        }
         const unsigned long long* const segs = F.seg_sorted + off;
-        // ---- clear the counters, count the brick's steps, reserve its part of the frame's tuple arrays ----
-        for (int i = tid; i < TSL_BRK3; i += SQ_NT) { s_hist[i] = 0u; s_pack[i] = 0ull; }
-        if (tid < 2) s_red[tid] = 0u;
+        unsigned long long* const temp = F.seg + off;                 // (k_scatter has consumed the raw segments; [off, off + n) belongs to this brick)
+        const int nbk = (nrays + (1 << SQ_BSHIFT) - 1) >> SQ_BSHIFT;
         __syncthreads();
-        {
-            uint32_t ts = 0u;
-            for (int k = tid; k < n; k += SQ_NT) ts += (uint32_t)(segs[k] & 63ull);
-            for (int d = 32; d > 0; d >>= 1) ts += (uint32_t)__shfl_xor((int)ts, d);
-            if (lane == 0) atomicAdd(&s_red[0], ts);
+        for (int i = tid; i < SQ_NBK_MAX; i += SQ_NT) s_bk[i] = 0u;
+        __syncthreads();
+        for (int k = tid; k < n; k += SQ_NT) {
+            const int ray = (int)((segs[k] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
+            atomicAdd(&s_bk[rank_of_ray[ray] >> SQ_BSHIFT], 1u);
         }
         __syncthreads();
-        const uint32_t T = s_red[0];
+        (void)sq_scan_excl<SQ_NBK_MAX / SQ_NT>(s_bk, s_w);
+        for (int k = tid; k < n; k += SQ_NT) {
+            const unsigned long long sg = segs[k];
+            const int ray = (int)((sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
+            temp[atomicAdd(&s_bk[rank_of_ray[ray] >> SQ_BSHIFT], 1u)] = sg;          // afterwards s_bk[k] = END of bucket k
+        }
+        __syncthreads();
+        if (tid == 0) {      // consecutive buckets while they fit the sort buffer
+            int nch = 0; uint32_t start = 0u, prev = 0u; bool bad = false;
+            s_ch[0] = 0u;
+            for (int k = 0; k < nbk && !bad; ++k) {
+                const uint32_t e = s_bk[k];
+                if (e - start > (uint32_t)SQ_SORTCAP) {
+                    if (prev == start || nch + 1 >= SQ_CHUNK_MAX) { bad = true; break; }      // one bucket beyond the sort buffer (more than 8 segments per ray and brick) / too many chunks
+                    s_ch[++nch] = prev; start = prev;
+                    if (e - start > (uint32_t)SQ_SORTCAP) { bad = true; break; }
+                }
+                prev = e;
+            }
+            if (!bad && (uint32_t)n > start) { if (nch + 1 > SQ_CHUNK_MAX) bad = true; else s_ch[++nch] = (uint32_t)n; }
+            int slot0 = -1;
+            if (!bad) {
+                slot0 = __hip_atomic_fetch_add(&F.counters[HDR_SEQ_SLOTS], nch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot0 + nch > S.slot_cap) bad = true;
+            }
+            if (bad) { frame_fail(M, F, 4); F.bslab[b] = 0; nch = 0; }
+            else F.bslab[b] = slot0 | (nch << SQ_SLOT_BITS);
+            s_n[0] = nch; s_n[1] = slot0;
+        }
+        __syncthreads();
+        const int nch = s_n[0], slot0 = s_n[1];
+        for (int c = tid; c < nch; c += SQ_NT) S.items[slot0 + c] = make_int4(off + (int)s_ch[c], (int)(s_ch[c + 1] - s_ch[c]), slot0 + c, 1);
+        __syncthreads();
+    }
+}
+
+template <bool TEX>
+__global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+{
+    const int q = blockIdx.y;
+    if (q >= B.n) return;
+    const FrameDev& F = B.f[q];
+    const FrameParams& P = *B.p[q];
+    const SeqDev S = SD[q];
+    __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: the item's segments: rank 22 | first step 12 | steps 6 | ray 22
+    __shared__ uint32_t s_pre[SQ_SORTCAP];                       //  8 KiB: replay position of a sorted segment's first step
+    __shared__ uint32_t s_hist[TSL_BRK3];                        // 16 KiB: tuples per voxel -> run offsets -> run cursors
+    __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, tuples of each of the four waves in the current 256-tuple block (16 bits each)
+    __shared__ uint32_t s_w[4];
+    __shared__ unsigned long long s_rb;
+    const int tid = threadIdx.x, wid = tid >> 6;
+    if (F.counters[HDR_FAIL] != 0) return;
+    const int nitems = min(F.counters[HDR_SEQ_SLOTS], S.slot_cap);
+    const uint32_t* __restrict__ rank_of_ray = F.vals;
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int4 item = S.items[it];
+        const int m = item.y;
+        const unsigned long long* const src = (item.w ? F.seg : F.seg_sorted) + item.x;
+        uint32_t* const csr = S.csr + (size_t)item.z * SQ_CSR_STRIDE;
+        // ---- clear the counters; the segments in (rank, first step) order ----
+        for (int i = tid; i < TSL_BRK3; i += SQ_NT) { s_hist[i] = 0u; s_pack[i] = 0ull; }
+        int P2 = 1; while (P2 < m) P2 <<= 1;
+        for (int k = tid; k < P2; k += SQ_NT) {
+            unsigned long long key = ~0ull;
+            if (k < m) {
+                const unsigned long long sg = src[k];
+                const unsigned long long ray = (sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1);
+                key = ((unsigned long long)rank_of_ray[ray] << 40) | (((sg >> SEG_CNT_BITS) & 0xfffull) << 28) | ((sg & 63ull) << 22) | ray;
+            }
+            s_seg[k] = key;
+        }
+        __syncthreads();
+        for (int kk = 2; kk <= P2; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P2 >> 1); t += SQ_NT) {
+                    const int i = 2 * t - (t & (j - 1)), ix = i + j;
+                    const unsigned long long a = s_seg[i], c = s_seg[ix];
+                    const bool up = (i & kk) == 0;
+                    if ((a > c) == up) { s_seg[i] = c; s_seg[ix] = a; }
+                }
+                __syncthreads();
+            }
+        for (int k = tid; k < SQ_SORTCAP; k += SQ_NT) s_pre[k] = k < m ? (uint32_t)((s_seg[k] >> 22) & 63ull) : 0u;
+        __syncthreads();
+        const uint32_t T = sq_scan_excl<SQ_SORTCAP / SQ_NT>(s_pre, s_w);           // the item's steps: its part of the frame's tuple arrays
         if (tid == 0) s_rb = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&F.counters[HDR_SEQ_TUPLES]), (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned long long rb = s_rb;
         if ((long long)(rb + T) > S.cap) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
         unsigned long long* const stash = S.stash + rb;
-        // ---- a heavy brick: its segments cut by rank into buckets of 256 rays (counting sort into the frame's spare segment array) ----
-        const bool heavy = n > SQ_SORTCAP;
-        const int nbk = heavy ? (nrays + (1 << SQ_BSHIFT) - 1) >> SQ_BSHIFT : 1;
-        unsigned long long* const temp = F.seg + off;                 // (k_scatter has consumed the raw segments; [off, off + n) belongs to this brick)
-        if (heavy) {
-            for (int k = tid; k < n; k += SQ_NT) {
-                const int ray = (int)((segs[k] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
-                atomicAdd(&s_bk[rank_of_ray[ray] >> SQ_BSHIFT], 1u);
+        // ---- walk: every step a tuple at its replay position, counted per voxel ----
+        for (int k = tid; k < m; k += SQ_NT) {
+            const unsigned long long sk = s_seg[k];
+            const int ray = (int)(sk & 0x3fffffull), cnt = (int)((sk >> 22) & 63ull), j0 = (int)((sk >> 28) & 0xfffull);
+            const uint4 rec = F.rayA[ray];
+            const float pf0 = h2f((h16)(rec.x & 0xffffu)), pf1 = h2f((h16)(rec.x >> 16)), pf2 = h2f((h16)(rec.y & 0xffffu));
+            const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
+            const unsigned long long zz = (unsigned long long)seq_w_code(__uint_as_float(rec.w)) << SQ_TUP_Z_SHIFT;
+            const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                     // :246
+            const size_t at = (size_t)s_pre[k];
+            for (int s = 0; s < cnt; ++s) {
+                const float jf = (float)(j0 + s);
+                const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
+                const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));   // :254
+                const int l = (((i0 + M.hN) & 15) << 8) | (((i1 + M.hN) & 15) << 4) | ((i2 + M.hNz) & 15);            // the segment lies inside this brick
+                const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2f - x2;                                                 // :258
+                const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
+                const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);                      // :259  (2^-96: below it sqrtf rescales)
+                const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
+                const float sd = dist * (float)sgn_f(dot);                                                              // :260
+                stash[at + s] = zz | ((unsigned long long)l << SQ_TUP_L_SHIFT) | (unsigned long long)__float_as_uint(sd);
+                if (TEX) S.stash_ray[rb + at + s] = (uint32_t)ray;
+                atomicAdd(&s_hist[l], 1u);
             }
-            __syncthreads();
-            (void)sq_scan_excl<SQ_NBK_MAX / SQ_NT>(s_bk, s_w);
-            for (int k = tid; k < n; k += SQ_NT) {
-                const unsigned long long sg = segs[k];
-                const int ray = (int)((sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
-                temp[atomicAdd(&s_bk[rank_of_ray[ray] >> SQ_BSHIFT], 1u)] = sg;      // afterwards s_bk[k] = END of bucket k
-            }
-            __syncthreads();
-        }
-        // ---- chunks of <= SQ_SORTCAP segments in rank order: sort, walk, stash the tuples at their replay positions, count per voxel ----
-        uint32_t Tb = 0u;                                              // tuples of the chunks before this one
-        int s0 = 0, k0 = 0;                                            // first segment / first bucket of the chunk
-        bool bad = false;
-        while (s0 < n) {
-            int m;
-            if (!heavy) m = n;
-            else {      // the longest run of buckets k0 .. e that fits (every thread searches the same LDS words)
-                int lo = k0, hi = nbk - 1;
-                if (s_bk[k0] > (uint32_t)(s0 + SQ_SORTCAP)) { bad = true; break; }      // one bucket beyond the sort buffer: more than 8 segments per ray and brick
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_bk[mid] <= (uint32_t)(s0 + SQ_SORTCAP)) lo = mid; else hi = mid - 1; }
-                m = (int)s_bk[lo] - s0; k0 = lo + 1;
-            }
-            int P2 = 1; while (P2 < m) P2 <<= 1;
-            const unsigned long long* const src = heavy ? temp + s0 : segs;
-            for (int k = tid; k < P2; k += SQ_NT) {
-                unsigned long long key = ~0ull;
-                if (k < m) {
-                    const unsigned long long sg = src[k];
-                    const unsigned long long ray = (sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1);
-                    key = ((unsigned long long)rank_of_ray[ray] << 40) | (((sg >> SEG_CNT_BITS) & 0xfffull) << 28) | ((sg & 63ull) << 22) | ray;
-                }
-                s_seg[k] = key;
-            }
-            __syncthreads();
-            for (int kk = 2; kk <= P2; kk <<= 1)
-                for (int j = kk >> 1; j > 0; j >>= 1) {
-                    for (int t = tid; t < (P2 >> 1); t += SQ_NT) {
-                        const int i = 2 * t - (t & (j - 1)), ix = i + j;
-                        const unsigned long long a = s_seg[i], c = s_seg[ix];
-                        const bool up = (i & kk) == 0;
-                        if ((a > c) == up) { s_seg[i] = c; s_seg[ix] = a; }
-                    }
-                    __syncthreads();
-                }
-            for (int k = tid; k < SQ_SORTCAP; k += SQ_NT) s_pre[k] = k < m ? (uint32_t)((s_seg[k] >> 22) & 63ull) : 0u;
-            __syncthreads();
-            const uint32_t Tc = sq_scan_excl<SQ_SORTCAP / SQ_NT>(s_pre, s_w);
-            for (int k = tid; k < m; k += SQ_NT) {
-                const unsigned long long sk = s_seg[k];
-                const int ray = (int)(sk & 0x3fffffull), cnt = (int)((sk >> 22) & 63ull), j0 = (int)((sk >> 28) & 0xfffull);
-                const uint4 rec = F.rayA[ray];
-                const float pf0 = h2f((h16)(rec.x & 0xffffu)), pf1 = h2f((h16)(rec.x >> 16)), pf2 = h2f((h16)(rec.y & 0xffffu));
-                const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
-                const unsigned long long zz = (unsigned long long)seq_w_code(__uint_as_float(rec.w)) << SQ_TUP_Z_SHIFT;
-                const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                     // :246
-                const size_t at = (size_t)Tb + s_pre[k];
-                for (int s = 0; s < cnt; ++s) {
-                    const float jf = (float)(j0 + s);
-                    const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
-                    const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));   // :254
-                    const int l = (((i0 + M.hN) & 15) << 8) | (((i1 + M.hN) & 15) << 4) | ((i2 + M.hNz) & 15);            // the segment lies inside this brick
-                    const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2f - x2;                                                 // :258
-                    const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
-                    const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);                      // :259  (2^-96: below it sqrtf rescales)
-                    const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
-                    const float sd = dist * (float)sgn_f(dot);                                                              // :260
-                    stash[at + s] = zz | ((unsigned long long)l << SQ_TUP_L_SHIFT) | (unsigned long long)__float_as_uint(sd);
-                    if (TEX) S.stash_ray[rb + at + s] = (uint32_t)ray;
-                    atomicAdd(&s_hist[l], 1u);
-                }
-            }
-            Tb += Tc; s0 += m;
-            __syncthreads();
-        }
-        if (bad) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
-        if (heavy) { for (int i = tid; i < TSL_BRK3; i += SQ_NT) s_pack[i] = 0ull; }      // the bucket ends lived in the packed counters
-        // ---- run offsets of the brick's voxels; distinct voxels updated = non-empty runs ----
-        {
-            uint32_t nz = 0u;
-            for (int i = tid; i < TSL_BRK3; i += SQ_NT) nz += s_hist[i] != 0u ? 1u : 0u;
-            for (int d = 32; d > 0; d >>= 1) nz += (uint32_t)__shfl_xor((int)nz, d);
-            if (lane == 0) atomicAdd(&s_red[1], nz);
         }
         __syncthreads();
+        // ---- run offsets of the brick's voxels for this item ----
         (void)sq_scan_excl<TSL_BRK3 / SQ_NT>(s_hist, s_w);
         for (int i = tid; i < TSL_BRK3; i += SQ_NT) csr[i] = s_hist[i];
-        if (tid == 0) { csr[TSL_BRK3] = T; csr[SQ_CSR_BASE] = (uint32_t)rb; csr[SQ_CSR_UNSAFE] = 0u; if (s_red[1]) atomic_add_i64(&F.stats->unique, (long long)s_red[1]); }
+        if (tid == 0) { csr[TSL_BRK3] = T; csr[SQ_CSR_BASE] = (uint32_t)rb; csr[SQ_CSR_UNSAFE] = 0u; }
         // ---- stable counting sort by voxel: blocks of 256 tuples in replay order ----
         float4* const tup = S.tup + rb;
         bool unsafe = false;
@@ -471,23 +495,43 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
             if (valid && my == 0 && lastw) { s_hist[l] += tot; s_pack[l] = 0ull; }
             __syncthreads();
         }
-        if (unsafe) csr[SQ_CSR_UNSAFE] = 1u;          // (csr[SQ_CSR_UNSAFE] was cleared with the offsets; whoever sees an odd tuple sets it)
+        if (unsafe) csr[SQ_CSR_UNSAFE] = 1u;          // (cleared with the offsets above; whoever saw an odd tuple sets it)
         __syncthreads();
     }
 }
 
+// one run of one voxel, applied by its lane: literal updates until the weight sits at Wmax (for good: w > 0) and the value is where the
+// division-free form is exact, that form from then on
+__device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint32_t t, uint32_t end, bool can_sat, h16& T0, h16& W0)
+{
+    while (t < end && !(can_sat && W0 == (h16)SQ_W_SAT && fabsf(h2f(T0)) <= 60.0f)) {
+        const float4 x = tp[t];
+        const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                                  // dense_tsdf.py:264
+        float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                                       // :267
+        T0 = Tn; W0 = f2h(wn);
+        ++t;
+    }
+    if (t < end) {
+        _Float16 Th = __builtin_bit_cast(_Float16, T0);
+        for (; t < end; ++t) { const float4 z = tp[t]; Th = seq_update_fast(Th, (_Float16)1000.0f, z.y, z.w, z.z); }
+        T0 = __builtin_bit_cast(h16, Th);
+    }
+}
+
 // phase B: one thread per voxel of every brick the batch integrates into (k_plan's unit tables with every brick a unit: brick id, pool index,
-// frames of the batch with segments in it); sixteen 256-voxel slices per brick.  A voxel whose longest run of the batch has fewer than SQ_LONG
-// updates is replayed by its lane, frame after frame (literal expression while the weight is below Wmax, the division-free form from then
-// on); the others -- a few thousand voxels around the sensor, among them the one every ray of a frame passes through -- are only LISTED
-// here and replayed by k_seq_replay_long, a wave each.
+// frames of the batch with segments in it); sixteen 256-voxel slices per brick.  A voxel whose longest frame of the batch has fewer than SQ_LONG
+// updates is replayed by its lane, frame after frame, slot after slot of the (frame, brick); the others -- a few thousand voxels around the
+// sensor, among them the one every ray of a frame passes through -- are only LISTED here and replayed by k_seq_replay_long, a wave each.
+// The frames' distinct-voxel statistics (voxels with a run) are counted here, for every voxel.
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, int4* __restrict__ long_list)
 {
     __shared__ int s_cum[PLAN_NCLS + 1];
+    __shared__ int s_uq[TSL_NB];
     uint32_t okmask = 0u;
 #pragma unroll
     for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
+    if (threadIdx.x < TSL_NB) s_uq[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[c] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
@@ -504,17 +548,36 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
         const int b = e.x, pool = e.z;
         const uint32_t tm = (uint32_t)e.w & okmask;
         if (pool < 0 || tm == 0u) continue;
-        // the run of this voxel in every frame of the batch: all offsets are requested before the first run is walked
-        uint32_t o0[TSL_NB], o1[TSL_NB], rb[TSL_NB], unsafe[TSL_NB];
+        // the runs of this voxel in every frame of the batch: the offsets of every frame's first slot are requested before a run is walked
+        uint32_t o0[TSL_NB], o1[TSL_NB], word[TSL_NB];
         bool is_long = false;
+        uint32_t has = 0u;
 #pragma unroll
         for (int q = 0; q < TSL_NB; ++q) {
-            o0[q] = o1[q] = rb[q] = unsafe[q] = 0u;
+            o0[q] = o1[q] = word[q] = 0u;
             if ((tm >> q) & 1u) {
-                const uint32_t* csr = SD[q].csr + (size_t)B.f[q].bslab[b] * SQ_CSR_STRIDE;
-                o0[q] = csr[l]; o1[q] = csr[l + 1]; rb[q] = csr[SQ_CSR_BASE]; unsafe[q] = csr[SQ_CSR_UNSAFE];
-                is_long = is_long || o1[q] - o0[q] >= (uint32_t)SQ_LONG;
+                word[q] = (uint32_t)B.f[q].bslab[b];
+                if (word[q] >> SQ_SLOT_BITS) {
+                    const uint32_t* csr = SD[q].csr + (size_t)(word[q] & ((1u << SQ_SLOT_BITS) - 1u)) * SQ_CSR_STRIDE;
+                    o0[q] = csr[l]; o1[q] = csr[l + 1];
+                }
             }
+        }
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {
+            uint32_t len = o1[q] - o0[q];
+            const uint32_t np = word[q] >> SQ_SLOT_BITS;
+            for (uint32_t p = 1u; p < np; ++p) {      // a brick next to the sensor: further slots (chunks of its segments in rank order)
+                const uint32_t* csr = SD[q].csr + (size_t)((word[q] & ((1u << SQ_SLOT_BITS) - 1u)) + p) * SQ_CSR_STRIDE;
+                len += csr[l + 1] - csr[l];
+            }
+            is_long = is_long || len >= (uint32_t)SQ_LONG;
+            has |= (len ? 1u : 0u) << q;
+        }
+#pragma unroll
+        for (int q = 0; q < TSL_NB; ++q) {           // dense_tsdf.py has no such counter; the frame statistics report the voxels a frame updated
+            const unsigned long long m = __ballot((has >> q) & 1u);
+            if (m && lane_id() == 0) atomicAdd(&s_uq[q], popc64(m));
         }
         {   // hand the long ones over (one reservation per wave); a voxel that does not fit the list stays here
             const unsigned long long lm = __ballot(is_long);
@@ -526,50 +589,46 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
                 if (is_long) { if (pos < SQ_LONG_CAP) long_list[pos] = make_int4(pool, b, l, (int)tm); else is_long = false; }
             }
         }
+        if (is_long || has == 0u) continue;
         const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
         const uint32_t old = M.tw[v];
         h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
-        bool touched = false;
-#pragma unroll
-        for (int q = 0; q < TSL_NB; ++q) {
-            if (is_long || o1[q] <= o0[q]) continue;
-            touched = true;
-            const float4* const tp = SD[q].tup + rb[q];
-            const uint32_t end = o1[q];
-            uint32_t t = o0[q];
-            // literal updates until the weight sits at Wmax (for good: w > 0) and the value is where the division-free form is exact
-            const bool can_sat = unsafe[q] == 0u;
-            while (t < end && !(can_sat && W0 == (h16)SQ_W_SAT && fabsf(h2f(T0)) <= 60.0f)) {
-                const float4 x = tp[t];
-                const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                          // dense_tsdf.py:264
-                float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                               // :267
-                T0 = Tn; W0 = f2h(wn);
-                ++t;
+        for (int q = 0; q < TSL_NB; ++q) {           // (the offsets are read again here -- cache hits -- instead of being carried in eight-deep register arrays)
+            if (!((has >> q) & 1u)) continue;
+            const uint32_t wq = (uint32_t)B.f[q].bslab[b];
+            const uint32_t np = wq >> SQ_SLOT_BITS, slot0 = wq & ((1u << SQ_SLOT_BITS) - 1u);
+            uint32_t last_ray_at = 0u;
+            for (uint32_t p = 0u; p < np; ++p) {
+                const uint32_t* csr = SD[q].csr + (size_t)(slot0 + p) * SQ_CSR_STRIDE;
+                const uint32_t a = csr[l], z = csr[l + 1], base = csr[SQ_CSR_BASE], us = csr[SQ_CSR_UNSAFE];
+                if (z <= a) continue;
+                seq_walk_run(SD[q].tup + base, a, z, us == 0u, T0, W0);
+                last_ray_at = base + z - 1u;
             }
-            if (t < end) {
-                _Float16 Th = __builtin_bit_cast(_Float16, T0);
-                for (; t < end; ++t) { const float4 z = tp[t]; Th = seq_update_fast(Th, (_Float16)1000.0f, z.y, z.w, z.z); }
-                T0 = __builtin_bit_cast(h16, Th);
-            }
-            if (TEX) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[rb[q] + end - 1u]]];        // :268-269: every step stores its ray's colour, the run's last ray stays
+            if (TEX) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[last_ray_at]]];          // :268-269: every step stores its ray's colour, the run's last ray stays
         }
-        if (touched) { M.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16); M.obs[v] = 1; }                                     // :265
-        if (__any(touched) && lane_id() == 0) M.touch[pool] = 1;
+        M.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16); M.obs[v] = 1;                                                      // :265
+        M.touch[pool] = 1;
     }
+    __syncthreads();
+    if (threadIdx.x < TSL_NB && s_uq[threadIdx.x]) atomic_add_i64(&B.f[threadIdx.x].stats->unique, (long long)s_uq[threadIdx.x]);
 }
 
 // The long runs: ONE WAVE PER VOXEL, wave-uniform.  A wave issues one instruction per four cycles however many lanes are active, so what a long
 // chain costs is instructions per update -- and the latency of whatever it waits for.  Here the wave's 64 lanes move a chunk of 256 replay
 // tuples from HBM into LDS with four coalesced loads (the next chunk is requested before the current one is replayed: the chain never waits
-// for memory), and the chain itself reads { c, D, 1 / D, W } from LDS -- eight instructions per update: ds_read_b128, v_mul_f16, v_fma_mix_f32,
-// v_mul_f32, three v_fma_f32, v_fma_mixlo_f16.  While the voxel's weight is still below Wmax the chunk's W sequence (four dependent
+// for memory), and the chain itself reads { c, D, 1 / D, W } from LDS -- ten instructions per update: ds_read_b128, v_mul_f16, v_cvt_f32_f16,
+// v_add_f32, v_mul_f32, four v_fma_f32, v_cvt_f16_f32.  While the voxel's weight is still below Wmax the chunk's W sequence (four dependent
 // instructions per update, independent of the values) is run first, then D = W + w and 1 / D are formed by the 64 lanes side by side.
+// The waves run at raised priority: phase A of the next batch (k_seq_group, eight waves per CU) shares the SIMDs, and a chain that gets
+// every third issue slot is three times as long.
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list)
 {
     __shared__ float4 s_t[4][SQ_LCHUNK];             // per wave: { c, D, 1 / D, W bits before the update } of the chunk's updates
     __shared__ float s_wv[4][SQ_LCHUNK];             // w
     __shared__ uint32_t s_wp[4][SQ_LCHUNK];          // W (f16 bits) before update k, while unsaturated
+    __builtin_amdgcn_s_setprio(3);
     const int wid = threadIdx.x >> 6, lane = lane_id();
     float4* const st = s_t[wid]; float* const sw = s_wv[wid]; uint32_t* const swp = s_wp[wid];
     uint32_t okmask = 0u;
@@ -585,9 +644,14 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
         uint32_t Tb = old & 0xffffu, Wb = old >> 16;
         for (int q = 0; q < TSL_NB; ++q) {
             if (!((tm >> q) & 1u)) continue;
-            const uint32_t* csr = SD[q].csr + (size_t)B.f[q].bslab[b] * SQ_CSR_STRIDE;
+            const uint32_t word = (uint32_t)uni_i(B.f[q].bslab[b]);
+            const uint32_t np = word >> SQ_SLOT_BITS, slot0 = word & ((1u << SQ_SLOT_BITS) - 1u);
+            uint32_t last_ray_at = 0xffffffffu;
+            for (uint32_t p = 0u; p < np; ++p) {
+            const uint32_t* csr = SD[q].csr + (size_t)(slot0 + p) * SQ_CSR_STRIDE;
             const uint32_t o0 = (uint32_t)uni_i((int)csr[l]), o1 = (uint32_t)uni_i((int)csr[l + 1]), rbq = (uint32_t)uni_i((int)csr[SQ_CSR_BASE]), unsafe = (uint32_t)uni_i((int)csr[SQ_CSR_UNSAFE]);
             if (o1 <= o0) continue;
+            last_ray_at = rbq + o1 - 1u;
             const float4* const tp = SD[q].tup + rbq;
             uint32_t t = o0;
             if (unsafe != 0u || !(fabsf(h2f((h16)Tb)) <= 60.0f)) {        // outside the division-free form's range: the literal expression (never seen in practice)
@@ -638,9 +702,9 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
                     }
                     _Float16 Th = __builtin_bit_cast(_Float16, (h16)Tb);
                     int k = 0;
-                    for (; k + 16 <= m; k += 16) {      // sixteen updates per trip: all sixteen LDS reads are issued in front of the chain (the LDS answers in
-                        float4 x[16];                   // order, so the chain waits for the first one only: ~100 cycles per 16 updates; the scheduling barrier keeps
-#pragma unroll                                          // the reads there -- left alone the scheduler moves each read next to its use and the chain waits every time)
+                    for (; k + 16 <= m; k += 16) {      // sixteen updates per trip: all sixteen LDS reads are issued in front of the chain (the scheduling barrier keeps
+                        float4 x[16];                   // them there -- left alone the scheduler moves each read next to its use and the chain waits for the LDS every time)
+#pragma unroll
                         for (int j = 0; j < 16; ++j) x[j] = st[k + j];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -656,7 +720,8 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
                     t += (uint32_t)m;
                 }
             }
-            if (TEX && lane == 0) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[rbq + o1 - 1u]]];      // :268-269
+            }
+            if (TEX && lane == 0 && last_ray_at != 0xffffffffu) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[last_ray_at]]];      // :268-269
         }
         if (lane == 0) { M.tw[v] = Tb | (Wb << 16); M.obs[v] = 1; M.touch[pool] = 1; }                                    // :265
     }
@@ -701,10 +766,12 @@ static int seq_ensure(tsl_tsdf* m)
     const bool tex = m->cfg.texture_enabled != 0;
     for (int si = 0; si < TSL_NSETS; ++si) {
         SeqDev& S = m->seq_h[si];
-        S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.tup_ray = nullptr;
+        S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.tup_ray = nullptr; S.items = nullptr;
         if ((rc = dev_alloc(m, (void**)&S.stash, 8 * (size_t)S.cap, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&S.tup, 16 * ((size_t)S.cap + 16), 0))) return rc;          // + spare tuples: the replay requests four ahead
-        if ((rc = dev_alloc(m, (void**)&S.csr, 4 * (size_t)m->F.max_frame_bricks * SQ_CSR_STRIDE, 0))) return rc;
+        S.slot_cap = m->F.max_frame_bricks + 1024;          // one slot per (frame, brick) + the further chunks of the few bricks next to the sensor
+        if ((rc = dev_alloc(m, (void**)&S.csr, 4 * (size_t)S.slot_cap * SQ_CSR_STRIDE, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&S.items, sizeof(int4) * (size_t)S.slot_cap, 0))) return rc;
         if (tex) {
             if ((rc = dev_alloc(m, (void**)&S.stash_ray, 4 * (size_t)S.cap, 0))) return rc;
             if ((rc = dev_alloc(m, (void**)&S.tup_ray, 4 * (size_t)S.cap, 0))) return rc;
@@ -729,7 +796,7 @@ static int seq_ensure(tsl_tsdf* m)
 }
 void seq_release(tsl_tsdf* m)
 {
-    for (auto& S : m->seq_h) { void* p[] = { S.stash, S.tup, S.csr, S.stash_ray, S.tup_ray }; for (void* x : p) if (x) (void)hipFree(x); S = SeqDev(); }
+    for (auto& S : m->seq_h) { void* p[] = { S.stash, S.tup, S.csr, S.stash_ray, S.tup_ray, S.items }; for (void* x : p) if (x) (void)hipFree(x); S = SeqDev(); }
     if (m->seq_d) (void)hipFree(m->seq_d);
     m->seq_d = nullptr;
     for (int bi = 0; bi < TSL_NBATCH; ++bi) {
@@ -761,7 +828,8 @@ int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int 
     hipLaunchKernelGGL(k_seq_ranks, dim3((total + 255) / 256), dim3(256), 0, st, B, (const uint32_t*)v1, total);
     prof_end(m, st);
     prof_begin(m, TSL_K_RAYS, st);
-    const int gx = m->F.max_frame_bricks < 2048 ? m->F.max_frame_bricks : 2048;
+    const int gx = m->F.max_frame_bricks < 1024 ? m->F.max_frame_bricks : 1024;
+    hipLaunchKernelGGL(k_seq_split, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     if (hp[0].tex) hipLaunchKernelGGL(k_seq_group<true>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     else hipLaunchKernelGGL(k_seq_group<false>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     prof_end(m, st);

@@ -88,6 +88,7 @@ struct FrameDev {
 #define HDR_CLAIM2 24          //   batch: next rank to claim of the parts-only launch (split launches)
 #define HDR_SEQ_TUPLES 26      //   [26..27] sequential semantics: ray-step tuples reserved in the frame's tuple arrays (one 64-bit counter)
 #define HDR_SEQ_LONG 28        //   batch: sequential semantics: voxels listed for k_seq_replay_long
+#define HDR_SEQ_SLOTS 29       //   sequential semantics: slots (= k_seq_group work items) of the frame
 
 // A frame that runs out of its own scratch (bit 1: frame bricks / parts, bit 2: ray segments) is not integrated at all: the flag
 // lives in the frame's header (counters[11], cleared by the frame's prologue), so it cannot leak into other frames, and it is
@@ -180,7 +181,8 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 struct SeqDev {
     unsigned long long* stash;        // [cap]
     float4* tup;                      // [cap + 16]
-    uint32_t* csr;                    // [max_frame_bricks][SQ_CSR_STRIDE]
+    uint32_t* csr;                    // [slot_cap][SQ_CSR_STRIDE]
+    int4* items; int slot_cap;        // k_seq_group's work items of the frame, one per slot: { first segment, segments, slot, 1: in the spare segment array }
     uint32_t* stash_ray;              // textured maps: [cap] ray of every stashed tuple
     uint32_t* tup_ray;                // textured maps: [cap] ray of every replay tuple (a run's last one colours the voxel)
     long long cap;
