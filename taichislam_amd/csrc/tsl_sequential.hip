@@ -19,6 +19,7 @@
 //   The chain of the voxel next to the sensor (every ray of the frame passes through it) is what bounds a frame: ~27 k dependent updates.
 #include "tsl_tsdf.hpp"
 #include <rocprim/rocprim.hpp>
+#include <type_traits>
 
 namespace tsl {
 
@@ -233,7 +234,10 @@ __device__ __forceinline__ float seq_div_sat(float n, float D, float r)
 __device__ __forceinline__ _Float16 seq_update_fast(_Float16 T, _Float16 W, float c, float D, float r)
 {
     const _Float16 a = T * W;                                  // RN16(T * W): one v_mul_f16 (f16 denormals are kept)
-    const float n = (float)a + c;
+    // n = RN32(a + c): the f16 product is read as it is by the mixed-precision FMA, a * 1.0 + c -- one instruction, one rounding, the same value
+    // as the conversion followed by the addition (the compiler folds fma(x, 1, c) back into those two)
+    float n;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(n) : "v"((uint32_t)__builtin_bit_cast(uint16_t, a)), "v"(c));
     float q = seq_div_sat(n, D, r);
     // the quotient is an f32 value that is THEN rounded to f16 (two roundings, as dense_tsdf.py:264 stores an f32 expression into an f16 field).
     // Left to itself the compiler folds the last FMA and the conversion into one v_fma_mixlo_f16, which rounds the exact FMA result to f16
@@ -246,7 +250,9 @@ __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstl
 #define SQ_W_SAT 0x63d0u          // 1000 as f16 bits
 #define SQ_LONG 64                // a voxel with a run of at least this many updates in some frame of the batch gets a wave of its own (k_seq_replay_long)
 #define SQ_LCHUNK 256             // updates staged in LDS at a time there
-#define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to k_seq_replay_long (beyond: they stay with their lane)
+#define SQ_XLONG 1024             // ... and with one of at least this many it is listed in front of the others: the longest chains start first
+#define SQ_XLONG_CAP 4096
+#define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to k_seq_replay_long (beyond: they stay with their lane); the first SQ_XLONG_CAP entries are the longest
 
 // exclusive prefix sums of a[0, C * SQ_NT) in LDS, in place; returns the total.  Every thread of the workgroup calls it with the data in
 // place and visible (a barrier before); two barriers inside, the result is visible on return.
@@ -523,8 +529,7 @@ __device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint
 // updates is replayed by its lane, frame after frame, slot after slot of the (frame, brick); the others -- a few thousand voxels around the
 // sensor, among them the one every ray of a frame passes through -- are only LISTED here and replayed by k_seq_replay_long, a wave each.
 // The frames' distinct-voxel statistics (voxels with a run) are counted here, for every voxel.
-template <bool TEX>
-__global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, int4* __restrict__ long_list)
+__global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* __restrict__ SD, int4* __restrict__ long_list, unsigned long long* __restrict__ lmask)
 {
     __shared__ int s_cum[PLAN_NCLS + 1];
     __shared__ int s_uq[TSL_NB];
@@ -548,12 +553,13 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
         const int b = e.x, pool = e.z;
         const uint32_t tm = (uint32_t)e.w & okmask;
         if (pool < 0 || tm == 0u) continue;
-        // the runs of this voxel in every frame of the batch: the offsets of every frame's first slot are requested before a run is walked
+        // the runs of this voxel in every frame of the batch: the offsets of every frame's first slot are requested before a run is walked.
+        // (The per-frame code is instantiated eight times with the frame as a compile-time constant: the offsets stay in registers.)
         uint32_t o0[TSL_NB], o1[TSL_NB], word[TSL_NB];
-        bool is_long = false;
+        bool is_long = false, is_xlong = false;
         uint32_t has = 0u;
-#pragma unroll
-        for (int q = 0; q < TSL_NB; ++q) {
+        auto load_frame = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
             o0[q] = o1[q] = word[q] = 0u;
             if ((tm >> q) & 1u) {
                 word[q] = (uint32_t)B.f[q].bslab[b];
@@ -562,43 +568,135 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
                     o0[q] = csr[l]; o1[q] = csr[l + 1];
                 }
             }
-        }
-#pragma unroll
-        for (int q = 0; q < TSL_NB; ++q) {
+        };
+        auto length_of_frame = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
             uint32_t len = o1[q] - o0[q];
             const uint32_t np = word[q] >> SQ_SLOT_BITS;
-            for (uint32_t p = 1u; p < np; ++p) {      // a brick next to the sensor: further slots (chunks of its segments in rank order)
-                const uint32_t* csr = SD[q].csr + (size_t)((word[q] & ((1u << SQ_SLOT_BITS) - 1u)) + p) * SQ_CSR_STRIDE;
-                len += csr[l + 1] - csr[l];
+            for (uint32_t p0 = 1u; p0 < np; p0 += 8u) {      // a brick next to the sensor: further slots (chunks of its segments in rank order), eight at a time in flight
+                uint32_t a[8], z[8];
+#pragma unroll
+                for (uint32_t k = 0u; k < 8u; ++k) {
+                    a[k] = z[k] = 0u;
+                    if (p0 + k < np) { const uint32_t* csr = SD[q].csr + (size_t)((word[q] & ((1u << SQ_SLOT_BITS) - 1u)) + p0 + k) * SQ_CSR_STRIDE; a[k] = csr[l]; z[k] = csr[l + 1]; }
+                }
+#pragma unroll
+                for (uint32_t k = 0u; k < 8u; ++k) len += z[k] - a[k];
             }
             is_long = is_long || len >= (uint32_t)SQ_LONG;
+            is_xlong = is_xlong || len >= (uint32_t)SQ_XLONG;
             has |= (len ? 1u : 0u) << q;
-        }
-#pragma unroll
-        for (int q = 0; q < TSL_NB; ++q) {           // dense_tsdf.py has no such counter; the frame statistics report the voxels a frame updated
-            const unsigned long long m = __ballot((has >> q) & 1u);
+            const unsigned long long m = __ballot(len != 0u);           // dense_tsdf.py has no such counter; the frame statistics report the voxels a frame updated
             if (m && lane_id() == 0) atomicAdd(&s_uq[q], popc64(m));
-        }
-        {   // hand the long ones over (one reservation per wave); a voxel that does not fit the list stays here
-            const unsigned long long lm = __ballot(is_long);
+        };
+#define SQ_ALL_FRAMES(F) F(std::integral_constant<int, 0>{}); F(std::integral_constant<int, 1>{}); F(std::integral_constant<int, 2>{}); F(std::integral_constant<int, 3>{}); \
+                         F(std::integral_constant<int, 4>{}); F(std::integral_constant<int, 5>{}); F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 7>{});
+        static_assert(TSL_NB == 8, "eight frames per batch");
+        SQ_ALL_FRAMES(load_frame)
+        SQ_ALL_FRAMES(length_of_frame)
+        {   // hand the long ones over (one reservation per wave); a voxel that does not fit the list stays here.  The longest chains -- they set the length of
+            // the whole replay -- go to a list of their own that k_seq_replay_long walks first.
+            const unsigned long long xm = __ballot(is_xlong);
+            if (xm) {
+                int base = 0;
+                if (lane_id() == (int)__builtin_ctzll(xm)) base = __hip_atomic_fetch_add(&B.f[0].counters[HDR_SEQ_XLONG], popc64(xm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = __shfl(base, (int)__builtin_ctzll(xm));
+                const int pos = base + rank_below(xm);
+                if (is_xlong) { if (pos < SQ_XLONG_CAP) long_list[pos] = make_int4(pool, b, l, (int)tm); else is_xlong = false; }
+            }
+            const bool plain = is_long && !is_xlong;
+            const unsigned long long lm = __ballot(plain);
             if (lm) {
                 int base = 0;
                 if (lane_id() == (int)__builtin_ctzll(lm)) base = __hip_atomic_fetch_add(&B.f[0].counters[HDR_SEQ_LONG], popc64(lm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 base = __shfl(base, (int)__builtin_ctzll(lm));
-                const int pos = base + rank_below(lm);
-                if (is_long) { if (pos < SQ_LONG_CAP) long_list[pos] = make_int4(pool, b, l, (int)tm); else is_long = false; }
+                const int pos = SQ_XLONG_CAP + base + rank_below(lm);
+                if (plain) { if (pos < SQ_LONG_CAP) long_list[pos] = make_int4(pool, b, l, (int)tm); else is_long = false; }
             }
         }
+        {   // which lanes of this wave k_seq_replay_long takes: the replay kernel's short-run role reads the word instead of measuring again
+            const unsigned long long lm = __ballot(is_long);
+            if (lane_id() == 0) lmask[(size_t)item * 4 + (threadIdx.x >> 6)] = lm;
+        }
+    }
+#undef SQ_ALL_FRAMES
+    __syncthreads();
+    if (threadIdx.x < TSL_NB && s_uq[threadIdx.x]) atomic_add_i64(&B.f[threadIdx.x].stats->unique, (long long)s_uq[threadIdx.x]);
+}
+
+template <bool TEX>
+__device__ __forceinline__ void seq_role_short(const MapDev& M, const BatchDev& B, const SeqDev* __restrict__ SD, const unsigned long long* __restrict__ lmask, int first_block, int nblocks)
+{
+    __shared__ int s_cum[PLAN_NCLS + 1];
+    uint32_t okmask = 0u;
+#pragma unroll
+    for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[c] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
+        s_cum[PLAN_NCLS] = acc;
+    }
+    __syncthreads();
+    const int total = s_cum[PLAN_NCLS] * 16;
+    for (int item = (int)blockIdx.x - first_block; item < total; item += nblocks) {
+        const int u = item >> 4, l = ((item & 15) << 8) | (int)threadIdx.x;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < PLAN_NCLS; ++j) c += u >= s_cum[j] ? 1 : 0;
+        const int4 e = B.f[0].unit_tab[(size_t)c * B.f[0].unit_cap + (u - s_cum[c])];
+        const int b = e.x, pool = e.z;
+        const uint32_t tm = (uint32_t)e.w & okmask;
+        if (pool < 0 || tm == 0u) continue;
+        // the runs of this voxel in every frame of the batch: the offsets of every frame's first slot are requested before a run is walked.
+        // (The per-frame code is instantiated eight times with the frame as a compile-time constant: the offsets stay in registers.)
+        uint32_t o0[TSL_NB], o1[TSL_NB], rb[TSL_NB], unsafe[TSL_NB], word[TSL_NB], pmask[TSL_NB];      // pmask: which of the slots 1..32 hold a run of this voxel (33..: always visited)
+        uint32_t has = 0u;
+        auto load_frame = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            o0[q] = o1[q] = rb[q] = unsafe[q] = word[q] = 0u;
+            if ((tm >> q) & 1u) {
+                word[q] = (uint32_t)B.f[q].bslab[b];
+                if (word[q] >> SQ_SLOT_BITS) {
+                    const uint32_t* csr = SD[q].csr + (size_t)(word[q] & ((1u << SQ_SLOT_BITS) - 1u)) * SQ_CSR_STRIDE;
+                    o0[q] = csr[l]; o1[q] = csr[l + 1]; rb[q] = csr[SQ_CSR_BASE]; unsafe[q] = csr[SQ_CSR_UNSAFE];
+                }
+            }
+        };
+        auto length_of_frame = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            uint32_t len = o1[q] - o0[q];
+            const uint32_t np = word[q] >> SQ_SLOT_BITS;
+            pmask[q] = 0u;
+            for (uint32_t p0 = 1u; p0 < np; p0 += 8u) {      // a brick next to the sensor: further slots (chunks of its segments in rank order), eight at a time in flight
+                uint32_t a[8], z[8];
+#pragma unroll
+                for (uint32_t k = 0u; k < 8u; ++k) {
+                    a[k] = z[k] = 0u;
+                    if (p0 + k < np) { const uint32_t* csr = SD[q].csr + (size_t)((word[q] & ((1u << SQ_SLOT_BITS) - 1u)) + p0 + k) * SQ_CSR_STRIDE; a[k] = csr[l]; z[k] = csr[l + 1]; }
+                }
+#pragma unroll
+                for (uint32_t k = 0u; k < 8u; ++k) { len += z[k] - a[k]; if (z[k] > a[k] && p0 + k <= 32u) pmask[q] |= 1u << (p0 + k - 1u); }
+            }
+            has |= (len ? 1u : 0u) << q;
+        };
+#define SQ_ALL_FRAMES(F) F(std::integral_constant<int, 0>{}); F(std::integral_constant<int, 1>{}); F(std::integral_constant<int, 2>{}); F(std::integral_constant<int, 3>{}); \
+                         F(std::integral_constant<int, 4>{}); F(std::integral_constant<int, 5>{}); F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 7>{});
+        static_assert(TSL_NB == 8, "eight frames per batch");
+        SQ_ALL_FRAMES(load_frame)
+        SQ_ALL_FRAMES(length_of_frame)
+        const bool is_long = (lmask[(size_t)item * 4 + (threadIdx.x >> 6)] >> (threadIdx.x & 63)) & 1ull;      // k_seq_classify's verdict: k_seq_replay_long's role takes it
         if (is_long || has == 0u) continue;
         const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
         const uint32_t old = M.tw[v];
         h16 T0 = (h16)(old & 0xffffu), W0 = (h16)(old >> 16);
-        for (int q = 0; q < TSL_NB; ++q) {           // (the offsets are read again here -- cache hits -- instead of being carried in eight-deep register arrays)
-            if (!((has >> q) & 1u)) continue;
-            const uint32_t wq = (uint32_t)B.f[q].bslab[b];
-            const uint32_t np = wq >> SQ_SLOT_BITS, slot0 = wq & ((1u << SQ_SLOT_BITS) - 1u);
+        auto walk_frame = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if (!((has >> q) & 1u)) return;
+            const uint32_t np = word[q] >> SQ_SLOT_BITS, slot0 = word[q] & ((1u << SQ_SLOT_BITS) - 1u);
             uint32_t last_ray_at = 0u;
-            for (uint32_t p = 0u; p < np; ++p) {
+            if (o1[q] > o0[q]) { seq_walk_run(SD[q].tup + rb[q], o0[q], o1[q], unsafe[q] == 0u, T0, W0); last_ray_at = rb[q] + o1[q] - 1u; }
+            for (uint32_t p = 1u; p < np; ++p) {
+                if (p <= 32u && !((pmask[q] >> (p - 1u)) & 1u)) continue;              // nothing of this voxel in that chunk
                 const uint32_t* csr = SD[q].csr + (size_t)(slot0 + p) * SQ_CSR_STRIDE;
                 const uint32_t a = csr[l], z = csr[l + 1], base = csr[SQ_CSR_BASE], us = csr[SQ_CSR_UNSAFE];
                 if (z <= a) continue;
@@ -606,12 +704,12 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
                 last_ray_at = base + z - 1u;
             }
             if (TEX) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[last_ray_at]]];          // :268-269: every step stores its ray's colour, the run's last ray stays
-        }
+        };
+        SQ_ALL_FRAMES(walk_frame)
+#undef SQ_ALL_FRAMES
         M.tw[v] = (uint32_t)T0 | ((uint32_t)W0 << 16); M.obs[v] = 1;                                                      // :265
         M.touch[pool] = 1;
     }
-    __syncthreads();
-    if (threadIdx.x < TSL_NB && s_uq[threadIdx.x]) atomic_add_i64(&B.f[threadIdx.x].stats->unique, (long long)s_uq[threadIdx.x]);
 }
 
 // The long runs: ONE WAVE PER VOXEL, wave-uniform.  A wave issues one instruction per four cycles however many lanes are active, so what a long
@@ -623,7 +721,7 @@ __global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const 
 // The waves run at raised priority: phase A of the next batch (k_seq_group, eight waves per CU) shares the SIMDs, and a chain that gets
 // every third issue slot is three times as long.
 template <bool TEX>
-__global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list)
+__device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list, int nblocks)
 {
     __shared__ float4 s_t[4][SQ_LCHUNK];             // per wave: { c, D, 1 / D, W bits before the update } of the chunk's updates
     __shared__ float s_wv[4][SQ_LCHUNK];             // w
@@ -634,9 +732,9 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
     uint32_t okmask = 0u;
 #pragma unroll
     for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
-    const int n = min(B.f[0].counters[HDR_SEQ_LONG], SQ_LONG_CAP);
-    for (int i = blockIdx.x * 4 + wid; i < n; i += gridDim.x * 4) {
-        const int4 e = long_list[i];
+    const int nx = min(B.f[0].counters[HDR_SEQ_XLONG], SQ_XLONG_CAP), n = nx + min(B.f[0].counters[HDR_SEQ_LONG], SQ_LONG_CAP - SQ_XLONG_CAP);
+    for (int i = blockIdx.x * 4 + wid; i < n; i += nblocks * 4) {         // the longest chains first
+        const int4 e = long_list[i < nx ? i : SQ_XLONG_CAP + (i - nx)];
         const int pool = uni_i(e.x), b = uni_i(e.y), l = uni_i(e.z);
         const uint32_t tm = (uint32_t)uni_i(e.w) & okmask;
         const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
@@ -647,10 +745,17 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
             const uint32_t word = (uint32_t)uni_i(B.f[q].bslab[b]);
             const uint32_t np = word >> SQ_SLOT_BITS, slot0 = word & ((1u << SQ_SLOT_BITS) - 1u);
             uint32_t last_ray_at = 0xffffffffu;
-            for (uint32_t p = 0u; p < np; ++p) {
-            const uint32_t* csr = SD[q].csr + (size_t)(slot0 + p) * SQ_CSR_STRIDE;
-            const uint32_t o0 = (uint32_t)uni_i((int)csr[l]), o1 = (uint32_t)uni_i((int)csr[l + 1]), rbq = (uint32_t)uni_i((int)csr[SQ_CSR_BASE]), unsafe = (uint32_t)uni_i((int)csr[SQ_CSR_UNSAFE]);
-            if (o1 <= o0) continue;
+            for (uint32_t pb = 0u; pb < np; pb += 64u) {
+            // the voxel's run in 64 slots at a time, one slot per lane: one memory round trip for all of them
+            uint4 meta = make_uint4(0u, 0u, 0u, 0u);
+            if (pb + (uint32_t)lane < np) {
+                const uint32_t* csr = SD[q].csr + (size_t)(slot0 + pb + (uint32_t)lane) * SQ_CSR_STRIDE;
+                meta = make_uint4(csr[l], csr[l + 1], csr[SQ_CSR_BASE], csr[SQ_CSR_UNSAFE]);
+            }
+            for (unsigned long long pm = __ballot(meta.y > meta.x); pm; pm &= pm - 1ull) {
+            const int src = (int)__builtin_ctzll(pm);
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)meta.x, src), o1 = (uint32_t)__builtin_amdgcn_readlane((int)meta.y, src),
+                           rbq = (uint32_t)__builtin_amdgcn_readlane((int)meta.z, src), unsafe = (uint32_t)__builtin_amdgcn_readlane((int)meta.w, src);
             last_ray_at = rbq + o1 - 1u;
             const float4* const tp = SD[q].tup + rbq;
             uint32_t t = o0;
@@ -721,10 +826,21 @@ __global__ void __launch_bounds__(256) k_seq_replay_long(MapDev M, BatchDev B, c
                 }
             }
             }
+            }
             if (TEX && lane == 0 && last_ray_at != 0xffffffffu) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[last_ray_at]]];      // :268-269
         }
         if (lane == 0) { M.tw[v] = Tb | (Wb << 16); M.obs[v] = 1; M.touch[pool] = 1; }                                    // :265
     }
+}
+
+// phase B of a batch, ONE launch: the first `nlong` workgroups replay the long runs (a wave per voxel, the longest chains first), the others the
+// short ones (a lane per voxel).  The two sets of voxels are disjoint (k_seq_classify), so nothing orders them against each other; in one
+// launch they run side by side, and the launch is as long as the longest chain -- the voxel next to the sensor -- not chain + the rest.
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_seq_replay(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list, const unsigned long long* __restrict__ lmask, int nlong)
+{
+    if ((int)blockIdx.x < nlong) seq_role_long<TEX>(M, B, SD, long_list, nlong);
+    else seq_role_short<TEX>(M, B, SD, lmask, nlong, (int)gridDim.x - nlong);
 }
 
 // tsl_selftest(2): the division-free update against the literal expression, 2^32 operand tuples drawn from what the replay sees (any f16 value
@@ -789,6 +905,7 @@ static int seq_ensure(tsl_tsdf* m)
         }
         if ((rc = dev_alloc(m, &m->seqb_temp[bi], m->seqb_temp_bytes, 0))) return rc;
         if ((rc = dev_alloc(m, &m->seqb_long[bi], sizeof(int4) * (size_t)SQ_LONG_CAP, 0))) return rc;
+        if ((rc = dev_alloc(m, &m->seqb_lmask[bi], 8 * 64 * (size_t)PLAN_NCLS * m->fset[0].F.unit_cap, 0))) return rc;          // a word per wave of 64 voxels of every brick a batch can list
     }
     TSL_HIP(hipStreamSynchronize(m->stream_));          // the fills ran on the main stream; the kernels below use the batch streams
     m->seq_ready = true;
@@ -803,7 +920,8 @@ void seq_release(tsl_tsdf* m)
         for (int k = 0; k < 2; ++k) { if (m->seqb_keys[bi][k]) (void)hipFree(m->seqb_keys[bi][k]); if (m->seqb_vals[bi][k]) (void)hipFree(m->seqb_vals[bi][k]); m->seqb_keys[bi][k] = m->seqb_vals[bi][k] = nullptr; }
         if (m->seqb_temp[bi]) (void)hipFree(m->seqb_temp[bi]);
         if (m->seqb_long[bi]) (void)hipFree(m->seqb_long[bi]);
-        m->seqb_temp[bi] = nullptr; m->seqb_long[bi] = nullptr;
+        if (m->seqb_lmask[bi]) (void)hipFree(m->seqb_lmask[bi]);
+        m->seqb_temp[bi] = nullptr; m->seqb_long[bi] = nullptr; m->seqb_lmask[bi] = nullptr;
     }
     m->seq_ready = false;
 }
@@ -832,6 +950,9 @@ int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int 
     hipLaunchKernelGGL(k_seq_split, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     if (hp[0].tex) hipLaunchKernelGGL(k_seq_group<true>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     else hipLaunchKernelGGL(k_seq_group<false>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    // which voxels get a wave of their own in the replay, the frames' distinct-voxel counts: run lengths only, nothing of the map
+    hipLaunchKernelGGL(k_seq_classify, dim3(16 * m->ncu), dim3(256), 0, st, B, (const SeqDev*)(m->seq_d + bi * TSL_NB), static_cast<int4*>(m->seqb_long[bi]),
+                       static_cast<unsigned long long*>(m->seqb_lmask[bi]));
     prof_end(m, st);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -839,14 +960,11 @@ int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int 
 int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi)
 {
     const SeqDev* sd = m->seq_d + bi * TSL_NB;
-    int4* ll = static_cast<int4*>(m->seqb_long[bi]);
-    if (P.tex) {
-        hipLaunchKernelGGL(k_seq_replay<true>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, ll);
-        hipLaunchKernelGGL(k_seq_replay_long<true>, dim3(4 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, (const int4*)ll);
-    } else {
-        hipLaunchKernelGGL(k_seq_replay<false>, dim3(16 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, ll);
-        hipLaunchKernelGGL(k_seq_replay_long<false>, dim3(4 * m->ncu), dim3(256), 0, m->stream_, m->M, B, sd, (const int4*)ll);
-    }
+    const int4* ll = static_cast<const int4*>(m->seqb_long[bi]);
+    const unsigned long long* lm = static_cast<const unsigned long long*>(m->seqb_lmask[bi]);
+    const int nlong = 4 * m->ncu, nshort = 12 * m->ncu;
+    if (P.tex) hipLaunchKernelGGL(k_seq_replay<true>, dim3(nlong + nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
+    else hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong + nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
