@@ -146,3 +146,71 @@ def test_two_processes_on_one_gpu_over_gloo(hip_lib, tmp_path):
     _assert_same(dict(r1), ref, "rank 1 vs single process")
     nvox_dense = (512 // 4) ** 3 * 20
     assert int(r0["nbytes"]) == int(r1["nbytes"]) and 0 < int(r0["nbytes"]) < nvox_dense // 2
+
+
+def test_config5_eight_submaps_at_512_cubed_against_the_oracle(hip_lib):
+    """BASELINE configs[4] at its full geometry, asserted: eight ranks, each with ONE submap of the 640 x 480 stream that
+    starts 45 degrees after the previous rank's (taichislam_amd.distributed.stream_start_deg), merged into a 512^3 / 2 cm global map through the
+    step protocol -- merge_begin -> MAX of the masks -> merge_pack -> SUM -> merge_finish -- with the eight ranks simulated in this process
+    (the reductions done with torch: exactly what the all-reduces compute).  The yardstick is NOT the HIP fusion: the ORACLE integrates the same
+    eight streams (BATCHED, the order-free semantics the merge is defined on) and fuses the eight submaps (dense_tsdf.py:272-318 over every
+    agent's submaps); the merged map must equal it bit for bit on every rank.  The bytes a rank puts on the links are asserted as well."""
+    import torch
+    from oracle import BATCHED, OracleTSDF
+    from taichislam_amd import distributed as D
+    from taichislam_amd.mapping import DenseTSDF
+    from util import C2
+    world, frames_per_rank = 8, 2
+    cfg = dict(C2, max_submap_num=8)
+
+    def stream(r):
+        return list(syn.sphere_room_stream(frames_per_rank, start_deg=D.stream_start_deg(r)))
+
+    # the oracle: one collection with the eight submaps, fused into one global map
+    osub = OracleTSDF(**cfg); osub.set_intrinsics(syn.K_DEPTH)
+    oglob = OracleTSDF(**dict(cfg, is_global_map=True))
+    for r in range(world):
+        fr = stream(r)
+        osub.set_active_submap(r); osub.set_base_pose_submap(r, fr[0][0], fr[0][1]); oglob.set_base_pose_submap(r, fr[0][0], fr[0][1])
+        for R, T, d in fr:
+            osub.integrate_depth(R, T, d, mode=BATCHED)
+    osub.set_active_submap(world)
+    oglob.fuse_submaps(osub, mode=BATCHED)
+    want = sort_export(oglob.export_sparse())
+    assert want["indices"].shape[0] > 5_000_000
+
+    subs, globs, masks = [], [], []
+    for r in range(world):
+        fr = stream(r)
+        s = DenseTSDF(**cfg); s.set_dep_camera_intrinsic(syn.K_DEPTH)
+        s.active_submap_id[None] = r
+        s.set_base_pose_submap(r, fr[0][0], fr[0][1])
+        for R, T, d in fr:
+            s.recast_depth_to_map(R, T, torch.from_numpy(d.view(np.int16)).cuda(), None)
+        s.active_submap_id[None] = r + 1
+        g = DenseTSDF(**dict(cfg, is_global_map=True))
+        for q in range(world):
+            g.set_base_pose_submap(q, *stream(q)[0][:2])
+        subs.append(s); globs.append(g)
+        masks.append(g.merge_begin(s))
+    union = masks[0]
+    for m in masks[1:]:
+        union = torch.maximum(union, m)
+    n_union = int(union.sum())
+    acc = cnt = None
+    for g in globs:                                        # SUM: one rank's packed planes at a time (8 x 220 MB would fit, this is the ring's order anyway)
+        a, c = g.merge_pack(union)
+        assert a.shape[0] == n_union
+        acc, cnt = (a, c) if acc is None else (acc + a, cnt + c)
+        del a, c
+    torch.cuda.synchronize()
+    nbytes = union.numel() + 1 + n_union * 4096 * 20       # what tsl_tsdf_allreduce_merge / distributed.allreduce_merge put through the all-reduces per rank
+    print(f"config 5: union {n_union} bricks, {nbytes / 1e6:.0f} MB all-reduced per rank, {want['indices'].shape[0]} global voxels")
+    assert 150e6 < nbytes < 350e6, nbytes                  # DESIGN section 5: ~2 700 bricks x 4096 voxels x 20 B = ~220 MB
+    for r in (0, 5):                                       # every rank ends with the same map (tested for all ranks at small size above): two of them here
+        globs[r].merge_finish(acc, cnt)
+        got = sort_export(globs[r].export_submap())
+        assert got["indices"].shape == want["indices"].shape and np.array_equal(got["indices"], want["indices"]), f"rank {r}: voxel sets differ"
+        ok = ~np.isnan(want["TSDF"].view(np.float16))
+        assert np.array_equal(np.isnan(got["TSDF"].view(np.float16)), ~ok)
+        assert np.array_equal(got["TSDF"][ok], want["TSDF"][ok]) and np.array_equal(got["W_TSDF"], want["W_TSDF"]) and np.array_equal(got["occupy"], want["occupy"]), f"rank {r}"
