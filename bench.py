@@ -146,7 +146,7 @@ def cpu_baseline_config(config, budget_s=10.0):
             f"observed voxels; the CPU restatement has no incremental update) per frame + mesh every 10th, {dt:.1f} s, 1 thread"}
 
 
-def sequential_leg(dev, frames, oracle_map):
+def sequential_leg(dev, frames, oracle_map, more=()):
     """Option semantics = 1 (csrc/tsl_sequential.hip): the reference-literal sequential replay on the GPU, for the frames the FAITHFUL
     baseline integrated -- its rate, and whether the map equals the FAITHFUL map bit for bit."""
     import torch
@@ -164,13 +164,13 @@ def sequential_leg(dev, frames, oracle_map):
     g.sync()
     dt = time.perf_counter() - t0
     a, b = g.export_submap(), oracle_map.export_sparse()
-    # the steady rate: the same frames four more times on the same map (poses repeat; the replay does not care), >= 300 frames behind a full pipeline
-    reps = max(1, -(-300 // len(frames)))
+    # the steady rate: the stream goes on (`more`: the frames behind the ones the CPU leg integrated) on the same map, behind a full pipeline
+    more = list(more)
+    dm = [torch.from_numpy(d.view(np.int16)).cuda(dev) for _, _, d in more]
     g.sync()
     t1 = time.perf_counter()
-    for _ in range(reps):
-        for (R, T, _), d in zip(frames, dd):
-            g.recast_depth_to_map(R, T, d, None)
+    for (R, T, _), d in zip(more, dm):
+        g.recast_depth_to_map(R, T, d, None)
     g.sync()
     dts = time.perf_counter() - t1
 
@@ -180,17 +180,17 @@ def sequential_leg(dev, frames, oracle_map):
         return e["indices"][o], np.asarray(e["TSDF"])[o].view(np.uint16), np.asarray(e["W_TSDF"])[o].view(np.uint16), e["occupy"][o]
     x, y = srt(a), srt(b)
     exact = all(u.shape == v.shape and np.array_equal(u, v) for u, v in zip(x, y))
-    rate, steady = (len(frames) - 1) / max(dt, 1e-9), reps * len(frames) / max(dts, 1e-9)
+    rate, steady = (len(frames) - 1) / max(dt, 1e-9), (len(more) / max(dts, 1e-9) if len(more) >= 64 else None)
     return {"value": rate, "unit": "frames/s", "frames": len(frames), "voxels": int(x[0].shape[0]),
             "bit_exact_with_oracle_FAITHFUL": bool(exact),
-            "value_steady": steady, "steady_frames": reps * len(frames),
-            "north_star": {"rate_target_frames_per_s": 2000, "rate_met": bool(min(rate, steady) >= 2000.0), "tsdf_tolerance": "1e-4 relative",
+            "value_steady": steady, "steady_frames": len(more),
+            "north_star": {"rate_target_frames_per_s": 2000, "rate_met": bool(min(rate, steady if steady else rate) >= 2000.0), "tsdf_tolerance": "1e-4 relative",
                            "tolerance_met": bool(exact), "how": "every TSDF / W bit equals the reference's struct-for serialisation (oracle FAITHFUL, pinned to the "
                            "reference's own source by tests/golden/ref_*.npz)"},
             "note": "tsl_tsdf_set_option(semantics, 1): rays in Taichi's struct-for order, every ray step applied on its own in f16 with the W clamp "
                     "(dense_tsdf.py:264-267) -- a legal schedule of the racy reference, equal to the sequential CPU replay on every TSDF / W bit.  Round 4: "
                     "per-brick replay runs on the brick pipeline (k_seq_group), a wave per long run (k_seq_replay_long); `value` = these frames behind an "
-                    "empty pipeline, `value_steady` = the same frames again on the same map"}
+                    "empty pipeline (first-touch allocation excluded), `value_steady` = the frames that follow them in the stream, same map"}
 
 
 def envelope_leg():
@@ -391,18 +391,22 @@ def main():
     # ---- the same frames handed over as HOST buffers, as the reference API does (H2D copy inside the timed loop; never `value`) ----
     host_rates = None
     if rank == 0:
-        nh = min(args.steps, 200)
-        pinned = torch.from_numpy(np.stack([host[args.warmup + i][2] for i in range(nh)]).view(np.int16)).pin_memory().numpy().view(np.uint16)
+        nsrc = min(args.steps, 200)                        # distinct host images
+        nh = max(nsrc, 300)                                # calls: a stream, like value_steady, not a burst (the images are handed over again and again)
+        pinned = torch.from_numpy(np.stack([host[args.warmup + i][2] for i in range(nsrc)]).view(np.int16)).pin_memory().numpy().view(np.uint16)
         host_rates = {}
-        for label, src in (("pageable", [host[args.warmup + i][2] for i in range(nh)]), ("pinned", [pinned[i] for i in range(nh)])):
+        for label, src in (("pageable", [host[args.warmup + i][2] for i in range(nsrc)]), ("pinned", [pinned[i] for i in range(nsrc)])):
             m.sync()
+            gc.collect(); gc.disable()
             th = time.perf_counter()
             for i in range(nh):
-                R, T = poses[args.warmup + i]
-                m.recast_depth_to_map(R, T, src[i], None)
+                R, T = poses[args.warmup + i % nsrc]
+                m.recast_depth_to_map(R, T, src[i % nsrc], None)
             m.sync()
             host_rates[label] = nh / (time.perf_counter() - th)
-        host_rates["note"] = f"{nh} frames, 614 kB uint16 numpy image per call through tsl_tsdf_integrate_depth (copy + stream sync per frame), rank 0 only"
+            gc.enable()
+        host_rates["note"] = (f"{nh} calls over {nsrc} images, 614 kB uint16 numpy image per call through tsl_tsdf_integrate_depth (the reference API's form, taichislam_node.py:381-382): "
+                              "the host copies the visited rows into a pinned ring, the H2D copy and the integration are asynchronous (no stream synchronisation per call); rank 0 only")
 
     # ---- steady state, driver-visible: >= 300 frames behind the contract region, same map, same clock (the contract's K may be a 20-frame
     #      burst, which is dominated by filling and draining the batch pipeline) ----
@@ -543,7 +547,7 @@ def main():
             except Exception as e:
                 out["parity_vs_faithful"] = {"error": repr(e)[:200]}
             try:
-                out["value_sequential"] = sequential_leg(dev, sample[:n_done], omap)
+                out["value_sequential"] = sequential_leg(dev, sample[:n_done], omap, more=host[n_done:n_done + 320])
             except Exception as e:
                 out["value_sequential"] = {"error": repr(e)[:200]}
             try:

@@ -161,7 +161,7 @@ def test_config5_eight_submaps_at_512_cubed_against_the_oracle(hip_lib):
     from taichislam_amd.mapping import DenseTSDF
     from util import C2
     world, frames_per_rank = 8, 2
-    cfg = dict(C2, max_submap_num=8)
+    cfg = dict(C2, max_submap_num=16)                      # ids 0..7 hold the submaps, a rank closes its submap by moving on to id r + 1
 
     def stream(r):
         return list(syn.sphere_room_stream(frames_per_rank, start_deg=D.stream_start_deg(r)))
@@ -182,7 +182,7 @@ def test_config5_eight_submaps_at_512_cubed_against_the_oracle(hip_lib):
     subs, globs, masks = [], [], []
     for r in range(world):
         fr = stream(r)
-        s = DenseTSDF(**cfg); s.set_dep_camera_intrinsic(syn.K_DEPTH)
+        s = DenseTSDF(**cfg, max_bricks=4096); s.set_dep_camera_intrinsic(syn.K_DEPTH)
         s.active_submap_id[None] = r
         s.set_base_pose_submap(r, fr[0][0], fr[0][1])
         for R, T, d in fr:
