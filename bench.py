@@ -406,7 +406,7 @@ def main():
             host_rates[label] = nh / (time.perf_counter() - th)
             gc.enable()
         host_rates["note"] = (f"{nh} calls over {nsrc} images, 614 kB uint16 numpy image per call through tsl_tsdf_integrate_depth (the reference API's form, taichislam_node.py:381-382): "
-                              "the host copies the visited rows into a pinned ring, the H2D copy and the integration are asynchronous (no stream synchronisation per call); rank 0 only")
+                              "the host copies the visited rows into a pinned, device-mapped buffer of the frame's working set and phase A reads them in place (no copy call, no stream synchronisation per call); rank 0 only")
 
     # ---- steady state, driver-visible: >= 300 frames behind the contract region, same map, same clock (the contract's K may be a 20-frame
     #      burst, which is dominated by filling and draining the batch pipeline) ----

@@ -186,3 +186,17 @@ def device_count():
     n = C.c_int(0)
     lib().tsl_device_count(C.byref(n))
     return n.value
+
+
+_HOST_FN = None
+
+
+def integrate_depth_host_fn():
+    """tsl_tsdf_integrate_depth bound a second time with integer pointer arguments (no ctypes pointer objects per call): the per-frame path of
+    a host-image stream, see DenseTSDF.recast_depth_to_map."""
+    global _HOST_FN
+    if _HOST_FN is None:
+        lib()
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int)
+        _HOST_FN = proto(("tsl_tsdf_integrate_depth", lib()))
+    return _HOST_FN

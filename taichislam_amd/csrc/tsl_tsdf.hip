@@ -587,11 +587,6 @@ static int launch_batch_t(tsl_tsdf* m)
         TSL_HIP(hipStreamWaitEvent(sa, e, 0));
     }
     m->nproducers = 0;
-    {   // host inputs of this batch's frames: the copy stream is in order, so the last staged frame's event covers the others
-        int last = -1;
-        for (int q = 0; q < n; ++q) { FSet& S = m->fset[bi * TSL_NB + q]; if (S.copy_pending) { last = q; S.copy_pending = false; } }
-        if (last >= 0 && m->overlap != 0) TSL_HIP(hipStreamWaitEvent(sa, m->fset[bi * TSL_NB + last].copy_done, 0));
-    }
     BatchDev B; ParamPack PP;
     for (int q = 0; q < n; ++q) { FSet& S = m->fset[bi * TSL_NB + q]; B.f[q] = S.F; B.p[q] = S.Pd; PP.p[q] = m->pend[q]; }
     for (int q = n; q < TSL_NB; ++q) { B.f[q] = B.f[0]; B.p[q] = B.p[0]; PP.p[q] = PP.p[0]; }
@@ -677,47 +672,35 @@ static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
     *set_index = m->cur * TSL_NB + m->npend;
     return TSL_OK;
 }
-// Host buffers: the visited rows are copied BY THE HOST into a pinned buffer of the frame's working set (the caller may reuse its buffers
-// after return), from there to the set's staging area on the copy stream -- asynchronously: no stream synchronisation per call (round 3 waited
-// for every copy: 12.7 k frames/s from pageable images against 30 k resident).  An event behind the copy is what phase A of the frame's
-// batch waits for (launch_batch_t); the pinned buffer is reused when the set comes round again, 24 frames later -- the event has long fired.
+// Host buffers: the visited rows are copied BY THE HOST into a pinned, device-mapped buffer of the frame's working set (the caller may reuse
+// its buffers after return) and phase A reads them from there, across the host link: 307 kB per 640 x 480 frame at recast_step 2, each pixel
+// once.  No copy call, no event, no stream synchronisation (round 3 staged through hipMemcpy2DAsync + a stream sync per call: 12.7 k frames/s
+// from pageable images; an asynchronous copy from the pinned buffer still cost 50-75 us of HOST time per call inside the runtime).  The
+// buffer is written again when the set comes round, three batches later: the host first makes sure phase A of the set's previous batch is done.
 // `in`: `rows` rows of `row_bytes` bytes, `src_pitch` bytes apart (rows == 1: one contiguous block); they are stored back to back
 static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int rows, size_t src_pitch, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev)
 {
     const size_t in_bytes = row_bytes * (size_t)rows;
     FSet& S = m->fset[si];
-    // a stream of its own for the copies: on a phase-A stream the copy would queue behind phase A of an older batch
-    hipStream_t sc = m->stream_;
-    if (m->overlap != 0) {
-        sc = m->copy_st;
-        BatchHost& H = m->batch[si / TSL_NB];
-        if (H.a_recorded) TSL_HIP(hipStreamWaitEvent(sc, H.a_done, 0));       // phase A of the slot's previous batch read this staging area
-    }
-    if (!S.copy_done) TSL_HIP(hipEventCreateWithFlags(&S.copy_done, hipEventDisableTiming));
-    if (S.copy_recorded) TSL_HIP(hipEventSynchronize(S.copy_done));           // the previous copy OUT of the pinned buffers (the set's last use)
-    const size_t need = in_bytes + ((tex && tex_bytes) ? tex_bytes : 0) + 64;
+    BatchHost& H = m->batch[si / TSL_NB];
+    if (m->overlap == 0) TSL_HIP(hipStreamSynchronize(m->stream_));          // one frame at a time on the main stream: nothing else orders the set's previous reader
+    else if (H.a_recorded) TSL_HIP(hipEventSynchronize(H.a_done));            // phase A of the slot's previous batch read these buffers
+    const size_t tex_off = (in_bytes + 255) & ~(size_t)255;
+    const size_t need = tex_off + ((tex && tex_bytes) ? tex_bytes : 0) + 256;
     if (S.pin_bytes < need) {
         if (S.pin) (void)hipHostFree(S.pin);
-        S.pin = nullptr; S.pin_bytes = 0;
-        TSL_HIP(hipHostMalloc(&S.pin, need + need / 4, hipHostMallocDefault));
+        S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr;
+        TSL_HIP(hipHostMalloc(&S.pin, need + need / 4, hipHostMallocMapped));
         S.pin_bytes = need + need / 4;
+        TSL_HIP(hipHostGetDevicePointer(&S.pin_dev, S.pin, 0));
     }
-    int rc = grow(&S.stage_in, &S.stage_in_bytes, in_bytes + 16); if (rc) return rc;
     char* pin = static_cast<char*>(S.pin);
     if (in_bytes) {
         if (rows > 1 && src_pitch != row_bytes) { for (int r = 0; r < rows; ++r) std::memcpy(pin + (size_t)r * row_bytes, static_cast<const char*>(in) + (size_t)r * src_pitch, row_bytes); }
         else std::memcpy(pin, in, in_bytes);
-        TSL_HIP(hipMemcpyAsync(S.stage_in, pin, in_bytes, hipMemcpyHostToDevice, sc));
     }
-    *in_dev = S.stage_in; *tex_dev = nullptr;
-    if (tex && tex_bytes) {
-        rc = grow(&S.stage_tex, &S.stage_tex_bytes, tex_bytes); if (rc) return rc;
-        std::memcpy(pin + in_bytes, tex, tex_bytes);
-        TSL_HIP(hipMemcpyAsync(S.stage_tex, pin + in_bytes, tex_bytes, hipMemcpyHostToDevice, sc));
-        *tex_dev = S.stage_tex;
-    }
-    TSL_HIP(hipEventRecord(S.copy_done, sc));
-    S.copy_recorded = true; S.copy_pending = true;
+    *in_dev = S.pin_dev; *tex_dev = nullptr;
+    if (tex && tex_bytes) { std::memcpy(pin + tex_off, tex, tex_bytes); *tex_dev = static_cast<char*>(S.pin_dev) + tex_off; }
     return TSL_OK;
 }
 
@@ -901,7 +884,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->cfg = *cfg; m->device = device; m->bytes = 0;
     TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
     m->overlap = TSL_NB; m->last_set = 0;
-    for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; S.pin = nullptr; S.pin_bytes = 0; S.copy_done = nullptr; S.copy_recorded = false; S.copy_pending = false; }
+    for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr; }
     for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.p_done = nullptr; H.b_pending = false; H.a_recorded = false; }
     m->frames_issued = 0; m->frames_consumed = 0; m->batch_seq = 0;
     for (int k = 0; k < TSL_INFLIGHT; ++k) { m->ring_ev[k] = nullptr; m->ring_upto[k] = 0; }
@@ -1059,7 +1042,6 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         if (S.stage_in) (void)hipFree(S.stage_in);
         if (S.stage_tex) (void)hipFree(S.stage_tex);
         if (S.pin) (void)hipHostFree(S.pin);
-        if (S.copy_done) (void)hipEventDestroy(S.copy_done);
 
     }
     esdf_release(m);

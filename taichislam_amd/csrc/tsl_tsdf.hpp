@@ -200,7 +200,7 @@ struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
     void* stage_in; size_t stage_in_bytes; void* stage_tex; size_t stage_tex_bytes;      // staging of host-pointer inputs of the frame queued into this set
-    void* pin; size_t pin_bytes; hipEvent_t copy_done; bool copy_recorded, copy_pending;     // pinned host side of the staging (the host copies the visited rows in), the event behind the H2D copy
+    void* pin; size_t pin_bytes; void* pin_dev;      // pinned, device-mapped host buffer the host copies the visited rows (and the texture) of a host-pointer input into; phase A reads it in place
     FrameParams* Pd;                       // this frame's parameters in device memory (written by the frame's prologue kernel)
     std::vector<void*> owned;
 };

@@ -10,3 +10,4 @@ print("roofline", {k: j["roofline"].get(k) for k in ("frac", "avg_launch_us", "f
 print("seq", j.get("value_sequential"))
 print("parity", {k: j["parity_vs_faithful"].get(k) for k in ("tsdf_rel_frac_le_1e-4", "frames")})
 PY
+timeout 100 python tools/host_input_probe.py 400 2>&1 | grep -v "^TSDF\|^Export" | tail -2
