@@ -150,6 +150,7 @@ def sequential_leg(dev, frames, oracle_map, more=()):
     """Option semantics = 1 (csrc/tsl_sequential.hip): the reference-literal sequential replay on the GPU, for the frames the FAITHFUL
     baseline integrated -- its rate, and whether the map equals the FAITHFUL map bit for bit."""
     import torch
+    from taichislam_amd import _lib
     from taichislam_amd.mapping import DenseTSDF
     from taichislam_amd.utils import synthetic as syn
     g = DenseTSDF(**C2, device=dev)
@@ -168,11 +169,25 @@ def sequential_leg(dev, frames, oracle_map, more=()):
     more = list(more)
     dm = [torch.from_numpy(d.view(np.int16)).cuda(dev) for _, _, d in more]
     g.sync()
+    g.enable_profiling(True, only=[_lib.K_INTEGRATE, _lib.K_RAYS, _lib.K_SORT])
     t1 = time.perf_counter()
     for (R, T, _), d in zip(more, dm):
         g.recast_depth_to_map(R, T, d, None)
     g.sync()
     dts = time.perf_counter() - t1
+    chain = None
+    try:      # what bounds the mode: the replay of a batch is as long as the chain of its most-visited voxel (the one next to the sensor)
+        kt = {k: g.kernel_time(i) for k, i in (("replay", _lib.K_INTEGRATE), ("group", _lib.K_RAYS), ("rank_sort", _lib.K_SORT))}
+        run = g.get_option("seq_longest_run")
+        rep_us = 1000.0 * kt["replay"][0] / max(1, kt["replay"][1])
+        chain = {"replay_us_per_batch": rep_us, "replay_launches": kt["replay"][1], "group_us_per_batch": 1000.0 * kt["group"][0] / max(1, kt["group"][1]),
+                 "rank_sort_us_per_batch": 1000.0 * kt["rank_sort"][0] / max(1, kt["rank_sort"][1]),
+                 "longest_voxel_run_updates_last_batch": run, "ns_per_update_if_the_chain_is_the_launch": 1000.0 * rep_us / max(1, run),
+                 "note": "k_seq_replay of a batch (eight frames) runs as long as the dependent chain of its most-visited voxel: one wave, ~10 instructions per update, "
+                         "one instruction per four cycles; phase A of the next batch (k_seq_group and the rank sort) runs beside it on the batch's stream"}
+    except Exception as e:
+        chain = {"error": repr(e)[:200]}
+    g.enable_profiling(False)
 
     def srt(e):
         i = e["indices"].astype(np.int64)
@@ -183,7 +198,7 @@ def sequential_leg(dev, frames, oracle_map, more=()):
     rate, steady = (len(frames) - 1) / max(dt, 1e-9), (len(more) / max(dts, 1e-9) if len(more) >= 64 else None)
     return {"value": rate, "unit": "frames/s", "frames": len(frames), "voxels": int(x[0].shape[0]),
             "bit_exact_with_oracle_FAITHFUL": bool(exact),
-            "value_steady": steady, "steady_frames": len(more),
+            "value_steady": steady, "steady_frames": len(more), "chain_floor": chain,
             "north_star": {"rate_target_frames_per_s": 2000, "rate_met": bool(min(rate, steady if steady else rate) >= 2000.0), "tsdf_tolerance": "1e-4 relative",
                            "tolerance_met": bool(exact), "how": "every TSDF / W bit equals the reference's struct-for serialisation (oracle FAITHFUL, pinned to the "
                            "reference's own source by tests/golden/ref_*.npz)"},
@@ -238,6 +253,24 @@ def reference_source_leg(dev):
         voxels += int(want["indices"].shape[0])
     return {"vectors": names, "voxels": voxels, "oracle_FAITHFUL_bit_exact": all(ora_ok), "hip_semantics_1_bit_exact": all(hip_ok),
             "note": "golden maps made by the reference's dense_tsdf.py + mapping_common.py, imported unmodified and run on tools/ti_seq (not by Taichi itself)"}
+
+
+def stored_counters():
+    """profiles/r04_traffic.json -- PMC counters of separate rocprofv3 passes over the driver's command (tools/gpu_profiles_r04.sh) -- or None when
+    the file was collected on OTHER kernels: it carries the hash of the kernel sources it was measured on (taichislam_amd.build.source_hash), and
+    a line never replays counters of kernels that have changed since."""
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/r04_traffic.json is missing"
+    try:
+        tj = json.load(open(path))
+        from taichislam_amd import build
+        have = build.source_hash()
+        if tj.get("lib_source_hash") != have:
+            return None, f"profiles/r04_traffic.json was collected on kernel sources {tj.get('lib_source_hash')}, these are {have}: counters not replayed"
+        return tj, None
+    except Exception as e:
+        return None, repr(e)[:200]
 
 
 def relaunch(args):
@@ -302,10 +335,12 @@ def main():
         line = bench_configs.run(args.config, args.steps, args.warmup, dev)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_config(args.config)
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if os.path.exists(tpath) and line.get("roofline"):
+        tall, why = stored_counters()
+        if tall is None and line.get("roofline"):
+            line["roofline"]["traffic_source"] = why
+        if tall is not None and line.get("roofline"):
             try:
-                tj = json.load(open(tpath)).get(f"config{args.config}")
+                tj = tall.get(f"config{args.config}")
                 if tj:
                     line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = tj.get("command")
@@ -500,10 +535,11 @@ def main():
             us = kern["integrate"]["avg_us"]
             ach = alg / (us * 1e-6) / 1e9
             traffic, traffic_src, valu = None, None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-            if os.path.exists(tpath):
+            tj, why = stored_counters()
+            if tj is None:
+                traffic_src = why
+            else:
                 try:
-                    tj = json.load(open(tpath))
                     traffic, traffic_src = tj["integrate"]["hbm_bytes_per_launch"], tj.get("command")
                     # what actually bounds the kernel: its VALU issue rate.  SQ_INSTS_VALU (wave instructions per launch, PMC pass of the same
                     # command) x 4 cycles per wave64 instruction / (SIMDs x cycles of THIS run's average launch)

@@ -31,6 +31,16 @@ def _deps():
         glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.hpp, *.h, the public header): stamps profiles/*_traffic.json, so that bench.py can tell whether the
+    counters it replays were collected on these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_deps()):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True

@@ -230,21 +230,28 @@ __device__ __forceinline__ float seq_div_sat(float n, float D, float r)
     e = __builtin_fmaf(-q, D, n);
     return __builtin_fmaf(e, r, q);
 }
-// { a = RN16(T * W), n = RN32(a + c), q = n / D, T' = RN16(q) } with D and r = RN32(1 / D) given; W as f16 (1000 once saturated)
-__device__ __forceinline__ _Float16 seq_update_fast(_Float16 T, _Float16 W, float c, float D, float r)
+// { a = RN16(T * W), n = RN32(a + c), q = n / D, T' = RN16(q) } with D and r = RN32(1 / D) given; W as f16 (1000 once saturated).
+// Eight instructions, written out: (i) the compiler turns `(float)a + c` into a conversion and an addition where the mixed-precision FMA
+// a * 1.0 + c reads the f16 product as it is (one rounding, the same value); (ii) left to itself it folds the last FMA and the conversion
+// into ONE v_fma_mixlo_f16, which rounds the exact FMA result to f16 once -- dense_tsdf.py:264 stores an f32 expression into an f16 field,
+// two roundings, and the two differ whenever the f32 rounding lands on an f16 tie (seen: 14 of 1.4 M voxels after 12 frames); (iii) every
+// separate asm statement costs a wait state behind it, and the chain of the voxel next to the sensor pays per instruction slot.
+// tsl_selftest(2) runs this against the literal expression on 2^32 operand tuples.
+// T and W travel as 32-bit registers whose LOW HALF is the f16 value (the f16 instructions read and write that half; nothing is masked in between)
+__device__ __forceinline__ uint32_t seq_update_fast(uint32_t T, uint32_t W, float c, float D, float r)
 {
-    const _Float16 a = T * W;                                  // RN16(T * W): one v_mul_f16 (f16 denormals are kept)
-    // n = RN32(a + c): the f16 product is read as it is by the mixed-precision FMA, a * 1.0 + c -- one instruction, one rounding, the same value
-    // as the conversion followed by the addition (the compiler folds fma(x, 1, c) back into those two)
-    float n;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(n) : "v"((uint32_t)__builtin_bit_cast(uint16_t, a)), "v"(c));
-    float q = seq_div_sat(n, D, r);
-    // the quotient is an f32 value that is THEN rounded to f16 (two roundings, as dense_tsdf.py:264 stores an f32 expression into an f16 field).
-    // Left to itself the compiler folds the last FMA and the conversion into one v_fma_mixlo_f16, which rounds the exact FMA result to f16
-    // once -- a different value whenever the f32 rounding lands on an f16 tie (seen: 14 of 1.4 M voxels after 12 frames).  The empty asm hides
-    // the FMA from the conversion.
-    asm("" : "+v"(q));
-    return (_Float16)q;
+    uint32_t t; float n, q;
+    asm("v_mul_f16 %0, %3, %4\n\t"                                   // a = RN16(T * W)   (f16 denormals are kept)
+        "v_fma_mix_f32 %1, %0, 1.0, %5 op_sel_hi:[1,0,0]\n\t"        // n = RN32(a + c)
+        "v_mul_f32 %2, %1, %7\n\t"                                   // q = RN32(n r)
+        "v_fma_f32 %0, -%2, %6, %1\n\t"                              // e = n - q D  (exact)
+        "v_fmac_f32 %2, %0, %7\n\t"                                  // q = RN32(q + e r): faithful
+        "v_fma_f32 %0, -%2, %6, %1\n\t"
+        "v_fmac_f32 %2, %0, %7\n\t"                                  // ... correctly rounded (seq_div_sat)
+        "v_cvt_f16_f32 %0, %2"                                        // T' = RN16(q)
+        : "=&v"(t), "=&v"(n), "=&v"(q)
+        : "v"(T), "v"(W), "v"(c), "v"(D), "v"(r));
+    return t;
 }
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: keep it in an SGPR
 #define SQ_W_SAT 0x63d0u          // 1000 as f16 bits
@@ -518,9 +525,9 @@ __device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint
         ++t;
     }
     if (t < end) {
-        _Float16 Th = __builtin_bit_cast(_Float16, T0);
-        for (; t < end; ++t) { const float4 z = tp[t]; Th = seq_update_fast(Th, (_Float16)1000.0f, z.y, z.w, z.z); }
-        T0 = __builtin_bit_cast(h16, Th);
+        uint32_t Tr = T0;
+        for (; t < end; ++t) { const float4 z = tp[t]; Tr = seq_update_fast(Tr, SQ_W_SAT, z.y, z.w, z.z); }
+        T0 = (h16)Tr;
     }
 }
 
@@ -533,10 +540,11 @@ __global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* 
 {
     __shared__ int s_cum[PLAN_NCLS + 1];
     __shared__ int s_uq[TSL_NB];
+    __shared__ unsigned s_mx[TSL_NB];                          // longest run of a voxel in every frame: the chain that bounds the replay
     uint32_t okmask = 0u;
 #pragma unroll
     for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
-    if (threadIdx.x < TSL_NB) s_uq[threadIdx.x] = 0;
+    if (threadIdx.x < TSL_NB) { s_uq[threadIdx.x] = 0; s_mx[threadIdx.x] = 0u; }
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int c = 0; c < PLAN_NCLS; ++c) { s_cum[c] = acc; acc += min(B.f[0].counters[HDR_UNITS + c], B.f[0].unit_cap); }
@@ -588,6 +596,9 @@ __global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* 
             has |= (len ? 1u : 0u) << q;
             const unsigned long long m = __ballot(len != 0u);           // dense_tsdf.py has no such counter; the frame statistics report the voxels a frame updated
             if (m && lane_id() == 0) atomicAdd(&s_uq[q], popc64(m));
+            uint32_t mx = len;
+            for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d); mx = o > mx ? o : mx; }
+            if (mx && lane_id() == 0) atomicMax(&s_mx[q], mx);
         };
 #define SQ_ALL_FRAMES(F) F(std::integral_constant<int, 0>{}); F(std::integral_constant<int, 1>{}); F(std::integral_constant<int, 2>{}); F(std::integral_constant<int, 3>{}); \
                          F(std::integral_constant<int, 4>{}); F(std::integral_constant<int, 5>{}); F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 7>{});
@@ -622,6 +633,7 @@ __global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* 
 #undef SQ_ALL_FRAMES
     __syncthreads();
     if (threadIdx.x < TSL_NB && s_uq[threadIdx.x]) atomic_add_i64(&B.f[threadIdx.x].stats->unique, (long long)s_uq[threadIdx.x]);
+    if (threadIdx.x < TSL_NB && threadIdx.x < (unsigned)B.n && s_mx[threadIdx.x]) atomicMax(reinterpret_cast<unsigned*>(&B.f[threadIdx.x].counters[HDR_SEQ_MAXRUN]), s_mx[threadIdx.x]);
 }
 
 template <bool TEX>
@@ -805,7 +817,7 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
-                    _Float16 Th = __builtin_bit_cast(_Float16, (h16)Tb);
+                    uint32_t Tr = Tb;
                     int k = 0;
                     for (; k + 16 <= m; k += 16) {      // sixteen updates per trip: all sixteen LDS reads are issued in front of the chain (the scheduling barrier keeps
                         float4 x[16];                   // them there -- left alone the scheduler moves each read next to its use and the chain waits for the LDS every time)
@@ -813,14 +825,14 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                         for (int j = 0; j < 16; ++j) x[j] = st[k + j];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) Th = seq_update_fast(Th, __builtin_bit_cast(_Float16, (h16)__float_as_uint(x[j].w)), x[j].x, x[j].y, x[j].z);
+                        for (int j = 0; j < 16; ++j) Tr = seq_update_fast(Tr, __float_as_uint(x[j].w), x[j].x, x[j].y, x[j].z);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     for (; k < m; ++k) {
                         const float4 x = st[k];
-                        Th = seq_update_fast(Th, __builtin_bit_cast(_Float16, (h16)__float_as_uint(x.w)), x.x, x.y, x.z);
+                        Tr = seq_update_fast(Tr, __float_as_uint(x.w), x.x, x.y, x.z);
                     }
-                    Tb = (uint32_t)uni_i((int)__builtin_bit_cast(h16, Th));
+                    Tb = (uint32_t)uni_i((int)(Tr & 0xffffu));
                     __builtin_amdgcn_wave_barrier();
                     t += (uint32_t)m;
                 }
@@ -865,8 +877,8 @@ __global__ void __launch_bounds__(256) k_selftest_seqdiv(unsigned long long* bad
         const uint32_t wb = (it & 1) ? SQ_W_SAT : (uint32_t)(((bq >> 8) ^ a) & 0x7fffu) % (SQ_W_SAT + 1u);
         const float D = h2f((h16)wb) + w;
         const h16 want = f2h((h2f(hmul((h16)tb, (h16)wb)) + c) / D);                                                      // the literal expression, dense_tsdf.py:264
-        const _Float16 got = seq_update_fast(__builtin_bit_cast(_Float16, (h16)tb), __builtin_bit_cast(_Float16, (h16)wb), c, D, 1.0f / D);
-        if (want != __builtin_bit_cast(h16, got)) ++nbad;
+        const uint32_t got = seq_update_fast(tb | (bq << 16), wb | (a << 16), c, D, 1.0f / D);      // (garbage in the high halves: they must not matter)
+        if (want != (h16)got) ++nbad;
     }
     nbad = wave_sum_ll(nbad);
     if (lane_id() == 0 && nbad) atomicAdd(bad, (unsigned long long)nbad);

@@ -552,6 +552,7 @@ static int launch_batch_t(tsl_tsdf* m)
     const int n = m->npend;
     if (n == 0) return TSL_OK;
     m->npend = 0;                                   // nothing below re-enters through ms()
+    m->last_batch_n = n;
     const int bi = m->cur;
     BatchHost& H = m->batch[bi];
     const bool serial = m->overlap == 0;
@@ -1125,6 +1126,17 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
         int v[40];
         TSL_HIP(hipMemcpy(v, m->fset[bi * TSL_NB].F.counters, sizeof(v), hipMemcpyDeviceToHost));
         *value = name[5] == 'h' ? v[14] : v[13];
+        return TSL_OK;
+    }
+    if (!std::strcmp(name, "seq_longest_run")) {
+        // sequential semantics, developer statistic: the most updates any one voxel received in a frame of the batch issued last, summed over the batch's
+        // frames -- the dependent chain that bounds the replay of that batch (one wave applies it, ~43 cycles per update)
+        TSL_REQUIRE(m->scratch_ready, "nothing integrated yet");
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        const int bi = (m->cur + TSL_NBATCH - 1) % TSL_NBATCH;
+        long long sum = 0;
+        for (int q = 0; q < m->last_batch_n; ++q) { int v[40]; TSL_HIP(hipMemcpy(v, m->fset[bi * TSL_NB + q].F.counters, sizeof(v), hipMemcpyDeviceToHost)); sum += (unsigned)v[31]; }
+        *value = (int)(sum > 0x7fffffffll ? 0x7fffffffll : sum);
         return TSL_OK;
     }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }

@@ -89,6 +89,7 @@ struct FrameDev {
 #define HDR_SEQ_TUPLES 26      //   [26..27] sequential semantics: ray-step tuples reserved in the frame's tuple arrays (one 64-bit counter)
 #define HDR_SEQ_LONG 28        //   batch: sequential semantics: voxels listed for k_seq_replay_long
 #define HDR_SEQ_XLONG 30       //   batch: ... of those, the ones with the longest chains (walked first)
+#define HDR_SEQ_MAXRUN 31      //   sequential semantics: the longest run of a voxel in this frame (updates)
 #define HDR_SEQ_SLOTS 29       //   sequential semantics: slots (= k_seq_group work items) of the frame
 
 // A frame that runs out of its own scratch (bit 1: frame bricks / parts, bit 2: ray segments) is not integrated at all: the flag
@@ -227,7 +228,7 @@ struct tsl_tsdf {
     int cur, npend, pend_points; tsl::FrameParams pend[TSL_NB]; int deferred_rc;      // frames queued for batch `cur`
     int64_t frames_issued, frames_consumed;  // frames handed to the device so far / of those, frames whose inputs have been read
     int64_t batch_seq; hipEvent_t ring_ev[TSL_INFLIGHT]; int64_t ring_upto[TSL_INFLIGHT];      // back-pressure ring: end of phase B of the last TSL_INFLIGHT batches
-    int last_set;
+    int last_set, last_batch_n;          // working set of the frame queued last; frames of the batch issued last
     hipStream_t producers[4]; int nproducers;   // producer streams of the queued device inputs (ordered before phase A when the batch is issued)
     hipEvent_t in_ev[8]; int in_ev_next;  // cached events ordering callers' producer streams before the input-reading stream (tsl_tsdf_input_stream)
     bool scratch_ready;                  // frame scratch allocated (first integrate call)
