@@ -540,7 +540,9 @@ def main():
                 traffic_src = why
             else:
                 try:
-                    traffic, traffic_src = tj["integrate"]["hbm_bytes_per_launch"], tj.get("command")
+                    # the counters are averages per launch of the PMC command (its launches cover other frame counts than this run's): per frame, x this run's frames per launch
+                    traffic = tj["integrate"]["hbm_bytes_per_launch"] / tj["integrate"]["frames_per_launch"] * fpl
+                    traffic_src = tj.get("command") + f" (hbm_bytes_per_launch / {tj['integrate']['frames_per_launch']:.2f} frames per launch there x {fpl:g} here; kernel sources {tj.get('lib_source_hash')})"
                     # what actually bounds the kernel: its VALU issue rate.  SQ_INSTS_VALU (wave instructions per launch, PMC pass of the same
                     # command) x 4 cycles per wave64 instruction / (SIMDs x cycles of THIS run's average launch)
                     vi, fpl_p = tj["integrate"].get("valu_wave_insts_per_launch"), tj["integrate"].get("frames_per_launch")

@@ -116,7 +116,7 @@ def test_the_vectors_cover_what_they_claim():
     assert "color" in t and (t["color"] != 0).any()
     _, _, _, steps, p = load("point_clouds")
     assert p["indices"].shape[0] > 10000 and sum(s["kind"] == "pcl" for s in steps) == 2
-    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + POSED + ["octomap", "session", "session_blk10"])
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))) == sorted(f"ref_{n}.npz" for n in NAMES + BLK10 + POSED + ["octomap", "session", "session_blk10", "esdf_defs"])
 
 
 # ------------------------------------------------------------------------------------------------------------------ HIP (GPU)

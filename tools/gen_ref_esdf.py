@@ -6,7 +6,7 @@ starts from (`propogate_esdf`, :313-330) and how a value moves to a neighbour (`
 EXECUTED, unmodified, on the sequential Taichi stand-in (tools/ti_seq): the module is loaded by path, an instance is made without its broken
 __init__ (object.__new__) and given exactly the attributes the three functions read -- 3-d fields on a pointer / dense tree, the queues, the 26
 neighbour vectors built as dense_esdf.py:141-146 builds them.  Scene: an analytic sphere SDF (values rounded to f16, the package's storage type)
-over the eight central 16^3 blocks of a 64^3 grid -- every voxel of an active block is observed (the reference treats an unobserved voxel of an
+over the central 16^3 block of a 48^3 grid -- every voxel of an active block is observed (the reference treats an unobserved voxel of an
 active block as a source of distance 0), the blocks around stay inactive (the reference indexes neighbours without a range check).  Committed as tests/golden/ref_esdf_defs.npz:
    init      ESDF after the initialisation branches alone (process_lower_queue stubbed out on the instance)
    one_pass  ESDF after propogate_esdf as written: initialisation + ONE pass over the lower queue, and the queue's order
@@ -14,7 +14,7 @@ active block as a source of distance 0), the blocks around stay inactive (the re
              process_lower_queue) until nothing changes: the fixed point of the reference's relaxation rule
 tests/test_ref_esdf.py compares the package (oracle Dijkstra, HIP incremental update) with them.
 
-    python tools/gen_ref_esdf.py            # ~10 minutes; needs /root/reference"""
+    python tools/gen_ref_esdf.py            # ~15 minutes (the stand-in interprets every operation); needs /root/reference"""
 import importlib.util
 import os
 import sys
@@ -26,8 +26,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/taichi_slam/mapping"
 sys.path.insert(0, os.path.join(ROOT, "tools", "ti_seq")); sys.path.insert(0, ROOT)
-N, BLK, VS, RADIUS, MAXRAY = 64, 16, 0.1, 0.8, 1.0
-LO, HI = 16, 48                                    # the observed region: the eight central blocks, every voxel of them (the blocks around stay inactive: ti.is_active skips them)
+N, BLK, VS, RADIUS, MAXRAY = 48, 16, 0.1, 0.45, 0.6
+LO, HI = 16, 32                                    # the observed region: the central block, every voxel of it (the blocks around stay inactive: ti.is_active skips them)
 
 
 def load():
