@@ -1081,7 +1081,7 @@ static int take_dev_err(tsl_tsdf* m)
     const int e = m->h_ints[28];
     if (!e) return TSL_OK;
     set_error(std::string("device capacity exhausted:") + ((e & 1) ? " brick pool (max_bricks)" : "") + ((e & 2) ? " frame scratch (max_frame_bricks)" : "") +
-              ((e & 4) ? " ray segments" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : "") + "; the affected frames / bricks were not integrated");
+              ((e & 4) ? " ray segments / ray-step tuples of the sequential semantics (seq_tuple_cap)" : "") + ((e & 8) ? " more than 16384 points in one sensor voxel" : "") + "; the affected frames / bricks were not integrated");
     TSL_HIP(hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream_));
     return TSL_ERR_CAPACITY;
 }

@@ -134,3 +134,57 @@ def test_sequential_fusion_textured_equals_faithful(hip_lib):
         assert eg["indices"].shape[0] > 50000 and np.array_equal(eg["indices"], eo["indices"])
         for k in ("TSDF", "W_TSDF", "occupy", "color"):
             assert np.array_equal(eg[k], eo[k]), k
+
+
+@pytest.mark.parametrize("opts", [{"seq_impl": 0}, {"overlap": 0}, {"overlap": 3}])
+def test_sequential_mode_variants_equal_faithful(hip_lib, opts):
+    """The same small stream through round 3's global-sort form (seq_impl 0, kept as a cross-check), one frame at a time on the main stream
+    (overlap 0) and batches of three: every form ends with the FAITHFUL map."""
+    from oracle import FAITHFUL
+    K, frames = small_stream(7)
+    g, o = make_pair(SMALL, K)
+    g.set_option("semantics", 1)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    for R, T, d in frames:
+        g.recast_depth_to_map(R, T, d, None)
+        so = o.integrate_depth(R, T, d, mode=FAITHFUL)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"sequential, {opts}")
+
+
+def test_sequential_mode_outside_the_division_free_range(hip_lib):
+    """Rays of up to 75 m into 50 cm voxels: signed distances beyond the +-60 the division-free update is proven for, so every (frame, brick) is
+    flagged and both replay roles walk the literal expression (IEEE division) -- the path no benchmark scene ever takes.  Still FAITHFUL, bit for bit."""
+    from oracle import FAITHFUL
+    cfg = dict(map_scale=[204.8, 204.8], voxel_scale=0.4, num_voxel_per_blk_axis=16, max_ray_length=80.0, min_ray_length=0.3, internal_voxels=10, recast_step=2)
+    h, w = 120, 160
+    K = syn.scaled_intrinsics(h, w)
+    g, o = make_pair(cfg, K)
+    g.set_option("semantics", 1)
+    for f in range(4):
+        R, T = syn.camera_pose(3 * f, orbit=5.0)
+        d = syn.sphere_room_depth(R, T, h, w, radius=69.0, K=K)        # optical-axis depth up to 64 m (uint16 millimetres hold 65.5 m); ranges beyond that
+        assert d.max() > 60000
+        g.recast_depth_to_map(R, T, d, None)
+        so = o.integrate_depth(R, T, d, mode=FAITHFUL)
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS} and sg["steps"] > 100000
+    e = g.export_submap()
+    assert np.abs(np.asarray(e["TSDF"], np.float32)).max() > 60.0
+    assert_export_equal(e, o.export_sparse(), "sequential, long rays")
+
+
+def test_sequential_mode_tuple_capacity_is_loud(hip_lib):
+    """A frame that yields more ray steps than seq_tuple_cap is dropped as a whole and reported (TSL_ERR_CAPACITY), the map keeps the frames before it."""
+    from oracle import FAITHFUL
+    from taichislam_amd._lib import TslError
+    K, frames = small_stream(3)
+    g, o = make_pair(SMALL, K)
+    g.set_option("semantics", 1)
+    g.set_option("seq_tuple_cap", 1 << 16)               # a 120 x 160 frame of the stream has ~330 k steps
+    with pytest.raises(TslError, match="capacity"):
+        g.recast_depth_to_map(*frames[0], None)
+        g.sync()
+    assert g.count_active() == 0
