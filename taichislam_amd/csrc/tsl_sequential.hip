@@ -20,6 +20,7 @@
 #include "tsl_tsdf.hpp"
 #include <rocprim/rocprim.hpp>
 #include <type_traits>
+#include <cstdlib>
 
 namespace tsl {
 
@@ -256,7 +257,6 @@ __device__ __forceinline__ uint32_t seq_update_fast(uint32_t T, uint32_t W, floa
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: keep it in an SGPR
 #define SQ_W_SAT 0x63d0u          // 1000 as f16 bits
 #define SQ_LONG 64                // a voxel with a run of at least this many updates in some frame of the batch gets a wave of its own (k_seq_replay_long)
-#define SQ_LCHUNK 256             // updates staged in LDS at a time there
 #define SQ_XLONG 1024             // ... and with one of at least this many it is listed in front of the others: the longest chains start first
 #define SQ_XLONG_CAP 4096
 #define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to k_seq_replay_long (beyond: they stay with their lane); the first SQ_XLONG_CAP entries are the longest
@@ -513,22 +513,29 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
     }
 }
 
-// one run of one voxel, applied by its lane: literal updates until the weight sits at Wmax (for good: w > 0) and the value is where the
-// division-free form is exact, that form from then on
-__device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint32_t t, uint32_t end, bool can_sat, h16& T0, h16& W0)
+// one run of one voxel, applied by its lane.  The division-free update (seq_update_fast) needs D = W + w and its correctly rounded reciprocal:
+// at Wmax both come with the tuple; below it -- and a weight can sit below Wmax for good: RN16(W + w) = W as soon as w is under half an f16 ulp
+// of W, e.g. w < 0.25 from W = 512 on -- the reciprocal is one IEEE division per update.  Outside the range the form is proven for (the
+// item's flag, |T| > 60) the literal expression.
+__device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint32_t t, uint32_t end, bool can_fast, h16& T0, h16& W0)
 {
-    while (t < end && !(can_sat && W0 == (h16)SQ_W_SAT && fabsf(h2f(T0)) <= 60.0f)) {
+    if (!(can_fast && fabsf(h2f(T0)) <= 60.0f)) {
+        for (; t < end; ++t) {
+            const float4 x = tp[t];
+            const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                              // dense_tsdf.py:264
+            float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                                   // :267
+            T0 = Tn; W0 = f2h(wn);
+        }
+        return;
+    }
+    uint32_t Tr = T0; h16 Wb = W0;
+    for (; t < end; ++t) {
         const float4 x = tp[t];
-        const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                                  // dense_tsdf.py:264
-        float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                                       // :267
-        T0 = Tn; W0 = f2h(wn);
-        ++t;
+        const float D = h2f(Wb) + x.x;                                                                                    // (= the tuple's Wmax + w at Wmax)
+        Tr = seq_update_fast(Tr, Wb, x.y, D, 1.0f / D);                                                                   // :264  (a convex combination: |T| <= 60 stays)
+        Wb = f2h(D > TSL_WMAX ? TSL_WMAX : D);                                                                            // :267
     }
-    if (t < end) {
-        uint32_t Tr = T0;
-        for (; t < end; ++t) { const float4 z = tp[t]; Tr = seq_update_fast(Tr, SQ_W_SAT, z.y, z.w, z.z); }
-        T0 = (h16)Tr;
-    }
+    T0 = (h16)Tr; W0 = Wb;
 }
 
 // phase B: one thread per voxel of every brick the batch integrates into (k_plan's unit tables with every brick a unit: brick id, pool index,
@@ -725,22 +732,16 @@ __device__ __forceinline__ void seq_role_short(const MapDev& M, const BatchDev& 
 }
 
 // The long runs: ONE WAVE PER VOXEL, wave-uniform.  A wave issues one instruction per four cycles however many lanes are active, so what a long
-// chain costs is instructions per update -- and the latency of whatever it waits for.  Here the wave's 64 lanes move a chunk of 256 replay
-// tuples from HBM into LDS with four coalesced loads (the next chunk is requested before the current one is replayed: the chain never waits
-// for memory), and the chain itself reads { c, D, 1 / D, W } from LDS -- ten instructions per update: ds_read_b128, v_mul_f16, v_cvt_f32_f16,
-// v_add_f32, v_mul_f32, four v_fma_f32, v_cvt_f16_f32.  While the voxel's weight is still below Wmax the chunk's W sequence (four dependent
-// instructions per update, independent of the values) is run first, then D = W + w and 1 / D are formed by the 64 lanes side by side.
+// chain costs is instructions per update -- unless the 64 lanes can do 64 updates at once, which they can wherever the f16 state has stopped
+// moving (see the chain below): the replay tuples stream from HBM 1 024 at a time and a round of 64 costs one evaluation (about twenty
+// instructions) as long as none of them changes (T, W).
 // The waves run at raised priority: phase A of the next batch (k_seq_group, eight waves per CU) shares the SIMDs, and a chain that gets
 // every third issue slot is three times as long.
 template <bool TEX>
 __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list, int nblocks)
 {
-    __shared__ float4 s_t[4][SQ_LCHUNK];             // per wave: { c, D, 1 / D, W bits before the update } of the chunk's updates
-    __shared__ float s_wv[4][SQ_LCHUNK];             // w
-    __shared__ uint32_t s_wp[4][SQ_LCHUNK];          // W (f16 bits) before update k, while unsaturated
     __builtin_amdgcn_s_setprio(3);
     const int wid = threadIdx.x >> 6, lane = lane_id();
-    float4* const st = s_t[wid]; float* const sw = s_wv[wid]; uint32_t* const swp = s_wp[wid];
     uint32_t okmask = 0u;
 #pragma unroll
     for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
@@ -781,60 +782,39 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                 }
                 Tb = (uint32_t)uni_i((int)T0); Wb = (uint32_t)uni_i((int)W0);
             } else {
-                float4 nx[SQ_LCHUNK / 64];
-#pragma unroll
-                for (int j = 0; j < SQ_LCHUNK / 64; ++j) { const uint32_t idx = t + (uint32_t)(j * 64 + lane); nx[j] = idx < o1 ? tp[idx] : make_float4(0.f, 0.f, 0.f, 0.f); }
+                // The chain.  Deep into a voxel's life an update mostly leaves BOTH f16 values as they are: the running mean stalls (an increment of
+                // w / W of the residual is far below half an f16 ulp of T), and so does the weight (RN16(W + w) = W once w is under half an ulp of W:
+                // w < 0.25 from W = 512 on -- a voxel seen from two metres never reaches Wmax).  Whether update k changes the state can be decided
+                // without the updates before it, as long as THEY did not: the 64 lanes evaluate 64 consecutive updates on the same (T, W); if none
+                // changes it, 64 updates are done; otherwise the first lane that does holds the true next state (everything before it was a no-op)
+                // and the lanes behind it go again.  Exact by construction; at worst -- a state that moves at every update, a voxel's first few
+                // hundred -- one evaluation per update, as in a plain walk.  The tuples come straight from HBM, 1 024 per trip: sixteen coalesced
+                // loads in flight, each the 64 updates of one round.
                 while (t < o1) {
-                    const int m = (int)min(o1 - t, (uint32_t)SQ_LCHUNK);
+                    float4 x[16];
 #pragma unroll
-                    for (int j = 0; j < SQ_LCHUNK / 64; ++j) {
-                        const int k = j * 64 + lane;
-                        st[k] = make_float4(nx[j].y, nx[j].w, nx[j].z, __uint_as_float(SQ_W_SAT)); sw[k] = nx[j].x;
-                    }
-                    {   // the next chunk rides under this one's chain (volatile: the request stays HERE, it is not sunk to its use behind the chain)
-                        const uint32_t tn = t + (uint32_t)m;
-#pragma unroll
-                        for (int j = 0; j < SQ_LCHUNK / 64; ++j) {
-                            const uint32_t idx = tn + (uint32_t)(j * 64 + lane);
-                            const volatile float4* src = tp + (idx < o1 ? idx : o1 - 1u);
-                            nx[j].x = src->x; nx[j].y = src->y; nx[j].z = src->z; nx[j].w = src->w;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (Wb != SQ_W_SAT) {
-                        float Wf = h2f((h16)Wb);
-                        for (int k = 0; k < m; ++k) {
-                            swp[k] = (uint32_t)f2h(Wf);
-                            float d = Wf + sw[k]; if (TSL_WMAX < d) d = TSL_WMAX;                                         // :267
-                            Wf = h2f(f2h(d));
-                        }
-                        Wb = (uint32_t)uni_i((int)f2h(Wf));
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int j = 0; j < SQ_LCHUNK / 64; ++j) {
-                            const int k = j * 64 + lane;
-                            if (k < m) { const float D = h2f((h16)swp[k]) + sw[k]; const float4 x = st[k]; st[k] = make_float4(x.x, D, 1.0f / D, __uint_as_float(swp[k])); }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    for (int r = 0; r < 16; ++r) x[r] = tp[min(t + (uint32_t)(r * 64 + lane), o1 - 1u)];
                     uint32_t Tr = Tb;
-                    int k = 0;
-                    for (; k + 16 <= m; k += 16) {      // sixteen updates per trip: all sixteen LDS reads are issued in front of the chain (the scheduling barrier keeps
-                        float4 x[16];                   // them there -- left alone the scheduler moves each read next to its use and the chain waits for the LDS every time)
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) x[j] = st[k + j];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) Tr = seq_update_fast(Tr, __float_as_uint(x[j].w), x[j].x, x[j].y, x[j].z);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    for (; k < m; ++k) {
-                        const float4 x = st[k];
-                        Tr = seq_update_fast(Tr, __float_as_uint(x.w), x.x, x.y, x.z);
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t base = t + (uint32_t)(r * 64);
+                        if (base >= o1) continue;                                  // (uniform)
+                        unsigned long long todo = __ballot(base + (uint32_t)lane < o1);
+                        while (todo) {
+                            float D = x[r].w, rc = x[r].z;                        // at Wmax: Wmax + w and its reciprocal come with the tuple
+                            if (Wb != SQ_W_SAT) { D = h2f((h16)Wb) + x[r].x; rc = 1.0f / D; }      // (uniform) below it: one IEEE division per evaluation
+                            const uint32_t Tn = seq_update_fast(Tr, Wb, x[r].y, D, rc);                                   // :264
+                            const uint32_t Wn = (uint32_t)f2h(D > TSL_WMAX ? TSL_WMAX : D);                                // :267
+                            const unsigned long long cm = __ballot((((Tn ^ Tr) & 0xffffu) | (Wn ^ Wb)) != 0u) & todo;
+                            if (cm == 0ull) break;
+                            const int j = (int)__builtin_ctzll(cm);
+                            Tr = (uint32_t)__builtin_amdgcn_readlane((int)Tn, j) & 0xffffu;
+                            Wb = (uint32_t)__builtin_amdgcn_readlane((int)Wn, j);
+                            todo &= ~((2ull << j) - 1ull);                        // the lanes behind j (j = 63: none)
+                        }
                     }
                     Tb = (uint32_t)uni_i((int)(Tr & 0xffffu));
-                    __builtin_amdgcn_wave_barrier();
-                    t += (uint32_t)m;
+                    t += 1024u;
                 }
             }
             }
@@ -975,6 +955,11 @@ int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int b
     const int4* ll = static_cast<const int4*>(m->seqb_long[bi]);
     const unsigned long long* lm = static_cast<const unsigned long long*>(m->seqb_lmask[bi]);
     const int nlong = 4 * m->ncu, nshort = 12 * m->ncu;
+    if (std::getenv("TSL_SEQ_SPLIT_ROLES")) {      // developer timing aid: the two roles as two launches (same result: the voxel sets are disjoint)
+        hipLaunchKernelGGL(k_seq_replay<false>, dim3(nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, 0);
+        hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
+        return TSL_OK;
+    }
     if (P.tex) hipLaunchKernelGGL(k_seq_replay<true>, dim3(nlong + nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
     else hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong + nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
     TSL_HIP(hipGetLastError());

@@ -1139,6 +1139,15 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
         *value = (int)(sum > 0x7fffffffll ? 0x7fffffffll : sum);
         return TSL_OK;
     }
+    if (!std::strcmp(name, "seq_long_voxels")) {
+        // sequential semantics, developer statistic: voxels of the batch issued last that were replayed by a wave of their own (>= 64 updates in a frame)
+        TSL_REQUIRE(m->scratch_ready, "nothing integrated yet");
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        const int bi = (m->cur + TSL_NBATCH - 1) % TSL_NBATCH;
+        int v[40]; TSL_HIP(hipMemcpy(v, m->fset[bi * TSL_NB].F.counters, sizeof(v), hipMemcpyDeviceToHost));
+        *value = v[28] + v[30];
+        return TSL_OK;
+    }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
     if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }

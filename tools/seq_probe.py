@@ -44,6 +44,8 @@ def main():
     g.sync()
     dt = time.perf_counter() - t0
     print(f"seq_impl {a.impl}: {a.frames} frames in {1e3 * dt:.1f} ms = {a.frames / dt:.0f} frames/s; last frame {g.last_frame_stats()}", flush=True)
+    if a.impl == 1:
+        print(f"  last batch: {g.get_option('seq_long_voxels')} voxels with a wave of their own, longest runs summed over its frames {g.get_option('seq_longest_run')} updates", flush=True)
     if a.check:
         from oracle import FAITHFUL, OracleTSDF
         from util import assert_export_equal
