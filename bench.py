@@ -183,8 +183,10 @@ def sequential_leg(dev, frames, oracle_map, more=()):
         chain = {"replay_us_per_batch": rep_us, "replay_launches": kt["replay"][1], "group_us_per_batch": 1000.0 * kt["group"][0] / max(1, kt["group"][1]),
                  "rank_sort_us_per_batch": 1000.0 * kt["rank_sort"][0] / max(1, kt["rank_sort"][1]),
                  "longest_voxel_run_updates_last_batch": run, "ns_per_update_if_the_chain_is_the_launch": 1000.0 * rep_us / max(1, run),
-                 "note": "k_seq_replay of a batch (eight frames) runs as long as the dependent chain of its most-visited voxel: one wave, ~10 instructions per update, "
-                         "one instruction per four cycles; phase A of the next batch (k_seq_group and the rank sort) runs beside it on the batch's stream"}
+                 "note": "k_seq_replay of a batch (eight frames) is as long as the run of its most-visited voxel takes one wave; where the f16 state (T, W) has "
+                         "stopped moving -- most of a long run -- the wave's 64 lanes settle 64 updates per evaluation (exact: the first lane whose update "
+                         "changes the state holds the true next state), so the chain is ~0.3 instead of ~10 instructions per update; phase A of the next "
+                         "batch (k_seq_group and the rank sort) runs beside it on the batch's stream and is now the longer of the two"}
     except Exception as e:
         chain = {"error": repr(e)[:200]}
     g.enable_profiling(False)
@@ -204,7 +206,7 @@ def sequential_leg(dev, frames, oracle_map, more=()):
                            "reference's own source by tests/golden/ref_*.npz)"},
             "note": "tsl_tsdf_set_option(semantics, 1): rays in Taichi's struct-for order, every ray step applied on its own in f16 with the W clamp "
                     "(dense_tsdf.py:264-267) -- a legal schedule of the racy reference, equal to the sequential CPU replay on every TSDF / W bit.  Round 4: "
-                    "per-brick replay runs on the brick pipeline (k_seq_group), a wave per long run (k_seq_replay_long); `value` = these frames behind an "
+                    "per-brick replay runs on the brick pipeline (k_seq_group), a wave per long run, a lane per short one (k_seq_replay); `value` = these frames behind an "
                     "empty pipeline (first-touch allocation excluded), `value_steady` = the frames that follow them in the stream, same map"}
 
 

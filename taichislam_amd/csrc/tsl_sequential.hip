@@ -391,6 +391,16 @@ __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const
     }
 }
 
+// phase A of the literal mode, one work item (k_seq_split) per workgroup at a time: the item's segments are put in replay order -- (ray rank,
+// first step) -- every step becomes a tuple at its replay position, and the tuples are then grouped by voxel, replay order kept inside a voxel
+// (a stable counting sort), as the run offsets (CSR) of the item's slot say.  Stages and what each costs were measured with the developer build
+// (-DTSL_SEQ_TIMING, tools/seq_timing_probe.py); this is the second form:
+//   * the bitonic network runs without workgroup barriers wherever a compare-exchange stays inside the quarter of the keys a wave owns (all but
+//     three of its ~55 stages): LDS operations of one wave complete in order;
+//   * the walk takes the segments longest first, dealt out in alternating directions (a counting sort by length, as the default path's brick
+//     kernel does): the 64 lanes of a wave walk segments of equal length.  Where a tuple goes is fixed by the replay order, not by who walks it;
+//   * the counting sort has no barrier at all: wave w owns quarter w of the tuple sequence, the walk has counted every voxel's tuples per quarter
+//     (four 16-bit fields of one LDS word), so a wave's cursor for a voxel starts behind the earlier quarters' tuples and only that wave moves it.
 template <bool TEX>
 __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
 {
@@ -401,52 +411,110 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
     const SeqDev S = SD[q];
     __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: the item's segments: rank 22 | first step 12 | steps 6 | ray 22
     __shared__ uint32_t s_pre[SQ_SORTCAP];                       //  8 KiB: replay position of a sorted segment's first step
-    __shared__ uint32_t s_hist[TSL_BRK3];                        // 16 KiB: tuples per voxel -> run offsets -> run cursors
-    __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, tuples of each of the four waves in the current 256-tuple block (16 bits each)
+    __shared__ uint32_t s_hist[TSL_BRK3];                        // 16 KiB: tuples per voxel -> run offsets
+    __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, its tuples in each quarter of the replay sequence (16 bits each) -> the quarters' cursors
+    __shared__ unsigned short s_perm[SQ_SORTCAP];                //  4 KiB: the sorted segments by length, longest first
+    __shared__ int s_bin[64];
     __shared__ uint32_t s_w[4];
     __shared__ unsigned long long s_rb;
-    const int tid = threadIdx.x, wid = tid >> 6;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     if (F.counters[HDR_FAIL] != 0) return;
     const int nitems = min(F.counters[HDR_SEQ_SLOTS], S.slot_cap);
     const uint32_t* __restrict__ rank_of_ray = F.vals;
+#ifdef TSL_SEQ_TIMING      // developer build: cycles per stage of an item, summed over the launch in dbg[0..7], items / segments / tuples in dbg[8..10]
+    long long _t0 = 0;
+#define SQ_TICK(k) { __syncthreads(); const long long _n = (long long)__builtin_readcyclecounter(); if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[k]), (unsigned long long)(_n - _t0)); _t0 = _n; }
+#else
+#define SQ_TICK(k)
+#endif
     for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int4 item = S.items[it];
+#ifdef TSL_SEQ_TIMING
+        __syncthreads(); _t0 = (long long)__builtin_readcyclecounter();
+#endif
+        const int4 item_v = S.items[it];
+        const int4 item = make_int4(uni_i(item_v.x), uni_i(item_v.y), uni_i(item_v.z), uni_i(item_v.w));      // (the same for every lane: scalar loop control below)
         const int m = item.y;
         const unsigned long long* const src = (item.w ? F.seg : F.seg_sorted) + item.x;
         uint32_t* const csr = S.csr + (size_t)item.z * SQ_CSR_STRIDE;
-        // ---- clear the counters; the segments in (rank, first step) order ----
-        for (int i = tid; i < TSL_BRK3; i += SQ_NT) { s_hist[i] = 0u; s_pack[i] = 0ull; }
-        int P2 = 1; while (P2 < m) P2 <<= 1;
-        for (int k = tid; k < P2; k += SQ_NT) {
-            unsigned long long key = ~0ull;
-            if (k < m) {
-                const unsigned long long sg = src[k];
-                const unsigned long long ray = (sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1);
-                key = ((unsigned long long)rank_of_ray[ray] << 40) | (((sg >> SEG_CNT_BITS) & 0xfffull) << 28) | ((sg & 63ull) << 22) | ray;
+        int P2 = 8; while (P2 < m) P2 <<= 1;
+        // ---- the segments, keyed; the counters cleared under the two memory round trips ----
+        unsigned long long sg[SQ_SORTCAP / SQ_NT];
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) { const int k = r * SQ_NT + tid; sg[r] = k < m ? src[k] : ~0ull; }
+        uint32_t rk[SQ_SORTCAP / SQ_NT];
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r)
+            rk[r] = sg[r] != ~0ull ? rank_of_ray[(sg[r] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1)] : 0u;
+        for (int i = tid; i < TSL_BRK3; i += SQ_NT) s_pack[i] = 0ull;
+        if (tid < 64) s_bin[tid] = 0;
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
+            const int k = r * SQ_NT + tid;
+            if (k < P2) {
+                unsigned long long key = ~0ull;
+                if (k < m) {
+                    const unsigned long long ray = (sg[r] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1);
+                    key = ((unsigned long long)rk[r] << 40) | (((sg[r] >> SEG_CNT_BITS) & 0xfffull) << 28) | ((sg[r] & 63ull) << 22) | ray;
+                }
+                s_seg[k] = key;
             }
-            s_seg[k] = key;
+        }
+        SQ_TICK(0)
+        __syncthreads();
+        // ---- bitonic network over P2 keys.  Wave w owns keys [w * P2 / 4, (w + 1) * P2 / 4) and the P2 / 8 compare-exchanges inside them: a stage
+        //      with distance j <= P2 / 8 never leaves a wave's keys and needs no workgroup barrier ----
+        {
+            const int per = P2 >> 3;                             // compare-exchanges of a wave per stage
+            for (int kk = 2; kk <= P2; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const bool local = j <= per;
+                    if (!local) __syncthreads();
+                    for (int u = lane; u < per; u += 64) {
+                        const int t = wid * per + u;
+                        const int i = 2 * t - (t & (j - 1)), ix = i + j;
+                        const unsigned long long a = s_seg[i], c = s_seg[ix];
+                        const bool up = (i & kk) == 0;
+                        if ((a > c) == up) { s_seg[i] = c; s_seg[ix] = a; }
+                    }
+                    if (!local) __syncthreads();
+                    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+                }
+        }
+        SQ_TICK(1)
+        __syncthreads();
+        // ---- replay positions (prefix of the step counts, sorted order); the segments by length ----
+        int lrank[SQ_SORTCAP / SQ_NT];
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
+            const int k = r * SQ_NT + tid;
+            const uint32_t cnt = k < m ? (uint32_t)((s_seg[k] >> 22) & 63ull) : 0u;
+            s_pre[k] = cnt;
+            lrank[r] = k < m ? atomicAdd(&s_bin[63 - (int)cnt], 1) : -1;
         }
         __syncthreads();
-        for (int kk = 2; kk <= P2; kk <<= 1)
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (P2 >> 1); t += SQ_NT) {
-                    const int i = 2 * t - (t & (j - 1)), ix = i + j;
-                    const unsigned long long a = s_seg[i], c = s_seg[ix];
-                    const bool up = (i & kk) == 0;
-                    if ((a > c) == up) { s_seg[i] = c; s_seg[ix] = a; }
-                }
-                __syncthreads();
-            }
-        for (int k = tid; k < SQ_SORTCAP; k += SQ_NT) s_pre[k] = k < m ? (uint32_t)((s_seg[k] >> 22) & 63ull) : 0u;
-        __syncthreads();
-        const uint32_t T = sq_scan_excl<SQ_SORTCAP / SQ_NT>(s_pre, s_w);           // the item's steps: its part of the frame's tuple arrays
+        if (tid < 64) {
+            const int cb = s_bin[tid]; int inc = cb;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+            s_bin[tid] = inc - cb;
+        }
+        const uint32_t T = (uint32_t)uni_i((int)sq_scan_excl<SQ_SORTCAP / SQ_NT>(s_pre, s_w));      // the item's steps: its part of the frame's tuple arrays (two barriers inside)
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
+            const int k = r * SQ_NT + tid;
+            if (lrank[r] >= 0) s_perm[s_bin[63 - (int)((s_seg[k] >> 22) & 63ull)] + lrank[r]] = (unsigned short)k;
+        }
         if (tid == 0) s_rb = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&F.counters[HDR_SEQ_TUPLES]), (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned long long rb = s_rb;
         if ((long long)(rb + T) > S.cap) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
         unsigned long long* const stash = S.stash + rb;
-        // ---- walk: every step a tuple at its replay position, counted per voxel ----
-        for (int k = tid; k < m; k += SQ_NT) {
+        const uint32_t Q = (((T + 3u) >> 2) + 63u) & ~63u;       // a quarter of the replay sequence, in whole groups of 64 tuples
+        SQ_TICK(2)
+        // ---- walk: every step a tuple at its replay position, counted per voxel and quarter ----
+        for (int r = 0; r * SQ_NT < m; ++r) {
+            const int idx = r * SQ_NT + ((r & 1) ? SQ_NT - 1 - tid : tid);
+            if (idx >= m) continue;
+            const int k = (int)s_perm[idx];
             const unsigned long long sk = s_seg[k];
             const int ray = (int)(sk & 0x3fffffull), cnt = (int)((sk >> 22) & 63ull), j0 = (int)((sk >> 28) & 0xfffull);
             const uint4 rec = F.rayA[ray];
@@ -454,7 +522,7 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
             const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
             const unsigned long long zz = (unsigned long long)seq_w_code(__uint_as_float(rec.w)) << SQ_TUP_Z_SHIFT;
             const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                     // :246
-            const size_t at = (size_t)s_pre[k];
+            const uint32_t at = s_pre[k];
             for (int s = 0; s < cnt; ++s) {
                 const float jf = (float)(j0 + s);
                 const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
@@ -465,51 +533,70 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
                 const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);                      // :259  (2^-96: below it sqrtf rescales)
                 const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
                 const float sd = dist * (float)sgn_f(dot);                                                              // :260
-                stash[at + s] = zz | ((unsigned long long)l << SQ_TUP_L_SHIFT) | (unsigned long long)__float_as_uint(sd);
-                if (TEX) S.stash_ray[rb + at + s] = (uint32_t)ray;
-                atomicAdd(&s_hist[l], 1u);
+                const uint32_t pos = at + (uint32_t)s;
+                stash[pos] = zz | ((unsigned long long)l << SQ_TUP_L_SHIFT) | (unsigned long long)__float_as_uint(sd);
+                if (TEX) S.stash_ray[rb + pos] = (uint32_t)ray;
+                const uint32_t qtr = (pos >= Q ? 1u : 0u) + (pos >= 2u * Q ? 1u : 0u) + (pos >= 3u * Q ? 1u : 0u);
+                atomicAdd(&s_pack[l], 1ull << (16u * qtr));
             }
         }
+        SQ_TICK(3)
         __syncthreads();
-        // ---- run offsets of the brick's voxels for this item ----
+        // ---- run offsets of the brick's voxels for this item; a voxel's four counts become the quarters' first positions inside its run ----
+        for (int i = tid; i < TSL_BRK3; i += SQ_NT) {
+            const unsigned long long v = s_pack[i];
+            const uint32_t c0 = (uint32_t)(v & 0xffffull), c1 = (uint32_t)((v >> 16) & 0xffffull), c2 = (uint32_t)((v >> 32) & 0xffffull), c3 = (uint32_t)(v >> 48);
+            s_hist[i] = c0 + c1 + c2 + c3;
+            s_pack[i] = ((unsigned long long)c0 << 16) | ((unsigned long long)(c0 + c1) << 32) | ((unsigned long long)(c0 + c1 + c2) << 48);
+        }
+        __syncthreads();
         (void)sq_scan_excl<TSL_BRK3 / SQ_NT>(s_hist, s_w);
         for (int i = tid; i < TSL_BRK3; i += SQ_NT) csr[i] = s_hist[i];
-        if (tid == 0) { csr[TSL_BRK3] = T; csr[SQ_CSR_BASE] = (uint32_t)rb; csr[SQ_CSR_UNSAFE] = 0u; }
-        // ---- stable counting sort by voxel: blocks of 256 tuples in replay order ----
+        if (tid == 0) { csr[TSL_BRK3] = T; csr[SQ_CSR_BASE] = (uint32_t)rb; }
+        SQ_TICK(4)
+        // ---- stable counting sort by voxel: wave w takes quarter w of the sequence, 64 tuples at a time, in replay order.  Tuples of one voxel
+        //      inside a group of 64 find each other with twelve ballots; the voxel's cursor for this quarter is moved by the first of them ----
         float4* const tup = S.tup + rb;
         bool unsafe = false;
-        for (uint32_t t0 = 0u; t0 < T; t0 += SQ_NT) {
-            const uint32_t t = t0 + (uint32_t)tid;
-            const bool valid = t < T;
-            const unsigned long long x = valid ? stash[t] : 0ull;
-            const int l = (int)((x >> SQ_TUP_L_SHIFT) & 4095ull);
-            unsigned long long mk = __ballot(valid);
+        {
+            const uint32_t e = min(T, (uint32_t)(wid + 1) * Q);
+            uint32_t t = (uint32_t)wid * Q + (uint32_t)lane;
+            unsigned long long xn = t < e ? stash[t] : 0ull;
+            for (uint32_t g0 = (uint32_t)wid * Q; g0 < e; g0 += 64u, t += 64u) {
+                const unsigned long long x = xn;
+                const bool valid = t < e;
+                xn = t + 64u < e ? stash[t + 64u] : 0ull;                       // the next group's tuples are under way while this one is placed
+                __builtin_amdgcn_sched_barrier(0);
+                const int l = (int)((x >> SQ_TUP_L_SHIFT) & 4095ull);
+                const unsigned long long vm = __ballot(valid);
+                uint32_t mlo = (uint32_t)vm, mhi = (uint32_t)(vm >> 32);
 #pragma unroll
-            for (int bit = 0; bit < 12; ++bit) { const bool on = (l >> bit) & 1; const unsigned long long bm = __ballot(on); mk &= on ? bm : ~bm; }
-            const int my = rank_below(mk), gs = popc64(mk);                       // tuples of my voxel before me in this wave / in this wave
-            if (valid && my == 0) atomicAdd(&s_pack[l], (unsigned long long)gs << (16 * wid));
-            __syncthreads();
-            bool lastw = false; uint32_t tot = 0u;
-            if (valid) {
-                const unsigned long long v = s_pack[l];
-                const uint32_t f0 = (uint32_t)(v & 0xffffull), f1 = (uint32_t)((v >> 16) & 0xffffull), f2 = (uint32_t)((v >> 32) & 0xffffull), f3 = (uint32_t)(v >> 48);
-                const uint32_t before = (wid > 0 ? f0 : 0u) + (wid > 1 ? f1 : 0u) + (wid > 2 ? f2 : 0u);
-                tot = f0 + f1 + f2 + f3;
-                lastw = (wid == 3) || (wid == 2 ? f3 == 0u : (wid == 1 ? (f2 | f3) == 0u : (f1 | f2 | f3) == 0u));      // no later wave holds this voxel
-                // the replay tuple: everything an update needs that does not depend on the voxel -- w, c = w * sd (:264), 1 / (Wmax + w), Wmax + w
-                const float sd = __uint_as_float((uint32_t)x), w = seq_w_of((h16)(x >> SQ_TUP_Z_SHIFT)), c = w * sd;
-                const float D = TSL_WMAX + w;
-                const uint32_t pos = s_hist[l] + before + (uint32_t)my;
-                tup[pos] = make_float4(w, c, 1.0f / D, D);
-                if (TEX) S.tup_ray[rb + pos] = S.stash_ray[rb + t];
-                unsafe = unsafe || !(fabsf(sd) <= 60.0f) || (c != 0.0f && fabsf(c) < 8.67e-19f);      // 2^-60: the residuals of the division-free quotient stay representable
+                for (int bit = 0; bit < 12; ++bit) {                              // lanes whose bit equals mine stay: m &= ~(ballot ^ (mine ? ~0 : 0))
+                    const uint32_t mine = (uint32_t)((int)((uint32_t)l << (31 - bit)) >> 31);
+                    const unsigned long long bm = __ballot(mine != 0u);
+                    mlo &= ~((uint32_t)bm ^ mine); mhi &= ~((uint32_t)(bm >> 32) ^ mine);
+                }
+                const unsigned long long mk = ((unsigned long long)mhi << 32) | mlo;
+                const int my = rank_below(mk), gs = popc64(mk);                   // tuples of my voxel before me in this group / in this group
+                if (valid) {
+                    const uint32_t cur = (uint32_t)(s_pack[l] >> (16 * wid)) & 0xffffu;
+                    if (my == 0) atomicAdd(&s_pack[l], (unsigned long long)gs << (16 * wid));      // (behind the read: LDS operations of a wave complete in order)
+                    // the replay tuple: everything an update needs that does not depend on the voxel -- w, c = w * sd (:264), 1 / (Wmax + w), Wmax + w
+                    const float sd = __uint_as_float((uint32_t)x), w = seq_w_of((h16)(x >> SQ_TUP_Z_SHIFT)), c = w * sd;
+                    const float D = TSL_WMAX + w;
+                    const uint32_t pos = s_hist[l] + cur + (uint32_t)my;
+                    tup[pos] = make_float4(w, c, 1.0f / D, D);
+                    if (TEX) S.tup_ray[rb + pos] = S.stash_ray[rb + t];
+                    unsafe = unsafe || !(fabsf(sd) <= 60.0f) || (c != 0.0f && fabsf(c) < 8.67e-19f);      // 2^-60: the residuals of the division-free quotient stay representable
+                }
             }
-            __syncthreads();
-            if (valid && my == 0 && lastw) { s_hist[l] += tot; s_pack[l] = 0ull; }
-            __syncthreads();
         }
-        if (unsafe) csr[SQ_CSR_UNSAFE] = 1u;          // (cleared with the offsets above; whoever saw an odd tuple sets it)
-        __syncthreads();
+        SQ_TICK(5)
+#ifdef TSL_SEQ_TIMING
+        if (tid == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[8]), 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[9]), (unsigned long long)m); atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[10]), (unsigned long long)T); }
+#endif
+        const int any_unsafe = __syncthreads_or(unsafe ? 1 : 0);                  // (also: every wave is done with the LDS arrays before the next item clears them)
+        if (tid == 0) csr[SQ_CSR_UNSAFE] = any_unsafe ? 1u : 0u;
     }
 }
 
