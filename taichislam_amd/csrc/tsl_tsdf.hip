@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_voxelize_depth(BatchDev B)
     unsigned long long vkey = 0ull;
     if (jj < P.hh && ii < P.ww) {
         const int j = jj * P.step, i = ii * P.step;
-        const uint16_t d = depth[(size_t)jj * P.rstride + i];
+        const uint16_t d = depth[(size_t)jj * P.rstride + (size_t)ii * P.cstride];
         K key = KeyOps<K>::invalid(P.pcl_bits);
         uint2 payload = make_uint2(0u, 0u);
         const float df = (float)d;
@@ -678,10 +678,21 @@ static int reserve_slot(tsl_tsdf* m, int points, int* set_index)
 // once.  No copy call, no event, no stream synchronisation (round 3 staged through hipMemcpy2DAsync + a stream sync per call: 12.7 k frames/s
 // from pageable images; an asynchronous copy from the pinned buffer still cost 50-75 us of HOST time per call inside the runtime).  The
 // buffer is written again when the set comes round, three batches later: the host first makes sure phase A of the set's previous batch is done.
-// `in`: `rows` rows of `row_bytes` bytes, `src_pitch` bytes apart (rows == 1: one contiguous block); they are stored back to back
-static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int rows, size_t src_pitch, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev)
+// `in`: `rows` rows of `row_bytes` bytes, `src_pitch` bytes apart (rows == 1: one contiguous block); they are stored back to back.
+// pick > 1 (depth images): a row is uint16 pixels and only every pick-th of them is visited (dense_tsdf.py:194-195): the row is stored as
+// row_bytes / 2 / pick pixels -- a quarter of a 640 x 480 image at recast_step 2, 154 kB, is all that crosses the link.
+template <int PICK>
+static void pick_pixels(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src, int n, int pick)
 {
-    const size_t in_bytes = row_bytes * (size_t)rows;
+    if (PICK) { for (int i = 0; i < n; ++i) dst[i] = src[(size_t)i * PICK]; }
+    else for (int i = 0; i < n; ++i) dst[i] = src[(size_t)i * pick];
+}
+static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int rows, size_t src_pitch, const void* tex, size_t tex_bytes, void** in_dev, void** tex_dev,
+                      int pick = 1)
+{
+    const int npick = pick > 1 ? (int)(row_bytes / sizeof(uint16_t)) / pick : 0;
+    const size_t out_row = pick > 1 ? (size_t)npick * sizeof(uint16_t) : row_bytes;
+    const size_t in_bytes = out_row * (size_t)rows;
     FSet& S = m->fset[si];
     BatchHost& H = m->batch[si / TSL_NB];
     if (m->overlap == 0) TSL_HIP(hipStreamSynchronize(m->stream_));          // one frame at a time on the main stream: nothing else orders the set's previous reader
@@ -696,7 +707,13 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int
         TSL_HIP(hipHostGetDevicePointer(&S.pin_dev, S.pin, 0));
     }
     char* pin = static_cast<char*>(S.pin);
-    if (in_bytes) {
+    if (in_bytes && pick > 1) {
+        for (int r = 0; r < rows; ++r) {
+            uint16_t* d = reinterpret_cast<uint16_t*>(pin + (size_t)r * out_row);
+            const uint16_t* sp = reinterpret_cast<const uint16_t*>(static_cast<const char*>(in) + (size_t)r * src_pitch);
+            if (pick == 2) pick_pixels<2>(d, sp, npick, 2); else if (pick == 4) pick_pixels<4>(d, sp, npick, 4); else pick_pixels<0>(d, sp, npick, pick);
+        }
+    } else if (in_bytes) {
         if (rows > 1 && src_pitch != row_bytes) { for (int r = 0; r < rows; ++r) std::memcpy(pin + (size_t)r * row_bytes, static_cast<const char*>(in) + (size_t)r * src_pitch, row_bytes); }
         else std::memcpy(pin, in, in_bytes);
     }
@@ -1202,10 +1219,10 @@ int tsl_tsdf_set_colormap(tsl_tsdf* m, const float* rgb)
     return TSL_OK;
 }
 
-// rstride: elements between two VISITED rows of the buffer -- recast_step * w for a caller's full image, w for a staged host image that holds
-// the visited rows only (a parameter, not a flag on the handle: a call that fails half way cannot leave it behind for the next one -- ADVICE r3)
+// packed: the buffer is a staged host image that holds the visited pixels only, ww = w / recast_step per visited row (a parameter, not a flag
+// on the handle: a call that fails half way cannot leave it behind for the next one -- ADVICE r3); otherwise the caller's full image
 static int integrate_depth_dev_impl(tsl_tsdf* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
-                                    const void* tex_dev, int th, int tw, bool rows_only)
+                                    const void* tex_dev, int th, int tw, bool packed)
 {
     TSL_REQUIRE(m && R && T && depth_dev, "integrate_depth: null argument");
     TSL_REQUIRE(h > 0 && w > 0, "integrate_depth: bad image size");
@@ -1216,7 +1233,8 @@ static int integrate_depth_dev_impl(tsl_tsdf* m, const double R[9], const double
     FrameParams& P = m->P;
     P.H = h; P.W = w;
     P.hh = (int)((float)h / (float)P.step); P.ww = (int)((float)w / (float)P.step);           // dense_tsdf.py:192,194
-    P.rstride = rows_only ? w : P.step * w;
+    P.rstride = packed ? w / P.step : P.step * w;
+    P.cstride = packed ? 1 : P.step;
     P.th = th; P.tw = tw; P.tex = (m->cfg.texture_enabled && tex_dev) ? 1 : 0; P.tex_input = (const uint8_t*)tex_dev;
     TSL_REQUIRE(!P.tex || (th > 0 && tw > 0 && (!P.same_proj || (th >= h && tw >= w))), "integrate_depth: texture smaller than the depth image");
     m->h_stats->p_used = (int64_t)P.hh * P.ww;
@@ -1234,10 +1252,11 @@ int tsl_tsdf_integrate_depth(tsl_tsdf* m, const double R[9], const double T[3], 
     int si = 0; int rc = reserve_slot(m, 0, &si); if (rc) return rc;
     const bool use_tex = tex && m->cfg.texture_enabled && th > 0 && tw > 0;
     void *ddev = nullptr, *tdev = nullptr;
-    // only the rows the kernel visits (every recast_step-th, dense_tsdf.py:192-195) cross the bus: half of a 640x480 image at recast_step 2
+    // only the pixels the kernel visits (every recast_step-th of every recast_step-th row, dense_tsdf.py:192-195) cross the bus: a quarter of a
+    // 640x480 image at recast_step 2
     const int step = m->P.step, hh = (int)((float)h / (float)step);
     rc = stage_host(m, si, depth, (size_t)w * sizeof(uint16_t), step > 1 ? hh : h, (size_t)(step > 1 ? step : 1) * w * sizeof(uint16_t),
-                    use_tex ? tex : nullptr, use_tex ? (size_t)th * tw * 3 : 0, &ddev, &tdev); if (rc) return rc;
+                    use_tex ? tex : nullptr, use_tex ? (size_t)th * tw * 3 : 0, &ddev, &tdev, step); if (rc) return rc;
     return integrate_depth_dev_impl(m, R, T, ddev, h, w, tdev, th, tw, step > 1);
 }
 

@@ -17,7 +17,8 @@ struct FrameParams {
     float internal_f;                  // internal_voxels
     int   pcl_lo, pcl_ext, pcl_bits;   // sensor-centred grid: index range [lo, lo+ext), bits per axis
     int   step, hh, ww, H, W;          // recast_step, visited rows/cols, image size
-    int   rstride;                     // elements between two VISITED rows of the depth buffer: step * W for the caller's image, W for a staged host image (only its visited rows are copied)
+    int   rstride;                     // elements between two VISITED rows of the depth buffer: step * W for the caller's image, W / step for a staged host image (only its visited pixels are copied)
+    int   cstride;                     // ... and between two visited pixels of a row: step, or 1 for a staged host image
     int   th, tw, tex, same_proj;
     int   slot;                        // map-side submap slot written by this frame
     int   variant, split;              // integrate kernel variant / lanes per ray
