@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes(MapDev M, int nused, int
 #define MC_T3 (MC_T * MC_T * MC_T)
 __device__ __forceinline__ int mc_tile(int x, int y, int z) { return (x * MC_T + y) * MC_T + z; }      // tile coords = brick coords + 1
 
+#define MC_SLAB 2         // x-layers of a brick per work item of k_marching_cubes_lds
 #define MC_LIST 4096             // triangles listed in LDS at a time
 // the cell at brick-local index l: its case (through *cube when asked for) and how many triangles the case has; 0 when the cell's own
 // voxel is unobserved or not below the threshold (:184), or a corner is unobserved (:133-138)
@@ -167,9 +168,35 @@ __device__ __forceinline__ int mc_cell(const uint16_t* s_t, const uint32_t* s_o,
     return n;
 }
 
-__global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused, float thres, float vs, long long max_tri,
-                                                            float* __restrict__ verts, float* __restrict__ normals, float* __restrict__ colors, int* counter)
+// Which bricks can hold a triangle at all: a cell emits one only if its eight corners are not all on one side of zero (the case table is empty
+// for 0 and 255, :141-177).  One coalesced pass over the stored values notes per brick whether it holds a value < 0 and whether it holds one that
+// is not (a voxel nobody wrote reads 0, as in the reference); k_marching_cubes_lds then skips a brick -- before it gathers the 19^3 tile from 27
+// bricks -- when it and the seven bricks its cells' corners reach into are all on one side.  In a map of a closed surface most bricks are.
+__global__ void __launch_bounds__(256) k_mc_summary(MapDev M, int nused, uint32_t* __restrict__ flags, int* counter)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;                  // :182 (the triangle counter of the mesh that follows)
+    if (nused < 0) nused = min(M.pool_top[0], M.max_bricks);                // (the bricks in use, read here: the host does not wait for the count)
+    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+        const uint4* tw = reinterpret_cast<const uint4*>(M.tw + (size_t)p * TSL_BRK3);
+        uint32_t f = 0u;
+#pragma unroll
+        for (int q = 0; q < TSL_BRK3 / 4 / 256; ++q) {
+            const uint4 v = tw[q * 256 + threadIdx.x];
+            const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f |= h2f((h16)(w4[u] & 0xffffu)) < 0.0f ? 1u : 2u;
+        }
+        const int neg = __syncthreads_or((int)(f & 1u)), nn = __syncthreads_or((int)(f & 2u));
+        if (threadIdx.x == 0) flags[p] = (neg ? 1u : 0u) | (nn ? 2u : 0u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused, float thres, float vs, long long max_tri,
+                                                            float* __restrict__ verts, float* __restrict__ normals, float* __restrict__ colors, int* counter,
+                                                            const uint32_t* __restrict__ flags)
+{
+    __shared__ int s_skip;
+    if (nused < 0) nused = min(M.pool_top[0], M.max_bricks);
     __shared__ unsigned long long s_tri[256];
     __shared__ uint32_t s_list[MC_LIST];
     __shared__ uint16_t s_t[MC_T3];                    // TSDF f16 bits (0 where nothing is stored: reading an inactive cell yields 0, A7)
@@ -177,24 +204,42 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
     __shared__ int s_nb[27];
     __shared__ int s_wtot[5], s_base;
     s_tri[threadIdx.x] = MC_TRI_PACKED[threadIdx.x];
-    for (int p = blockIdx.x; p < nused; p += gridDim.x) {
+    // a work item is a SLAB of a brick, MC_SLAB of its 16 x-layers: the surface crosses few bricks -- 56 of the 442 of a 128^3 sphere -- and a brick
+    // per workgroup left three quarters of the CUs idle while those few walked their cells and emitted their vertices (one wave per SIMD: every
+    // dependent instruction at its full latency)
+    for (int item = blockIdx.x; item < nused * (16 / MC_SLAB); item += gridDim.x) {
+        const int p = item / (16 / MC_SLAB), x0 = (item % (16 / MC_SLAB)) * MC_SLAB;
         const int owner = M.owner[p];
         const int s = owner / M.nb3, b = owner - s * M.nb3;
         const int bk = b % M.nbz, bj = (b / M.nbz) % M.nbx, bi = b / (M.nbz * M.nbx);
-        __syncthreads();                                                     // the previous brick's tile is no longer read
-        if (threadIdx.x < 27) {
-            const int i = bi + (int)threadIdx.x / 9 - 1, j = bj + ((int)threadIdx.x / 3) % 3 - 1, k = bk + (int)threadIdx.x % 3 - 1;
-            s_nb[threadIdx.x] = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+        __syncthreads();                                                     // the previous item's tile is no longer read
+        if (threadIdx.x < 64) {                                               // (the first wave)
+            int np = -1; bool corner = false;
+            if (threadIdx.x < 27) {
+                const int di = (int)threadIdx.x / 9 - 1, dj = ((int)threadIdx.x / 3) % 3 - 1, dk = (int)threadIdx.x % 3 - 1;
+                const int i = bi + di, j = bj + dj, k = bk + dk;
+                np = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+                s_nb[threadIdx.x] = np;
+                corner = di >= 0 && dj >= 0 && dk >= 0;                         // the eight bricks the corners of this brick's cells lie in
+            }
+            const uint32_t f = corner ? (np >= 0 ? flags[np] : 2u) : 0u;        // (no brick: the corners read 0)
+            const bool neg = __ballot((f & 1u) != 0u) != 0ull, nn = __ballot((f & 2u) != 0u) != 0ull;
+            if (threadIdx.x == 0) s_skip = (neg && nn) ? 0 : 1;
         }
         for (int i = threadIdx.x; i < (MC_T3 + 31) / 32; i += 256) s_o[i] = 0u;
         __syncthreads();
-        // the 6 859 tile entries, 27 per thread, gathered nine at a time as ONE batch of independent loads (loaded from a valid address
-        // unconditionally so that nothing separates the requests: a loop of dependent gathers costs a memory latency per entry)
-        for (int c = 0; c < 27; c += 9) {
-            uint32_t tw[9]; int8_t ob[9]; bool ok[9];
+        if (s_skip) continue;                                                // (uniform) every corner of every cell on one side of zero: no triangle
+        // the tile entries of the slab's cells, their corners and the normals' neighbours -- x-layers x0 .. x0 + MC_SLAB + 2 of the 19^3 tile --
+        // gathered MC_GB at a time as ONE batch of independent loads (loaded from a valid address unconditionally so that nothing separates
+        // the requests: a loop of dependent gathers costs a memory latency per entry)
+        constexpr int NT = (MC_SLAB + 3) * MC_T * MC_T, PER = (NT + 255) / 256, MC_GB = (PER + 1) / 2;
+        for (int c = 0; c < PER; c += MC_GB) {
+            uint32_t tw[MC_GB]; int8_t ob[MC_GB]; bool ok[MC_GB]; int tt[MC_GB];
 #pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                const int t = (int)threadIdx.x + (c + u) * 256;
+            for (int u = 0; u < MC_GB; ++u) {
+                const int tl = (int)threadIdx.x + (c + u) * 256;
+                const int t = tl < NT && c + u < PER ? x0 * MC_T * MC_T + tl : MC_T3;
+                tt[u] = t;
                 const int tc = t < MC_T3 ? t : 0;
                 const int tz = tc % MC_T, ty = (tc / MC_T) % MC_T, tx = tc / (MC_T * MC_T);
                 const int np = s_nb[(((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4)];
@@ -203,8 +248,8 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
                 tw[u] = M.tw[v]; ob[u] = M.obs[v];
             }
 #pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                const int t = (int)threadIdx.x + (c + u) * 256;
+            for (int u = 0; u < MC_GB; ++u) {
+                const int t = tt[u];
                 if (t >= MC_T3) continue;
                 s_t[t] = ok[u] ? (uint16_t)(tw[u] & 0xffffu) : (uint16_t)0;
                 if (ok[u] && ob[u] > 0) atomicOr(&s_o[t >> 5], 1u << (t & 31));
@@ -214,7 +259,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
         // ---- pass 1: the brick's triangle count.  ONE reservation per brick (a reservation per wave and 256 cells -- the first form of
         //      this kernel -- put ~2 000 returning atomics on one address per mesh, ~12 ns each in the L2) ----
         int mine = 0;
-        for (int l0 = 0; l0 < TSL_BRK3; l0 += 256) mine += mc_cell(s_t, s_o, s_tri, l0 + threadIdx.x, thres, nullptr);
+        for (int l0 = x0 << 8; l0 < (x0 + MC_SLAB) << 8; l0 += 256) mine += mc_cell(s_t, s_o, s_tri, l0 + threadIdx.x, thres, nullptr);
         int incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane_id() >= d) incl += o; }
         if (lane_id() == 63) s_wtot[threadIdx.x >> 6] = incl;
@@ -236,7 +281,7 @@ __global__ void __launch_bounds__(256) k_marching_cubes_lds(MapDev M, int nused,
         for (int w0 = 0; w0 < total; w0 += MC_LIST) {                     // (one window unless the brick is noise: MC_LIST triangles at a time)
             if (w0) __syncthreads();
             int at = first;
-            for (int l0 = 0; l0 < TSL_BRK3 && mine; l0 += 256) {
+            for (int l0 = x0 << 8; l0 < ((x0 + MC_SLAB) << 8) && mine; l0 += 256) {
                 const int l = l0 + threadIdx.x;
                 int cube = 0;
                 const int n = mc_cell(s_t, s_o, s_tri, l, thres, &cube);
@@ -311,12 +356,19 @@ int tsl_mesh_generate(tsl_tsdf* m, int step, float surface_thres, int64_t max_tr
         m->mesh_cap = max_tri;
     }
     if (!m->mesh_count) { if ((rc = dev_alloc(m, (void**)&m->mesh_count, sizeof(int) * 4, 0))) return rc; }
-    int nused = 0; if ((rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;
-    TSL_HIP(hipMemsetAsync(m->mesh_count, 0, sizeof(int), ms(m)));                          // :182
+    const bool tiles = step == 1 && !m->mesh_gather;     // the LDS-tile kernel: it reads the number of bricks in use on the device (one host round trip per mesh less)
+    int nused = 0; if (!tiles && (rc = tsl_tsdf_bricks_in_use(m, &nused))) return rc;
+    if (!m->mesh_flags) { if ((rc = dev_alloc(m, (void**)&m->mesh_flags, sizeof(uint32_t) * (size_t)m->M.max_bricks, 0))) return rc; }
+    (void)ms(m);                                         // the queued frames are issued first: the mesh is of the map behind them
     prof_begin(m, TSL_K_MESH);
-    if (nused > 0 && step == 1 && !m->mesh_gather)
-        hipLaunchKernelGGL(k_marching_cubes_lds, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, ms(m), m->M, nused,
-                           surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);
+    if (!tiles) TSL_HIP(hipMemsetAsync(m->mesh_count, 0, sizeof(int), ms(m)));                          // :182
+    if (tiles) {
+        const int g1 = m->M.max_bricks < 2048 ? m->M.max_bricks : 2048, g2 = m->M.max_bricks < 1024 ? m->M.max_bricks * (16 / MC_SLAB) : 8192;
+        hipLaunchKernelGGL(k_mc_summary, dim3(g1), dim3(256), 0, ms(m), m->M, -1, m->mesh_flags, m->mesh_count);
+        hipLaunchKernelGGL(k_marching_cubes_lds, dim3(g2), dim3(256), 0, ms(m), m->M, -1,
+                           surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count,
+                           (const uint32_t*)m->mesh_flags);
+    }
     else if (nused > 0)             // coarser meshes (step > 1) reach beyond the brick's halo: every value through the brick table
         hipLaunchKernelGGL(k_marching_cubes, dim3(nused < 16384 ? nused : 16384), dim3(256), 0, ms(m), m->M, nused, step,
                            surface_thres, m->P.vs, (long long)max_tri, m->mesh_v, m->mesh_n, m->M.col ? m->mesh_c : (float*)nullptr, m->mesh_count);

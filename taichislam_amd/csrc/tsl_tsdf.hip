@@ -954,7 +954,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->active = 0; m->variant = 2; m->split = 2; m->semantics = 0; m->seq_impl = 1; m->seq_ready = false; m->seq_d = nullptr; m->seq_tuple_cap = 0;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
-    m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0;
+    m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0; m->mesh_flags = nullptr;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
     m->esdf = nullptr; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_gate_mask = 0; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
@@ -1066,7 +1066,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     seq_release(m);
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
-                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_nbr, m->esdf_note, m->fseq_keys[0], m->fseq_keys[1], m->fseq_vals[0], m->fseq_vals[1], m->fseq_temp, m->fseq_ctr, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
+                     m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->mesh_flags, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_nbr, m->esdf_note, m->fseq_keys[0], m->fseq_keys[1], m->fseq_vals[0], m->fseq_vals[1], m->fseq_temp, m->fseq_ctr, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
                      m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);

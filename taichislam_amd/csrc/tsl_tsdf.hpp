@@ -253,6 +253,7 @@ struct tsl_tsdf {
     // sparse export staging
     void* xbuf; size_t xbuf_bytes;
     // mesh buffers (mesh_vertices / mesh_normals / mesh_colors, num_facelets)  marching_cube_mesher.py:16-22
+    uint32_t* mesh_flags;                        // per pool brick: bit 0 a stored TSDF value < 0, bit 1 one that is not (k_mc_summary)
     float *mesh_v, *mesh_n, *mesh_c; int* mesh_count; int64_t mesh_cap; int mesh_gather;      // mesh_gather: option, 1 = global-gather kernel also for step 1 (A/B)
     void *fuse_acc, *fuse_cnt, *fuse_cacc; bool fuse_dirty;      // global-map fusion scratch ({num,den} int64 pairs, count|occupancy, colour sums); dirty: a splat was not followed by its finalise / pack
     uint8_t* mrg_mask; int *mrg_list, *mrg_count; int mrg_nunion;      // multi-GPU merge: touched-brick mask, union list (tsl_merge.hip)
