@@ -256,10 +256,10 @@ __device__ __forceinline__ uint32_t seq_update_fast(uint32_t T, uint32_t W, floa
 }
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: keep it in an SGPR
 #define SQ_W_SAT 0x63d0u          // 1000 as f16 bits
-#define SQ_LONG 64                // a voxel with a run of at least this many updates in some frame of the batch gets a wave of its own (k_seq_replay_long)
+#define SQ_LONG 64                // a voxel with a run of at least this many updates in some frame of the batch gets a wave of its own (the long role of k_seq_replay)
 #define SQ_XLONG 1024             // ... and with one of at least this many it is listed in front of the others: the longest chains start first
 #define SQ_XLONG_CAP 4096
-#define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to k_seq_replay_long (beyond: they stay with their lane); the first SQ_XLONG_CAP entries are the longest
+#define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to the long role of k_seq_replay (beyond: they stay with their lane); the first SQ_XLONG_CAP entries are the longest
 
 // exclusive prefix sums of a[0, C * SQ_NT) in LDS, in place; returns the total.  Every thread of the workgroup calls it with the data in
 // place and visible (a barrier before); two barriers inside, the result is visible on return.
@@ -628,7 +628,7 @@ __device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint
 // phase B: one thread per voxel of every brick the batch integrates into (k_plan's unit tables with every brick a unit: brick id, pool index,
 // frames of the batch with segments in it); sixteen 256-voxel slices per brick.  A voxel whose longest frame of the batch has fewer than SQ_LONG
 // updates is replayed by its lane, frame after frame, slot after slot of the (frame, brick); the others -- a few thousand voxels around the
-// sensor, among them the one every ray of a frame passes through -- are only LISTED here and replayed by k_seq_replay_long, a wave each.
+// sensor, among them the one every ray of a frame passes through -- are only LISTED here and replayed by the long role of k_seq_replay, a wave each.
 // The frames' distinct-voxel statistics (voxels with a run) are counted here, for every voxel.
 __global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* __restrict__ SD, int4* __restrict__ long_list, unsigned long long* __restrict__ lmask)
 {
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* 
         SQ_ALL_FRAMES(load_frame)
         SQ_ALL_FRAMES(length_of_frame)
         {   // hand the long ones over (one reservation per wave); a voxel that does not fit the list stays here.  The longest chains -- they set the length of
-            // the whole replay -- go to a list of their own that k_seq_replay_long walks first.
+            // the whole replay -- go to a list of their own that the long role of k_seq_replay walks first.
             const unsigned long long xm = __ballot(is_xlong);
             if (xm) {
                 int base = 0;
@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(256) k_seq_classify(BatchDev B, const SeqDev* 
                 if (plain) { if (pos < SQ_LONG_CAP) long_list[pos] = make_int4(pool, b, l, (int)tm); else is_long = false; }
             }
         }
-        {   // which lanes of this wave k_seq_replay_long takes: the replay kernel's short-run role reads the word instead of measuring again
+        {   // which lanes of this wave the long role of k_seq_replay takes: the replay kernel's short-run role reads the word instead of measuring again
             const unsigned long long lm = __ballot(is_long);
             if (lane_id() == 0) lmask[(size_t)item * 4 + (threadIdx.x >> 6)] = lm;
         }
@@ -790,7 +790,7 @@ __device__ __forceinline__ void seq_role_short(const MapDev& M, const BatchDev& 
         static_assert(TSL_NB == 8, "eight frames per batch");
         SQ_ALL_FRAMES(load_frame)
         SQ_ALL_FRAMES(length_of_frame)
-        const bool is_long = (lmask[(size_t)item * 4 + (threadIdx.x >> 6)] >> (threadIdx.x & 63)) & 1ull;      // k_seq_classify's verdict: k_seq_replay_long's role takes it
+        const bool is_long = (lmask[(size_t)item * 4 + (threadIdx.x >> 6)] >> (threadIdx.x & 63)) & 1ull;      // k_seq_classify's verdict: the long role takes it
         if (is_long || has == 0u) continue;
         const size_t v = (size_t)pool * TSL_BRK3 + (size_t)l;
         const uint32_t old = M.tw[v];

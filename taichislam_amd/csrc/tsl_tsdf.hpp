@@ -88,7 +88,7 @@ struct FrameDev {
 #define HDR_UNITS 20           //   batch: [20..23] units per class
 #define HDR_CLAIM2 24          //   batch: next rank to claim of the parts-only launch (split launches)
 #define HDR_SEQ_TUPLES 26      //   [26..27] sequential semantics: ray-step tuples reserved in the frame's tuple arrays (one 64-bit counter)
-#define HDR_SEQ_LONG 28        //   batch: sequential semantics: voxels listed for k_seq_replay_long
+#define HDR_SEQ_LONG 28        //   batch: sequential semantics: voxels listed for the long role of k_seq_replay
 #define HDR_SEQ_XLONG 30       //   batch: ... of those, the ones with the longest chains (walked first)
 #define HDR_SEQ_MAXRUN 31      //   sequential semantics: the longest run of a voxel in this frame (updates)
 #define HDR_SEQ_SLOTS 29       //   sequential semantics: slots (= k_seq_group work items) of the frame
