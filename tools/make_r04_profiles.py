@@ -30,7 +30,7 @@ ib = [k for k in sec["fetch"]["k"] if "k_integrate_batch" in k][0]
 lib_hash = open(os.path.join(S, "lib_source_hash.txt")).read().strip() if os.path.exists(os.path.join(S, "lib_source_hash.txt")) else None
 out = {"lib_source_hash": lib_hash, "_source": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only) over the benched configuration, averages per launch, MI355X; "
                   "tools/gpu_profiles_r03.sh, raw output profiles/r04_pmc_summary.txt.  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the x2 on FETCH_SIZE is the "
-                  "gfx950 correction of MI355X_MICROARCH.md (exact for wide coalesced reads, an upper estimate for the 4-16 B gathers here).",
+                  "gfx950 correction of MI355X_MICROARCH.md; profiles/r04_fetch_calibration.txt (tools/ubench/fetch_calib.hip) shows it holds for 1- and 4-byte gathers too: the counter is 64 B per distinct 128-byte line, and the lines move whole.",
        "command": sec["fetch"]["command"].replace("FETCH_SIZE", "<CTR>")}
 t = hbm("fetch", "write", ib)
 launches = t["launches"]
@@ -65,6 +65,12 @@ for c, short in ((1, "k_marching_cubes_lds"), (3, "k_octo_depth"), (4, "k_esdf_r
     k = [x for x in sec[f"fetch_c{c}"]["k"] if short in x]
     if k:
         e = hbm(f"fetch_c{c}", f"write_c{c}", k[0])
+        if c == 1:      # one mesh = the brick sign summary + the tile kernel
+            ks = [x for x in sec["fetch_c1"]["k"] if "k_mc_summary" in x]
+            if ks:
+                e2 = hbm("fetch_c1", "write_c1", ks[0])
+                e["kernels"] = {"k_marching_cubes_lds": e["hbm_bytes_per_launch"], "k_mc_summary": e2["hbm_bytes_per_launch"]}
+                e["hbm_bytes_per_launch"] += e2["hbm_bytes_per_launch"]; e["note"] = "per mesh: k_mc_summary + k_marching_cubes_lds"
         if c == 4:      # one ESDF update = all round launches of the update: the bench line's unit
             upd = sec["fetch_c4"]["k"][[x for x in sec["fetch_c4"]["k"] if "k_esdf_collect" in x][0]]["FETCH_SIZE"][1]
             e["launches_per_update"] = e["launches"] / upd
