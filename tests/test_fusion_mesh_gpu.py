@@ -74,6 +74,50 @@ def test_marching_cubes_sphere_config1(hip_lib):
     assert np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 2e-3
 
 
+def _mesh_pair(g, o, thres=0.1, cap=400000):
+    from taichislam_amd.mapping import MarchingCubeMesher
+    mesher = MarchingCubeMesher(g, cap, tsdf_surface_thres=thres)
+    mesher.generate_mesh(1)
+    ov, on, _, ontri = o.generate_mesh(1, thres, cap)
+    gv, gn, _ = mesher.get_mesh()
+    assert mesher.num_facelets[None] == ontri
+    a, b = _tri_keys(gv, gn), _tri_keys(ov, on)
+    assert np.array_equal(a[:, :9], b[:, :9]), "mesh vertices differ"
+    assert np.array_equal(np.nan_to_num(a[:, 9:]), np.nan_to_num(b[:, 9:])), "mesh normals differ"
+    return ontri
+
+
+@pytest.mark.parametrize("plane", ["face", "edge", "corner", "inside"])
+def test_marching_cubes_surface_on_brick_boundaries(hip_lib, plane):
+    """The brick sign summary (k_mc_summary) lets the tile kernel skip a brick when it and the seven bricks its cells' corners reach into hold
+    values on one side of zero only.  Here the surface lies exactly BETWEEN two storage bricks -- across a face, along an edge, at a corner -- so
+    every brick is one-sided by itself and the triangles come from cells whose corners are in the neighbours; then the map changes (the flags
+    of the first mesh are stale) and is meshed again.  marching_cube_mesher.py:127-187."""
+    from taichislam_amd.mapping import DenseTSDF
+    from oracle import OracleTSDF
+    cfg = dict(map_scale=[3.2, 3.2], voxel_scale=0.05, num_voxel_per_blk_axis=16)
+    g, o = DenseTSDF(**cfg), OracleTSDF(**cfg)
+    r = np.arange(-24, 24, dtype=np.int16)                                  # three bricks per axis around the origin (brick faces at multiples of 16 from -32)
+    ii, jj, kk = np.meshgrid(r, r, r, indexing="ij")
+    idx = np.stack([ii, jj, kk], -1).reshape(-1, 3)
+    x, y, z = (idx[:, a].astype(np.float32) for a in range(3))
+    c = -0.5 if plane != "inside" else 3.3                                   # the zero crossing between voxels -1 | 0 = between two bricks
+    d = {"face": x - c, "edge": np.maximum(x - c, y - c), "corner": np.maximum(np.maximum(x - c, y - c), z - c), "inside": x - c}[plane]
+    t = (d * np.float32(0.05)).astype(np.float16)
+
+    def load(tt):
+        w, occ = np.ones(len(tt), np.float16), np.zeros(len(tt), np.int8)
+        g.reset(); g.load_numpy(0, idx, tt, w, occ, None)
+        o.reset(); o.import_sparse(0, idx, tt, w, occ)
+    load(t)
+    n1 = _mesh_pair(g, o, thres=10.0)
+    assert n1 > 500
+    # the surface moves by half a brick (other bricks become two-sided, the first ones one-sided): nothing of the first mesh's summary may survive
+    load(((d - 8.0) * np.float32(0.05)).astype(np.float16))
+    n2 = _mesh_pair(g, o, thres=10.0)
+    assert n2 > 500
+
+
 def test_mesh_capacity_clamp(hip_lib):
     from taichislam_amd.mapping import DenseTSDF, MarchingCubeMesher
     g = DenseTSDF(map_scale=[6.4, 6.4], voxel_scale=0.05, num_voxel_per_blk_axis=16)
