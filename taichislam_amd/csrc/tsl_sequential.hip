@@ -259,6 +259,7 @@ __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstl
 #define SQ_LONG 64                // a voxel with a run of at least this many updates in some frame of the batch gets a wave of its own (the long role of k_seq_replay)
 #define SQ_XLONG 1024             // ... and with one of at least this many it is listed in front of the others: the longest chains start first
 #define SQ_XLONG_CAP 4096
+#define SQ_LG 8                   // groups of 64 updates a long run requests per trip
 #define SQ_LONG_CAP (1 << 20)     // voxels a batch may hand to the long role of k_seq_replay (beyond: they stay with their lane); the first SQ_XLONG_CAP entries are the longest
 
 // exclusive prefix sums of a[0, C * SQ_NT) in LDS, in place; returns the total.  Every thread of the workgroup calls it with the data in
@@ -827,8 +828,13 @@ __device__ __forceinline__ void seq_role_short(const MapDev& M, const BatchDev& 
 template <bool TEX>
 __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B, const SeqDev* __restrict__ SD, const int4* __restrict__ long_list, int nblocks)
 {
+    __shared__ uint32_t s_lx[4][64], s_ls[4][64];    // per wave: the concatenated sequence of a voxel's runs in 64 slots (first update of each slot; tuple index - that)
     __builtin_amdgcn_s_setprio(3);
     const int wid = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* const s_ex = s_lx[wid]; uint32_t* const s_st = s_ls[wid];
+#ifdef TSL_SEQ_DBG
+    int dbg_e = 0, dbg_t = 0, dbg_w = 0;      // developer build: evaluations, commits that moved T, commits that moved W only
+#endif
     uint32_t okmask = 0u;
 #pragma unroll
     for (int q = 0; q < TSL_NB; ++q) if (q < B.n && B.f[q].counters[HDR_FAIL] == 0) okmask |= 1u << q;
@@ -846,69 +852,121 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
             const uint32_t np = word >> SQ_SLOT_BITS, slot0 = word & ((1u << SQ_SLOT_BITS) - 1u);
             uint32_t last_ray_at = 0xffffffffu;
             for (uint32_t pb = 0u; pb < np; pb += 64u) {
-            // the voxel's run in 64 slots at a time, one slot per lane: one memory round trip for all of them
-            uint4 meta = make_uint4(0u, 0u, 0u, 0u);
-            if (pb + (uint32_t)lane < np) {
-                const uint32_t* csr = SD[q].csr + (size_t)(slot0 + pb + (uint32_t)lane) * SQ_CSR_STRIDE;
-                meta = make_uint4(csr[l], csr[l + 1], csr[SQ_CSR_BASE], csr[SQ_CSR_UNSAFE]);
-            }
-            for (unsigned long long pm = __ballot(meta.y > meta.x); pm; pm &= pm - 1ull) {
-            const int src = (int)__builtin_ctzll(pm);
-            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)meta.x, src), o1 = (uint32_t)__builtin_amdgcn_readlane((int)meta.y, src),
-                           rbq = (uint32_t)__builtin_amdgcn_readlane((int)meta.z, src), unsafe = (uint32_t)__builtin_amdgcn_readlane((int)meta.w, src);
-            last_ray_at = rbq + o1 - 1u;
-            const float4* const tp = SD[q].tup + rbq;
-            uint32_t t = o0;
-            if (unsafe != 0u || !(fabsf(h2f((h16)Tb)) <= 60.0f)) {        // outside the division-free form's range: the literal expression (never seen in practice)
-                h16 T0 = (h16)Tb, W0 = (h16)Wb;
-                for (; t < o1; ++t) {
-                    const float4 x = tp[t];
-                    const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                      // dense_tsdf.py:264
-                    float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                           // :267
-                    T0 = Tn; W0 = f2h(wn);
+                // the voxel's run of this frame in 64 slots at a time, one slot per lane: one memory round trip for all of them
+                uint4 meta = make_uint4(0u, 0u, 0u, 0u);
+                if (pb + (uint32_t)lane < np) {
+                    const uint32_t* csr = SD[q].csr + (size_t)(slot0 + pb + (uint32_t)lane) * SQ_CSR_STRIDE;
+                    meta = make_uint4(csr[l], csr[l + 1], csr[SQ_CSR_BASE], csr[SQ_CSR_UNSAFE]);
                 }
-                Tb = (uint32_t)uni_i((int)T0); Wb = (uint32_t)uni_i((int)W0);
-            } else {
+                const bool has = meta.y > meta.x;
+                const unsigned long long pm = __ballot(has);
+                if (pm == 0ull) continue;
+                last_ray_at = (uint32_t)__builtin_amdgcn_readlane((int)(meta.z + meta.y - 1u), 63 - (int)__builtin_clzll(pm));
+                if (__ballot(has && meta.w != 0u) != 0ull || !(fabsf(h2f((h16)Tb)) <= 60.0f)) {
+                    // outside the division-free form's range: the literal expression, slot after slot (never seen in practice)
+                    h16 T0 = (h16)Tb, W0 = (h16)Wb;
+                    for (unsigned long long pq = pm; pq; pq &= pq - 1ull) {
+                        const int src = (int)__builtin_ctzll(pq);
+                        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)meta.x, src), o1 = (uint32_t)__builtin_amdgcn_readlane((int)meta.y, src);
+                        const float4* const tp = SD[q].tup + (uint32_t)__builtin_amdgcn_readlane((int)meta.z, src);
+                        for (uint32_t t = o0; t < o1; ++t) {
+                            const float4 x = tp[t];
+                            const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                              // dense_tsdf.py:264
+                            float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                   // :267
+                            T0 = Tn; W0 = f2h(wn);
+                        }
+                    }
+                    Tb = (uint32_t)uni_i((int)T0); Wb = (uint32_t)uni_i((int)W0);
+                    continue;
+                }
                 // The chain.  Deep into a voxel's life an update mostly leaves BOTH f16 values as they are: the running mean stalls (an increment of
                 // w / W of the residual is far below half an f16 ulp of T), and so does the weight (RN16(W + w) = W once w is under half an ulp of W:
                 // w < 0.25 from W = 512 on -- a voxel seen from two metres never reaches Wmax).  Whether update k changes the state can be decided
                 // without the updates before it, as long as THEY did not: the 64 lanes evaluate 64 consecutive updates on the same (T, W); if none
                 // changes it, 64 updates are done; otherwise the first lane that does holds the true next state (everything before it was a no-op)
                 // and the lanes behind it go again.  Exact by construction; at worst -- a state that moves at every update, a voxel's first few
-                // hundred -- one evaluation per update, as in a plain walk.  The tuples come straight from HBM, 1 024 per trip: sixteen coalesced
-                // loads in flight, each the 64 updates of one round.
-                while (t < o1) {
-                    float4 x[16];
+                // hundred -- one evaluation per update, as in a plain walk.
+                // The 64 consecutive updates have to be FOUND first: next to the sensor a brick's segments are cut into tens of chunks by ray rank
+                // (k_seq_split) and a voxel's run of a frame is scattered over their slots, a few tuples in each -- walked slot by slot the wave spent
+                // ~150 instructions on every two or three updates (77 M wave-instructions per batch, twice the short runs' role).  So the runs of
+                // the 64 slots are concatenated: a prefix sum of their lengths over the lanes, update k of the sequence found by a binary search
+                // in it (wave-private LDS), the tuples gathered 512 per trip.
+                const uint32_t len = has ? meta.y - meta.x : 0u;
+                uint32_t incl = len;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) x[r] = tp[min(t + (uint32_t)(r * 64 + lane), o1 - 1u)];
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                s_ex[lane] = incl - len;                                             // first update of the slot in the concatenated sequence
+                s_st[lane] = meta.z + meta.x - (incl - len);                         // + k = the tuple of update k
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // (LDS operations of a wave complete in order)
+                const float4* const tq = SD[q].tup;
+                for (uint32_t k0 = 0u; k0 < n; k0 += 64u * SQ_LG) {
+                    float4 x[SQ_LG];
+#pragma unroll
+                    for (int g = 0; g < SQ_LG; ++g) {
+                        const uint32_t k = min(k0 + (uint32_t)(g * 64 + lane), n - 1u);
+                        uint32_t lo = 0u;
+#pragma unroll
+                        for (uint32_t step = 32u; step; step >>= 1) lo += s_ex[lo + step] <= k ? step : 0u;      // the last slot that starts at or before k (it is not empty)
+                        x[g] = tq[s_st[lo] + k];
+                    }
                     uint32_t Tr = Tb;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t base = t + (uint32_t)(r * 64);
-                        if (base >= o1) continue;                                  // (uniform)
-                        unsigned long long todo = __ballot(base + (uint32_t)lane < o1);
+                    for (int g = 0; g < SQ_LG; ++g) {
+                        const uint32_t base = k0 + (uint32_t)(g * 64);
+                        if (base >= n) continue;                                   // (uniform)
+                        unsigned long long todo = __ballot(base + (uint32_t)lane < n);
                         while (todo) {
-                            float D = x[r].w, rc = x[r].z;                        // at Wmax: Wmax + w and its reciprocal come with the tuple
-                            if (Wb != SQ_W_SAT) { D = h2f((h16)Wb) + x[r].x; rc = 1.0f / D; }      // (uniform) below it: one IEEE division per evaluation
-                            const uint32_t Tn = seq_update_fast(Tr, Wb, x[r].y, D, rc);                                   // :264
-                            const uint32_t Wn = (uint32_t)f2h(D > TSL_WMAX ? TSL_WMAX : D);                                // :267
-                            const unsigned long long cm = __ballot((((Tn ^ Tr) & 0xffffu) | (Wn ^ Wb)) != 0u) & todo;
-                            if (cm == 0ull) break;
+#ifdef TSL_SEQ_DBG
+                            ++dbg_e;
+#endif
+                            // every lane of `todo` evaluates its update on a CANDIDATE state: T as it is, W as the updates before it in the group
+                            // are expected to have left it; the lane is consistent if T comes out unchanged and W comes out as the next lane's candidate.
+                            // Lanes before the first inconsistent one are thereby verified one after the other (each started from a true state), and so
+                            // are that lane's inputs: its outputs are the true next state.  At Wmax, and where the weight has stalled below it, the
+                            // candidate is W itself; while the weight still grows it is W + the increments rounded to W's f16 grid, summed over the lanes
+                            // before (a guess: ties, a binade crossed on the way or an inexact f32 sum only make a lane inconsistent, never the result wrong).
+                            uint32_t Tn, Wn, bad;
+                            if (Wb == SQ_W_SAT) {                                  // (uniform)
+                                Tn = seq_update_fast(Tr, Wb, x[g].y, x[g].w, x[g].z);                                     // :264  Wmax + w and its reciprocal come with the tuple
+                                Wn = SQ_W_SAT;                                                                            // :267
+                                bad = (Tn ^ Tr) & 0xffffu;
+                            } else {
+                                const float Wf = h2f((h16)Wb);
+                                const uint32_t eb = (Wb >> 10) & 31u;
+                                const float grid = __uint_as_float((eb ? eb + 102u : 103u) << 23), ginv = __uint_as_float((eb ? 152u - eb : 151u) << 23);      // ulp of W in f16: 2^(e - 25), 2^-24 for a subnormal; and 1 / that
+                                const float inc = ((todo >> lane) & 1ull) ? rintf(x[g].x * ginv) * grid : 0.0f;
+                                float incl = inc;
+#pragma unroll
+                                for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                                const float cand = fminf(Wf + (incl - inc), TSL_WMAX), candn = fminf(Wf + incl, TSL_WMAX);
+                                const uint32_t Wc = (uint32_t)f2h(cand);
+                                const float D = h2f((h16)Wc) + x[g].x;
+                                Tn = seq_update_fast(Tr, Wc, x[g].y, D, 1.0f / D);                                        // :264
+                                Wn = (uint32_t)f2h(D > TSL_WMAX ? TSL_WMAX : D);                                          // :267
+                                bad = ((Tn ^ Tr) & 0xffffu) | (Wn ^ (uint32_t)f2h(candn));
+                            }
+                            const unsigned long long cm = __ballot(bad != 0u) & todo;
+                            if (cm == 0ull) { Wb = (uint32_t)__builtin_amdgcn_readlane((int)Wn, 63 - (int)__builtin_clzll(todo)); break; }      // every update of the group verified: W as the last one left it
                             const int j = (int)__builtin_ctzll(cm);
+#ifdef TSL_SEQ_DBG
+                            { const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)Tn, j) & 0xffffu; if (tn != Tr) ++dbg_t; else ++dbg_w; }
+#endif
                             Tr = (uint32_t)__builtin_amdgcn_readlane((int)Tn, j) & 0xffffu;
                             Wb = (uint32_t)__builtin_amdgcn_readlane((int)Wn, j);
                             todo &= ~((2ull << j) - 1ull);                        // the lanes behind j (j = 63: none)
                         }
                     }
                     Tb = (uint32_t)uni_i((int)(Tr & 0xffffu));
-                    t += 1024u;
                 }
-            }
-            }
+                __builtin_amdgcn_wave_barrier();                                   // (the rows are written again for the next 64 slots)
             }
             if (TEX && lane == 0 && last_ray_at != 0xffffffffu) reinterpret_cast<uint2*>(M.col)[v] = B.f[q].colpix[B.f[q].rayFirst[SD[q].tup_ray[last_ray_at]]];      // :268-269
         }
         if (lane == 0) { M.tw[v] = Tb | (Wb << 16); M.obs[v] = 1; M.touch[pool] = 1; }                                    // :265
+#ifdef TSL_SEQ_DBG
+        if (lane == 0) { atomicAdd(&B.f[0].counters[32], dbg_e); atomicAdd(&B.f[0].counters[33], dbg_t); atomicAdd(&B.f[0].counters[34], dbg_w); } dbg_e = dbg_t = dbg_w = 0;
+#endif
     }
 }
 

@@ -1163,6 +1163,9 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
         const int bi = (m->cur + TSL_NBATCH - 1) % TSL_NBATCH;
         int v[40]; TSL_HIP(hipMemcpy(v, m->fset[bi * TSL_NB].F.counters, sizeof(v), hipMemcpyDeviceToHost));
         *value = v[28] + v[30];
+#ifdef TSL_SEQ_DBG
+        fprintf(stderr, "seq dbg (long role, last batch): evaluations %d, commits that moved T %d, commits that moved W only %d\n", v[32], v[33], v[34]);
+#endif
         return TSL_OK;
     }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
