@@ -403,16 +403,19 @@ __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const
 //   * the counting sort has no barrier at all: wave w owns quarter w of the tuple sequence, the walk has counted every voxel's tuples per quarter
 //     (four 16-bit fields of one LDS word), so a wave's cursor for a voxel starts behind the earlier quarters' tuples and only that wave moves it.
 template <bool TEX>
-__global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+__global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
 {
     const int q = blockIdx.y;
     if (q >= B.n) return;
     const FrameDev& F = B.f[q];
     const FrameParams& P = *B.p[q];
     const SeqDev S = SD[q];
-    __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: the item's segments: rank 22 | first step 12 | steps 6 | ray 22
-    __shared__ uint32_t s_pre[SQ_SORTCAP];                       //  8 KiB: replay position of a sorted segment's first step
-    __shared__ uint32_t s_hist[TSL_BRK3];                        // 16 KiB: tuples per voxel -> run offsets
+    // 52 KiB of LDS, three workgroups per CU (every stage waits for LDS or memory round trips: more resident waves is what hides them).  One 16 KiB
+    // region holds, in turn: the sort keys; the sorted segments in 32 bits + their replay positions; the voxels' run offsets.
+    __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: the item's segments as sort keys: rank 22 | first step 12 | steps 6 | ray 22
+    uint32_t* const s_sr = reinterpret_cast<uint32_t*>(s_seg);   //   after the sort, [0, 2048): ray 21 | steps 6 of the k-th segment in replay order
+    uint32_t* const s_pre = s_sr + SQ_SORTCAP;                   //   after the sort, [2048, 4096): replay position of its first step 17 | first step 12
+    uint32_t* const s_hist = s_sr;                               //   after the walk, all of it: tuples per voxel -> run offsets
     __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, its tuples in each quarter of the replay sequence (16 bits each) -> the quarters' cursors
     __shared__ unsigned short s_perm[SQ_SORTCAP];                //  4 KiB: the sorted segments by length, longest first
     __shared__ int s_bin[64];
@@ -485,13 +488,19 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
         __syncthreads();
         // ---- replay positions (prefix of the step counts, sorted order); the segments by length ----
         int lrank[SQ_SORTCAP / SQ_NT];
+        uint32_t cj[SQ_SORTCAP / SQ_NT], sr[SQ_SORTCAP / SQ_NT];     // steps | first step << 8; ray | steps << 21
 #pragma unroll
         for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
             const int k = r * SQ_NT + tid;
-            const uint32_t cnt = k < m ? (uint32_t)((s_seg[k] >> 22) & 63ull) : 0u;
-            s_pre[k] = cnt;
+            const unsigned long long key = k < m ? s_seg[k] : 0ull;
+            const uint32_t cnt = (uint32_t)((key >> 22) & 63ull);
+            cj[r] = cnt | ((uint32_t)((key >> 28) & 0xfffull) << 8);
+            sr[r] = (uint32_t)(key & 0x1fffffull) | (cnt << 21);                  // (a ray index has 21 bits: max_points <= 2^21 in this mode)
             lrank[r] = k < m ? atomicAdd(&s_bin[63 - (int)cnt], 1) : -1;
         }
+        __syncthreads();                                                          // every key is in registers: the region changes hands
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) { const int k = r * SQ_NT + tid; s_sr[k] = sr[r]; s_pre[k] = cj[r] & 63u; }
         __syncthreads();
         if (tid < 64) {
             const int cb = s_bin[tid]; int inc = cb;
@@ -502,7 +511,8 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
 #pragma unroll
         for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
             const int k = r * SQ_NT + tid;
-            if (lrank[r] >= 0) s_perm[s_bin[63 - (int)((s_seg[k] >> 22) & 63ull)] + lrank[r]] = (unsigned short)k;
+            if (lrank[r] >= 0) s_perm[s_bin[63 - (int)(cj[r] & 63u)] + lrank[r]] = (unsigned short)k;
+            s_pre[k] |= (cj[r] >> 8) << 17;                                       // (the item's steps number fewer than 2^17)
         }
         if (tid == 0) s_rb = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&F.counters[HDR_SEQ_TUPLES]), (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -516,14 +526,14 @@ __global__ void __launch_bounds__(SQ_NT, 2) k_seq_group(MapDev M, BatchDev B, co
             const int idx = r * SQ_NT + ((r & 1) ? SQ_NT - 1 - tid : tid);
             if (idx >= m) continue;
             const int k = (int)s_perm[idx];
-            const unsigned long long sk = s_seg[k];
-            const int ray = (int)(sk & 0x3fffffull), cnt = (int)((sk >> 22) & 63ull), j0 = (int)((sk >> 28) & 0xfffull);
+            const uint32_t sk = s_sr[k], pj = s_pre[k];
+            const int ray = (int)(sk & 0x1fffffu), cnt = (int)(sk >> 21), j0 = (int)(pj >> 17);
             const uint4 rec = F.rayA[ray];
             const float pf0 = h2f((h16)(rec.x & 0xffffu)), pf1 = h2f((h16)(rec.x >> 16)), pf2 = h2f((h16)(rec.y & 0xffffu));
             const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
             const unsigned long long zz = (unsigned long long)seq_w_code(__uint_as_float(rec.w)) << SQ_TUP_Z_SHIFT;
             const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                     // :246
-            const uint32_t at = s_pre[k];
+            const uint32_t at = pj & 0x1ffffu;
             for (int s = 0; s < cnt; ++s) {
                 const float jf = (float)(j0 + s);
                 const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
