@@ -64,4 +64,10 @@ import sys; sys.path.insert(0, ".")
 from taichislam_amd import build
 print(build.source_hash())
 PY
+# the counters are in: reduce them here too (profiles/r04_traffic.json of THIS copy, stamped with these sources' hash) and print the bench lines
+# again, now with `roofline.traffic` from counters collected on the same sources a minute ago
+cd $R && python tools/make_r04_profiles.py > /dev/null 2>&1
+cd $R && timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+cd $R && timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+for c in 1 3 4; do timeout 300 python bench.py --config $c --steps 100 --warmup 10 2>/dev/null | tail -1 > $O/bench_c$c.json; done
 ls $O; grep -c . $O/pmc_summary.txt
