@@ -733,8 +733,16 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     //                         a workgroup's barriers and LDS round trips are covered by the other's walk.
     constexpr int CSEGS = SPT * NT, VPT = TSL_BRK3 / NT, CH = VPT < FLUSH_CHUNK ? VPT : FLUSH_CHUNK;
     static_assert(VPT <= 16, "the written / first-touch masks hold 16 voxels per thread");
+#ifdef TSL_EXP_SLOT16      // developer A/B: {num, den} of a voxel side by side in one 16-byte slot instead of two 32 KiB planes
+    __shared__ ulonglong2 s_acc[TSL_BRK3];                      // 64 KiB
+#define S_NUM(i) s_acc[i].x
+#define S_DEN(i) s_acc[i].y
+#else
     __shared__ unsigned long long s_num[TSL_BRK3];              // 32 KiB
     __shared__ unsigned long long s_den[TSL_BRK3];              // 32 KiB
+#define S_NUM(i) s_num[i]
+#define S_DEN(i) s_den[i]
+#endif
     __shared__ unsigned long long s_keys[CSEGS];                // 8 / 16 KiB: length sort of the NEXT step's keys while the planes hold the current sums
     __shared__ uint32_t s_win[TEX ? TSL_BRK3 : 1];              // texture: colour winner per voxel (first pixel of the ray + 1)
     __shared__ int s_bin[64];
@@ -868,8 +876,12 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
     }
 
     {   // the sums are zero between items: cleared here once, afterwards by whoever reads them
+#ifdef TSL_EXP_SLOT16
+        for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_acc[i] = make_ulonglong2(0ull, 0ull);
+#else
         ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
         for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) { zn[i] = make_ulonglong2(0ull, 0ull); zd[i] = make_ulonglong2(0ull, 0ull); }
+#endif
         if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
         __syncthreads();
@@ -941,7 +953,14 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
             const uint32_t wid = wids[q];
             // lanes start at different offsets inside their (equally long) segments: rays that enter a brick together -- all
             // of them next to the sensor -- would otherwise hit the same few voxels in the same iteration
-            int off = ((int)(threadIdx.x & 63u) * cnt) >> 6;
+            // ... and NEIGHBOURING lanes far apart: the lanes of a wave hold segments of equal length, so neighbours in the sorted order are often
+            // neighbours in space, and 1 / 64 of a segment apart (the first form: lane * cnt / 64) they still added to the same voxel in the same
+            // instruction -- three quarters of the LDS conflict cycles were same-address ones.  27 / 64 of a segment apart: SQ_LDS_ADDR_CONFLICT
+            // 8.9 M -> 2.4 M per launch, conflict cycles 53 % -> 45 % of the active LDS cycles (profiles/r04_brick_kernel_experiments.txt)
+#ifndef TSL_EXP_STAGGER
+#define TSL_EXP_STAGGER 27  // (developer A/B: 1 = the first form)
+#endif
+            int off = ((int)((threadIdx.x * (unsigned)TSL_EXP_STAGGER) & 63u) * cnt) >> 6;
             for (int s = 0; s < cnt; s += 2) {
                 const int ja = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
                 const int jb = j0 + off; off = (off + 1 == cnt) ? 0 : off + 1;
@@ -950,14 +969,17 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
                 step_eval<FASTDIV>(R, K, jb, &lb, &qb);
                 long long na = (long long)(int)qa, nb = (long long)(int)qb;
                 if (__builtin_expect(__any(!(fabsf(qa) < 2147483648.0f) || !(fabsf(qb) < 2147483648.0f)), 0)) { na = __float2ll_rn(qa); nb = __float2ll_rn(qb); }
-                atomicAdd(&s_num[la], (unsigned long long)na);
-                atomicAdd(&s_den[la], (unsigned long long)R.qden);
+                atomicAdd(&S_NUM(la), (unsigned long long)na);
+                atomicAdd(&S_DEN(la), (unsigned long long)R.qden);
                 if (TEX) atomicMax(&s_win[la], wid);                                           // dense_tsdf.py:268-269, order-free winner
-                // the second step of an odd segment's last pair adds zeros to a voxel of the brick (no effect, no branch)
                 const bool vb = s + 1 < cnt;
-                atomicAdd(&s_num[lb], (unsigned long long)(vb ? nb : 0ll));
-                atomicAdd(&s_den[lb], (unsigned long long)(vb ? R.qden : 0ll));
+#ifdef TSL_EXP_ADDZERO      // developer A/B: the first form -- the missing second step of an odd segment's last pair adds zeros (no branch)
+                atomicAdd(&S_NUM(lb), (unsigned long long)(vb ? nb : 0ll));
+                atomicAdd(&S_DEN(lb), (unsigned long long)(vb ? R.qden : 0ll));
                 if (TEX) atomicMax(&s_win[lb], vb ? wid : 0u);
+#else                       // ... or is skipped: 5 % fewer LDS conflict cycles, the launch 4 % shorter (profiles/r04_brick_kernel_experiments.txt)
+                if (vb) { atomicAdd(&S_NUM(lb), (unsigned long long)nb); atomicAdd(&S_DEN(lb), (unsigned long long)R.qden); if (TEX) atomicMax(&s_win[lb], wid); }
+#endif
             }
         }
         __syncthreads();
@@ -1001,7 +1023,7 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
                     const int ls = acc_swz5((h + q) * NT + threadIdx.x);
-                    qn[q] = (long long)s_num[ls]; qd[q] = (long long)s_den[ls]; s_num[ls] = 0ull; s_den[ls] = 0ull;
+                    qn[q] = (long long)S_NUM(ls); qd[q] = (long long)S_DEN(ls); S_NUM(ls) = 0ull; S_DEN(ls) = 0ull;
                     small = small && fits_i32(qn[q]) && fits_i32(qd[q]); anyu = anyu || qd[q] != 0;
                 }
                 if (!__any(anyu)) continue;                      // none of this wave's 64 x CH voxels was touched by the frame
@@ -1038,13 +1060,17 @@ __global__ void __launch_bounds__(NT, WPE) k_integrate_batch(MapDev M, BatchDev 
 #pragma unroll
             for (int q = 0; q < VPT; ++q) {
                 const int l = q * NT + threadIdx.x, ls = acc_swz5(l);
-                acc[l] = make_ulonglong2(s_num[ls], s_den[ls]);
-                s_num[ls] = 0ull; s_den[ls] = 0ull;
+                acc[l] = make_ulonglong2(S_NUM(ls), S_DEN(ls));
+                S_NUM(ls) = 0ull; S_DEN(ls) = 0ull;
                 if (TEX) { F.accw[(size_t)rk * TSL_BRK3 + l] = s_win[ls]; s_win[ls] = 0u; }
             }
         } else {                                                          // brick pool exhausted (reported by k_plan): drop the sums
+#ifdef TSL_EXP_SLOT16
+            for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_acc[i] = make_ulonglong2(0ull, 0ull);
+#else
             ulonglong2* zn = reinterpret_cast<ulonglong2*>(s_num); ulonglong2* zd = reinterpret_cast<ulonglong2*>(s_den);
             for (int i = threadIdx.x; i < TSL_BRK3 / 2; i += NT) { zn[i] = make_ulonglong2(0ull, 0ull); zd[i] = make_ulonglong2(0ull, 0ull); }
+#endif
             if (TEX) for (int i = threadIdx.x; i < TSL_BRK3; i += NT) s_win[i] = 0u;
         }
 #ifdef TSL_TIMING
