@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
             const unsigned long long zz = (unsigned long long)seq_w_code(__uint_as_float(rec.w)) << SQ_TUP_Z_SHIFT;
             const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                     // :246
             const uint32_t at = pj & 0x1ffffu;
-            for (int s = 0; s < cnt; ++s) {
+            for (int s = 0; s < cnt; ++s) {          // (starting the lanes at different steps, as the default path's walk does, changed nothing here: 6 110 against 6 080 frames/s)
                 const float jf = (float)(j0 + s);
                 const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
                 const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));   // :254
@@ -1110,7 +1110,8 @@ int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int b
     const int4* ll = static_cast<const int4*>(m->seqb_long[bi]);
     const unsigned long long* lm = static_cast<const unsigned long long*>(m->seqb_lmask[bi]);
     const int nlong = 4 * m->ncu, nshort = 12 * m->ncu;
-    if (std::getenv("TSL_SEQ_SPLIT_ROLES")) {      // developer timing aid: the two roles as two launches (same result: the voxel sets are disjoint)
+    static const bool split_roles = std::getenv("TSL_SEQ_SPLIT_ROLES") != nullptr;
+    if (split_roles && !P.tex) {                   // developer timing aid: the two roles as two launches (same result: the voxel sets are disjoint)
         hipLaunchKernelGGL(k_seq_replay<false>, dim3(nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, 0);
         hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
         return TSL_OK;
