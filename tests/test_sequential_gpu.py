@@ -51,6 +51,36 @@ def test_sequential_mode_equals_faithful_at_the_benchmark_size(hip_lib):
     assert_export_equal(e, o.export_sparse(), "sequential vs FAITHFUL, C2, 12 frames")
 
 
+@pytest.mark.parametrize("inp", ["host", "device"])
+def test_sequential_mode_long_pipelined_stream_with_readers_in_between(hip_lib, inp):
+    """44 frames queued without a synchronisation per frame -- every batch slot and frame working set is used twice over, batches of eight in
+    flight -- as host numpy images (the visited pixels staged into the mapped pinned buffers) or as device tensors; a mesh, an ESDF update and a
+    surface export read the map in between (each issues the queued frames first).  Map and frame counters == FAITHFUL.  dense_tsdf.py:236-270."""
+    import torch
+    from oracle import FAITHFUL
+    from taichislam_amd.mapping import MarchingCubeMesher
+    K, frames = small_stream(44)
+    g, o = make_pair(SMALL, K)
+    g.set_option("semantics", 1)
+    dev = [torch.from_numpy(d.view(np.int16)).cuda() for _, _, d in frames] if inp == "device" else None
+    mesher = MarchingCubeMesher(g, 400000, tsdf_surface_thres=5 * SMALL["voxel_scale"])
+    for f, (R, T, d) in enumerate(frames):
+        g.recast_depth_to_map(R, T, dev[f] if dev else d, None)
+        so = o.integrate_depth(R, T, d, mode=FAITHFUL)
+        if f == 13:
+            mesher.generate_mesh(1)
+            ov, on, _, ontri = o.generate_mesh(1, 5 * SMALL["voxel_scale"], 400000)
+            assert mesher.num_facelets[None] == ontri > 1000
+        if f == 21:
+            g.update_esdf(wait=False)
+        if f == 30:
+            g.cvt_TSDF_surface_to_voxels()
+            assert g.num_TSDF_particles[None] > 0
+    sg = g.last_frame_stats()
+    assert {k: sg[k] for k in STAT_KEYS} == {k: so[k] for k in STAT_KEYS}
+    assert_export_equal(g.export_submap(), o.export_sparse(), f"sequential, 44 pipelined frames, {inp} input")
+
+
 def test_sequential_mode_points_crowded_voxels_and_out_of_volume_rays(hip_lib):
     """recast_pcl_to_map in sequential mode: random directions and ranges (rays that leave the volume, degenerate points at the origin)
     plus a cluster of 3 000 points inside a few sensor voxels (the crowded-voxel replay of k_segments); two frames, FAITHFUL bit for bit."""
