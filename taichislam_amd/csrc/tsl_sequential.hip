@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
         SQ_TICK(4)
         // ---- stable counting sort by voxel: wave w takes quarter w of the sequence, 64 tuples at a time, in replay order.  Tuples of one voxel
         //      inside a group of 64 find each other with twelve ballots; the voxel's cursor for this quarter is moved by the first of them ----
-        float4* const tup = S.tup + rb;
+        float2* const tup = S.tup + rb;
         bool unsafe = false;
         {
             const uint32_t e = min(T, (uint32_t)(wid + 1) * Q);
@@ -592,11 +592,10 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
                 if (valid) {
                     const uint32_t cur = (uint32_t)(s_pack[l] >> (16 * wid)) & 0xffffu;
                     if (my == 0) atomicAdd(&s_pack[l], (unsigned long long)gs << (16 * wid));      // (behind the read: LDS operations of a wave complete in order)
-                    // the replay tuple: everything an update needs that does not depend on the voxel -- w, c = w * sd (:264), 1 / (Wmax + w), Wmax + w
+                    // the replay tuple: what an update needs that does not depend on the voxel -- w and c = w * sd (:264)
                     const float sd = __uint_as_float((uint32_t)x), w = seq_w_of((h16)(x >> SQ_TUP_Z_SHIFT)), c = w * sd;
-                    const float D = TSL_WMAX + w;
                     const uint32_t pos = s_hist[l] + cur + (uint32_t)my;
-                    tup[pos] = make_float4(w, c, 1.0f / D, D);
+                    tup[pos] = make_float2(w, c);
                     if (TEX) S.tup_ray[rb + pos] = S.stash_ray[rb + t];
                     unsafe = unsafe || !(fabsf(sd) <= 60.0f) || (c != 0.0f && fabsf(c) < 8.67e-19f);      // 2^-60: the residuals of the division-free quotient stay representable
                 }
@@ -615,11 +614,11 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
 // at Wmax both come with the tuple; below it -- and a weight can sit below Wmax for good: RN16(W + w) = W as soon as w is under half an f16 ulp
 // of W, e.g. w < 0.25 from W = 512 on -- the reciprocal is one IEEE division per update.  Outside the range the form is proven for (the
 // item's flag, |T| > 60) the literal expression.
-__device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint32_t t, uint32_t end, bool can_fast, h16& T0, h16& W0)
+__device__ __forceinline__ void seq_walk_run(const float2* __restrict__ tp, uint32_t t, uint32_t end, bool can_fast, h16& T0, h16& W0)
 {
     if (!(can_fast && fabsf(h2f(T0)) <= 60.0f)) {
         for (; t < end; ++t) {
-            const float4 x = tp[t];
+            const float2 x = tp[t];
             const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                                              // dense_tsdf.py:264
             float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                                   // :267
             T0 = Tn; W0 = f2h(wn);
@@ -628,7 +627,7 @@ __device__ __forceinline__ void seq_walk_run(const float4* __restrict__ tp, uint
     }
     uint32_t Tr = T0; h16 Wb = W0;
     for (; t < end; ++t) {
-        const float4 x = tp[t];
+        const float2 x = tp[t];
         const float D = h2f(Wb) + x.x;                                                                                    // (= the tuple's Wmax + w at Wmax)
         Tr = seq_update_fast(Tr, Wb, x.y, D, 1.0f / D);                                                                   // :264  (a convex combination: |T| <= 60 stays)
         Wb = f2h(D > TSL_WMAX ? TSL_WMAX : D);                                                                            // :267
@@ -878,9 +877,9 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                     for (unsigned long long pq = pm; pq; pq &= pq - 1ull) {
                         const int src = (int)__builtin_ctzll(pq);
                         const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)meta.x, src), o1 = (uint32_t)__builtin_amdgcn_readlane((int)meta.y, src);
-                        const float4* const tp = SD[q].tup + (uint32_t)__builtin_amdgcn_readlane((int)meta.z, src);
+                        const float2* const tp = SD[q].tup + (uint32_t)__builtin_amdgcn_readlane((int)meta.z, src);
                         for (uint32_t t = o0; t < o1; ++t) {
-                            const float4 x = tp[t];
+                            const float2 x = tp[t];
                             const h16 Tn = f2h((h2f(hmul(T0, W0)) + x.y) / (h2f(W0) + x.x));                              // dense_tsdf.py:264
                             float wn = h2f(W0) + x.x; if (TSL_WMAX < wn) wn = TSL_WMAX;                                   // :267
                             T0 = Tn; W0 = f2h(wn);
@@ -909,9 +908,9 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                 s_ex[lane] = incl - len;                                             // first update of the slot in the concatenated sequence
                 s_st[lane] = meta.z + meta.x - (incl - len);                         // + k = the tuple of update k
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // (LDS operations of a wave complete in order)
-                const float4* const tq = SD[q].tup;
+                const float2* const tq = SD[q].tup;
                 for (uint32_t k0 = 0u; k0 < n; k0 += 64u * SQ_LG) {
-                    float4 x[SQ_LG];
+                    float2 x[SQ_LG];
 #pragma unroll
                     for (int g = 0; g < SQ_LG; ++g) {
                         const uint32_t k = min(k0 + (uint32_t)(g * 64 + lane), n - 1u);
@@ -938,7 +937,8 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                             // before (a guess: ties, a binade crossed on the way or an inexact f32 sum only make a lane inconsistent, never the result wrong).
                             uint32_t Tn, Wn, bad;
                             if (Wb == SQ_W_SAT) {                                  // (uniform)
-                                Tn = seq_update_fast(Tr, Wb, x[g].y, x[g].w, x[g].z);                                     // :264  Wmax + w and its reciprocal come with the tuple
+                                const float D = TSL_WMAX + x[g].x;
+                                Tn = seq_update_fast(Tr, Wb, x[g].y, D, 1.0f / D);                                        // :264
                                 Wn = SQ_W_SAT;                                                                            // :267
                                 bad = (Tn ^ Tr) & 0xffffu;
                             } else {
@@ -1031,7 +1031,7 @@ static int seq_ensure(tsl_tsdf* m)
         SeqDev& S = m->seq_h[si];
         S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.tup_ray = nullptr; S.items = nullptr;
         if ((rc = dev_alloc(m, (void**)&S.stash, 8 * (size_t)S.cap, 0))) return rc;
-        if ((rc = dev_alloc(m, (void**)&S.tup, 16 * ((size_t)S.cap + 16), 0))) return rc;          // + spare tuples: the replay requests four ahead
+        if ((rc = dev_alloc(m, (void**)&S.tup, 8 * ((size_t)S.cap + 16), 0))) return rc;
         S.slot_cap = m->F.max_frame_bricks + 1024;          // one slot per (frame, brick) + the further chunks of the few bricks next to the sensor
         if ((rc = dev_alloc(m, (void**)&S.csr, 4 * (size_t)S.slot_cap * SQ_CSR_STRIDE, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&S.items, sizeof(int4) * (size_t)S.slot_cap, 0))) return rc;

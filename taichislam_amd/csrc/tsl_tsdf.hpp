@@ -183,7 +183,7 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 #define SQ_CSR_UNSAFE 4098
 struct SeqDev {
     unsigned long long* stash;        // [cap]
-    float4* tup;                      // [cap + 16]
+    float2* tup;                      // [cap + 16]
     uint32_t* csr;                    // [slot_cap][SQ_CSR_STRIDE]
     int4* items; int slot_cap;        // k_seq_group's work items of the frame, one per slot: { first segment, segments, slot, 1: in the spare segment array }
     uint32_t* stash_ray;              // textured maps: [cap] ray of every stashed tuple
