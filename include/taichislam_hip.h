@@ -260,10 +260,10 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 LDS counting sort of the steps by voxel), phase B is one thread per voxel applying its runs frame after frame (k_seq_replay);
                 memory: 2 x 8 bytes x "seq_tuple_cap" + 16 KiB x max_frame_bricks per working set, 24 working sets, allocated by the first
                 sequential frame.  0: round 3's form -- every ray step a 16-byte tuple, two global radix sorts, one frame per batch
-     "seq_longest_run" (get only) the longest run of updates of one voxel in a frame, summed over the frames of the batch issued last: the dependent
-                chain that bounds that batch's replay
+     "seq_longest_run" (get only) the longest run of updates of one voxel in a frame, summed over the frames of the batch issued last (the voxel next
+                to the sensor; a wave of its own settles it 64 updates per evaluation where its f16 state has stopped moving)
      "seq_long_voxels" (get only) voxels of the batch issued last that were replayed by a wave of their own (a run of >= 64 updates in a frame)
-     "seq_tuple_cap" ray steps one frame may produce under seq_impl 1 (default 2^24; a frame beyond it is dropped with TSL_ERR_CAPACITY);
+     "seq_tuple_cap" ray steps one frame may produce under seq_impl 1 (default 2^23; a frame beyond it is dropped with TSL_ERR_CAPACITY);
                 set before the first sequential frame
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 8; three batch slots: phase A of up to two
                 batches is in flight beside phase B of a third)
