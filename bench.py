@@ -197,9 +197,11 @@ def sequential_leg(dev, frames, oracle_map, more=()):
         return e["indices"][o], np.asarray(e["TSDF"])[o].view(np.uint16), np.asarray(e["W_TSDF"])[o].view(np.uint16), e["occupy"][o]
     x, y = srt(a), srt(b)
     exact = all(u.shape == v.shape and np.array_equal(u, v) for u, v in zip(x, y))
+    names = ("indices", "TSDF", "W_TSDF", "occupy")
+    where = None if exact else first_difference(dict(zip(names, x)), dict(zip(names, y)), names[1:], sensor_xyz=frames[-1][1], voxel_scale=C2["voxel_scale"])
     rate, steady = (len(frames) - 1) / max(dt, 1e-9), (len(more) / max(dts, 1e-9) if len(more) >= 64 else None)
     return {"value": rate, "unit": "frames/s", "frames": len(frames), "voxels": int(x[0].shape[0]),
-            "bit_exact_with_oracle_FAITHFUL": bool(exact),
+            "bit_exact_with_oracle_FAITHFUL": bool(exact), "differences": where,
             "value_steady": steady, "steady_frames": len(more), "chain_floor": chain,
             "north_star": {"rate_target_frames_per_s": 2000, "rate_met": bool(min(rate, steady if steady else rate) >= 2000.0), "tsdf_tolerance": "1e-4 relative",
                            "tolerance_met": bool(exact), "how": "every TSDF / W bit equals the reference's struct-for serialisation (oracle FAITHFUL, pinned to the "
@@ -208,6 +210,37 @@ def sequential_leg(dev, frames, oracle_map, more=()):
                     "(dense_tsdf.py:264-267) -- a legal schedule of the racy reference, equal to the sequential CPU replay on every TSDF / W bit.  Round 4: "
                     "per-brick replay runs on the brick pipeline (k_seq_group), a wave per long run, a lane per short one (k_seq_replay); `value` = these frames behind an "
                     "empty pipeline (first-touch allocation excluded), `value_steady` = the frames that follow them in the stream, same map"}
+
+
+def default_exact_leg(dev, frames):
+    """The benchmarked default path against the oracle's BATCHED mode (its definition), bit for bit, on the first frames of the stream -- queued back to
+    back as host images and as device tensors, one synchronisation at the end, so phase A of a batch really runs beside phase B of the batch before."""
+    import torch
+    from oracle import BATCHED, OracleTSDF
+    from taichislam_amd.mapping import DenseTSDF
+    from taichislam_amd.utils import synthetic as syn
+    o = OracleTSDF(**C2)
+    o.set_intrinsics(syn.K_DEPTH)
+    for R, T, d in frames:
+        o.integrate_depth(R, T, d, mode=BATCHED)
+
+    def srt(e):
+        i = e["indices"].astype(np.int64)
+        k = np.argsort(((i[:, 0] + 32768) << 32) | ((i[:, 1] + 32768) << 16) | (i[:, 2] + 32768))
+        return {"indices": e["indices"][k], "TSDF": np.asarray(e["TSDF"])[k].view(np.uint16), "W_TSDF": np.asarray(e["W_TSDF"])[k].view(np.uint16), "occupy": e["occupy"][k]}
+    want, res, where = srt(o.export_sparse()), {}, {}
+    dd = [torch.from_numpy(d.view(np.int16)).cuda(dev) for _, _, d in frames]
+    for kind in ("device", "host"):
+        g = DenseTSDF(**C2, device=dev)
+        g.set_dep_camera_intrinsic(syn.K_DEPTH)
+        for (R, T, d), t in zip(frames, dd):
+            g.recast_depth_to_map(R, T, t if kind == "device" else d, None)
+        got = srt(g.export_submap())
+        res[kind] = all(got[k].shape == want[k].shape and np.array_equal(got[k], want[k]) for k in want)
+        if not res[kind]:
+            where[kind] = first_difference(got, want, ("TSDF", "W_TSDF", "occupy"), sensor_xyz=frames[-1][1], voxel_scale=C2["voxel_scale"])
+    return {"frames": len(frames), "voxels": int(want["indices"].shape[0]), "bit_exact_with_oracle_BATCHED": all(res.values()), "per_input": res, "differences": where or None,
+            "note": "semantics = 0 (the path `value` measures) == oracle BATCHED on every voxel index, TSDF / W bit and occupancy byte; frames queued back to back"}
 
 
 def envelope_leg():
@@ -245,16 +278,37 @@ def reference_source_leg(dev):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
     import test_ref_golden as tr
     from oracle import FAITHFUL
-    names, ora_ok, hip_ok, voxels = ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points", "blk10_two_submaps", "two_submaps_fused", "aligned_submap_fused"], [], [], 0
+    names, ora_ok, hip_ok, voxels, detail = ["depth_stream", "point_clouds", "weight_clamp", "textured", "textured_points", "blk10_two_submaps", "two_submaps_fused", "aligned_submap_fused"], {}, {}, 0, {}
     for name in names:
         cfg, K, Kc, steps, want = tr.load(name)
         keys = ("indices", "TSDF", "W_TSDF", "occupy") + (("color",) if "color" in want else ())
         same = lambda got: all(got[k].shape == want[k].shape and np.array_equal(got[k], want[k]) for k in keys)
-        ora_ok.append(bool(same(tr.replay(lambda over: tr._Ora({**cfg, **over}, K, Kc), steps, K, Kc, {"mode": FAITHFUL}, lambda g, m: g.o.fuse_submaps(m.o, mode=FAITHFUL)))))
-        hip_ok.append(bool(same(tr.replay(lambda over: tr._Hip({**cfg, **over, "device": dev}, K, Kc, 1), steps, K, Kc, {}, lambda g, m: g.m.fuse_submaps(m.m)))))
+        ora_ok[name] = bool(same(tr.replay(lambda over: tr._Ora({**cfg, **over}, K, Kc), steps, K, Kc, {"mode": FAITHFUL}, lambda g, m: g.o.fuse_submaps(m.o, mode=FAITHFUL))))
+        got = tr.replay(lambda over: tr._Hip({**cfg, **over, "device": dev}, K, Kc, 1), steps, K, Kc, {}, lambda g, m: g.m.fuse_submaps(m.m))
+        hip_ok[name] = bool(same(got))
+        if not hip_ok[name]:
+            detail[name] = first_difference(got, want, keys[1:])
         voxels += int(want["indices"].shape[0])
-    return {"vectors": names, "voxels": voxels, "oracle_FAITHFUL_bit_exact": all(ora_ok), "hip_semantics_1_bit_exact": all(hip_ok),
+    return {"vectors": names, "voxels": voxels, "oracle_FAITHFUL_bit_exact": all(ora_ok.values()), "hip_semantics_1_bit_exact": all(hip_ok.values()),
+            "per_vector": {n: {"oracle_FAITHFUL": ora_ok[n], "hip_semantics_1": hip_ok[n]} for n in names}, "differences": detail or None,
             "note": "golden maps made by the reference's dense_tsdf.py + mapping_common.py, imported unmodified and run on tools/ti_seq (not by Taichi itself)"}
+
+
+def first_difference(got, want, keys, sensor_xyz=None, voxel_scale=None):
+    """Where two sorted sparse exports differ: voxel counts, or per field the number of differing voxels, the first one and -- with a sensor position --
+    how far from the sensor the differing voxels lie (a false exactness flag has to say where)."""
+    if got["indices"].shape != want["indices"].shape or not np.array_equal(got["indices"], want["indices"]):
+        return {"voxel_sets_differ": True, "voxels_got": int(got["indices"].shape[0]), "voxels_want": int(want["indices"].shape[0])}
+    out = {}
+    for k in keys:
+        bad = np.nonzero(np.atleast_1d((got[k] != want[k]).reshape(got[k].shape[0], -1).any(axis=1)))[0]
+        if bad.size:
+            idx = want["indices"][bad].astype(np.int64)
+            out[k] = {"differing_voxels": int(bad.size), "first_index": idx[0].tolist(), "got_bits": np.atleast_1d(got[k][bad[0]]).tolist(), "want_bits": np.atleast_1d(want[k][bad[0]]).tolist()}
+            if sensor_xyz is not None and voxel_scale:
+                d = np.linalg.norm(idx * float(voxel_scale) - np.asarray(sensor_xyz, dtype=np.float64)[None, :], axis=1)
+                out[k]["distance_from_sensor_m_min_median_max"] = [float(d.min()), float(np.median(d)), float(d.max())]
+    return out
 
 
 def stored_counters():
@@ -523,6 +577,7 @@ def main():
         merge_timed_out = not merge_box["done"]
     merge = {"error": "timeout: the merge leg did not finish (first multi-rank run on hardware?)"} if merge_timed_out else merge_box["merge"]
 
+    parity_failed = False
     if rank == 0 or dry:
         fps = (1 if dry else world) * args.steps / dt
         # algorithmic bytes (SURVEY.md section 8d / DESIGN.md): phase A = 2*P_used + 24*P_valid, phase B = 9*U + V_pcl
@@ -598,6 +653,19 @@ def main():
                 out["reference_source_vectors"] = reference_source_leg(dev)
             except Exception as e:
                 out["reference_source_vectors"] = {"error": repr(e)[:200]}
+            try:
+                out["default_path_exact"] = default_exact_leg(dev, sample[:24])
+            except Exception as e:
+                out["default_path_exact"] = {"error": repr(e)[:200]}
+            # ONE word for every live exactness check of this run, at the top level of the line, and a non-zero exit code behind the line when it is
+            # false (a false flag three levels down stopped nobody)
+            checks = {"value_sequential.bit_exact_with_oracle_FAITHFUL": out["value_sequential"].get("bit_exact_with_oracle_FAITHFUL"),
+                      "reference_source_vectors.hip_semantics_1_bit_exact": out["reference_source_vectors"].get("hip_semantics_1_bit_exact"),
+                      "reference_source_vectors.oracle_FAITHFUL_bit_exact": out["reference_source_vectors"].get("oracle_FAITHFUL_bit_exact"),
+                      "default_path_exact.bit_exact_with_oracle_BATCHED": out["default_path_exact"].get("bit_exact_with_oracle_BATCHED")}
+            out["parity_checks"] = checks
+            out["parity_ok"] = all(v is True for v in checks.values())
+            parity_failed = not out["parity_ok"]
         emit(out)
     if merge_timed_out:
         sys.stderr.write("bench.py: merge leg timed out; leaving without further collectives\n"); real_stdout.flush()
@@ -605,6 +673,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.stderr.write("bench.py: a live exactness check FAILED (parity_ok false, see parity_checks in the line): exit code 3\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -58,10 +58,27 @@ def build_library(force=False, verbose=False):
             return LIB          # GPU box without a toolchain: use the prebuilt library that travelled with the repo
         raise RuntimeError("hipcc not found and no prebuilt libtaichislam_hip.so present")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [cc] + HIPCC_FLAGS + os.environ.get("TSL_EXTRA_FLAGS", "").split() + sources() + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one object per source, compiled side by side (the seven files take ~60 s one after the other), only the stale ones; then one link
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("TSL_EXTRA_FLAGS", "").split()
+    stamp = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    hdr_t = max(os.path.getmtime(h) for h in _deps() if not h.endswith(".hip"))
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            cmd = [cc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed on " + ", ".join(failed))
+    open(stamp, "w").write(" ".join(flags))
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"])
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -1307,6 +1307,7 @@ int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, i
     const long long ncand = (long long)nsrc * Q.cand;
     TSL_REQUIRE(ncand < (1ll << (29 - Q.cellbits)), "sequential fusion: too many source bricks for the replay key at this num_voxel_per_blk_axis");
     hipStream_t q = ms(g);
+    (void)hipGetLastError();                        // (rocPRIM returns the thread's last error: a stale one is not this call's)
     int rc;
     if (!g->fseq_ctr) { if ((rc = dev_alloc(g, (void**)&g->fseq_ctr, 64, 0))) return rc; }
     // 0. how many cells splat: sizes the tuple arrays (a worst-case allocation was ~0.9 GB per 1000 source bricks: ADVICE r3)

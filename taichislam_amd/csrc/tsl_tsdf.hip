@@ -552,13 +552,17 @@ static int launch_batch_t(tsl_tsdf* m)
     const int n = m->npend;
     if (n == 0) return TSL_OK;
     m->npend = 0;                                   // nothing below re-enters through ms()
+    // rocPRIM (and the checks below) read the THREAD's last HIP error, which any earlier call of the process may have left behind -- the caller's own
+    // HIP / torch calls included.  A stale error must not drop this batch: it is discarded here.
+    (void)hipGetLastError();
     m->last_batch_n = n;
     const int bi = m->cur;
     BatchHost& H = m->batch[bi];
     const bool serial = m->overlap == 0;
     {   // has the pipeline run dry?  (phase B of the batch issued last has completed)
         const BatchHost& L = m->batch[(bi + TSL_NBATCH - 1) % TSL_NBATCH];
-        if (!L.b_pending || hipEventQuery(L.b_done) == hipSuccess) m->ramp = 0; else if (m->ramp < 1000) ++m->ramp;
+        if (!L.b_pending || hipEventQuery(L.b_done) == hipSuccess) { m->ramp = 0; ++m->dry_launches; } else if (m->ramp < 1000) ++m->ramp;
+        m->shape_hash = (m->shape_hash ^ (uint32_t)n) * 16777619u;
     }
     hipStream_t sa = serial ? m->stream_ : H.st;
     // back-pressure: the host never runs more than TSL_INFLIGHT batches ahead of the device (bounded queues, bounded lifetime of the
@@ -625,7 +629,10 @@ static int launch_batch_t(tsl_tsdf* m)
         if (m->pend[0].variant == 2) {
             if (any) {
                 hipEvent_t ea = nullptr, eb = nullptr;
-                const bool timed = prof_slot(m, TSL_K_INTEGRATE, 1, &ea, &eb);
+                // (a timing slot is only taken where its events are attached to a dispatch: round 4 took one for the sequential branches as well and never
+                //  recorded it -- hipEventElapsedTime on it left "invalid resource handle" as the thread's last error, which the NEXT rocPRIM call,
+                //  of whatever handle, returned as its own: bench.py's first reference-source vector lost its frames that way)
+                const bool timed = !m->pend[0].seq && prof_slot(m, TSL_K_INTEGRATE, 1, &ea, &eb);
                 if (seq_bricks) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_seq_apply(m, B, m->pend[0], bi); prof_end(m); }
                 else if (m->pend[0].seq) { prof_begin(m, TSL_K_INTEGRATE); rc = launch_apply_sequential(m, B, m->pend[0]); prof_end(m); }
                 else if (split) {
@@ -661,7 +668,9 @@ int flush_pending(tsl_tsdf* m)
     if (rc && !m->deferred_rc) m->deferred_rc = rc;
     return rc;
 }
-hipStream_t ms(tsl_tsdf* m) { m->clean = false; (void)flush_pending(m); return m->stream_; }
+// (the first call behind a synchronisation also discards a stale "last error" of the thread -- the caller's own HIP / torch calls leave theirs there, and
+//  the launch checks below and rocPRIM would report it as this library's)
+hipStream_t ms(tsl_tsdf* m) { if (m->clean) (void)hipGetLastError(); m->clean = false; (void)flush_pending(m); return m->stream_; }
 
 static int batch_cap(const tsl_tsdf* m)
 { return (m->overlap > 0 && m->variant == 2 && m->P.group && (!m->semantics || m->seq_impl)) ? (m->overlap < TSL_NB ? m->overlap : TSL_NB) : 1; }
@@ -702,7 +711,10 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int
     if (S.pin_bytes < need) {
         if (S.pin) (void)hipHostFree(S.pin);
         S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr;
-        TSL_HIP(hipHostMalloc(&S.pin, need + need / 4, hipHostMallocMapped));
+        // COHERENT (fine-grained) host memory: the device reads it uncached, so what the host wrote before the batch was issued is what phase A
+        // sees.  With hipHostMallocMapped alone the kind of memory is the runtime's choice; TSL_PIN_LEGACY=1 is the developer A/B.
+        static const bool legacy = std::getenv("TSL_PIN_LEGACY") != nullptr;
+        TSL_HIP(hipHostMalloc(&S.pin, need + need / 4, legacy ? hipHostMallocMapped : (hipHostMallocMapped | hipHostMallocCoherent)));
         S.pin_bytes = need + need / 4;
         TSL_HIP(hipHostGetDevicePointer(&S.pin_dev, S.pin, 0));
     }
@@ -900,6 +912,7 @@ int tsl_device_count(int* n)
 static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
 {
     m->cfg = *cfg; m->device = device; m->bytes = 0;
+    (void)hipGetLastError();                        // (a stale error of the thread is not this handle's: rocPRIM's size queries below would return it)
     TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
     m->overlap = TSL_NB; m->last_set = 0;
     for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr; }
@@ -1121,12 +1134,15 @@ int tsl_tsdf_sync(tsl_tsdf* m)
 }
 int tsl_tsdf_memory_bytes(const tsl_tsdf* m, int64_t* b) { TSL_REQUIRE(m && b, "null"); *b = m->bytes; return TSL_OK; }
 
+// A batch that could not be issued (flush_pending inside ms()) leaves its error in deferred_rc: every entry point that hands results to the caller
+// reports it -- a reader must never return the map of frames that were silently dropped (round 5: an export of 0 voxels with status OK).
+static int take_deferred(tsl_tsdf* m) { const int rc = m->deferred_rc; m->deferred_rc = 0; return rc; }
 static int read_int(tsl_tsdf* m, const int* dev, int* out)
 {
     TSL_HIP(hipMemcpyAsync(m->h_ints, dev, sizeof(int), hipMemcpyDeviceToHost, ms(m)));
     TSL_HIP(hipStreamSynchronize(ms(m)));
     *out = m->h_ints[0];
-    return TSL_OK;
+    return take_deferred(m);
 }
 static int check_dev_err(tsl_tsdf* m) { (void)ms(m); return take_dev_err(m); }
 int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
@@ -1169,6 +1185,8 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
         return TSL_OK;
     }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
+    if (!std::strcmp(name, "batch_shape_hash")) { *value = (int)(m->shape_hash & 0x7fffffffu); return TSL_OK; }
+    if (!std::strcmp(name, "dry_launches")) { *value = m->dry_launches; return TSL_OK; }
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
     if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
@@ -1355,7 +1373,7 @@ int tsl_tsdf_count_active(tsl_tsdf* m, int64_t* n)
     TSL_HIP(hipMemcpyAsync(&v, tmp, sizeof(long long), hipMemcpyDeviceToHost, ms(m)));
     TSL_HIP(hipStreamSynchronize(ms(m)));
     *n = v;
-    return TSL_OK;
+    return take_deferred(m);
 }
 
 static int export_common(tsl_tsdf* m, int mode, int16_t* idx, uint16_t* t, uint16_t* w, int8_t* occ, uint16_t* col, int64_t cap, int64_t* n)
@@ -1507,6 +1525,7 @@ int tsl_tsdf_prof_query(tsl_tsdf* m, int kid, double* total_ms, int64_t* launche
         m->prof_free.push_back(s.a); m->prof_free.push_back(s.b);
     }
     m->prof.clear();
+    (void)hipGetLastError();                        // a pair that was never recorded must not leave its error behind for the next caller
     if (total_ms) *total_ms = m->prof_ms[kid];
     if (launches) *launches = m->prof_n[kid];
     m->prof_ms[kid] = 0.0; m->prof_n[kid] = 0;

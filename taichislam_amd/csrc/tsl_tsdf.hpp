@@ -279,6 +279,7 @@ struct tsl_tsdf {
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;
+    uint32_t shape_hash; int dry_launches;      // developer statistics: FNV hash over the sizes of the batches issued so far; batches issued into a dry pipeline
 };
 
 namespace tsl {
