@@ -472,7 +472,11 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
             for (int kk = 2; kk <= P2; kk <<= 1)
                 for (int j = kk >> 1; j > 0; j >>= 1) {
                     const bool local = j <= per;
-                    if (!local) __syncthreads();
+                    // (the explicit wait: behind a barrier-free stage the compiler's scoreboard takes the wave's LDS writes for done -- it emitted a bare
+                    //  s_barrier here, and a wave of the next stage read keys whose exchange was still in the LDS queue of another SIMD: a segment of
+                    //  the item lost and another one walked twice, one (frame, brick) in a few hundred batches -- round 5, tools/repro_r5.py benchlike,
+                    //  caught by TSL_SEQ_VERIFY's brute-force check)
+                    if (!local) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }
                     for (int u = lane; u < per; u += 64) {
                         const int t = wid * per + u;
                         const int i = 2 * t - (t & (j - 1)), ix = i + j;
@@ -552,6 +556,12 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
             }
         }
         SQ_TICK(3)
+        // The stash is GLOBAL memory written by one wave and read back by another behind the barrier below.  __syncthreads() only drains the LDS
+        // counter (the compiler's workgroup-scope release waits for lgkmcnt(0) alone: it counts on the CU's L1 to keep its waves' accesses in order),
+        // and on gfx950 a load of another wave did overtake a store still in flight: a few 128-byte lines of an item came back with the tuples the
+        // working set held three batches earlier -- one (frame, brick) in a few hundred batches with some tuples in the wrong voxel's run (round 5;
+        // tools/repro_r5.py benchlike).  Every storing wave therefore waits for its stores before it signals the barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---- run offsets of the brick's voxels for this item; a voxel's four counts become the quarters' first positions inside its run ----
         for (int i = tid; i < TSL_BRK3; i += SQ_NT) {
@@ -1020,6 +1030,113 @@ __global__ void __launch_bounds__(256) k_selftest_seqdiv(unsigned long long* bad
 }
 int selftest_seqdiv(unsigned long long* bad_dev) { hipLaunchKernelGGL(k_selftest_seqdiv, dim3(8192), dim3(256), 0, 0, bad_dev); return TSL_OK; }
 
+// Developer aid (TSL_SEQ_VERIFY=1; round 5's hunt for a one-brick-in-a-few-hundred-batches difference): an order-free checksum of every work item's run
+// offsets and replay tuples, taken behind k_seq_group on the batch's stream (stage 0), in front of the replay on the main stream (1) and behind it
+// (2).  Stages 1 and 2 compare with stage 0 and log what differs: { batch, frame | stage << 8, slot, 1: offsets 2: tuples }.
+struct SeqVerify { unsigned long long* sum; int* log; int log_cap; };      // sum: [TSL_NB][slot_cap][2]; log: [0] = entries, then int4 records
+__global__ void __launch_bounds__(256) k_seq_hash(BatchDev B, const SeqDev* __restrict__ SD, SeqVerify V, int stage, int batch_no)
+{
+    const int q = blockIdx.y;
+    if (q >= B.n) return;
+    const FrameDev& F = B.f[q];
+    const SeqDev S = SD[q];
+    if (F.counters[HDR_FAIL] != 0) return;
+    const int nitems = min(F.counters[HDR_SEQ_SLOTS], S.slot_cap);
+    __shared__ unsigned long long s_sum[2];
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint32_t* csr = S.csr + (size_t)it * SQ_CSR_STRIDE;
+        if (threadIdx.x < 2) s_sum[threadIdx.x] = 0ull;
+        __syncthreads();
+        unsigned long long a = 0ull, b = 0ull;
+        for (int i = threadIdx.x; i < SQ_CSR_UNSAFE + 1; i += 256) a += ((unsigned long long)csr[i] + 0x9E3779B97F4A7C15ull) * (unsigned long long)(2 * i + 1);
+        const uint32_t T = csr[TSL_BRK3], rb = csr[SQ_CSR_BASE];
+        const unsigned long long* tp = reinterpret_cast<const unsigned long long*>(S.tup + rb);
+        for (uint32_t i = threadIdx.x; i < T; i += 256) b += (tp[i] ^ 0xD6E8FEB86659FD93ull) * (unsigned long long)(2u * i + 1u);
+        a = (unsigned long long)wave_sum_ll((long long)a); b = (unsigned long long)wave_sum_ll((long long)b);
+        if (lane_id() == 0) { atomicAdd(&s_sum[0], a); atomicAdd(&s_sum[1], b); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long* rec = V.sum + ((size_t)q * S.slot_cap + it) * 2;
+            if (stage == 0) { rec[0] = s_sum[0]; rec[1] = s_sum[1]; }
+            else {
+                const int what = (rec[0] != s_sum[0] ? 1 : 0) | (rec[1] != s_sum[1] ? 2 : 0);
+                if (what) { const int e = atomicAdd(&V.log[0], 1); if (e < V.log_cap) reinterpret_cast<int4*>(V.log + 4)[e] = make_int4(batch_no, q | (stage << 8), it, what | ((int)T << 4)); }
+            }
+        }
+        __syncthreads();
+    }
+}
+// TSL_SEQ_VERIFY, second check: every item recomputed from its segment list by brute force -- per voxel the number of steps and an order-free sum over
+// their replay tuples -- and compared with what k_seq_group left (run lengths from the offsets, the same sum over the voxel's run).  Log record:
+// { batch, frame | 3 << 8, slot, voxel | (expected steps << 12) | (found << 22) }.
+__global__ void __launch_bounds__(256) k_seq_check(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, SeqVerify V, int batch_no)
+{
+    const int q = blockIdx.y;
+    if (q >= B.n) return;
+    const FrameDev& F = B.f[q];
+    const FrameParams& P = *B.p[q];
+    const SeqDev S = SD[q];
+    if (F.counters[HDR_FAIL] != 0) return;
+    const int nitems = min(F.counters[HDR_SEQ_SLOTS], S.slot_cap);
+    __shared__ uint32_t s_cnt[TSL_BRK3];
+    __shared__ uint32_t s_sum[TSL_BRK3];
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int4 item = S.items[it];
+        const unsigned long long* const src = (item.w ? F.seg : F.seg_sorted) + item.x;
+        const uint32_t* csr = S.csr + (size_t)item.z * SQ_CSR_STRIDE;
+        for (int i = threadIdx.x; i < TSL_BRK3; i += 256) { s_cnt[i] = 0u; s_sum[i] = 0u; }
+        __syncthreads();
+        for (int k = threadIdx.x; k < item.y; k += 256) {
+            const unsigned long long sg = src[k];
+            const int cnt = (int)(sg & 63ull), j0 = (int)((sg >> SEG_CNT_BITS) & 0xfffull), ray = (int)((sg >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1));
+            const uint4 rec = F.rayA[ray];
+            const float pf0 = h2f((h16)(rec.x & 0xffffu)), pf1 = h2f((h16)(rec.x >> 16)), pf2 = h2f((h16)(rec.y & 0xffffu));
+            const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
+            const float w = seq_w_of(seq_w_code(__uint_as_float(rec.w)));
+            const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];
+            for (int st = 0; st < cnt; ++st) {
+                const float jf = (float)(j0 + st);
+                const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];
+                const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));
+                const int l = (((i0 + M.hN) & 15) << 8) | (((i1 + M.hN) & 15) << 4) | ((i2 + M.hNz) & 15);
+                const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2f - x2;
+                const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
+                const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);
+                const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
+                const float sd = dist * (float)sgn_f(dot);
+                const float c = w * sd;
+                atomicAdd(&s_cnt[l], 1u);
+                atomicAdd(&s_sum[l], __float_as_uint(w) * 2654435761u + __float_as_uint(c) * 40503u + 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t rb = csr[SQ_CSR_BASE];
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const uint32_t a = csr[l], z = csr[l + 1];
+            uint32_t sum = 0u;
+            for (uint32_t t = a; t < z && t < a + 100000u; ++t) { const float2 x = S.tup[rb + t]; sum += __float_as_uint(x.x) * 2654435761u + __float_as_uint(x.y) * 40503u + 1u; }
+            if (z - a != s_cnt[l] || sum != s_sum[l]) {
+                const int e = atomicAdd(&V.log[0], 1);
+                if (e < V.log_cap) reinterpret_cast<int4*>(V.log + 4)[e] = make_int4(batch_no, q | (3 << 8), item.z, l | ((int)min(s_cnt[l], 1023u) << 12) | ((int)min(z - a, 1023u) << 22));
+            }
+        }
+        __syncthreads();
+    }
+}
+static bool seq_verify_on() { static const bool on = std::getenv("TSL_SEQ_VERIFY") != nullptr; return on; }
+static int launch_seq_hash(tsl_tsdf* m, const BatchDev& B, int bi, int stage, hipStream_t st)
+{
+    SeqVerify V = { static_cast<unsigned long long*>(m->seqv_sum[bi]), m->seqv_log, 4096 };
+    hipLaunchKernelGGL(k_seq_hash, dim3(512, B.n), dim3(256), 0, st, B, (const SeqDev*)(m->seq_d + bi * TSL_NB), V, stage, (int)m->batch_seq);
+    return TSL_OK;
+}
+int seq_verify_report(tsl_tsdf* m, int* out, int cap)      // out: [0] = mismatches logged, then 4 ints each
+{
+    if (!m->seqv_log) { out[0] = -1; return TSL_OK; }
+    TSL_HIP(hipMemcpy(out, m->seqv_log, sizeof(int) * (size_t)cap, hipMemcpyDeviceToHost));
+    return TSL_OK;
+}
+
 static int seq_ensure(tsl_tsdf* m)
 {
     if (m->seq_ready) return TSL_OK;
@@ -1054,6 +1171,10 @@ static int seq_ensure(tsl_tsdf* m)
         if ((rc = dev_alloc(m, &m->seqb_long[bi], sizeof(int4) * (size_t)SQ_LONG_CAP, 0))) return rc;
         if ((rc = dev_alloc(m, &m->seqb_lmask[bi], 8 * 64 * (size_t)PLAN_NCLS * m->fset[0].F.unit_cap, 0))) return rc;          // a word per wave of 64 voxels of every brick a batch can list
     }
+    if (seq_verify_on()) {
+        for (int bi = 0; bi < TSL_NBATCH; ++bi) if ((rc = dev_alloc(m, &m->seqv_sum[bi], 16 * (size_t)TSL_NB * m->seq_h[0].slot_cap, 0))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->seqv_log, sizeof(int) * (4 + 4 * 4096), 0))) return rc;
+    }
     TSL_HIP(hipStreamSynchronize(m->stream_));          // the fills ran on the main stream; the kernels below use the batch streams
     m->seq_ready = true;
     return TSL_OK;
@@ -1069,7 +1190,11 @@ void seq_release(tsl_tsdf* m)
         if (m->seqb_long[bi]) (void)hipFree(m->seqb_long[bi]);
         if (m->seqb_lmask[bi]) (void)hipFree(m->seqb_lmask[bi]);
         m->seqb_temp[bi] = nullptr; m->seqb_long[bi] = nullptr; m->seqb_lmask[bi] = nullptr;
+        if (m->seqv_sum[bi]) (void)hipFree(m->seqv_sum[bi]);
+        m->seqv_sum[bi] = nullptr;
     }
+    if (m->seqv_log) (void)hipFree(m->seqv_log);
+    m->seqv_log = nullptr;
     m->seq_ready = false;
 }
 
@@ -1097,6 +1222,11 @@ int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int 
     hipLaunchKernelGGL(k_seq_split, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     if (hp[0].tex) hipLaunchKernelGGL(k_seq_group<true>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
     else hipLaunchKernelGGL(k_seq_group<false>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    if (seq_verify_on()) {
+        launch_seq_hash(m, B, bi, 0, st);
+        SeqVerify V = { static_cast<unsigned long long*>(m->seqv_sum[bi]), m->seqv_log, 4096 };
+        hipLaunchKernelGGL(k_seq_check, dim3(512, B.n), dim3(256), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB), V, (int)m->batch_seq);
+    }
     // which voxels get a wave of their own in the replay, the frames' distinct-voxel counts: run lengths only, nothing of the map
     hipLaunchKernelGGL(k_seq_classify, dim3(16 * m->ncu), dim3(256), 0, st, B, (const SeqDev*)(m->seq_d + bi * TSL_NB), static_cast<int4*>(m->seqb_long[bi]),
                        static_cast<unsigned long long*>(m->seqb_lmask[bi]));
@@ -1116,8 +1246,10 @@ int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int b
         hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
         return TSL_OK;
     }
+    if (seq_verify_on()) launch_seq_hash(m, B, bi, 1, m->stream_);
     if (P.tex) hipLaunchKernelGGL(k_seq_replay<true>, dim3(nlong + nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
     else hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong + nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);
+    if (seq_verify_on()) launch_seq_hash(m, B, bi, 2, m->stream_);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }

@@ -11,6 +11,7 @@
 #include "tsl_tsdf.hpp"
 #include <rocprim/rocprim.hpp>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -1185,6 +1186,16 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
         return TSL_OK;
     }
     if (!std::strcmp(name, "fastdiv")) { *value = m->P.fastdiv; return TSL_OK; }
+    if (!std::strcmp(name, "seq_verify_mismatches")) {      // developer aid (TSL_SEQ_VERIFY=1): -1 when off; the records go to stderr
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        std::vector<int> buf(4 + 4 * 64);
+        rc = seq_verify_report(m, buf.data(), (int)buf.size()); if (rc) return rc;
+        *value = buf[0];
+        for (int e = 0; e < buf[0] && e < 64; ++e)
+            fprintf(stderr, "seq_verify: batch %d frame %d stage %d slot %d what %d T %d  (stage 3: voxel %d expected %d found %d)\n", buf[4 + 4 * e], buf[5 + 4 * e] & 255, buf[5 + 4 * e] >> 8, buf[6 + 4 * e], buf[7 + 4 * e] & 15, buf[7 + 4 * e] >> 4,
+                    buf[7 + 4 * e] & 4095, (buf[7 + 4 * e] >> 12) & 1023, (buf[7 + 4 * e] >> 22) & 1023);
+        return TSL_OK;
+    }
     if (!std::strcmp(name, "batch_shape_hash")) { *value = (int)(m->shape_hash & 0x7fffffffu); return TSL_OK; }
     if (!std::strcmp(name, "dry_launches")) { *value = m->dry_launches; return TSL_OK; }
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }

@@ -279,6 +279,7 @@ struct tsl_tsdf {
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;
+    void* seqv_sum[TSL_NBATCH]; int* seqv_log;      // TSL_SEQ_VERIFY (developer aid, tsl_sequential.hip): per-item checksums, mismatch log
     uint32_t shape_hash; int dry_launches;      // developer statistics: FNV hash over the sizes of the batches issued so far; batches issued into a dry pipeline
 };
 
@@ -301,5 +302,6 @@ int  launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int
 int  launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi);                       // tsl_sequential.hip, phase B of a batch: every voxel's runs applied in frame order
 void seq_release(tsl_tsdf* m);
 int  selftest_seqdiv(unsigned long long* bad_dev);
+int  seq_verify_report(tsl_tsdf* m, int* out, int cap);
 int  launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // tsl_sequential.hip: phase B of one frame, sequential semantics      // phase B, variant 2: apply a batch of frames (one launch)
 }

@@ -189,13 +189,16 @@ def main():
                 for R, T, d in frames[:40]:
                     g.recast_depth_to_map(R, T, d, None)
                 return g.export_submap()["TSDF"].shape[0]
-            nv = parity_like()                                   # (the handle is garbage now: a reference cycle, freed by the collector whenever it runs)
-            if rep % 2 == 0:
+            if not os.environ.get("BL_NOJUNK"):
+                nv = parity_like()                               # (the handle is garbage now: a reference cycle, freed by the collector whenever it runs)
+            if rep % 2 == 0 and not os.environ.get("BL_NOOMP"):
                 for R, T, d in frames[1:4]:
                     p.integrate_depth_mt(R, T, d, min(ncpu, 32))
             g = DenseTSDF(**C2, device=0)
             g.set_dep_camera_intrinsic(syn.K_DEPTH)
             g.set_option("semantics", 1)
+            for kv in os.environ.get("BL_OPTS", "").split():
+                g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
             dd = [torch.from_numpy(d.view(np.int16)).cuda(0) for _, _, d in frames]
             g.recast_depth_to_map(frames[0][0], frames[0][1], dd[0], None)
             g.sync()
@@ -208,7 +211,7 @@ def main():
             r = diff(e, want)
             shape = None
             try:
-                shape = [g.get_option("batch_shape_hash"), g.get_option("dry_launches")]
+                shape = [g.get_option("batch_shape_hash"), g.get_option("dry_launches"), g.get_option("seq_verify_mismatches")]
             except Exception:
                 pass
             say(stage="benchlike", rep=rep, fps=(NS - 1) / dt, shape=shape, **r)
@@ -216,6 +219,8 @@ def main():
                 bad = np.nonzero((e["TSDF"] != want["TSDF"]) | (e["W_TSDF"] != want["W_TSDF"]))[0]
                 np.savez(os.path.join(outdir, f"diff_rep{rep}.npz"), indices=want["indices"][bad], got_T=e["TSDF"][bad], got_W=e["W_TSDF"][bad], want_T=want["TSDF"][bad], want_W=want["W_TSDF"][bad])
             del g, dd
+            if rep % 10 == 9:
+                gc.collect()
     if "vec1" in stages:
         run_vectors("vec1")
     if "bisect" in stages:
