@@ -944,7 +944,8 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                             // Lanes before the first inconsistent one are thereby verified one after the other (each started from a true state), and so
                             // are that lane's inputs: its outputs are the true next state.  At Wmax, and where the weight has stalled below it, the
                             // candidate is W itself; while the weight still grows it is W + the increments rounded to W's f16 grid, summed over the lanes
-                            // before (a guess: ties, a binade crossed on the way or an inexact f32 sum only make a lane inconsistent, never the result wrong).
+                            // before (a guess: ties, a binade crossed on the way or an inexact f32 sum only make a lane inconsistent, never the result wrong:
+                            // INVARIANT -- lane i + 1 evaluates on exactly the f16 weight lane i is checked against).
                             uint32_t Tn, Wn, bad;
                             if (Wb == SQ_W_SAT) {                                  // (uniform)
                                 const float D = TSL_WMAX + x[g].x;
@@ -959,12 +960,16 @@ __device__ __forceinline__ void seq_role_long(const MapDev& M, const BatchDev& B
                                 float incl = inc;
 #pragma unroll
                                 for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-                                const float cand = fminf(Wf + (incl - inc), TSL_WMAX), candn = fminf(Wf + incl, TSL_WMAX);
-                                const uint32_t Wc = (uint32_t)f2h(cand);
+                                // the weight a lane EXPECTS to leave behind is, literally, the weight the next lane starts from (the value travels one lane
+                                // up; the first lane of `todo` starts from the true W): a lane whose result equals its expectation has thereby verified the
+                                // next lane's input, whatever the f32 prefix sums rounded to -- exact by construction, not by the sums being exact
+                                const uint32_t Wexp = (uint32_t)f2h(fminf(Wf + incl, TSL_WMAX));
+                                const uint32_t Wprev = (uint32_t)__shfl_up((int)Wexp, 1);
+                                const uint32_t Wc = lane == (int)__builtin_ctzll(todo) ? Wb : Wprev;
                                 const float D = h2f((h16)Wc) + x[g].x;
                                 Tn = seq_update_fast(Tr, Wc, x[g].y, D, 1.0f / D);                                        // :264
                                 Wn = (uint32_t)f2h(D > TSL_WMAX ? TSL_WMAX : D);                                          // :267
-                                bad = ((Tn ^ Tr) & 0xffffu) | (Wn ^ (uint32_t)f2h(candn));
+                                bad = ((Tn ^ Tr) & 0xffffu) | (Wn ^ Wexp);
                             }
                             const unsigned long long cm = __ballot(bad != 0u) & todo;
                             if (cm == 0ull) { Wb = (uint32_t)__builtin_amdgcn_readlane((int)Wn, 63 - (int)__builtin_clzll(todo)); break; }      // every update of the group verified: W as the last one left it

@@ -573,7 +573,10 @@ static int launch_batch_t(tsl_tsdf* m)
         TSL_HIP(hipEventSynchronize(m->ring_ev[ring]));
         if (m->ring_upto[ring] > m->frames_consumed) m->frames_consumed = m->ring_upto[ring];
     }
-    if (!serial && H.b_pending) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
+    // (TSL_FAULT_NO_BDONE_WAIT: fault injection for tests/test_pipeline_overlap_gpu.py -- without this wait phase A of a batch overwrites working sets the
+    //  replay three batches back still reads; the back-to-back parity tests must notice)
+    static const bool fault_no_wait = std::getenv("TSL_FAULT_NO_BDONE_WAIT") != nullptr;
+    if (!serial && H.b_pending && !fault_no_wait) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
     if (!serial && m->esdf_gate_set) {
         // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip).  The gate stays armed until every phase-A stream has waited for
         // it: the batch after next uses a third stream, which is ordered behind neither the update's stream nor the first waiter
@@ -1198,6 +1201,7 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
     }
     if (!std::strcmp(name, "batch_shape_hash")) { *value = (int)(m->shape_hash & 0x7fffffffu); return TSL_OK; }
     if (!std::strcmp(name, "dry_launches")) { *value = m->dry_launches; return TSL_OK; }
+    if (!std::strcmp(name, "overlapped_launches")) { *value = (int)m->batch_seq - m->dry_launches; return TSL_OK; }      // batches whose phase A was issued while phase B of the batch before was still pending
     if (!std::strcmp(name, "variant")) { *value = m->variant; return TSL_OK; }
     if (!std::strcmp(name, "split")) { *value = m->split; return TSL_OK; }
     set_error("unknown option"); return TSL_ERR_ARG;
