@@ -243,6 +243,28 @@ def default_exact_leg(dev, frames):
             "note": "semantics = 0 (the path `value` measures) == oracle BATCHED on every voxel index, TSDF / W bit and occupancy byte; frames queued back to back"}
 
 
+def configs_leg(dev, host, cpu=True):
+    """BASELINE.json's other single-GPU configurations as compact sub-legs of the default line, so that the driver's one command puts all of `configs` under
+    its clock: [0] marching cubes on the 128^3 sphere, [2] the stream into the Octomap 1024^3 / 5 cm, [3] TSDF + incremental ESDF every
+    frame + a mesh every 10th.  The full-length forms with their own lines: --config 1 / 3 / 4."""
+    from taichislam_amd.utils import bench_configs
+    out = {}
+    for key, config, steps, warmup in (("c1_marching_cubes_128", 1, 200, 20), ("c3_octomap_1024", 3, 100, 10), ("c4_tsdf_esdf_mesh", 4, 60, 10)):
+        try:
+            t0 = time.perf_counter()
+            line = bench_configs.run(config, steps, warmup, dev, host=host)
+            r = line.get("roofline") or {}
+            out[key] = {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "steps": steps, "warmup": warmup, "ms_per_step": line["ms_per_step"],
+                        "roofline": {"kernel": r.get("kernel"), "bound": "hbm", "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": "GB/s", "frac": r.get("frac"),
+                                     "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"), "avg_launch_us": r.get("avg_launch_us")},
+                        "detail": {k: v for k, v in line["config"].items() if k not in ("workload", "frame_stats")}, "leg_wall_s": time.perf_counter() - t0}
+            if cpu:
+                out[key]["cpu_baseline"] = cpu_baseline_config(config, budget_s=1.5)
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
+    return out
+
+
 def envelope_leg():
     """profiles/r04_parity_envelope.json (tools/parity_envelope.py, CPU only): the reference's own schedule-to-schedule spread on this stream and where the
     order-free default path lies in it.  A stored study of the ORACLE (it does not depend on the kernels): the default HIP path equals oracle BATCHED bit for bit."""
@@ -263,7 +285,7 @@ def envelope_leg():
             "by_distance_m": [{"from": x["from_m"], "to": x["to_m"], "n": x["n"], "default_inside_or_1ulp": x["batched_inside_or_1ulp"],
                                "a_schedule_inside_the_others_or_1ulp_min_mean_max": x["schedule_inside_others_or_1ulp_min_mean_max"],
                                "mean_abs_m_vs_float64_sequence": x.get("mean_abs_m_vs_float64_sequence")} for x in r["by_distance_from_the_sensor_path"]],
-            "verdict": "two legal schedules of dense_tsdf.py:239 (random ray orders) agree on 56 % of the TSDF bits after 77 frames -- the reference does not reproduce "
+            "verdict": f"two legal schedules of dense_tsdf.py:239 (random ray orders) agree on {100.0 * rnd['tsdf_bits_identical']:.0f} % of the TSDF bits after {int(key.split('_')[1])} frames -- the reference does not reproduce "
                        "itself within 1e-4; the order-free default path lies inside the schedules' envelope far from the sensor and OUTSIDE it within ~1 m of the "
                        "sensor path (one exact mean per frame instead of the in-frame W clamp and per-step f16 rounding), where it is the map closer to the float64 "
                        "sequence.  The conforming mode is semantics = 1 (value_sequential)"}
@@ -569,7 +591,7 @@ def main():
         merge_box["done"] = True
 
     merge_timed_out = False
-    if distributed or args.merge or dry:
+    if distributed or args.merge or dry or not args.no_cpu_baseline:          # (the default N = 1 line carries configs[4]'s one-GPU form as well)
         import threading
         th = threading.Thread(target=merge_leg, daemon=True)
         th.start()
@@ -653,6 +675,11 @@ def main():
                 out["reference_source_vectors"] = reference_source_leg(dev)
             except Exception as e:
                 out["reference_source_vectors"] = {"error": repr(e)[:200]}
+            try:
+                out["configs"] = configs_leg(dev, host)
+                out["configs"]["c5_merge_one_gpu"] = merge
+            except Exception as e:
+                out["configs"] = {"error": repr(e)[:200]}
             try:
                 out["default_path_exact"] = default_exact_leg(dev, sample[:24])
             except Exception as e:

@@ -252,19 +252,25 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 read-modify-write with the W clamp, colours by last writer; on a GLOBAL map: tsl_tsdf_fuse_submaps replays fuse_submaps_kernel
                 (dense_tsdf.py:272-318) the same way, submap cells in struct-for order, corners in loop order -- bit-exact with oracle FAITHFUL and
                 with the maps the reference's own source produces on tools/ti_seq (tests/golden/ref_*.npz); needs variant 2 and group 1, at
-                most 2^21 points per frame and maps of at most 2^17 bricks.  The integration follows the struct-for order for any num_voxel_per_blk_axis; the fusion
-                walks the submaps in 16^3-brick order, which is the reference's struct-for order when num_voxel_per_blk_axis is 16 and
-                another sequential schedule of the same racy kernel otherwise
+                most 2^21 points per frame and maps of at most 2^17 bricks.  Integration and fusion both follow the reference's struct-for order for any
+                num_voxel_per_blk_axis of the submaps, 4..32 (the fusion orders the source cells by the sorted list of the blocks their 16^3 storage bricks overlap).
+                Switching the mode on allocates the replay scratch of "seq_impl" 1 (an allocation failure is reported by this call)
      "seq_impl" how semantics 1 integrates.  1 (default): on the brick pipeline, whole batches -- behind phase A every (frame, brick) gets its
                 ray steps as 8-byte tuples, stably grouped by voxel in replay order (k_seq_group: LDS sort of the brick's segments by ray rank,
                 LDS counting sort of the steps by voxel), phase B is one thread per voxel applying its runs frame after frame (k_seq_replay);
-                memory: 2 x 8 bytes x "seq_tuple_cap" + 16 KiB x max_frame_bricks per working set, 24 working sets, allocated by the first
-                sequential frame.  0: round 3's form -- every ray step a 16-byte tuple, two global radix sorts, one frame per batch
+                memory: 2 x 8 bytes x "seq_tuple_cap" + 16 KiB x (max_frame_bricks + 1024) per working set, 24 working sets -- ~5.6 GB at the
+                defaults -- allocated when "semantics" is set to 1.  0: round 3's form -- every ray step a 16-byte tuple, two global radix sorts, one frame per batch
      "seq_longest_run" (get only) the longest run of updates of one voxel in a frame, summed over the frames of the batch issued last (the voxel next
                 to the sensor; a wave of its own settles it 64 updates per evaluation where its f16 state has stopped moving)
      "seq_long_voxels" (get only) voxels of the batch issued last that were replayed by a wave of their own (a run of >= 64 updates in a frame)
+     "overlapped_launches" / "dry_launches" (get only) batches issued while phase B of the batch before was still pending / into a pipeline that had run
+                dry: what the back-to-back parity tests assert on (tests/test_pipeline_overlap_gpu.py); "batch_shape_hash" (get only): FNV hash over the
+                sizes of the batches issued so far (two runs that batched the stream alike have the same hash)
+     "seq_verify_mismatches" (get only; developer aid, environment TSL_SEQ_VERIFY=1, else -1) literal mode: every (frame, brick) work item is recomputed by
+                brute force behind k_seq_group and its offsets / tuples are checksummed behind k_seq_group, in front of the replay and behind it;
+                the number of disagreements logged (records on stderr).  Found round 5's one-brick difference
      "seq_tuple_cap" ray steps one frame may produce under seq_impl 1 (default 2^23; a frame beyond it is dropped with TSL_ERR_CAPACITY);
-                set before the first sequential frame
+                synchronises; scratch that exists already is rebuilt at the new size
      "overlap"  0 = one frame at a time on the main stream, n = frames per batch (default and maximum 8; three batch slots: phase A of up to two
                 batches is in flight beside phase B of a third)
      "adaptive" 1 = queued frames are also issued as soon as phase A of the previous batch has completed (a slow sensor gets every frame

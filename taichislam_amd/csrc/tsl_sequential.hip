@@ -1174,7 +1174,7 @@ static int seq_ensure(tsl_tsdf* m)
         }
         if ((rc = dev_alloc(m, &m->seqb_temp[bi], m->seqb_temp_bytes, 0))) return rc;
         if ((rc = dev_alloc(m, &m->seqb_long[bi], sizeof(int4) * (size_t)SQ_LONG_CAP, 0))) return rc;
-        if ((rc = dev_alloc(m, &m->seqb_lmask[bi], 8 * 64 * (size_t)PLAN_NCLS * m->fset[0].F.unit_cap, 0))) return rc;          // a word per wave of 64 voxels of every brick a batch can list
+        if ((rc = dev_alloc(m, &m->seqb_lmask[bi], 8 * 64 * (size_t)PLAN_NCLS * TSL_NB * m->F.max_frame_bricks, 0))) return rc;          // a word per wave of 64 voxels of every brick a batch can list (unit_cap bricks per class)
     }
     if (seq_verify_on()) {
         for (int bi = 0; bi < TSL_NBATCH; ++bi) if ((rc = dev_alloc(m, &m->seqv_sum[bi], 16 * (size_t)TSL_NB * m->seq_h[0].slot_cap, 0))) return rc;
@@ -1183,6 +1183,14 @@ static int seq_ensure(tsl_tsdf* m)
     TSL_HIP(hipStreamSynchronize(m->stream_));          // the fills ran on the main stream; the kernels below use the batch streams
     m->seq_ready = true;
     return TSL_OK;
+}
+// the literal mode's scratch, allocated when the mode is switched on (tsl_tsdf_set_option: a failure is reported there, with nothing queued that could be
+// lost, and what was allocated is handed back -- ADVICE r4); the first sequential batch finds it ready
+int seq_prepare(tsl_tsdf* m)
+{
+    const int rc = seq_ensure(m);
+    if (rc) seq_release(m);
+    return rc;
 }
 void seq_release(tsl_tsdf* m)
 {
@@ -1207,7 +1215,7 @@ void seq_release(tsl_tsdf* m)
 int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int bi, hipStream_t st)
 {
     TSL_REQUIRE(hp[0].group && hp[0].variant == 2, "sequential semantics: the hash-grouped brick path (variant 2, group 1)");
-    int rc = seq_ensure(m); if (rc) return rc;
+    int rc = seq_prepare(m); if (rc) return rc;
     int stride = 0;
     for (int q = 0; q < B.n; ++q) stride = hp[q].total > stride ? hp[q].total : stride;
     if (stride <= 0) return TSL_OK;

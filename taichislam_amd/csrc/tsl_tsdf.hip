@@ -1583,6 +1583,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
         TSL_REQUIRE(value == 0 || (m->variant == 2 && m->P.group), "sequential semantics needs variant 2 and the hash grouping (group 1)");
         TSL_REQUIRE(value == 0 || m->F.max_points <= (1 << 21), "sequential semantics: at most 2^21 points per frame");
         int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        if (value && m->seq_impl && !m->cfg.is_global_map) { TSL_HIP(hipSetDevice(m->device)); rc = seq_prepare(m); if (rc) return rc; }      // ~5.6 GB of replay scratch at the default sizes (header)
         m->semantics = value; m->P.seq = value; return TSL_OK;
     }
     if (!std::strcmp(name, "seq_impl")) {
@@ -1591,8 +1592,15 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
         m->seq_impl = value; return TSL_OK;
     }
     if (!std::strcmp(name, "seq_tuple_cap")) {
-        TSL_REQUIRE(value >= (1 << 16) && !m->seq_ready, "seq_tuple_cap: at least 2^16 ray steps per frame, set before the first sequential frame");
-        m->seq_tuple_cap = value; return TSL_OK;
+        TSL_REQUIRE(value >= (1 << 16), "seq_tuple_cap: at least 2^16 ray steps per frame");
+        int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        m->seq_tuple_cap = value;
+        if (m->seq_ready) {          // the scratch exists already (allocated when the mode was switched on): it is rebuilt at the new size
+            TSL_HIP(hipSetDevice(m->device));
+            seq_release(m);
+            if (m->semantics && m->seq_impl) { rc = seq_prepare(m); if (rc) return rc; }
+        }
+        return TSL_OK;
     }
     if (!std::strcmp(name, "fastdiv")) { if (value == 0) m->P.fastdiv = 0; return TSL_OK; }
     if (!std::strcmp(name, "mesh_gather")) { m->mesh_gather = value != 0; return TSL_OK; }

@@ -301,6 +301,7 @@ int  launch_slab_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);
 int  launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int bi, hipStream_t st);      // tsl_sequential.hip, phase A tail: replay ranks of the rays, per-brick replay runs
 int  launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int bi);                       // tsl_sequential.hip, phase B of a batch: every voxel's runs applied in frame order
 void seq_release(tsl_tsdf* m);
+int  seq_prepare(tsl_tsdf* m);
 int  selftest_seqdiv(unsigned long long* bad_dev);
 int  seq_verify_report(tsl_tsdf* m, int* out, int cap);
 int  launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P);      // tsl_sequential.hip: phase B of one frame, sequential semantics      // phase B, variant 2: apply a batch of frames (one launch)

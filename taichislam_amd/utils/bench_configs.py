@@ -31,7 +31,8 @@ def _roof(kernel, alg_bytes, us, note):
             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": us, "note": note}
 
 
-def run(config, steps, warmup, dev):
+def run(config, steps, warmup, dev, host=None):
+    """`host`: frames of the stream made by the caller (bench.py's default line runs the configurations as compact sub-legs over its own frames)"""
     import torch
     from taichislam_amd import _lib
     from taichislam_amd.mapping import DenseTSDF, MarchingCubeMesher, Octomap
@@ -58,7 +59,7 @@ def run(config, steps, warmup, dev):
                      "BASELINE configs[0]: analytic sphere SDF r = 1.5 m in a 128^3 / 5 cm map (100^3 observed voxels), generate_mesh(1), count read back per call",
                      {"observed_voxels": a, "triangles": tri}, _roof("tsl::k_marching_cubes_lds", 3 * a + 72 * tri, us, "3 B per scanned voxel + 72 B per triangle"))
     nframes = warmup + steps
-    host = list(syn.sphere_room_stream(nframes))
+    host = list(host[:nframes]) if host is not None and len(host) >= nframes else list(syn.sphere_room_stream(nframes))
     depth_dev = torch.from_numpy(np.stack([d for _, _, d in host]).view(np.int16)).cuda(dev)
     if config == 3:
         oc = Octomap(map_scale=[51.2, 51.2], voxel_scale=0.05, K=2, max_ray_length=5.0, max_submap_num=4, device=dev)
