@@ -10,6 +10,7 @@
 //   K5 k_finalize                             : one weighted running-average update per touched voxel
 #include "tsl_tsdf.hpp"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -505,6 +506,24 @@ static PoseF pose_of(const tsl_tsdf* m, int s)
     return B;
 }
 
+// Host inputs of a batch: pinned (device-mapped) buffer -> device staging buffer, 16 bytes per lane, at the head of the batch's phase A.  Round 4 let
+// k_voxelize_depth read the pinned buffer in place: 2 bytes per lane in 16 x 16 pixel tiles, i.e. 32-byte reads across the host link -- 117 us per
+// batch against 31 us from device memory.  One launch per batch, no copy call, no event on the way in.
+__global__ void __launch_bounds__(256) k_stage_host(StageCopy C)
+{
+    const int k = blockIdx.y;
+    const int n = C.n16[k];
+    const uint4* __restrict__ src = C.src[k];
+    uint4* __restrict__ dst = C.dst[k];
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {      // four independent 16-byte loads per lane in flight
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = i + u * 256; v[u] = j < n ? src[j] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = i + u * 256; if (j < n) dst[j] = v[u]; }
+    }
+}
+
 // per-frame prologue of a working set: publish the frame's parameters, clear stats | nrays | counters (256 bytes)
 __global__ void k_set_params(ParamPack PP, SetPtrs S)
 {
@@ -603,6 +622,24 @@ static int launch_batch_t(tsl_tsdf* m)
     SetPtrs SP;                                     // (the parameter blocks and the working sets together exceed the 4 KiB of kernel arguments)
     for (int q = 0; q < TSL_NB; ++q) { SP.p[q] = const_cast<FrameParams*>(B.p[q]); SP.header[q] = reinterpret_cast<int*>(B.f[q].stats); }
     hipLaunchKernelGGL(k_set_params, dim3(n), dim3(64), 0, sa, PP, SP);
+    {   // host inputs: out of the pinned buffers, into the sets' device staging buffers (the frames' parameters already point there)
+        StageCopy C; int most = 0; bool any_host = false;
+        for (int q = 0; q < TSL_NB; ++q) {
+            FSet& S = m->fset[bi * TSL_NB + q];
+            const bool on = q < n;
+            C.src[2 * q] = static_cast<const uint4*>(S.pin_dev); C.dst[2 * q] = static_cast<uint4*>(S.stage_in); C.n16[2 * q] = on ? (int)((S.copy_in + 15) / 16) : 0;
+            C.src[2 * q + 1] = reinterpret_cast<const uint4*>(static_cast<const char*>(S.pin_dev) + S.copy_tex_off); C.dst[2 * q + 1] = static_cast<uint4*>(S.stage_tex); C.n16[2 * q + 1] = on ? (int)((S.copy_tex + 15) / 16) : 0;
+            most = std::max(most, std::max(C.n16[2 * q], C.n16[2 * q + 1]));
+            any_host = any_host || C.n16[2 * q] || C.n16[2 * q + 1];
+            if (on) { S.copy_in = 0; S.copy_tex = 0; }
+        }
+        if (any_host) {
+            prof_begin(m, TSL_K_VOXELIZE, sa);
+            hipLaunchKernelGGL(k_stage_host, dim3(std::min(64, (most + 1023) / 1024), 2 * n), dim3(256), 0, sa, C);
+            prof_end(m, sa);
+            if (!serial) { TSL_HIP(hipEventRecord(H.c_done, sa)); H.c_recorded = true; }
+        }
+    }
     if (m->phases & 1) { int rc = enqueue_phase_a<K>(m, B, m->pend, sa); if (rc) return rc; }
     const bool seq_bricks = m->pend[0].seq && m->seq_impl && m->pend[0].variant == 2;
     if (seq_bricks && (m->phases & 1)) { int rc = launch_seq_group(m, B, m->pend, bi, sa); if (rc) return rc; }      // sequential semantics: replay runs per (frame, brick), still map-independent
@@ -708,8 +745,9 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int
     const size_t in_bytes = out_row * (size_t)rows;
     FSet& S = m->fset[si];
     BatchHost& H = m->batch[si / TSL_NB];
+    // the pinned buffer is free again once the copy kernel of the slot's previous batch has run (round 4 read it in place during all of phase A)
     if (m->overlap == 0) TSL_HIP(hipStreamSynchronize(m->stream_));          // one frame at a time on the main stream: nothing else orders the set's previous reader
-    else if (H.a_recorded) TSL_HIP(hipEventSynchronize(H.a_done));            // phase A of the slot's previous batch read these buffers
+    else if (H.c_recorded) TSL_HIP(hipEventSynchronize(H.c_done));
     const size_t tex_off = (in_bytes + 255) & ~(size_t)255;
     const size_t need = tex_off + ((tex && tex_bytes) ? tex_bytes : 0) + 256;
     if (S.pin_bytes < need) {
@@ -733,8 +771,16 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int
         if (rows > 1 && src_pitch != row_bytes) { for (int r = 0; r < rows; ++r) std::memcpy(pin + (size_t)r * row_bytes, static_cast<const char*>(in) + (size_t)r * src_pitch, row_bytes); }
         else std::memcpy(pin, in, in_bytes);
     }
-    *in_dev = S.pin_dev; *tex_dev = nullptr;
-    if (tex && tex_bytes) { std::memcpy(pin + tex_off, tex, tex_bytes); *tex_dev = static_cast<char*>(S.pin_dev) + tex_off; }
+    // device staging buffers of the set (phase A of the slot's previous batch reads them until a_done: they are only re-allocated behind it)
+    const size_t in16 = (in_bytes + 15) & ~(size_t)15, tex16 = ((tex && tex_bytes) ? tex_bytes + 15 : 0) & ~(size_t)15;
+    if (S.stage_in_bytes < in16 || S.stage_tex_bytes < tex16) {
+        if (m->overlap != 0 && H.a_recorded) TSL_HIP(hipEventSynchronize(H.a_done));
+        int rc = grow(&S.stage_in, &S.stage_in_bytes, in16); if (rc) return rc;
+        if (tex16) { rc = grow(&S.stage_tex, &S.stage_tex_bytes, tex16); if (rc) return rc; }
+    }
+    *in_dev = S.stage_in; *tex_dev = nullptr;
+    S.copy_in = in_bytes; S.copy_tex = 0; S.copy_tex_off = tex_off;
+    if (tex && tex_bytes) { std::memcpy(pin + tex_off, tex, tex_bytes); *tex_dev = S.stage_tex; S.copy_tex = tex_bytes; }
     return TSL_OK;
 }
 
@@ -919,8 +965,8 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     (void)hipGetLastError();                        // (a stale error of the thread is not this handle's: rocPRIM's size queries below would return it)
     TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
     m->overlap = TSL_NB; m->last_set = 0;
-    for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr; }
-    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.p_done = nullptr; H.b_pending = false; H.a_recorded = false; }
+    for (auto& S : m->fset) { S.sort_temp = nullptr; S.header = nullptr; S.Pd = nullptr; S.stage_in = nullptr; S.stage_in_bytes = 0; S.stage_tex = nullptr; S.stage_tex_bytes = 0; S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr; S.copy_in = S.copy_tex = S.copy_tex_off = 0; }
+    for (auto& H : m->batch) { H.st = nullptr; H.a_done = nullptr; H.b_done = nullptr; H.p_done = nullptr; H.c_done = nullptr; H.b_pending = false; H.a_recorded = false; H.c_recorded = false; }
     m->frames_issued = 0; m->frames_consumed = 0; m->batch_seq = 0;
     for (int k = 0; k < TSL_INFLIGHT; ++k) { m->ring_ev[k] = nullptr; m->ring_upto[k] = 0; }
     m->cur = 0; m->npend = 0; m->pend_points = 0; m->deferred_rc = 0;
@@ -1013,6 +1059,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
         if (bi < TSL_NSTREAMS) TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking)); else H.st = m->batch[bi % TSL_NSTREAMS].st;
         TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
         TSL_HIP(hipEventCreateWithFlags(&H.p_done, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&H.c_done, hipEventDisableTiming));
     }
     for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], hipEventDisableTiming));
     TSL_HIP(hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking));
@@ -1070,6 +1117,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
         if (H.st && bi < TSL_NSTREAMS) (void)hipStreamDestroy(H.st);
         if (H.a_done) (void)hipEventDestroy(H.a_done);
         if (H.p_done) (void)hipEventDestroy(H.p_done);
+        if (H.c_done) (void)hipEventDestroy(H.c_done);
     }
     for (auto& S : m->fset) {
 

@@ -202,7 +202,8 @@ struct ProfSlot { hipEvent_t a, b; int kid; int count; };
 struct FSet {
     FrameDev F; void* sort_temp; void* header; size_t header_bytes;
     void* stage_in; size_t stage_in_bytes; void* stage_tex; size_t stage_tex_bytes;      // staging of host-pointer inputs of the frame queued into this set
-    void* pin; size_t pin_bytes; void* pin_dev;      // pinned, device-mapped host buffer the host copies the visited rows (and the texture) of a host-pointer input into; phase A reads it in place
+    void* pin; size_t pin_bytes; void* pin_dev;      // pinned, device-mapped host buffer the host copies the visited rows (and the texture) of a host-pointer input into
+    size_t copy_in, copy_tex, copy_tex_off;          // bytes of the queued frame's input / texture waiting in `pin` for the batch's copy kernel (0: a device input)
     FrameParams* Pd;                       // this frame's parameters in device memory (written by the frame's prologue kernel)
     std::vector<void*> owned;
 };
@@ -210,7 +211,8 @@ struct FSet {
 struct BatchDev { FrameDev f[TSL_NB]; const FrameParams* p[TSL_NB]; int n; };
 struct ParamPack { FrameParams p[TSL_NB]; };
 struct SetPtrs { FrameParams* p[TSL_NB]; int* header[TSL_NB]; };        // k_set_params: where the parameters go, the headers to clear
-struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done, p_done; bool b_pending, a_recorded; };      // p_done: the batch's parts-only brick launch (split launches)
+struct BatchHost { hipStream_t st; hipEvent_t a_done, b_done, p_done, c_done; bool b_pending, a_recorded, c_recorded; };      // p_done: the batch's parts-only brick launch (split launches); c_done: its host inputs have left the pinned buffers
+struct StageCopy { const uint4* src[2 * TSL_NB]; uint4* dst[2 * TSL_NB]; int n16[2 * TSL_NB]; };      // k_stage_host: per frame of the batch its input and its texture, in 16-byte units
 #define TSL_INFLIGHT 8          // batches the host may run ahead of the device
 
 int fuse_submaps_sequential(tsl_tsdf* g, tsl_tsdf* sub, const float* pose_dev, int nsrc);      // tsl_sequential.hip
