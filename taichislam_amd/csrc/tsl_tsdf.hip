@@ -1052,16 +1052,21 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
         F.seg_cap = (int)(cap > (1ll << 30) ? (1ll << 30) : cap);
     }
     if ((rc = sort_temp_size(m, &m->sort_temp_bytes))) return rc;
+    // The pipeline's events order streams of ONE device against each other (and tell the host that a batch has finished, nothing about memory): they
+    // need no system-scope fence -- the cache write-back + invalidate a default event adds when it is recorded sat between k_apply_slab of a batch and
+    // the brick kernel of the next (round 5, TSL_EV_SYS=1 restores the default for A/B).  Results reach the host through stream synchronisations and copies.
+    static const bool ev_sys = std::getenv("TSL_EV_SYS") != nullptr;
+    const unsigned evf = hipEventDisableTiming | (ev_sys ? 0u : (unsigned)hipEventDisableSystemFence);
     for (int bi = 0; bi < TSL_NBATCH; ++bi) {
         BatchHost& H = m->batch[bi];
         // more batch slots than streams: the device runs four hardware queues efficiently (main + TSL_NSTREAMS), a slot beyond that shares
         // the stream of slot bi - TSL_NSTREAMS (its phase A is ordered behind that slot's, which is two or three batches older)
         if (bi < TSL_NSTREAMS) TSL_HIP(hipStreamCreateWithFlags(&H.st, hipStreamNonBlocking)); else H.st = m->batch[bi % TSL_NSTREAMS].st;
-        TSL_HIP(hipEventCreateWithFlags(&H.a_done, hipEventDisableTiming));
-        TSL_HIP(hipEventCreateWithFlags(&H.p_done, hipEventDisableTiming));
-        TSL_HIP(hipEventCreateWithFlags(&H.c_done, hipEventDisableTiming));
+        TSL_HIP(hipEventCreateWithFlags(&H.a_done, evf));
+        TSL_HIP(hipEventCreateWithFlags(&H.p_done, evf));
+        TSL_HIP(hipEventCreateWithFlags(&H.c_done, evf));
     }
-    for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < TSL_INFLIGHT; ++k) TSL_HIP(hipEventCreateWithFlags(&m->ring_ev[k], evf));
     TSL_HIP(hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking));
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     TSL_HIP(hipHostMalloc((void**)&m->h_ints, sizeof(long long) * 256, hipHostMallocDefault));
