@@ -123,8 +123,10 @@ int  tsl_tsdf_queued_frames(const tsl_tsdf* m, int32_t* n);
  * library never queues more than eight batches (64 frames) ahead of the device -- the integrate call that would exceed that waits for
  * the oldest batch -- and that wait, like every synchronising call, advances the count. */
 int  tsl_tsdf_frames_consumed(tsl_tsdf* m, int64_t* queued_total, int64_t* consumed);
-/* The integrate calls only QUEUE the frame (host buffers are copied before they return; device buffers must stay unchanged until
- * the next call that returns data, or tsl_tsdf_sync).  Queued frames are issued eight at a time (four for the first two batches after the pipeline ran dry), or as soon
+/* The integrate calls only QUEUE the frame (host buffers are copied before they return -- the visited pixels of a depth image, the points, the texture,
+ * into a pinned buffer of the frame's working set, from where ONE copy kernel per batch takes them to device memory at the head of the batch;
+ * device buffers must stay unchanged until the next call that returns data, or tsl_tsdf_sync).  A batch that could not be issued (an allocation
+ * or launch failure) is reported by the next call that returns data or synchronises -- never by a map that silently lacks its frames.  Queued frames are issued eight at a time (four for the first two batches after the pipeline ran dry), or as soon
  * as any other call needs the map (option "adaptive": also as soon as the device is ready for them), so results never depend on the queueing; frames still queued when a handle is destroyed are dropped. */
 /* counters of the most recent integrate call (synchronises) */
 int  tsl_tsdf_last_frame_stats(tsl_tsdf* m, tsl_frame_stats* out);

@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
     uint32_t* const s_pre = s_sr + SQ_SORTCAP;                   //   after the sort, [2048, 4096): replay position of its first step 17 | first step 12
     uint32_t* const s_hist = s_sr;                               //   after the walk, all of it: tuples per voxel -> run offsets
     __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, its tuples in each quarter of the replay sequence (16 bits each) -> the quarters' cursors
-    __shared__ unsigned short s_perm[SQ_SORTCAP];                //  4 KiB: the sorted segments by length, longest first
+    __shared__ __attribute__((aligned(8))) unsigned short s_perm[SQ_SORTCAP];      //  4 KiB: the sorted segments by length, longest first (before that: the sample sort's splitters)
     __shared__ int s_bin[64];
     __shared__ uint32_t s_w[4];
     __shared__ unsigned long long s_rb;
@@ -451,6 +451,75 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
             rk[r] = sg[r] != ~0ull ? rank_of_ray[(sg[r] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1)] : 0u;
         for (int i = tid; i < TSL_BRK3; i += SQ_NT) s_pack[i] = 0ull;
         if (tid < 64) s_bin[tid] = 0;
+#ifndef TSL_SEQ_BITONIC
+        // ---- the segments in replay order: a SAMPLE SORT (round 5).  The bitonic network that stood here took 27 % of the kernel -- ~55 dependent LDS
+        //      round trips per item at three waves per SIMD (and needed an explicit wait in front of its barriers, see the #else branch).  Now: 64 of the
+        //      keys, sorted by one wave in registers (21 shuffle stages), cut the key space into 64 buckets; a key finds its bucket by a binary search in
+        //      the 63 splitters and its place in the bucket with one LDS add, the buckets are laid out by a 64-entry scan, and a key's final position is
+        //      its bucket's start + the number of smaller keys in the bucket (~m / 64 of them): seven barriers, ~12 dependent round trips.  Any splitters
+        //      give the sorted order (the bucket of a key is monotone in the key, keys are distinct); bad ones only make a bucket long.
+        unsigned long long key[SQ_SORTCAP / SQ_NT];
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
+            const int k = r * SQ_NT + tid;
+            key[r] = ~0ull;
+            if (k < m) {
+                const unsigned long long ray = (sg[r] >> (SEG_CNT_BITS + SEG_J_BITS)) & ((1u << STG_RAY_BITS) - 1);
+                key[r] = ((unsigned long long)rk[r] << 40) | (((sg[r] >> SEG_CNT_BITS) & 0xfffull) << 28) | ((sg[r] & 63ull) << 22) | ray;
+                s_seg[k] = key[r];
+            }
+        }
+        SQ_TICK(0)
+        __syncthreads();
+        unsigned long long* const s_spl = reinterpret_cast<unsigned long long*>(s_perm);      // (free until the length bins are filled)
+        if (wid == 0) {
+            unsigned long long v = s_seg[((uint32_t)lane * (uint32_t)m) >> 6];
+            for (int kk = 2; kk <= 64; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j) << 32) | (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)v, j);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                    v = keep_min ? (o < v ? o : v) : (o > v ? o : v);
+                }
+            s_spl[lane] = v;                                       // ascending; s_spl[1..63] are the splitters
+        }
+        __syncthreads();
+        int bkt[SQ_SORTCAP / SQ_NT], bpos[SQ_SORTCAP / SQ_NT];
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
+            bkt[r] = 0; bpos[r] = 0;
+            if (r * SQ_NT + tid < m) {
+                int lo = 0;                                        // splitters <= key
+#pragma unroll
+                for (int step = 32; step; step >>= 1) { const int idx = lo + step; if (idx <= 63 && s_spl[idx] <= key[r]) lo = idx; }
+                bkt[r] = lo; bpos[r] = atomicAdd(&s_bin[lo], 1);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int cb = s_bin[tid]; int inc = cb;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+            s_bin[tid] = inc - cb;                                 // first place of the bucket
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) if (r * SQ_NT + tid < m) s_seg[s_bin[bkt[r]] + bpos[r]] = key[r];
+        __syncthreads();
+        int fin[SQ_SORTCAP / SQ_NT];
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
+            fin[r] = 0;
+            if (r * SQ_NT + tid < m) {
+                const int o = s_bin[bkt[r]], e = bkt[r] == 63 ? m : s_bin[bkt[r] + 1];
+                int c = 0;
+                for (int i = o; i < e; ++i) c += s_seg[i] < key[r] ? 1 : 0;
+                fin[r] = o + c;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) if (r * SQ_NT + tid < m) s_seg[fin[r]] = key[r];
+        if (tid < 64) s_bin[tid] = 0;                              // the length bins below start from zero
+#else   // the first form (developer A/B: -DTSL_SEQ_BITONIC)
 #pragma unroll
         for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
             const int k = r * SQ_NT + tid;
@@ -488,6 +557,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
                     else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
                 }
         }
+#endif
         SQ_TICK(1)
         __syncthreads();
         // ---- replay positions (prefix of the step counts, sorted order); the segments by length ----
