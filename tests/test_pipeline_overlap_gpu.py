@@ -6,7 +6,7 @@ submap_mapping.py:171-181) -- one synchronisation, THEN the oracle: >= 100 frame
 literal path (== oracle FAITHFUL), host images and device tensors, the small stream with readers in between; the library reports how many batches were issued
 into a busy pipeline (`overlapped_launches`).  And the two failures round 4's bench line carried without anyone noticing, as tests:
   * a stale HIP error of the thread (left by an unrecorded timing event, or by the caller's own HIP calls) must not cost a batch its frames;
-  * the literal stream repeated in one process beside garbage handles (bench.py's process history) is exact every time -- 3.5 % of the runs were not while
+  * the literal stream repeated in one process beside garbage handles (bench.py's process history) is exact every time -- 3.7 % of the runs were not while
     k_seq_group's bitonic network signalled a barrier with LDS writes in flight.
 The fault-injection test shows the suite is sensitive: with the batch slot's "phase B has read the sets" wait removed the same comparison fails."""
 import ctypes
