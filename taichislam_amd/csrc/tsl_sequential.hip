@@ -545,7 +545,11 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
                     //  s_barrier here, and a wave of the next stage read keys whose exchange was still in the LDS queue of another SIMD: a segment of
                     //  the item lost and another one walked twice, one (frame, brick) in a few hundred batches -- round 5, tools/repro_r5.py benchlike,
                     //  caught by TSL_SEQ_VERIFY's brute-force check)
+#ifdef TSL_SEQ_BITONIC_NOWAIT      // (round 4's form, kept so that tests/test_barrier_scan_cpu.py can show the scanner the bare s_barrier)
+                    if (!local) __syncthreads();
+#else
                     if (!local) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }
+#endif
                     for (int u = lane; u < per; u += 64) {
                         const int t = wid * per + u;
                         const int i = 2 * t - (t & (j - 1)), ix = i + j;
