@@ -200,6 +200,10 @@ int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P
 // =====================================================================================================================================
 #define SQ_NT 256
 #define SQ_SORTCAP 2048           // segments sorted in LDS at a time
+#ifndef SQ_CHUNKSEGS
+#define SQ_CHUNKSEGS 2048         // segments of a CHUNK of a heavy brick (k_seq_split).  The chunks of the bricks next to the sensor are the longest items of k_seq_group's
+#endif                            //   launch (300-350 us beside 45 us for the median item); chunks of 1 024 shorten that launch (484 -> 436 us alone) but double the slots the
+                                  //   replay walks per voxel there: replay 830 -> 1 080 us per batch, 7 150 -> 6 760 frames/s in a stream (round 5) -- so the sort buffer it is
 #define SQ_BSHIFT 8               // rank bucket of a heavy brick = rank >> 8: 256 rays, at most 8 segments per ray and brick (lanes per ray) = SQ_SORTCAP
 #define SQ_NBK_MAX 8192           // rank buckets (aliases the 32 KiB of the packed counters): 2 M rays per frame
 #define SQ_TUP_L_SHIFT 32
@@ -316,6 +320,7 @@ __global__ void __launch_bounds__(256) k_seq_ranks(BatchDev B, const uint32_t* _
 // that IS the replay order.  (One workgroup per heavy brick took ~0.9 ms for the brick around the sensor; its chunks now run side by side.)
 #define SQ_SLOT_BITS 20
 #define SQ_CHUNK_MAX 1024
+#define SQ_HEAVY 1024             // k_seq_group claims the items with more segments than this first
 __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
 {
     const int q = blockIdx.y;
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const
         const int n = F.bnseg[b], off = F.boffset[b];
         if (tid == 0) { F.bhist[b] = 0; F.bcursor[b] = 0; }                            // the set's per-brick words are zero between frames
         if (failed || n <= 0) { if (tid == 0) F.bslab[b] = 0; continue; }               // (uniform) nothing of a frame that overflowed its scratch is integrated
-        if (n <= SQ_SORTCAP) {
+        if (n <= SQ_CHUNKSEGS) {
             if (tid == 0) {
                 const int slot = __hip_atomic_fetch_add(&F.counters[HDR_SEQ_SLOTS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (slot >= S.slot_cap) { frame_fail(M, F, 4); F.bslab[b] = 0; }
@@ -368,10 +373,10 @@ __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const
             s_ch[0] = 0u;
             for (int k = 0; k < nbk && !bad; ++k) {
                 const uint32_t e = s_bk[k];
-                if (e - start > (uint32_t)SQ_SORTCAP) {
-                    if (prev == start || nch + 1 >= SQ_CHUNK_MAX) { bad = true; break; }      // one bucket beyond the sort buffer (more than 8 segments per ray and brick) / too many chunks
-                    s_ch[++nch] = prev; start = prev;
-                    if (e - start > (uint32_t)SQ_SORTCAP) { bad = true; break; }
+                if (e - start > (uint32_t)SQ_CHUNKSEGS) {
+                    // (a single bucket may exceed the chunk size -- it then is a chunk of its own -- but not the sort buffer)
+                    if (prev != start) { if (nch + 1 >= SQ_CHUNK_MAX) { bad = true; break; } s_ch[++nch] = prev; start = prev; }
+                    if (e - start > (uint32_t)SQ_SORTCAP) { bad = true; break; }      // one bucket beyond the sort buffer (more than 8 segments per ray and brick)
                 }
                 prev = e;
             }
@@ -403,13 +408,8 @@ __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const
 //   * the counting sort has no barrier at all: wave w owns quarter w of the tuple sequence, the walk has counted every voxel's tuples per quarter
 //     (four 16-bit fields of one LDS word), so a wave's cursor for a voxel starts behind the earlier quarters' tuples and only that wave moves it.
 template <bool TEX>
-__global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD)
+__global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, unsigned short* __restrict__ perm_all)
 {
-    const int q = blockIdx.y;
-    if (q >= B.n) return;
-    const FrameDev& F = B.f[q];
-    const FrameParams& P = *B.p[q];
-    const SeqDev S = SD[q];
     // 52 KiB of LDS, three workgroups per CU (every stage waits for LDS or memory round trips: more resident waves is what hides them).  One 16 KiB
     // region holds, in turn: the sort keys; the sorted segments in 32 bits + their replay positions; the voxels' run offsets.
     __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: the item's segments as sort keys: rank 22 | first step 12 | steps 6 | ray 22
@@ -417,12 +417,26 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
     uint32_t* const s_pre = s_sr + SQ_SORTCAP;                   //   after the sort, [2048, 4096): replay position of its first step 17 | first step 12
     uint32_t* const s_hist = s_sr;                               //   after the walk, all of it: tuples per voxel -> run offsets
     __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, its tuples in each quarter of the replay sequence (16 bits each) -> the quarters' cursors
-    __shared__ __attribute__((aligned(8))) unsigned short s_perm[SQ_SORTCAP];      //  4 KiB: the sorted segments by length, longest first (before that: the sample sort's splitters)
+    // (the item's segments by length, longest first -- 4 KiB of 16-bit indices -- live in GLOBAL memory, a row per workgroup of the launch: with them in LDS
+    //  the kernel needed 53.8 KB and only TWO workgroups fitted a CU (the trace of round 5 showed exactly 512 items alive at the start of a launch of 768);
+    //  the walk reads an entry per segment, next to the segment's 16-byte ray record)
+    unsigned short* const g_perm = perm_all + (size_t)blockIdx.x * SQ_SORTCAP;
     __shared__ int s_bin[64];
     __shared__ uint32_t s_w[4];
     __shared__ unsigned long long s_rb;
+    __shared__ int s_claim;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    if (F.counters[HDR_FAIL] != 0) return;
+    // PERSISTENT workgroups (round 5): the launch is exactly the workgroups the CUs hold (three per CU), and each claims items through the frame's counter
+    // until the batch has none left -- first the heavy ones (a chunk of a brick next to the sensor: ~2 000 segments, 35 k tuples, 200 us), then the light
+    // ones (median 450 segments, 38 us), so the launch does not end on a late heavy item.  The first form launched one workgroup per possible item (1 024 per
+    // frame, 44 % of them empty): a traced batch of eight frames kept 346 of the 768 workgroup slots busy on average and took 667 us for 231 ms of item time
+    // (tools/seq_trace_probe.py) -- slots waited for the dispatcher, not for work.
+    for (int dq = 0; dq < B.n; ++dq) {
+    const int q = ((int)blockIdx.x + dq) % B.n;          // a workgroup starts on "its" frame and moves on when that frame has no items left
+    const FrameDev& F = B.f[q];
+    const FrameParams& P = *B.p[q];
+    const SeqDev S = SD[q];
+    if (F.counters[HDR_FAIL] != 0) continue;
     const int nitems = min(F.counters[HDR_SEQ_SLOTS], S.slot_cap);
     const uint32_t* __restrict__ rank_of_ray = F.vals;
 #ifdef TSL_SEQ_TIMING      // developer build: cycles per stage of an item, summed over the launch in dbg[0..7], items / segments / tuples in dbg[8..10]
@@ -431,12 +445,23 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
 #else
 #define SQ_TICK(k)
 #endif
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    for (;;) {
+        if (tid == 0) s_claim = __hip_atomic_fetch_add(&F.counters[HDR_SEQ_CLAIM], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int claimed = uni_i(s_claim);
+        __syncthreads();                                 // (the word is written again by the next claim)
+        if (claimed >= 2 * nitems) break;
+        const bool heavy_pass = claimed < nitems;        // claims [0, nitems): the heavy items; [nitems, 2 nitems): the others
+        const int it = heavy_pass ? claimed : claimed - nitems;
 #ifdef TSL_SEQ_TIMING
         __syncthreads(); _t0 = (long long)__builtin_readcyclecounter();
 #endif
+#ifdef TSL_SEQ_TRACE       // developer build: per work item { start, end (100 MHz clock), segments, tuples | CU id << 32 } at dbg[1024 + 4 * (frame * 1024 + item)], items < 1024 per frame
+        const long long _tr0 = wall_clock64();
+#endif
         const int4 item_v = S.items[it];
         const int4 item = make_int4(uni_i(item_v.x), uni_i(item_v.y), uni_i(item_v.z), uni_i(item_v.w));      // (the same for every lane: scalar loop control below)
+        if ((item.y > SQ_HEAVY) != heavy_pass) continue;
         const int m = item.y;
         const unsigned long long* const src = (item.w ? F.seg : F.seg_sorted) + item.x;
         uint32_t* const csr = S.csr + (size_t)item.z * SQ_CSR_STRIDE;
@@ -471,7 +496,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
         }
         SQ_TICK(0)
         __syncthreads();
-        unsigned long long* const s_spl = reinterpret_cast<unsigned long long*>(s_perm);      // (free until the length bins are filled)
+        unsigned long long* const s_spl = s_seg;                   // (the unsorted keys are in registers; the first 64 words are free once the samples are read)
         if (wid == 0) {
             unsigned long long v = s_seg[((uint32_t)lane * (uint32_t)m) >> 6];
             for (int kk = 2; kk <= 64; kk <<= 1)
@@ -589,10 +614,11 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
 #pragma unroll
         for (int r = 0; r < SQ_SORTCAP / SQ_NT; ++r) {
             const int k = r * SQ_NT + tid;
-            if (lrank[r] >= 0) s_perm[s_bin[63 - (int)(cj[r] & 63u)] + lrank[r]] = (unsigned short)k;
+            if (lrank[r] >= 0) g_perm[s_bin[63 - (int)(cj[r] & 63u)] + lrank[r]] = (unsigned short)k;
             s_pre[k] |= (cj[r] >> 8) << 17;                                       // (the item's steps number fewer than 2^17)
         }
         if (tid == 0) s_rb = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&F.counters[HDR_SEQ_TUPLES]), (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (g_perm: global stores of one wave read by another behind the barrier -- __syncthreads() waits for the LDS counter only)
         __syncthreads();
         const unsigned long long rb = s_rb;
         if ((long long)(rb + T) > S.cap) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
@@ -603,7 +629,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
         for (int r = 0; r * SQ_NT < m; ++r) {
             const int idx = r * SQ_NT + ((r & 1) ? SQ_NT - 1 - tid : tid);
             if (idx >= m) continue;
-            const int k = (int)s_perm[idx];
+            const int k = (int)g_perm[idx];
             const uint32_t sk = s_sr[k], pj = s_pre[k];
             const int ray = (int)(sk & 0x1fffffu), cnt = (int)(sk >> 21), j0 = (int)(pj >> 17);
             const uint4 rec = F.rayA[ray];
@@ -691,7 +717,15 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
 #endif
         const int any_unsafe = __syncthreads_or(unsafe ? 1 : 0);                  // (also: every wave is done with the LDS arrays before the next item clears them)
         if (tid == 0) csr[SQ_CSR_UNSAFE] = any_unsafe ? 1u : 0u;
+#ifdef TSL_SEQ_TRACE
+        if (tid == 0 && it < 1024) {
+            uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            long long* rec = F.dbg + 1024 + 4 * ((size_t)q * 1024 + it);
+            rec[0] = _tr0; rec[1] = wall_clock64(); rec[2] = m; rec[3] = (long long)T | ((long long)hwid << 32);
+        }
+#endif
     }
+    }      // frames
 }
 
 // one run of one voxel, applied by its lane.  The division-free update (seq_update_fast) needs D = W + w and its correctly rounded reciprocal:
@@ -1248,6 +1282,7 @@ static int seq_ensure(tsl_tsdf* m)
         }
         if ((rc = dev_alloc(m, &m->seqb_temp[bi], m->seqb_temp_bytes, 0))) return rc;
         if ((rc = dev_alloc(m, &m->seqb_long[bi], sizeof(int4) * (size_t)SQ_LONG_CAP, 0))) return rc;
+        if ((rc = dev_alloc(m, &m->seqb_perm[bi], sizeof(unsigned short) * SQ_SORTCAP * 3 * (size_t)m->ncu, 0))) return rc;          // k_seq_group: a row per workgroup of its launch
         if ((rc = dev_alloc(m, &m->seqb_lmask[bi], 8 * 64 * (size_t)PLAN_NCLS * TSL_NB * m->F.max_frame_bricks, 0))) return rc;          // a word per wave of 64 voxels of every brick a batch can list (unit_cap bricks per class)
     }
     if (seq_verify_on()) {
@@ -1276,6 +1311,8 @@ void seq_release(tsl_tsdf* m)
         if (m->seqb_temp[bi]) (void)hipFree(m->seqb_temp[bi]);
         if (m->seqb_long[bi]) (void)hipFree(m->seqb_long[bi]);
         if (m->seqb_lmask[bi]) (void)hipFree(m->seqb_lmask[bi]);
+        if (m->seqb_perm[bi]) (void)hipFree(m->seqb_perm[bi]);
+        m->seqb_perm[bi] = nullptr;
         m->seqb_temp[bi] = nullptr; m->seqb_long[bi] = nullptr; m->seqb_lmask[bi] = nullptr;
         if (m->seqv_sum[bi]) (void)hipFree(m->seqv_sum[bi]);
         m->seqv_sum[bi] = nullptr;
@@ -1307,8 +1344,8 @@ int launch_seq_group(tsl_tsdf* m, const BatchDev& B, const FrameParams* hp, int 
     prof_begin(m, TSL_K_RAYS, st);
     const int gx = m->F.max_frame_bricks < 1024 ? m->F.max_frame_bricks : 1024;
     hipLaunchKernelGGL(k_seq_split, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
-    if (hp[0].tex) hipLaunchKernelGGL(k_seq_group<true>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
-    else hipLaunchKernelGGL(k_seq_group<false>, dim3(gx, B.n), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB));
+    if (hp[0].tex) hipLaunchKernelGGL(k_seq_group<true>, dim3(3 * m->ncu), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB), static_cast<unsigned short*>(m->seqb_perm[bi]));
+    else hipLaunchKernelGGL(k_seq_group<false>, dim3(3 * m->ncu), dim3(SQ_NT), 0, st, m->M, B, (const SeqDev*)(m->seq_d + bi * TSL_NB), static_cast<unsigned short*>(m->seqb_perm[bi]));
     if (seq_verify_on()) {
         launch_seq_hash(m, B, bi, 0, st);
         SeqVerify V = { static_cast<unsigned long long*>(m->seqv_sum[bi]), m->seqv_log, 4096 };

@@ -91,6 +91,7 @@ struct FrameDev {
 #define HDR_SEQ_LONG 28        //   batch: sequential semantics: voxels listed for the long role of k_seq_replay
 #define HDR_SEQ_XLONG 30       //   batch: ... of those, the ones with the longest chains (walked first)
 #define HDR_SEQ_MAXRUN 31      //   sequential semantics: the longest run of a voxel in this frame (updates)
+#define HDR_SEQ_CLAIM 35       //   sequential semantics: next item of the frame a workgroup of k_seq_group claims (two passes over the slots: heavy items, then the others)
 #define HDR_SEQ_SLOTS 29       //   sequential semantics: slots (= k_seq_group work items) of the frame
 
 // A frame that runs out of its own scratch (bit 1: frame bricks / parts, bit 2: ray segments) is not integrated at all: the flag
@@ -277,7 +278,7 @@ struct tsl_tsdf {
     int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
     int seq_impl;                        // 1: per-brick replay runs built on the brick pipeline (default), 0: round 3's two global radix sorts (one frame per batch; kept as a cross-check)
     bool seq_ready; tsl::SeqDev seq_h[TSL_NSETS]; tsl::SeqDev* seq_d;      // seq_impl 1: tuple arrays of every working set (allocated by the first sequential batch)
-    void *seqb_keys[TSL_NBATCH][2], *seqb_vals[TSL_NBATCH][2], *seqb_temp[TSL_NBATCH], *seqb_long[TSL_NBATCH], *seqb_lmask[TSL_NBATCH]; size_t seqb_temp_bytes; long long seq_tuple_cap;      // per batch slot: the rays' struct-for keys of all its frames, sorted in one call
+    void *seqb_keys[TSL_NBATCH][2], *seqb_vals[TSL_NBATCH][2], *seqb_temp[TSL_NBATCH], *seqb_long[TSL_NBATCH], *seqb_lmask[TSL_NBATCH], *seqb_perm[TSL_NBATCH]; size_t seqb_temp_bytes; long long seq_tuple_cap;      // per batch slot: the rays' struct-for keys of all its frames, sorted in one call
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;
     int64_t bytes;

@@ -19,7 +19,9 @@ def main():
     from util import C2, sort_export
     nchk = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     ntim = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-    opts = [a.split("=") for a in sys.argv[3:]]
+    sync_every = max([int(a.split("=")[1]) for a in sys.argv[3:] if a.startswith("sync_every=")] + [0])      # a synchronisation every n timed frames: every batch alone on the device
+    opts = [a.split("=") for a in sys.argv[3:] if not a.startswith("late:") and not a.startswith("sync_every=")]
+    late = [a[5:].split("=") for a in sys.argv[3:] if a.startswith("late:")]      # options set behind the exactness check (e.g. late:phases=1: phase A alone)
     frames = list(syn.sphere_room_stream(nchk + ntim))
     dd = [torch.from_numpy(d.view(np.int16)).cuda() for _, _, d in frames]
     g = DenseTSDF(**C2)
@@ -37,10 +39,14 @@ def main():
     w = sort_export(o.export_sparse())
     exact = all(e[k].shape == w[k].shape and np.array_equal(e[k], w[k]) for k in ("indices", "TSDF", "W_TSDF", "occupy"))
     print(f"exact vs FAITHFUL after {nchk} frames: {exact} ({w['indices'].shape[0]} voxels)", flush=True)
+    for k, v in late:
+        g.set_option(k, int(v))
     g.enable_profiling(True, only=[_lib.K_INTEGRATE, _lib.K_RAYS, _lib.K_SORT])
     t0 = time.perf_counter()
-    for (R, T, _), d in zip(frames[nchk:], dd[nchk:]):
+    for f, ((R, T, _), d) in enumerate(zip(frames[nchk:], dd[nchk:])):
         g.recast_depth_to_map(R, T, d, None)
+        if sync_every and f % sync_every == sync_every - 1:
+            g.sync()
     g.sync()
     dt = time.perf_counter() - t0
     kt = {k: g.kernel_time(i) for k, i in (("replay", _lib.K_INTEGRATE), ("split+group+classify", _lib.K_RAYS), ("rank", _lib.K_SORT))}
