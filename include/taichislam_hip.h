@@ -258,10 +258,12 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                 num_voxel_per_blk_axis of the submaps, 4..32 (the fusion orders the source cells by the sorted list of the blocks their 16^3 storage bricks overlap).
                 Switching the mode on allocates the replay scratch of "seq_impl" 1 (an allocation failure is reported by this call)
      "seq_impl" how semantics 1 integrates.  1 (default): on the brick pipeline, whole batches -- behind phase A every (frame, brick) gets its
-                ray steps as 8-byte tuples, stably grouped by voxel in replay order (k_seq_group: LDS sort of the brick's segments by ray rank,
-                LDS counting sort of the steps by voxel), phase B is one thread per voxel applying its runs frame after frame (k_seq_replay);
-                memory: 2 x 8 bytes x "seq_tuple_cap" + 16 KiB x (max_frame_bricks + 1024) per working set, 24 working sets -- ~5.6 GB at the
-                defaults -- allocated when "semantics" is set to 1.  0: round 3's form -- every ray step a 16-byte tuple, two global radix sorts, one frame per batch
+                ray steps as 8-byte tuples, stably grouped by voxel in replay order (k_seq_group: persistent workgroups claim the items heavy-first; LDS sample
+                sort of the brick's segments by ray rank, a counting walk, then a placing pass that evaluates every step at its replay position),
+                phase B is one thread per voxel applying its runs frame after frame (k_seq_replay);
+                memory: 8 bytes x "seq_tuple_cap" + 16 KiB x (max_frame_bricks + 1024) per working set, 24 working sets -- ~4.1 GB at the
+                defaults -- allocated when "semantics" is set to 1 (round 5: a step is evaluated twice and written once; the first form also kept every
+                step in a "stash" array in replay order, 1.5 GB more and 16 bytes of traffic per step).  0: round 3's form -- every ray step a 16-byte tuple, two global radix sorts, one frame per batch
      "seq_longest_run" (get only) the longest run of updates of one voxel in a frame, summed over the frames of the batch issued last (the voxel next
                 to the sensor; a wave of its own settles it 64 updates per evaluation where its f16 state has stopped moving)
      "seq_long_voxels" (get only) voxels of the batch issued last that were replayed by a wave of their own (a run of >= 64 updates in a frame)

@@ -415,7 +415,9 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
     __shared__ unsigned long long s_seg[SQ_SORTCAP];             // 16 KiB: the item's segments as sort keys: rank 22 | first step 12 | steps 6 | ray 22
     uint32_t* const s_sr = reinterpret_cast<uint32_t*>(s_seg);   //   after the sort, [0, 2048): ray 21 | steps 6 of the k-th segment in replay order
     uint32_t* const s_pre = s_sr + SQ_SORTCAP;                   //   after the sort, [2048, 4096): replay position of its first step 17 | first step 12
-    uint32_t* const s_hist = s_sr;                               //   after the walk, all of it: tuples per voxel -> run offsets
+#ifdef TSL_SEQ_STASH
+    uint32_t* const s_hist = s_sr;                               //   after the walk, all of it: tuples per voxel -> run offsets (the first form; now they go straight to the slot's table)
+#endif
     __shared__ unsigned long long s_pack[TSL_BRK3];              // 32 KiB: per voxel, its tuples in each quarter of the replay sequence (16 bits each) -> the quarters' cursors
     // (the item's segments by length, longest first -- 4 KiB of 16-bit indices -- live in GLOBAL memory, a row per workgroup of the launch: with them in LDS
     //  the kernel needed 53.8 KB and only TWO workgroups fitted a CU (the trace of round 5 showed exactly 512 items alive at the start of a launch of 768);
@@ -425,7 +427,10 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
     __shared__ uint32_t s_w[4];
     __shared__ unsigned long long s_rb;
     __shared__ int s_claim;
+    __shared__ uint32_t s_rw[64];                                // (row, wave) totals of the run-offset scan
+    __shared__ uint32_t s_flag[4][64];                           // per wave: start offsets of the next segments inside the group of 64 positions being placed (zero between groups)
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    s_flag[wid][lane] = 0u;
     // PERSISTENT workgroups (round 5): the launch is exactly the workgroups the CUs hold (three per CU), and each claims items through the frame's counter
     // until the batch has none left -- first the heavy ones (a chunk of a brick next to the sensor: ~2 000 segments, 35 k tuples, 200 us), then the light
     // ones (median 450 segments, 38 us), so the launch does not end on a late heavy item.  The first form launched one workgroup per possible item (1 024 per
@@ -622,6 +627,147 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
         __syncthreads();
         const unsigned long long rb = s_rb;
         if ((long long)(rb + T) > S.cap) { if (tid == 0) frame_fail(M, F, 4); __syncthreads(); continue; }
+#ifndef TSL_SEQ_STASH
+        // ---- Round 5: NO STASH.  The first form wrote every step as an 8-byte tuple at its replay position (the "stash") and read it back in the counting
+        //      sort: 16 bytes per step through memory on top of the 8 of the replay tuple, and the mode is bound by exactly that -- one more 8-byte store
+        //      per step costs it 12.6 % (profiles/r05_literal_experiments.txt).  Now the first walk only COUNTS (voxel of every step, per quarter of the replay
+        //      sequence: no distance, no store), and the placing pass -- wave w over quarter w, 64 consecutive replay positions at a time -- finds every
+        //      position's (segment, step) and evaluates the step THERE: the arithmetic of a step twice, its bytes once.
+        const uint32_t Q = (((T + 3u) >> 2) + 63u) & ~63u;       // a quarter of the replay sequence, in whole groups of 64 tuples
+        SQ_TICK(2)
+        // ---- walk 1: every step's voxel, counted per voxel and quarter ----
+        for (int r = 0; r * SQ_NT < m; ++r) {
+            const int idx = r * SQ_NT + ((r & 1) ? SQ_NT - 1 - tid : tid);
+            if (idx >= m) continue;
+            const int k = (int)g_perm[idx];
+            const uint32_t sk = s_sr[k], pj = s_pre[k];
+            const int ray = (int)(sk & 0x1fffffu), cnt = (int)(sk >> 21), j0 = (int)(pj >> 17);
+            const uint4 rec = F.rayA[ray];
+            const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
+            const uint32_t at = pj & 0x1ffffu;
+            for (int s = 0; s < cnt; ++s) {
+                const float jf = (float)(j0 + s);
+                const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
+                const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));   // :254
+                const int l = (((i0 + M.hN) & 15) << 8) | (((i1 + M.hN) & 15) << 4) | ((i2 + M.hNz) & 15);            // the segment lies inside this brick
+                const uint32_t pos = at + (uint32_t)s;
+                const uint32_t qtr = (pos >= Q ? 1u : 0u) + (pos >= 2u * Q ? 1u : 0u) + (pos >= 3u * Q ? 1u : 0u);
+                atomicAdd(&s_pack[l], 1ull << (16u * qtr));
+            }
+        }
+        SQ_TICK(3)
+        __syncthreads();
+        // ---- run offsets of the brick's voxels for this item, straight into the slot's offset table in global memory (the LDS region that used to hold them
+        //      keeps the segments for the placing pass); a voxel's four counts become the quarters' first positions inside its run.  Thread t owns voxels
+        //      q * 256 + t: sixteen row scans in registers (wave shuffles), the 64 (row, wave) totals scanned by one wave ----
+        {
+            uint32_t tot[TSL_BRK3 / SQ_NT], inc[TSL_BRK3 / SQ_NT];
+#pragma unroll
+            for (int qq = 0; qq < TSL_BRK3 / SQ_NT; ++qq) {
+                const int i = qq * SQ_NT + tid;
+                const unsigned long long v = s_pack[i];
+                const uint32_t c0 = (uint32_t)(v & 0xffffull), c1 = (uint32_t)((v >> 16) & 0xffffull), c2 = (uint32_t)((v >> 32) & 0xffffull), c3 = (uint32_t)(v >> 48);
+                tot[qq] = c0 + c1 + c2 + c3;
+                s_pack[i] = ((unsigned long long)c0 << 16) | ((unsigned long long)(c0 + c1) << 32) | ((unsigned long long)(c0 + c1 + c2) << 48);
+                uint32_t x = tot[qq];
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)x, d); if (lane >= d) x += o; }
+                inc[qq] = x;
+                if (lane == 63) s_rw[qq * 4 + wid] = x;            // total of (row qq, wave wid)
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const uint32_t cb = s_rw[tid]; uint32_t x = cb;
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)x, d); if (tid >= d) x += o; }
+                s_rw[tid] = x - cb;                                // tuples in front of (row, wave)
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < TSL_BRK3 / SQ_NT; ++qq) csr[qq * SQ_NT + tid] = s_rw[qq * 4 + wid] + inc[qq] - tot[qq];
+            if (tid == 0) { csr[TSL_BRK3] = T; csr[SQ_CSR_BASE] = (uint32_t)rb; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the offsets are global stores of one wave read by another behind the barrier: it only drains the LDS counter)
+        __syncthreads();
+        SQ_TICK(4)
+        // ---- placing pass = stable counting sort by voxel: wave w takes quarter w of the replay sequence, 64 consecutive positions at a time.  The segment a
+        //      position belongs to: the wave carries the last segment that starts at or before the group (kcur); the next 64 segments flag their start
+        //      offsets in a wave-private LDS row, one ballot over the row gives every lane the number of starts up to its position.  Tuples of one voxel
+        //      inside a group find each other with twelve ballots; the voxel's cursor for this quarter is moved by the first of them ----
+        float2* const tup = S.tup + rb;
+        bool unsafe = false;
+        {
+            const uint32_t e = min(T, (uint32_t)(wid + 1) * Q);
+            uint32_t g0 = (uint32_t)wid * Q;
+            int kcur = 0;
+            if (g0 < e) {                                         // (uniform) the last segment whose first position is <= g0
+                int lo = 0, hi = m - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((s_pre[mid] & 0x1ffffu) <= g0) lo = mid; else hi = mid - 1; }
+                kcur = uni_i(lo);
+            }
+            uint32_t* const flag = s_flag[wid];
+            // the (segment, step) of a group's positions and the rays' records are requested ONE GROUP AHEAD (the record is a global load at the end of a
+            // dependent LDS chain: unhidden it cost the pass more than the stash had)
+            uint32_t pj_n = 0u, ray_n = 0u; uint4 rec_n = make_uint4(0u, 0u, 0u, 0u); bool valid_n = false;
+            auto locate = [&](uint32_t g) {
+                const uint32_t t = g + (uint32_t)lane;
+                valid_n = t < e;
+                const int ki = kcur + 1 + lane;
+                const uint32_t ri = ki < m ? (s_pre[ki] & 0x1ffffu) - g : 0xffffffffu;      // offset of the start of segment ki inside the group (starts increase strictly)
+                if (ri >= 1u && ri <= 63u) flag[ri] = 1u;
+                const unsigned long long adv = __ballot(ri >= 1u && ri <= 64u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // (wave-private row: LDS operations of a wave complete in order)
+                const uint32_t fl = flag[lane];
+                const unsigned long long starts = __ballot(fl != 0u);
+                if (fl) flag[lane] = 0u;                                                       // the row is zero again for the next group
+                const int k = kcur + popc64(starts & ((2ull << lane) - 1ull));                 // starts at offsets 1 .. lane (offset 0 is never flagged)
+                kcur += popc64(adv);
+                if (valid_n) { const uint32_t sk = s_sr[k]; pj_n = s_pre[k]; ray_n = sk & 0x1fffffu; rec_n = F.rayA[ray_n]; }
+            };
+            if (g0 < e) locate(g0);
+            for (; g0 < e; g0 += 64u) {
+                const uint32_t t = g0 + (uint32_t)lane;
+                const bool valid = valid_n;
+                const uint32_t pj = pj_n, ray = ray_n; const uint4 rec = rec_n;
+                if (g0 + 64u < e) locate(g0 + 64u);
+                __builtin_amdgcn_sched_barrier(0);
+                int l = 0; float sd = 0.0f, w = 0.0f; uint32_t off = 0u;
+                if (valid) {
+                    const float pf0 = h2f((h16)(rec.x & 0xffffu)), pf1 = h2f((h16)(rec.x >> 16)), pf2 = h2f((h16)(rec.y & 0xffffu));
+                    const float d0 = h2f((h16)(rec.y >> 16)), d1 = h2f((h16)(rec.z & 0xffffu)), d2 = h2f((h16)(rec.z >> 16));
+                    const float P0 = pf0 + P.T[0], P1 = pf1 + P.T[1], P2f = pf2 + P.T[2];                                 // :246
+                    const float jf = (float)((int)(pj >> 17) + (int)(t - (pj & 0x1ffffu)));
+                    const float x0 = (d0 * jf) * P.vs + P.T[0], x1 = (d1 * jf) * P.vs + P.T[1], x2 = (d2 * jf) * P.vs + P.T[2];     // :253
+                    const int i0 = rnd_i(div_vs(x0, P.vs, P.rvs, P.fastdiv)), i1 = rnd_i(div_vs(x1, P.vs, P.rvs, P.fastdiv)), i2 = rnd_i(div_vs(x2, P.vs, P.rvs, P.fastdiv));   // :254
+                    l = (((i0 + M.hN) & 15) << 8) | (((i1 + M.hN) & 15) << 4) | ((i2 + M.hNz) & 15);
+                    off = csr[l];                                                                                          // (requested here: the distance and the ballots run under it)
+                    const float v0 = P0 - x0, v1 = P1 - x1, v2 = P2f - x2;                                                 // :258
+                    const float s2 = (v0 * v0 + v1 * v1) + v2 * v2;
+                    const float dist = s2 >= 1.2621774483536189e-29f ? sqrt_rn_norm(s2) : sqrt_rn(s2);                      // :259  (2^-96: below it sqrtf rescales)
+                    const float dot = (v0 * pf0 + v1 * pf1) + v2 * pf2;
+                    sd = dist * (float)sgn_f(dot);                                                                         // :260
+                    w = seq_w_of(seq_w_code(__uint_as_float(rec.w)));                                                       // (the weight as the 16-bit code of the first form carried it)
+                }
+                const unsigned long long vm = __ballot(valid);
+                uint32_t mlo = (uint32_t)vm, mhi = (uint32_t)(vm >> 32);
+#pragma unroll
+                for (int bit = 0; bit < 12; ++bit) {                              // lanes whose bit equals mine stay: m &= ~(ballot ^ (mine ? ~0 : 0))
+                    const uint32_t mine = (uint32_t)((int)((uint32_t)l << (31 - bit)) >> 31);
+                    const unsigned long long bm = __ballot(mine != 0u);
+                    mlo &= ~((uint32_t)bm ^ mine); mhi &= ~((uint32_t)(bm >> 32) ^ mine);
+                }
+                const unsigned long long mk = ((unsigned long long)mhi << 32) | mlo;
+                const int my = rank_below(mk), gs = popc64(mk);                   // tuples of my voxel before me in this group / in this group
+                if (valid) {
+                    const uint32_t cur = (uint32_t)(s_pack[l] >> (16 * wid)) & 0xffffu;
+                    if (my == 0) atomicAdd(&s_pack[l], (unsigned long long)gs << (16 * wid));      // (behind the read: LDS operations of a wave complete in order)
+                    const float c = w * sd;                                       // the replay tuple: w and c = w * sd (:264)
+                    const uint32_t pos = off + cur + (uint32_t)my;
+                    tup[pos] = make_float2(w, c);
+                    if (TEX) S.tup_ray[rb + pos] = ray;
+                    unsafe = unsafe || !(fabsf(sd) <= 60.0f) || (c != 0.0f && fabsf(c) < 8.67e-19f);      // 2^-60: the residuals of the division-free quotient stay representable
+                }
+            }
+        }
+#else   // the first form: every step through the stash (developer A/B: -DTSL_SEQ_STASH; the stash arrays are then allocated)
         unsigned long long* const stash = S.stash + rb;
         const uint32_t Q = (((T + 3u) >> 2) + 63u) & ~63u;       // a quarter of the replay sequence, in whole groups of 64 tuples
         SQ_TICK(2)
@@ -650,6 +796,9 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
                 const float sd = dist * (float)sgn_f(dot);                                                              // :260
                 const uint32_t pos = at + (uint32_t)s;
                 stash[pos] = zz | ((unsigned long long)l << SQ_TUP_L_SHIFT) | (unsigned long long)__float_as_uint(sd);
+#ifdef TSL_EXP_EXTRA_STORE      // developer experiment: 8 more bytes written per step (into the place the counting sort overwrites later): how sensitive is the mode to its memory traffic?
+                reinterpret_cast<unsigned long long*>(S.tup + rb)[pos] = zz | (unsigned long long)__float_as_uint(sd);
+#endif
                 if (TEX) S.stash_ray[rb + pos] = (uint32_t)ray;
                 const uint32_t qtr = (pos >= Q ? 1u : 0u) + (pos >= 2u * Q ? 1u : 0u) + (pos >= 3u * Q ? 1u : 0u);
                 atomicAdd(&s_pack[l], 1ull << (16u * qtr));
@@ -711,10 +860,13 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
                 }
             }
         }
+#endif
         SQ_TICK(5)
 #ifdef TSL_SEQ_TIMING
         if (tid == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[8]), 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[9]), (unsigned long long)m); atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[10]), (unsigned long long)T); }
 #endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // (the placing pass orders its wave-private LDS row with a wavefront-scope fence: behind one the compiler
+                                                                                    //  emits bare barriers -- the cursor adds must have landed before the next item clears the counters)
         const int any_unsafe = __syncthreads_or(unsafe ? 1 : 0);                  // (also: every wave is done with the LDS arrays before the next item clears them)
         if (tid == 0) csr[SQ_CSR_UNSAFE] = any_unsafe ? 1u : 0u;
 #ifdef TSL_SEQ_TRACE
@@ -1260,13 +1412,18 @@ static int seq_ensure(tsl_tsdf* m)
     for (int si = 0; si < TSL_NSETS; ++si) {
         SeqDev& S = m->seq_h[si];
         S.cap = m->seq_tuple_cap; S.stash_ray = nullptr; S.tup_ray = nullptr; S.items = nullptr;
+        S.stash = nullptr;
+#ifdef TSL_SEQ_STASH
         if ((rc = dev_alloc(m, (void**)&S.stash, 8 * (size_t)S.cap, 0))) return rc;
+#endif
         if ((rc = dev_alloc(m, (void**)&S.tup, 8 * ((size_t)S.cap + 16), 0))) return rc;
         S.slot_cap = m->F.max_frame_bricks + 1024;          // one slot per (frame, brick) + the further chunks of the few bricks next to the sensor
         if ((rc = dev_alloc(m, (void**)&S.csr, 4 * (size_t)S.slot_cap * SQ_CSR_STRIDE, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&S.items, sizeof(int4) * (size_t)S.slot_cap, 0))) return rc;
         if (tex) {
+#ifdef TSL_SEQ_STASH
             if ((rc = dev_alloc(m, (void**)&S.stash_ray, 4 * (size_t)S.cap, 0))) return rc;
+#endif
             if ((rc = dev_alloc(m, (void**)&S.tup_ray, 4 * (size_t)S.cap, 0))) return rc;
         }
     }

@@ -1636,7 +1636,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
         TSL_REQUIRE(value == 0 || (m->variant == 2 && m->P.group), "sequential semantics needs variant 2 and the hash grouping (group 1)");
         TSL_REQUIRE(value == 0 || m->F.max_points <= (1 << 21), "sequential semantics: at most 2^21 points per frame");
         int rc = tsl_tsdf_sync(m); if (rc) return rc;
-        if (value && m->seq_impl && !m->cfg.is_global_map) { TSL_HIP(hipSetDevice(m->device)); rc = seq_prepare(m); if (rc) return rc; }      // ~5.6 GB of replay scratch at the default sizes (header)
+        if (value && m->seq_impl && !m->cfg.is_global_map) { TSL_HIP(hipSetDevice(m->device)); rc = seq_prepare(m); if (rc) return rc; }      // ~4.1 GB of replay scratch at the default sizes (header)
         m->semantics = value; m->P.seq = value; return TSL_OK;
     }
     if (!std::strcmp(name, "seq_impl")) {
