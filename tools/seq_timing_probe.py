@@ -1,4 +1,7 @@
-"""Developer probe: per-stage cycles of k_seq_group in a TSL_SEQ_TIMING build (TSL_EXTRA_FLAGS=-DTSL_SEQ_TIMING python -m taichislam_amd.build)."""
+"""Developer probe: per-stage cycles of k_seq_group in a TSL_SEQ_TIMING build (TSL_EXTRA_FLAGS=-DTSL_SEQ_TIMING python -m taichislam_amd.build).
+Round 5: the stage table in DESIGN.md section 4 was taken with round 4's kernel; on the persistent, stash-free k_seq_group the TSL_SEQ_TIMING build has NOT been
+revalidated (it ended in a GPU memory fault twice, while the shipping build passes every test and TSL_SEQ_VERIFY's brute-force recount) -- use the per-item
+trace instead: TSL_EXTRA_FLAGS=-DTSL_SEQ_TRACE + tools/seq_trace_probe.py."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
