@@ -188,12 +188,13 @@ int launch_apply_sequential(tsl_tsdf* m, const BatchDev& B, const FrameParams& P
 // order, step along the ray).  Phase A already delivers, per frame, the ray segments of every 16^3 brick (k_segments / k_plan / k_scatter).
 // Added behind it on the batch's phase-A stream (nothing here reads the map, so it runs beside phase B of the batch before):
 //   k_seq_keys + ONE radix sort per batch + k_seq_ranks   struct-for rank of every ray of every frame of the batch (keys = frame | struct-for key)
-//   k_seq_group   one workgroup per (frame, brick): the brick's segments are put in (rank, first step) order in LDS (bitonic sort, <= 2048
-//                 at a time; a brick with more is first cut by rank into chunks that fit), walked -- every step becomes an 8-byte tuple
-//                 { signed distance | voxel | z^2 } written at its replay position -- and counted per voxel; a stable counting sort by voxel
-//                 (offsets by an LDS scan; position of a tuple = its voxel's cursor + the tuples of the same voxel before it in a 256-tuple
-//                 block: 12 ballots inside a wave, one packed LDS word per voxel across the four waves) leaves every voxel's run contiguous
-//                 and in replay order, with the 4097 run offsets of the brick beside it.
+//   k_seq_group   one work item per (frame, brick) -- a brick with more than 2 048 segments is first cut by rank into chunks that fit (k_seq_split); persistent
+//                 workgroups, three per CU, claim the items heavy-first (round 5).  The item's segments are put in (rank, first step) order in LDS (a sample
+//                 sort), a first walk counts every step's voxel per quarter of the replay sequence, the run offsets of the brick's 4 096 voxels go to the
+//                 slot's table, and a placing pass -- wave w over quarter w, 64 consecutive replay positions at a time -- evaluates every step at its
+//                 position and writes its 8-byte replay tuple { w, w * sd } behind its voxel's cursor (+ the tuples of the same voxel before it in the group:
+//                 12 ballots): every voxel's run contiguous and in replay order.  (Round 4 wrote every step to a "stash" in replay order first and read it
+//                 back in the counting sort: -DTSL_SEQ_STASH.)
 // Phase B (main stream, batches in order): k_seq_replay, one thread per voxel of every brick the batch touches: the voxel's runs of the batch's
 // frames, frame after frame, applied exactly as dense_tsdf.py:264-267 -- no LDS, no barrier, no atomics; the voxel next to the sensor
 // (every ray of a frame passes through it) is one long chain in one lane, everything else finishes around it.
@@ -398,14 +399,14 @@ __global__ void __launch_bounds__(SQ_NT) k_seq_split(MapDev M, BatchDev B, const
 }
 
 // phase A of the literal mode, one work item (k_seq_split) per workgroup at a time: the item's segments are put in replay order -- (ray rank,
-// first step) -- every step becomes a tuple at its replay position, and the tuples are then grouped by voxel, replay order kept inside a voxel
-// (a stable counting sort), as the run offsets (CSR) of the item's slot say.  Stages and what each costs were measured with the developer build
-// (-DTSL_SEQ_TIMING, tools/seq_timing_probe.py); this is the second form:
-//   * the bitonic network runs without workgroup barriers wherever a compare-exchange stays inside the quarter of the keys a wave owns (all but
-//     three of its ~55 stages): LDS operations of one wave complete in order;
-//   * the walk takes the segments longest first, dealt out in alternating directions (a counting sort by length, as the default path's brick
+// first step) --, every step gets its replay position, and the steps are grouped by voxel, replay order kept inside a voxel (a stable counting
+// sort), as the run offsets (CSR) of the item's slot say.  What each part costs was measured per stage with round 4's kernel (-DTSL_SEQ_TIMING) and per
+// work item with this one (-DTSL_SEQ_TRACE, tools/seq_trace_probe.py; DESIGN.md section 4, "The second half of round 5"):
+//   * persistent workgroups -- exactly the three per CU the device holds -- claim items through the frame's counter, heavy ones first;
+//   * the sort is a sample sort with explicit barriers only (round 4's bitonic network: -DTSL_SEQ_BITONIC);
+//   * the walks take the segments longest first, dealt out in alternating directions (a counting sort by length, as the default path's brick
 //     kernel does): the 64 lanes of a wave walk segments of equal length.  Where a tuple goes is fixed by the replay order, not by who walks it;
-//   * the counting sort has no barrier at all: wave w owns quarter w of the tuple sequence, the walk has counted every voxel's tuples per quarter
+//   * the placing pass has no workgroup barrier: wave w owns quarter w of the replay sequence, the first walk has counted every voxel's steps per quarter
 //     (four 16-bit fields of one LDS word), so a wave's cursor for a voxel starts behind the earlier quarters' tuples and only that wave moves it.
 template <bool TEX>
 __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, const SeqDev* __restrict__ SD, unsigned short* __restrict__ perm_all)

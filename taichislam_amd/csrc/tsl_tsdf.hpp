@@ -175,9 +175,9 @@ __device__ __forceinline__ bool finish_ray(const FrameParams& P, const FrameDev&
 }
 
 
-// Sequential semantics on the brick pipeline (tsl_sequential.hip): per frame working set, the ray steps of every (frame, brick) -- first as
-// 8-byte tuples { signed distance f32 | voxel 12 | z^2 f16 } in replay order (stash), then stably grouped by voxel as 8-byte replay tuples
-// { w, w * sd } (tup) with the run offsets of the brick's 4096 voxels (csr).  Lives in device memory (the batch's working
+// Sequential semantics on the brick pipeline (tsl_sequential.hip): per frame working set, the ray steps of every (frame, brick) stably grouped by voxel
+// as 8-byte replay tuples { w, w * sd } (tup) with the run offsets of the brick's 4096 voxels (csr).  (`stash`: round 4's intermediate copy of every step
+// in replay order, { signed distance f32 | voxel 12 | z^2 f16 }; only allocated by -DTSL_SEQ_STASH builds.)  Lives in device memory (the batch's working
 // sets already fill the 4 KiB of kernel arguments).
 #define SQ_CSR_STRIDE 4104            // words per (frame, brick): 4097 run offsets | first tuple of the brick's region | "a tuple outside the fast path's range"
 #define SQ_CSR_BASE 4097
