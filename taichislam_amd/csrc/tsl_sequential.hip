@@ -442,8 +442,13 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
     const FrameDev& F = B.f[q];
     const FrameParams& P = *B.p[q];
     const SeqDev S = SD[q];
-    if (F.counters[HDR_FAIL] != 0) continue;
-    const int nitems = min(F.counters[HDR_SEQ_SLOTS], S.slot_cap);
+    // ONE decision for the whole workgroup: another workgroup of this launch may set the frame's fail word at its tuple-cap check while this one
+    // reads it, and four waves that disagree would meet different barriers of the claim loop below.  Thread 0 reads, everybody takes its answer.
+    if (tid == 0) { s_claim = F.counters[HDR_FAIL] != 0 ? -1 : min(F.counters[HDR_SEQ_SLOTS], S.slot_cap); }
+    __syncthreads();
+    const int nitems = uni_i(s_claim);
+    __syncthreads();                                     // (the word is written again by the first claim)
+    if (nitems < 0) continue;
     const uint32_t* __restrict__ rank_of_ray = F.vals;
 #ifdef TSL_SEQ_TIMING      // developer build: cycles per stage of an item, summed over the launch in dbg[0..7], items / segments / tuples in dbg[8..10]
     long long _t0 = 0;

@@ -218,3 +218,29 @@ def test_sequential_mode_tuple_capacity_is_loud(hip_lib):
         g.recast_depth_to_map(*frames[0], None)
         g.sync()
     assert g.count_active() == 0
+
+
+def test_tuple_capacity_overflow_in_a_queued_batch_leaves_the_other_frames_exact(hip_lib):
+    """k_seq_group's persistent workgroups read the frame's fail word while other workgroups of the same launch may be setting it at their
+    tuple-cap check; the decision has to be one per workgroup (thread 0 reads, a barrier, everybody takes its answer), or the waves of a workgroup meet
+    different barriers.  Eight frames queued back to back, every second one too big for seq_tuple_cap: the big ones are dropped as wholes and reported,
+    the small ones -- same batch, same launch -- must come out exactly as the oracle integrates them."""
+    from oracle import FAITHFUL
+    from taichislam_amd._lib import TslError
+    K, frames = small_stream(8)
+    for rep in range(3):
+        g, o = make_pair(SMALL, K)
+        g.set_option("semantics", 1)
+        g.set_option("seq_tuple_cap", 1 << 16)           # a full 120 x 160 frame has ~330 k steps; a 24-row band of it ~60 k
+        kept = 0
+        for f, (R, T, d) in enumerate(frames):
+            if f % 2 == 0:
+                d = d.copy(); d[:48] = 0; d[72:] = 0     # rows 48..71 only
+                st = o.integrate_depth(R, T, d, mode=FAITHFUL)
+                assert 0 < st["steps"] < (1 << 16)
+                kept += 1
+            g.recast_depth_to_map(R, T, d, None)
+        with pytest.raises(TslError, match="capacity"):
+            g.sync()
+        assert kept == 4
+        assert_export_equal(g.export_submap(), o.export_sparse(), f"small frames beside overflowing ones, repetition {rep}")
