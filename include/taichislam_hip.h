@@ -311,6 +311,20 @@ int  tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value);   /* also "
                                                                            read-only: "last_heavy_bricks" / "last_slab_slots" = bricks walked in parts and
                                                                            merge-slab slots handed out by the batch issued last (synchronises) */
 
+/* ---- environment switches ------------------------------------------------------------------------
+ * The product library (lib/libtaichislam_hip.so) reads ONE environment variable:
+ *   TSL_SEQ_VERIFY=1   semantics = 1 only: every work item of the literal mode is recounted by brute force from its segment list and an order-free
+ *                      checksum of its tuples is compared behind k_seq_group, in front of the replay and behind it; mismatches are counted in
+ *                      get_option("seq_verify_mismatches").  Slows the mode down by ~10x; never changes a result.
+ * Everything else is compiled only into the developer build lib/libtaichislam_hip_testhooks.so (-DTSL_TEST_HOOKS, built beside the product library
+ * by taichislam_amd/build.py; load it with TSL_LIB=<path> in the Python shims):
+ *   TSL_FAULT_NO_BDONE_WAIT=1   FAULT INJECTION: phase A of a batch does not wait for the phase B that still reads the batch slot's working sets --
+ *                               the map becomes wrong; tests/test_pipeline_overlap_gpu.py uses it to show that the parity tests see the overlap
+ *   TSL_PIN_LEGACY=1            host staging buffers without hipHostMallocCoherent (A/B of round 4's allocation)
+ *   TSL_EV_SYS=1                pipeline events with the default system-scope fence (A/B of round 5's hipEventDisableSystemFence)
+ *   TSL_SEQ_SPLIT_ROLES=1       the two roles of k_seq_replay as separate launches (profiling aid)
+ * (the sort-grouped phase A that TSL_GROUP_SORT selected is the backend option "group" = 0.) */
+
 /* ---- profiling: HIP-event timing of the per-frame kernels on the handle's stream ----------------- */
 int  tsl_tsdf_prof_enable(tsl_tsdf* m, int on);   /* 0 off, 1 every kernel, 2*mask: only the kernel ids whose bit is set in mask */
 int  tsl_tsdf_prof_query(tsl_tsdf* m, int kernel_id, double* total_ms, int64_t* launches);   /* synchronises, resets */

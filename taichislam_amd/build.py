@@ -8,6 +8,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtaichislam_hip.so")
+# the same library with -DTSL_TEST_HOOKS on the files that have hooks: fault injection (TSL_FAULT_NO_BDONE_WAIT) and the developer A/B switches
+# (include/taichislam_hip.h, "environment switches") exist ONLY there; tests/test_pipeline_overlap_gpu.py loads it in a child process through TSL_LIB
+HOOKS_LIB = os.path.join(LIBDIR, "libtaichislam_hip_testhooks.so")
+HOOK_SOURCES = ("tsl_tsdf.hip", "tsl_sequential.hip")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # bit-exact parity with the CPU oracle: no FMA contraction, IEEE divide/sqrt, keep denormals
@@ -41,10 +45,22 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def _flags():
+    return [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("TSL_EXTRA_FLAGS", "").split()
+
+
+def _link_flags(flags):
+    """the link line follows the compile flags' targets (an --offload-arch override used to compile for one target and link for another)"""
+    return [f for f in flags if f.startswith("--offload-arch")] + ["-shared", "-fPIC"]
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HOOKS_LIB):
         return True
-    t = os.path.getmtime(LIB)
+    stamp = os.path.join(LIBDIR, "obj", "flags.txt")
+    if _hipcc() is not None and (not os.path.exists(stamp) or open(stamp).read() != " ".join(_flags())):
+        return True             # built with other flags (a developer -D build left behind): not the library the next normal build wants
+    t = min(os.path.getmtime(LIB), os.path.getmtime(HOOKS_LIB))
     return any(os.path.getmtime(s) > t for s in _deps())
 
 
@@ -61,7 +77,7 @@ def build_library(force=False, verbose=False):
     # one object per source, compiled side by side (the seven files take ~60 s one after the other), only the stale ones; then one link
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("TSL_EXTRA_FLAGS", "").split()
+    flags = _flags()
     stamp = os.path.join(objdir, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     hdr_t = max(os.path.getmtime(h) for h in _deps() if not h.endswith(".hip"))
@@ -74,12 +90,21 @@ def build_library(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             jobs.append((src, subprocess.Popen(cmd)))
+    hook_objs = {}
+    for src in sources():
+        if os.path.basename(src) in HOOK_SOURCES:
+            obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".hooks.o")
+            hook_objs[os.path.basename(src)[:-4] + ".o"] = obj
+            if force or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+                jobs.append((src, subprocess.Popen([cc] + flags + ["-DTSL_TEST_HOOKS", "-c", src, "-o", obj])))
     failed = [src for src, p in jobs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed on " + ", ".join(failed))
     open(stamp, "w").write(" ".join(flags))
-    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"])
+    subprocess.check_call([cc] + _link_flags(flags) + objs + ["-o", LIB + ".tmp"])
     os.replace(LIB + ".tmp", LIB)
+    subprocess.check_call([cc] + _link_flags(flags) + [hook_objs.get(os.path.basename(o), o) for o in objs] + ["-o", HOOKS_LIB + ".tmp"])
+    os.replace(HOOKS_LIB + ".tmp", HOOKS_LIB)
     return LIB
 
 

@@ -450,12 +450,7 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
     __syncthreads();                                     // (the word is written again by the first claim)
     if (nitems < 0) continue;
     const uint32_t* __restrict__ rank_of_ray = F.vals;
-#ifdef TSL_SEQ_TIMING      // developer build: cycles per stage of an item, summed over the launch in dbg[0..7], items / segments / tuples in dbg[8..10]
-    long long _t0 = 0;
-#define SQ_TICK(k) { __syncthreads(); const long long _n = (long long)__builtin_readcyclecounter(); if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[k]), (unsigned long long)(_n - _t0)); _t0 = _n; }
-#else
-#define SQ_TICK(k)
-#endif
+#define SQ_TICK(k)         // (stage marks of round 4's -DTSL_SEQ_TIMING build, which did not survive the persistent workgroups and was removed in round 6; per-item times: -DTSL_SEQ_TRACE)
     for (;;) {
         if (tid == 0) s_claim = __hip_atomic_fetch_add(&F.counters[HDR_SEQ_CLAIM], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -464,9 +459,6 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
         if (claimed >= 2 * nitems) break;
         const bool heavy_pass = claimed < nitems;        // claims [0, nitems): the heavy items; [nitems, 2 nitems): the others
         const int it = heavy_pass ? claimed : claimed - nitems;
-#ifdef TSL_SEQ_TIMING
-        __syncthreads(); _t0 = (long long)__builtin_readcyclecounter();
-#endif
 #ifdef TSL_SEQ_TRACE       // developer build: per work item { start, end (100 MHz clock), segments, tuples | CU id << 32 } at dbg[1024 + 4 * (frame * 1024 + item)], items < 1024 per frame
         const long long _tr0 = wall_clock64();
 #endif
@@ -868,9 +860,6 @@ __global__ void __launch_bounds__(SQ_NT, 3) k_seq_group(MapDev M, BatchDev B, co
         }
 #endif
         SQ_TICK(5)
-#ifdef TSL_SEQ_TIMING
-        if (tid == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[8]), 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[9]), (unsigned long long)m); atomicAdd(reinterpret_cast<unsigned long long*>(&F.dbg[10]), (unsigned long long)T); }
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // (the placing pass orders its wave-private LDS row with a wavefront-scope fence: behind one the compiler
                                                                                     //  emits bare barriers -- the cursor adds must have landed before the next item clears the counters)
         const int any_unsafe = __syncthreads_or(unsafe ? 1 : 0);                  // (also: every wave is done with the LDS arrays before the next item clears them)
@@ -1460,7 +1449,9 @@ static int seq_ensure(tsl_tsdf* m)
 // lost, and what was allocated is handed back -- ADVICE r4); the first sequential batch finds it ready
 int seq_prepare(tsl_tsdf* m)
 {
+    const int64_t before = m->bytes;
     const int rc = seq_ensure(m);
+    m->seq_bytes0 += m->bytes - before;          // what the literal scratch added to the handle's account (also of a failed attempt: released below)
     if (rc) seq_release(m);
     return rc;
 }
@@ -1483,6 +1474,7 @@ void seq_release(tsl_tsdf* m)
     if (m->seqv_log) (void)hipFree(m->seqv_log);
     m->seqv_log = nullptr;
     m->seq_ready = false;
+    m->bytes -= m->seq_bytes0; m->seq_bytes0 = 0;      // tsl_tsdf_memory_bytes counted the scratch once and must not count it again after a rebuild
 }
 
 // behind phase A of a batch, on its stream: struct-for ranks of the batch's rays (one sort), then every (frame, brick)'s replay runs
@@ -1527,7 +1519,11 @@ int launch_seq_apply(tsl_tsdf* m, const BatchDev& B, const FrameParams& P, int b
     const int4* ll = static_cast<const int4*>(m->seqb_long[bi]);
     const unsigned long long* lm = static_cast<const unsigned long long*>(m->seqb_lmask[bi]);
     const int nlong = 4 * m->ncu, nshort = 12 * m->ncu;
+#ifdef TSL_TEST_HOOKS      // developer build only (include/taichislam_hip.h, "environment switches")
     static const bool split_roles = std::getenv("TSL_SEQ_SPLIT_ROLES") != nullptr;
+#else
+    constexpr bool split_roles = false;
+#endif
     if (split_roles && !P.tex) {                   // developer timing aid: the two roles as two launches (same result: the voxel sets are disjoint)
         hipLaunchKernelGGL(k_seq_replay<false>, dim3(nshort), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, 0);
         hipLaunchKernelGGL(k_seq_replay<false>, dim3(nlong), dim3(256), 0, m->stream_, m->M, B, sd, ll, lm, nlong);

@@ -594,7 +594,11 @@ static int launch_batch_t(tsl_tsdf* m)
     }
     // (TSL_FAULT_NO_BDONE_WAIT: fault injection for tests/test_pipeline_overlap_gpu.py -- without this wait phase A of a batch overwrites working sets the
     //  replay three batches back still reads; the back-to-back parity tests must notice)
+#ifdef TSL_TEST_HOOKS      // compiled into lib/libtaichislam_hip_testhooks.so only: the product library has no switch that makes the map wrong
     static const bool fault_no_wait = std::getenv("TSL_FAULT_NO_BDONE_WAIT") != nullptr;
+#else
+    constexpr bool fault_no_wait = false;
+#endif
     if (!serial && H.b_pending && !fault_no_wait) TSL_HIP(hipStreamWaitEvent(sa, H.b_done, 0));      // phase B of this batch's previous frames still reads the sets
     if (!serial && m->esdf_gate_set) {
         // an ESDF update in flight has taken its brick snapshot (tsl_esdf.hip).  The gate stays armed until every phase-A stream has waited for
@@ -755,7 +759,11 @@ static int stage_host(tsl_tsdf* m, int si, const void* in, size_t row_bytes, int
         S.pin = nullptr; S.pin_bytes = 0; S.pin_dev = nullptr;
         // COHERENT (fine-grained) host memory: the device reads it uncached, so what the host wrote before the batch was issued is what phase A
         // sees.  With hipHostMallocMapped alone the kind of memory is the runtime's choice; TSL_PIN_LEGACY=1 is the developer A/B.
+#ifdef TSL_TEST_HOOKS
         static const bool legacy = std::getenv("TSL_PIN_LEGACY") != nullptr;
+#else
+        constexpr bool legacy = false;
+#endif
         TSL_HIP(hipHostMalloc(&S.pin, need + need / 4, legacy ? hipHostMallocMapped : (hipHostMallocMapped | hipHostMallocCoherent)));
         S.pin_bytes = need + need / 4;
         TSL_HIP(hipHostGetDevicePointer(&S.pin_dev, S.pin, 0));
@@ -1011,10 +1019,10 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     for (int s = 0; s < m->npose; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }
     std::memset(m->gbaseR, 0, sizeof(m->gbaseR)); std::memset(m->gbaseT, 0, sizeof(m->gbaseT));
     for (int i = 0; i < 3; ++i) m->gbaseR[i * 4] = 1.0;
-    m->P.group = std::getenv("TSL_GROUP_SORT") ? 0 : 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->ugrid = 75; m->pgrid = 25; m->split_launch = 0; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
+    m->P.group = 1; m->phases = 3; m->wg = 512; m->spt = 2; m->adaptive = 0; m->ramp_batches = 2; m->ramp_size = 4; m->bgrid = 75; m->ugrid = 75; m->pgrid = 25; m->split_launch = 0; m->chunks = 4; m->unit_max = 1024 * TSL_NB; m->unit_half = 1 << 20; m->unit_floor = 4096; m->batch_gen = 0;
     // (unit_half >= unit: the middle tier of k_plan is off by default -- measured neutral-to-negative once the brick kernel runs on 75 % of the slots)
     { hipDeviceProp_t pr; TSL_HIP(hipGetDeviceProperties(&pr, device)); m->ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    m->active = 0; m->variant = 2; m->split = 2; m->semantics = 0; m->seq_impl = 1; m->seq_ready = false; m->seq_d = nullptr; m->seq_tuple_cap = 0;
+    m->active = 0; m->variant = 2; m->split = 2; m->semantics = 0; m->seq_impl = 1; m->seq_ready = false; m->seq_bytes0 = 0; m->seq_d = nullptr; m->seq_tuple_cap = 0;
     m->prof_on = false; m->prof_open = false; m->prof_group = false; m->prof_mask = ~0u; std::memset(m->prof_ms, 0, sizeof(m->prof_ms)); std::memset(m->prof_n, 0, sizeof(m->prof_n));
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0; m->mesh_flags = nullptr;
@@ -1055,7 +1063,11 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     // The pipeline's events order streams of ONE device against each other (and tell the host that a batch has finished, nothing about memory): they
     // need no system-scope fence -- the cache write-back + invalidate a default event adds when it is recorded sat between k_apply_slab of a batch and
     // the brick kernel of the next (round 5, TSL_EV_SYS=1 restores the default for A/B).  Results reach the host through stream synchronisations and copies.
+#ifdef TSL_TEST_HOOKS
     static const bool ev_sys = std::getenv("TSL_EV_SYS") != nullptr;
+#else
+    constexpr bool ev_sys = false;
+#endif
     const unsigned evf = hipEventDisableTiming | (ev_sys ? 0u : (unsigned)hipEventDisableSystemFence);
     for (int bi = 0; bi < TSL_NBATCH; ++bi) {
         BatchHost& H = m->batch[bi];
@@ -1647,11 +1659,18 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "seq_tuple_cap")) {
         TSL_REQUIRE(value >= (1 << 16), "seq_tuple_cap: at least 2^16 ray steps per frame");
         int rc = tsl_tsdf_sync(m); if (rc) return rc;
+        const long long old_cap = m->seq_tuple_cap;
         m->seq_tuple_cap = value;
         if (m->seq_ready) {          // the scratch exists already (allocated when the mode was switched on): it is rebuilt at the new size
             TSL_HIP(hipSetDevice(m->device));
             seq_release(m);
-            if (m->semantics && m->seq_impl) { rc = seq_prepare(m); if (rc) return rc; }
+            if (m->semantics && m->seq_impl && (rc = seq_prepare(m))) {
+                // the new size does not fit: back to the old one, reported HERE; if even that fails the handle leaves the literal mode rather than
+                // meeting the failure in the middle of a batch
+                m->seq_tuple_cap = old_cap;
+                if (seq_prepare(m)) m->semantics = 0;
+                return rc;
+            }
         }
         return TSL_OK;
     }

@@ -277,7 +277,8 @@ struct tsl_tsdf {
     double prof_ms[TSL_K_COUNT]; int64_t prof_n[TSL_K_COUNT];
     int semantics;                       // 0: BATCHED (exact per-frame sums applied once), 1: the reference-literal sequential replay (tsl_sequential.hip)
     int seq_impl;                        // 1: per-brick replay runs built on the brick pipeline (default), 0: round 3's two global radix sorts (one frame per batch; kept as a cross-check)
-    bool seq_ready; tsl::SeqDev seq_h[TSL_NSETS]; tsl::SeqDev* seq_d;      // seq_impl 1: tuple arrays of every working set (allocated by the first sequential batch)
+    bool seq_ready; int64_t seq_bytes0;      /* bytes of the literal scratch inside m->bytes: seq_release takes exactly those out of the account again */
+    tsl::SeqDev seq_h[TSL_NSETS]; tsl::SeqDev* seq_d;      // seq_impl 1: tuple arrays of every working set (allocated by the first sequential batch)
     void *seqb_keys[TSL_NBATCH][2], *seqb_vals[TSL_NBATCH][2], *seqb_temp[TSL_NBATCH], *seqb_long[TSL_NBATCH], *seqb_lmask[TSL_NBATCH], *seqb_perm[TSL_NBATCH]; size_t seqb_temp_bytes; long long seq_tuple_cap;      // per batch slot: the rays' struct-for keys of all its frames, sorted in one call
     unsigned long long *seq_keys[2], *seq_vals[2], *seq_ctr; void* seq_temp; size_t seq_temp_bytes; long long seq_cap;
     int variant, split, phases, wg, spt, ncu, chunks, unit_max, unit_half, unit_floor, bgrid, ugrid, pgrid, split_launch, adaptive, ramp, ramp_batches, ramp_size; bool clean; uint64_t batch_gen;

@@ -250,7 +250,9 @@ def test_the_suite_notices_a_missing_pipeline_wait(hip_lib, c2_frames, c2_oracle
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "fault.py"
     script.write_text(_FAULT_SCRIPT)
-    env = dict(os.environ, TSL_FAULT_NO_BDONE_WAIT="1")
+    from taichislam_amd import build
+    assert os.path.exists(build.HOOKS_LIB), "the -DTSL_TEST_HOOKS build of the library is missing (taichislam_amd/build.py makes it beside the product one)"
+    env = dict(os.environ, TSL_FAULT_NO_BDONE_WAIT="1", TSL_LIB=build.HOOKS_LIB)      # the fault switch exists only in the test-hooks build
     r = subprocess.run([sys.executable, str(script), root, str(tmp_path / "want.npz"), str(N_C2)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("MISMATCHING_RUNS")]

@@ -244,3 +244,18 @@ def test_tuple_capacity_overflow_in_a_queued_batch_leaves_the_other_frames_exact
             g.sync()
         assert kept == 4
         assert_export_equal(g.export_submap(), o.export_sparse(), f"small frames beside overflowing ones, repetition {rep}")
+
+
+def test_rebuilding_the_literal_scratch_does_not_double_count_its_bytes(hip_lib):
+    """set_option("seq_tuple_cap") on a live handle frees and reallocates the literal scratch; tsl_tsdf_memory_bytes must follow."""
+    from taichislam_amd.mapping import DenseTSDF
+    g = DenseTSDF(**SMALL)
+    b0 = g.memory_bytes()
+    g.set_option("semantics", 1)
+    b1 = g.memory_bytes()
+    assert b1 > b0
+    g.set_option("seq_tuple_cap", 1 << 22)
+    b2 = g.memory_bytes()
+    g.set_option("seq_tuple_cap", 1 << 23)
+    assert g.memory_bytes() == b1 and b0 < b2 < b1
+    g.set_option("semantics", 0)

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/roles; mkdir -p $O
-cd /tmp && TSL_SEQ_SPLIT_ROLES=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t -o p -- python $GRAFT_REPO_ROOT/tools/seq_probe.py --frames 72 > $O/prof.log 2>&1
+cd /tmp && TSL_SEQ_SPLIT_ROLES=1 TSL_LIB=$GRAFT_REPO_ROOT/taichislam_amd/lib/libtaichislam_hip_testhooks.so timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t -o p -- python $GRAFT_REPO_ROOT/tools/seq_probe.py --frames 72 > $O/prof.log 2>&1
 python - "$(find $O/t -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # VALU wave-instructions of the two roles of k_seq_replay launched apart (TSL_SEQ_SPLIT_ROLES=1): short runs first, long runs second
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/roles; mkdir -p $O
-cd /tmp && TSL_SEQ_SPLIT_ROLES=1 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/t -o p -- python $GRAFT_REPO_ROOT/tools/seq_probe.py --frames 72 > $O/pmc.log 2>&1
+cd /tmp && TSL_SEQ_SPLIT_ROLES=1 TSL_LIB=$GRAFT_REPO_ROOT/taichislam_amd/lib/libtaichislam_hip_testhooks.so timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/t -o p -- python $GRAFT_REPO_ROOT/tools/seq_probe.py --frames 72 > $O/pmc.log 2>&1
 python - "$(find $O/t -name '*counter_collection.csv' | head -1)" <<'PY'
 import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_seq_replay" in r["Kernel_Name"]]
