@@ -58,7 +58,10 @@ struct EsdfDev {
     int* dirty;                // [max_bricks] dirty list
     uint32_t* note;            // [2][max_bricks] per round parity: bit q = neighbour q (of 27) changed its boundary layer in the previous round
     int* work;                 // [3][max_bricks] work lists of rounds k, k+1, k+2 (mod 3)
-    int* nbr;                  // [max_bricks][27] pool indices of the bricks around a region brick (-1: absent), written by k_esdf_init
+    int* nbr;                  // [max_bricks][27] pool indices of the bricks around a region brick (-1: absent), written by k_esdf_init (esdf_mode 0)
+    uint8_t* par;              // [max_bricks][4096] esdf_mode 1: direction code of the voxel's PARENT -- the neighbour its value was taken from --
+                               // (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1), 13 = none (band voxel, max_dist, unobserved)          dense_esdf.py:96, :290, :296
+    uint8_t* ok;               // [max_bricks] esdf_mode 1: the brick's mag / fl / par describe the current (submap, gamma, max_dist)
     int cap;                   // max_bricks
     unsigned long long* tm;    // developer timing (TSL_TIMING builds): ticks per phase, summed over relaxations
     int* ctr_next;             // the counter block of the NEXT update (the two alternate): zeroed by this update's collect kernel, so that an update
@@ -79,6 +82,7 @@ __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ES_CTR + ES_STAT_SLOTS * 16; i += gridDim.x * 256) E.ctr_next[i] = 0;
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool take = false;
+    if (all && E.ok && p < E.cap) E.ok[p] = 0;               // (esdf_mode 1) a full recompute forgets every brick's state, also of bricks the pool has not handed out yet
     if (p < nused) {
         const bool mine = M.owner[p] / M.nb3 == s;
         if (mine) { take = all || M.touch[p] != 0; M.touch[p] = 0; }
@@ -553,6 +557,451 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
     }
 }
 
+// =====================================================================================================================================
+// esdf_mode 1 (default since round 6): the update as a RAISE / LOWER WAVEFRONT with parent directions, dense_esdf.py:255-333.
+//
+// The reference keeps `parent_dir` per voxel (:96): a lowered voxel remembers the neighbour it took its value from (:290, :296); when a
+// voxel's value goes up, the raise queue visits exactly the voxels whose parent chain passes through it (:255-273), and the lower queue then
+// repairs them from whatever is still valid (:275-299).  Here the same bookkeeping drives the brick pipeline:
+//   * INVARIANT (between updates).  Every observed non-band voxel x either sits at max_dist without a parent, or has a parent n = x + dir on its
+//     own side with  value(x) == fl(value(n) + |dir| * voxel)  ("supported"), and no neighbour offers less ("relaxed").  Supported chains
+//     descend strictly and end in band voxels, so every value is a realisable path cost; relaxed + realisable == the least fixed point, the
+//     same field the regional recompute (esdf_mode 0), the full recompute and the oracle's Dijkstra give, bit for bit.
+//   * k_esdf_diff visits the bricks an integrate kernel wrote and compares each voxel's ESDF INPUTS (observed, side, band membership, band
+//     value) with the stored ones: a band voxel takes its new value, a voxel that left the band / changed side / is new starts from
+//     max_dist without a parent, everything else keeps value AND parent.  Only bricks where something changed start the wave; nothing is
+//     dilated, nothing is re-initialised.
+//   * A visit of a brick (k_esdf_wave) stages the 18^3 tile and the parent codes, then
+//       RAISE: every voxel whose parent link no longer holds is re-derived THROUGH THAT LINK -- value := fl(value(parent) + cost), the value
+//              its own chain gives it now; max_dist and no parent if the parent left its side -- parents before children, by six concurrent
+//              directional sweeps that only follow parent links (a chain in free space advances along one dominant axis, so one sweep carries a
+//              whole chain).  This is the reference's raise wave with one difference: a raised voxel is not thrown back to max_dist when its
+//              chain still exists, it keeps the chain's new cost -- still a realisable upper bound, and for the common case (the band's f16
+//              values drift by an ulp from frame to frame) already the final value.  Descendants inside the tile are all re-derived before
+//              anything is lowered, so no voxel can be lowered from a stale descendant of itself inside a brick.
+//       LOWER: the six directional pull sweeps of esdf_mode 0 (atomic min on the tile), to the local fixed point.
+//       PARENTS of the voxels the lower wave wrote: the neighbour that supports the final value (one exists at the fixed point).
+//     and writes back the voxels (and parent codes) that changed.
+//   * The wave crosses bricks through the work lists: a brick lists neighbour B for the next round iff, seen from here, a voxel of B in this
+//     tile's halo is unsupported (its parent is one of this brick's voxels and the link no longer holds: RAISE) or could be lowered from this
+//     brick (LOWER) -- a test on B's STAGED state, exact when B was not visited in this round -- or B was visited in this same round (it may
+//     have staged values this visit has since changed) and the layer of this brick next to B changed.  At quiescence every brick's last
+//     visit saw its neighbours' final values or was followed by a neighbour's test on its final state: the invariant holds everywhere.
+//     (A value that has to rise by more than its descendants' lead -- the surface under it vanished -- can borrow from a stale descendant in
+//     ANOTHER brick and is then corrected round by round; should the rounds launched not suffice, the host repairs with a full recompute,
+//     as for esdf_mode 0.)
+#define EP_NONE 13u
+__device__ __forceinline__ int esdf_code_off(uint32_t code) { const int a = (int)(code / 9u), b = (int)((code / 3u) % 3u), c = (int)(code % 3u); return (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1); }
+// what the parent link `code` of the voxel at tile index idx (word own) gives it now: side | fl(parent + cost) and the code, or side | max_dist and no parent
+__device__ __forceinline__ void esdf_rederive(const uint32_t* s_t, int idx, uint32_t code, uint32_t own, float c1, float c2, float c3, float max_dist, uint32_t& nw, uint32_t& npar)
+{
+    const int a = (int)(code / 9u), b = (int)((code / 3u) % 3u), c = (int)(code % 3u);
+    const int nz = (a != 1) + (b != 1) + (c != 1);
+    const uint32_t pw = ES_LD(&s_t[idx + (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1)]);
+    const bool ok = ((pw ^ own) & 0x80000000u) == 0u && (pw & 0x7fffffffu) <= ES_INF;          // the parent is observed and on this voxel's side
+    const float tv = __uint_as_float(pw & 0x7fffffffu) + (nz == 1 ? c1 : (nz == 2 ? c2 : c3));
+    const bool keep = ok && tv < max_dist;
+    nw = (own & 0x80000000u) | (keep ? __float_as_uint(tv) : __float_as_uint(max_dist));
+    npar = keep ? code : EP_NONE;
+}
+
+// 2'. the bricks an integrate kernel wrote: new ESDF inputs against the stored ones
+__global__ void __launch_bounds__(256) k_esdf_diff(MapDev M, EsdfDev E, int s, int all, float gamma, float max_dist)
+{
+    const int nd = E.ctr[0];
+    const uint32_t maxd = __float_as_uint(max_dist);
+    for (int d = blockIdx.x; d < nd; d += gridDim.x) {
+        const int pd = E.dirty[d];
+        const bool fresh = all || E.ok[pd] == 0;              // nothing valid stored for this brick: everything counts as unobserved before
+        const size_t v = (size_t)pd * TSL_BRK3 + (size_t)threadIdx.x * 16;
+        const uint4 ob = *reinterpret_cast<const uint4*>(M.obs + v);
+        uint4 fo = make_uint4(0u, 0u, 0u, 0u), po = make_uint4(0x0d0d0d0du, 0x0d0d0d0du, 0x0d0d0d0du, 0x0d0d0d0du);
+        uint4 tw[4], mo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { tw[q] = reinterpret_cast<const uint4*>(M.tw + v)[q]; mo[q] = make_uint4(ES_UNOBS, ES_UNOBS, ES_UNOBS, ES_UNOBS); }
+        if (!fresh) {
+            fo = *reinterpret_cast<const uint4*>(E.fl + v); po = *reinterpret_cast<const uint4*>(E.par + v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mo[q] = reinterpret_cast<const uint4*>(E.mag + v)[q];
+        }
+        const uint32_t ow[4] = { ob.x, ob.y, ob.z, ob.w }, fw[4] = { fo.x, fo.y, fo.z, fo.w }, pw[4] = { po.x, po.y, po.z, po.w };
+        const uint32_t tv[16] = { tw[0].x, tw[0].y, tw[0].z, tw[0].w, tw[1].x, tw[1].y, tw[1].z, tw[1].w, tw[2].x, tw[2].y, tw[2].z, tw[2].w, tw[3].x, tw[3].y, tw[3].z, tw[3].w };
+        const uint32_t mv[16] = { mo[0].x, mo[0].y, mo[0].z, mo[0].w, mo[1].x, mo[1].y, mo[1].z, mo[1].w, mo[2].x, mo[2].y, mo[2].z, mo[2].w, mo[3].x, mo[3].y, mo[3].z, mo[3].w };
+        uint32_t nf[4] = { 0u, 0u, 0u, 0u }, np[4] = { 0u, 0u, 0u, 0u }, nm[16];
+        bool changed = false, seed = false;
+#pragma unroll
+        for (int z = 0; z < 16; ++z) {
+            uint32_t f; float mg;
+            esdf_inputs((ow[z >> 2] >> ((z & 3) * 8)) & 0xffu, tv[z], gamma, max_dist, &f, &mg);
+            const uint32_t fs = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu, ps = (pw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
+            const uint32_t side = (f & EF_NEG) ? 0x80000000u : 0u;
+            uint32_t w, pc = EP_NONE;
+            if (!(f & EF_NODE)) w = ES_UNOBS;
+            else if (f & EF_FIXED) w = __float_as_uint(mg) | side;                              // band: the TSDF value itself (:313-317)
+            else if (fs == f) { w = mv[z]; pc = ps; }                                           // same class as before, outside the band: value and parent stand
+            else w = maxd | side;                                                               // new / left the band / changed side (:325, :329): to be lowered
+            changed = changed || w != mv[z] || fs != f;
+            seed = seed || (f & EF_FIXED);
+            nf[z >> 2] |= f << ((z & 3) * 8); np[z >> 2] |= pc << ((z & 3) * 8); nm[z] = w;
+        }
+        if (changed || fresh) {                                 // (a brick without a valid state is written whole: its arrays hold whatever an earlier map left)
+            *reinterpret_cast<uint4*>(E.fl + v) = make_uint4(nf[0], nf[1], nf[2], nf[3]);
+            *reinterpret_cast<uint4*>(E.par + v) = make_uint4(np[0], np[1], np[2], np[3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(E.mag + v)[q] = make_uint4(nm[4 * q], nm[4 * q + 1], nm[4 * q + 2], nm[4 * q + 3]);
+        }
+        const bool any = __syncthreads_or(changed) != 0;
+        const bool band = __syncthreads_or(seed) != 0;
+        if (threadIdx.x == 0) {
+            if (fresh) E.ok[pd] = 1;
+            if (any) {
+                E.region[pd] = 1;                               // its first visit of this update looks at everything
+                __hip_atomic_fetch_add(ES_STAT(E, 5), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // a full recompute starts from the bricks that hold a source; the others wait until a neighbour reports something for them
+                if (!all || band) { const int q = __hip_atomic_fetch_add(&E.ctr[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); E.work[q] = pd; E.stamp[pd] = 0; }
+            }
+        }
+    }
+}
+
+// the RAISE sweep of the calling wave: voxels whose parent lies in the plane before (along AXIS, direction SIGN) take the value their link gives them now
+template <int AXIS, int SIGN>
+__device__ __forceinline__ void esdf_rsweep(uint32_t* s_t, uint8_t* s_par, uint32_t* s_chg, unsigned long long mT, const float c1, const float c2, const float c3, const float max_dist, int& raised)
+{
+    const int lane = (int)(threadIdx.x & 63u), q = lane & 3, r = lane >> 2;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i, mT >>= 4) {
+        const uint32_t tn = (uint32_t)mT & 15u;
+        if (!__any(tn != 0u)) continue;
+        const int sp = SIGN > 0 ? i : 15 - i;
+        uint32_t cm = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = AXIS == 0 ? sp : r, y = AXIS == 0 ? r : (AXIS == 1 ? sp : 4 * q + j), z = AXIS == 2 ? sp : 4 * q + j;
+            const int l = (x << 8) | (y << 4) | z, idx = (x + 1) * ES_SX + (y + 1) * ES_SY + z + 1;
+            const uint32_t code = s_par[l];
+            const uint32_t comp = AXIS == 0 ? code / 9u : (AXIS == 1 ? (code / 3u) % 3u : code % 3u);
+            if (!((tn >> j) & 1u) || code == EP_NONE || comp != (SIGN > 0 ? 0u : 2u)) continue;
+            const uint32_t own = ES_LD(&s_t[idx]);
+            uint32_t nw, npar;
+            esdf_rederive(s_t, idx, code, own, c1, c2, c3, max_dist, nw, npar);
+            if (nw != own) {
+                __hip_atomic_store(&s_t[idx], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (npar != code) s_par[l] = (uint8_t)npar;
+                __hip_atomic_fetch_or(&s_chg[l >> 5], 1u << (l & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                cm |= 1u << j;
+            }
+        }
+        raised += __builtin_popcount(cm);
+    }
+}
+
+__global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E, int s, float vs, float max_dist, int round)
+{
+    constexpr int NH = ESDF_T3 - TSL_BRK3, HPER = (NH + 383) / 384;      // 1736 halo entries, 5 per thread
+    __shared__ uint32_t s_t[ES_TILE];                      // the tile: side << 31 | magnitude, ES_UNOBS where unobserved
+    __shared__ __attribute__((aligned(16))) uint8_t s_par[TSL_BRK3];   // parent codes of the interior voxels
+    __shared__ uint8_t s_hp[HPER * 384];                   // parent codes of the halo entries (for the notification test)
+    __shared__ __attribute__((aligned(4))) uint16_t s_tgt16[256], s_neg16[256];
+    __shared__ uint32_t s_chg[TSL_BRK3 / 32];              // interior voxels lowered in this visit (their parents are looked up afterwards)
+    __shared__ uint32_t s_chr[TSL_BRK3 / 32];              // interior voxels re-derived by the raise sweeps
+    __shared__ int s_nb[27];
+    __shared__ int s_notify, s_flags, s_layer;
+    const uint32_t* const s_tgt = reinterpret_cast<const uint32_t*>(s_tgt16);
+    const uint32_t* const s_neg = reinterpret_cast<const uint32_t*>(s_neg16);
+    const int cur = round % 3, nxt = (round + 1) % 3, clr = (round + 2) % 3;
+    const int n = E.ctr[2 + cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) { E.ctr[7] = round + 1; if (round < 16) E.ctr[240 + round] = n; } }
+    if (n == 0) return;
+    const int nused = min(E.ctr[10], M.max_bricks);
+    const float c1 = 1.0f * vs, c2 = sqrtf(2.0f) * vs, c3 = sqrtf(3.0f) * vs;                   // dense_esdf.py:286
+    const int* list = E.work + (size_t)cur * E.cap;
+    int* next = E.work + (size_t)nxt * E.cap;
+    const int wave = (int)(threadIdx.x >> 6);
+    uint32_t hpk[HPER], hnb[HPER];                        // as in k_esdf_round: tile index | brick of 27 << 13 | voxel in it << 18; the interior voxels next to the entry
+#pragma unroll
+    for (int q = 0; q < HPER; ++q) {
+        const int h = q * 384 + (int)threadIdx.x;
+        int tx, ty, tz;
+        if (h < 2 * ESDF_T * ESDF_T) { const int r = h % (ESDF_T * ESDF_T); tx = (h / (ESDF_T * ESDF_T)) * 17; ty = r / ESDF_T; tz = r % ESDF_T; }
+        else if (h < 2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T) { const int g = h - 2 * ESDF_T * ESDF_T, r = g % (2 * ESDF_T); tx = 1 + g / (2 * ESDF_T); ty = (r / ESDF_T) * 17; tz = r % ESDF_T; }
+        else { const int g = h - (2 * ESDF_T * ESDF_T + 16 * 2 * ESDF_T); tx = 1 + g / 32; ty = 1 + (g % 32) / 2; tz = (g & 1) * 17; }
+        const uint32_t hq = (uint32_t)((((tx + 15) >> 4) * 3 + ((ty + 15) >> 4)) * 3 + ((tz + 15) >> 4));
+        const uint32_t vo = (uint32_t)((((tx + 15) & 15) << 8) | (((ty + 15) & 15) << 4) | ((tz + 15) & 15));
+        hpk[q] = h < NH ? (uint32_t)(tx * ES_SX + ty * ES_SY + tz) | hq << 13 | vo << 18 : ~0u;
+        const int fx = tx == 0 || tx == 17, fy = ty == 0 || ty == 17, fz = tz == 0 || tz == 17;
+        const int ix = tx == 0 ? 1 : (tx == 17 ? 16 : tx), iy = ty == 0 ? 1 : (ty == 17 ? 16 : ty), iz = tz == 0 ? 1 : (tz == 17 ? 16 : tz);
+        const int ucode = !fx ? 1 : (!fy ? 2 : (!fz ? 3 : 0)), vcode = !fx ? (!fy ? 2 : (!fz ? 3 : 0)) : ((!fy && !fz) ? 3 : 0);
+        const int cu = ucode == 1 ? tx : (ucode == 2 ? ty : tz), cv = vcode == 2 ? ty : tz;
+        hnb[q] = (uint32_t)(ix * ES_SX + iy * ES_SY + iz) | (uint32_t)ucode << 13 | (uint32_t)vcode << 15 | (uint32_t)cu << 17 | (uint32_t)cv << 22 | (uint32_t)(fx + fy + fz) << 27;
+    }
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+#ifdef TSL_TIMING
+        long long _t = wall_clock64();
+#endif
+        const int p = list[w];
+        if (threadIdx.x < 27) {                                     // the 27 bricks around this one (a brick allocated after the update's snapshot is not part of it)
+            const int t = (int)threadIdx.x, b = M.owner[p] - s * M.nb3;
+            const int i = b / (M.nbz * M.nbx) + t / 9 - 1, j = (b / M.nbz) % M.nbx + (t / 3) % 3 - 1, k = b % M.nbz + t % 3 - 1;
+            int np = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+            if (np >= nused) np = -1;
+            s_nb[t] = np;
+        }
+        if (threadIdx.x == 0) { s_notify = 0; s_flags = 0; s_layer = 0; }
+        if (threadIdx.x < TSL_BRK3 / 32) { s_chg[threadIdx.x] = 0u; s_chr[threadIdx.x] = 0u; }
+        const bool first = E.region[p] == 1;                        // changed by k_esdf_diff and not visited since: every link and every plane is looked at
+        uint32_t* const my_note = E.note + (size_t)(round & 1) * E.cap + p;
+        const uint32_t note = first ? ~0u : *my_note;
+        __syncthreads();
+        ESDF_TICK(0);
+        if (threadIdx.x == 0) *my_note = 0u;
+        // ---- stage brick + halo, values and parent codes, as ONE batch of independent loads ----
+        int flags = 0;
+        {
+            const int row = (int)threadIdx.x & 255;
+            const size_t v0 = (size_t)p * TSL_BRK3 + (size_t)row * 16;
+            uint4 dq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dq[q] = reinterpret_cast<const uint4*>(E.mag + v0)[q];
+            const uint4 fq = *reinterpret_cast<const uint4*>(E.fl + v0);
+            const uint4 pq = *reinterpret_cast<const uint4*>(E.par + v0);
+            uint32_t hd[HPER], hk[HPER]; uint8_t hc[HPER];
+#pragma unroll
+            for (int q = 0; q < HPER; ++q) {
+                hk[q] = hpk[q];
+                asm volatile("" : "+v"(hk[q]));
+                const int np = hk[q] != ~0u ? s_nb[(hk[q] >> 13) & 31u] : -1;
+                if (np < 0) hk[q] = ~0u;
+                const size_t at = (size_t)(np >= 0 ? np : p) * TSL_BRK3 + (np >= 0 ? hk[q] >> 18 : 0u);
+                hd[q] = __float_as_uint(E.mag[at]); hc[q] = E.par[at];
+            }
+            if (threadIdx.x < 256) {
+                const uint32_t dl[16] = { dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w, dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w };
+                const uint32_t fw[4] = { fq.x, fq.y, fq.z, fq.w };
+                const int t0 = ((int)(threadIdx.x >> 4) + 1) * ES_SX + ((int)(threadIdx.x & 15) + 1) * ES_SY + 1;
+                uint32_t tg = 0u, ng = 0u;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const uint32_t f = (fw[z >> 2] >> ((z & 3) * 8)) & 0xffu;
+                    s_t[t0 + z] = dl[z];
+                    if (__uint_as_float(dl[z] & 0x7fffffffu) + c1 < max_dist) flags |= 2;
+                    tg |= ((f & (EF_NODE | EF_FIXED)) == EF_NODE ? 1u : 0u) << z;
+                    ng |= ((f & EF_NEG) ? 1u : 0u) << z;
+                }
+                s_tgt16[threadIdx.x] = (uint16_t)tg; s_neg16[threadIdx.x] = (uint16_t)ng;
+                *reinterpret_cast<uint4*>(s_par + threadIdx.x * 16) = pq;
+                if (tg != 0u) flags |= 1;
+            }
+#pragma unroll
+            for (int q = 0; q < HPER; ++q) {
+                if (hpk[q] == ~0u) continue;
+                const uint32_t hw = hk[q] != ~0u ? hd[q] : ES_UNOBS;
+                s_t[hpk[q] & 0x1fffu] = hw;
+                s_hp[q * 384 + threadIdx.x] = hk[q] != ~0u ? hc[q] : (uint8_t)EP_NONE;
+                if (__uint_as_float(hw & 0x7fffffffu) + c1 < max_dist) flags |= 2;
+            }
+        }
+        {
+            const int f1 = __any(flags & 1) ? 1 : 0, f2 = __any(flags & 2) ? 2 : 0;
+            if ((threadIdx.x & 63u) == 0 && (f1 | f2)) atomicOr(&s_flags, f1 | f2);
+        }
+        __syncthreads();
+        const bool targets = (s_flags & 1) != 0, work = s_flags == 3;
+        ESDF_TICK(1);
+        int lowered = 0, raised = 0, sets = 0;
+        bool any_raise = false;
+        unsigned long long mT = 0ull, mN = 0ull;
+        if (targets) {
+            switch (wave) {
+            case 0: esdf_masks<0, +1>(s_tgt, s_neg, mT, mN); break;
+            case 1: esdf_masks<0, -1>(s_tgt, s_neg, mT, mN); break;
+            case 2: esdf_masks<1, +1>(s_tgt, s_neg, mT, mN); break;
+            case 3: esdf_masks<1, -1>(s_tgt, s_neg, mT, mN); break;
+            case 4: esdf_masks<2, +1>(s_tgt, s_neg, mT, mN); break;
+            default: esdf_masks<2, -1>(s_tgt, s_neg, mT, mN); break;
+            }
+            // ---- RAISE: links that no longer hold, re-derived parents first.  A flat check of every link decides whether a set of sweeps is needed
+            //      (and, behind one, whether it sufficed: the six waves race, and a chain that bends against its sweep takes another set) ----
+            for (int rs = 0; ; ++rs) {
+                bool broken = false;
+                for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
+                    const uint32_t code = s_par[l];
+                    if (code == EP_NONE) continue;
+                    const int idx = ((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1;
+                    const uint32_t own = ES_LD(&s_t[idx]);
+                    uint32_t nw, npar;
+                    esdf_rederive(s_t, idx, code, own, c1, c2, c3, max_dist, nw, npar);
+                    broken = broken || nw != own;
+                }
+                if (!__syncthreads_or(broken)) break;
+                if (rs >= 48) { if (threadIdx.x == 0) E.ctr[8] = 1; break; }          // (never seen: the host repairs with a full recompute)
+                any_raise = true;
+                switch (wave) {
+                case 0: esdf_rsweep<0, +1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
+                case 1: esdf_rsweep<0, -1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
+                case 2: esdf_rsweep<1, +1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
+                case 3: esdf_rsweep<1, -1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
+                case 4: esdf_rsweep<2, +1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
+                default: esdf_rsweep<2, -1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
+                }
+                __syncthreads();
+            }
+        }
+        ESDF_TICK(5);
+        // ---- LOWER: the pull sweeps (esdf_sweep above).  Everything in the tile is a realisable value now ----
+        if (work) {
+            const uint32_t entry_mask = wave == 0 ? 0x1ffu : wave == 1 ? 0x1ffu << 18 : wave == 2 ? 0x01c0e07u : wave == 3 ? 0x01c0e07u << 6 : wave == 4 ? 0x1249249u : 0x1249249u << 2;
+            bool full = first || any_raise;
+            for (;;) {
+                bool chg = false;
+                if (full || (note & entry_mask)) {
+                    switch (wave) {
+                    case 0: chg = esdf_sweep<0, +1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 1: chg = esdf_sweep<0, -1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 2: chg = esdf_sweep<1, +1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 3: chg = esdf_sweep<1, -1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    case 4: chg = esdf_sweep<2, +1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    default: chg = esdf_sweep<2, -1>(s_t, s_chg, mT, mN, c1, c2, c3, !full, lowered); break;
+                    }
+                }
+                ++sets;
+                if (!__syncthreads_or(chg)) break;
+                full = true;
+            }
+        }
+#ifdef TSL_TIMING
+        if (threadIdx.x == 0) { const long long _n = wall_clock64(); const int pb = sets < 31 ? sets : 31;
+            atomicAdd(&E.tm[8 + pb], (unsigned long long)(_n - _t)); atomicAdd(&E.tm[40 + pb], 1ull); atomicMax(&E.tm[72], (unsigned long long)(_n - _t)); }
+        { const long long pw = wave_sum_ll((long long)(lowered + raised)); if (lane_id() == 0) atomicAdd(&E.tm[80 + (sets < 31 ? sets : 31)], (unsigned long long)pw); }
+#endif
+        ESDF_TICK(2);
+        // ---- PARENTS of the voxels the lower wave wrote: the neighbour whose value + edge cost IS the voxel's value.  At the local fixed point the
+        //      neighbour a voxel was last lowered from still offers exactly that (it can only have been lowered since, and then the voxel with it) ----
+        int orphans = 0;
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
+            if (!((s_chg[l >> 5] >> (l & 31)) & 1u)) continue;
+            const int idx = ((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1;
+            const uint32_t own = ES_LD(&s_t[idx]);
+            uint32_t found = EP_NONE;
+#pragma unroll 1
+            for (uint32_t code = 0; code < 27u; ++code) {
+                if (code == EP_NONE) continue;
+                uint32_t nw, npar;
+                esdf_rederive(s_t, idx, code, own, c1, c2, c3, max_dist, nw, npar);
+                if (npar != EP_NONE && nw == own) { found = code; break; }
+            }
+            if (found == EP_NONE) ++orphans;
+            s_par[l] = (uint8_t)found;
+        }
+        __syncthreads();
+        // ---- write back the rows that changed (values + parent codes), and note which of the 26 outer layers did ----
+        if (threadIdx.x < 256) {
+            const int row = (int)threadIdx.x, x = row >> 4, y = row & 15;
+            const uint32_t m16 = ((s_chg[row >> 1] | s_chr[row >> 1]) >> ((row & 1) * 16)) & 0xffffu;
+            if (m16) {
+                const int t0 = (x + 1) * ES_SX + (y + 1) * ES_SY + 1;
+                uint32_t wv[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z) wv[z] = s_t[t0 + z];
+                const size_t v0 = (size_t)p * TSL_BRK3 + (size_t)row * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(E.mag + v0)[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+                *reinterpret_cast<uint4*>(E.par + v0) = *reinterpret_cast<const uint4*>(s_par + row * 16);
+                // the neighbours (qx, qy, qz in {0, 1, 2}) whose halo holds a voxel of this row that changed
+                int lay = 0;
+#pragma unroll
+                for (int qx = 0; qx < 3; ++qx)
+#pragma unroll
+                    for (int qy = 0; qy < 3; ++qy)
+#pragma unroll
+                        for (int qz = 0; qz < 3; ++qz) {
+                            const bool okx = qx == 1 || (qx == 0 ? x == 0 : x == 15), oky = qy == 1 || (qy == 0 ? y == 0 : y == 15);
+                            const uint32_t zm = qz == 1 ? m16 : (qz == 0 ? (m16 & 1u) : (m16 >> 15));
+                            if (okx && oky && zm) lay |= 1 << ((qx * 3 + qy) * 3 + qz);
+                        }
+                atomicOr(&s_layer, lay & ~(1 << 13));
+            }
+        }
+        // ---- which neighbours to tell.  Seen from here a voxel z of a neighbour (an entry of this tile's halo, as STAGED) needs a visit of its brick iff
+        //      RAISE: its parent is a voxel of this brick and the link no longer holds, or LOWER: a voxel of this brick now offers it less ----
+        if (first || __syncthreads_or((lowered | raised) != 0)) {
+            int told = 0;
+#pragma unroll
+            for (int q = 0; q < HPER; ++q) {
+                uint32_t hk = hpk[q], hn = hnb[q];
+                asm volatile("" : "+v"(hk), "+v"(hn));
+                if (hk == ~0u) continue;
+                const int hidx = (int)(hk & 0x1fffu);
+                const uint32_t hw = ES_LD(&s_t[hidx]);
+                if (hw == ES_UNOBS) continue;
+                const uint32_t hcode = s_hp[q * 384 + threadIdx.x];
+                if (hcode != EP_NONE) {
+                    const int pidx = hidx + esdf_code_off(hcode);
+                    const int px = pidx / ES_SX, py = (pidx - px * ES_SX) / ES_SY, pz = pidx - px * ES_SX - py * ES_SY;
+                    if (px >= 1 && px <= 16 && py >= 1 && py <= 16 && pz >= 1 && pz <= 16) {          // the parent is one of this brick's voxels
+                        uint32_t nw, npar;
+                        esdf_rederive(s_t, hidx, hcode, hw, c1, c2, c3, max_dist, nw, npar);
+                        if (nw != hw) told |= 1 << ((hk >> 13) & 31u);
+                    }
+                }
+                const uint32_t sb = hw & 0x80000000u;
+                const int base = (int)(hn & 0x1fffu), uc = (int)((hn >> 13) & 3u), vc = (int)((hn >> 15) & 3u), cu = (int)((hn >> 17) & 31u), cv = (int)((hn >> 22) & 31u), nf = (int)(hn >> 27);
+                const int su = uc == 1 ? ES_SX : (uc == 2 ? ES_SY : (uc == 3 ? 1 : 0)), sv = vc == 2 ? ES_SY : (vc == 3 ? 1 : 0);
+                uint32_t m[3] = { ~0u, ~0u, ~0u };
+#pragma unroll
+                for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                    for (int b = -1; b <= 1; ++b) {
+                        const bool ok = (a == 0 || (uc != 0 && cu + a >= 1 && cu + a <= 16)) && (b == 0 || (vc != 0 && cv + b >= 1 && cv + b <= 16));
+                        const uint32_t x = ES_LD(&s_t[base + (ok ? a * su + b * sv : 0)]) ^ sb;
+                        if (ok) m[(a != 0) + (b != 0)] = min(m[(a != 0) + (b != 0)], x);
+                    }
+                const float cc[5] = { 0.0f, c1, c2, c3, __uint_as_float(ES_INF) };
+                float best = __uint_as_float(ES_INF);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) best = fminf(best, __uint_as_float(min(m[e], ES_INF)) + cc[min(nf + e, 4)]);
+                if (__float_as_uint(best) < (hw & 0x7fffffffu)) told |= 1 << ((hk >> 13) & 31u);
+            }
+            told &= ~(1 << 13);
+            for (int d = 32; d >= 1; d >>= 1) told |= __shfl_xor(told, d);
+            if ((threadIdx.x & 63u) == 0 && told) atomicOr(&s_notify, told);
+        }
+        __syncthreads();
+        ESDF_TICK(3);
+        {
+            const long long lw = wave_sum_ll((long long)(lowered + raised));
+            if (lane_id() == 0 && lw) __hip_atomic_fetch_add(ES_STAT(E, 1), (int)lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long ow = wave_sum_ll((long long)orphans);
+            if (lane_id() == 0 && ow) __hip_atomic_fetch_add(&E.ctr[9], (int)ow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x < 64) {
+            const int q = (int)threadIdx.x;
+            bool put = false; int np = -1;
+            if (q < 27 && q != 13 && (np = s_nb[q]) >= 0) {
+                const bool told = (s_notify >> q) & 1, layer = (s_layer >> q) & 1;
+                // a neighbour visited in THIS round may have staged values this visit has changed since: it looks again (and so does this brick, by the
+                // neighbour's same rule, if the neighbour's layer next to it changed)
+                if (told || (layer && __hip_atomic_load(&E.stamp[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round)) {
+                    const int seen = __hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(E.note + (size_t)((round + 1) & 1) * E.cap + np, 1u << (26 - q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    put = seen != round + 1;
+                }
+            }
+            const int at = wave_reserve(&E.ctr[2 + nxt], put);
+            if (put) next[at] = np;
+        }
+        if (threadIdx.x == 0) {
+            if (E.region[p] != 2) __hip_atomic_fetch_add(ES_STAT(E, 4), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // bricks the wave reached
+            E.region[p] = 2;
+            __hip_atomic_fetch_add(ES_STAT(E, 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ES_STAT(E, 2), sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(ES_STAT(E, 3), sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        ESDF_TICK(4);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_esdf_export(MapDev M, int s, int nused, const float* esdf, float gamma, float max_dist, int16_t* idx, float* out, long long cap, int* counter)
 {
     for (int p = blockIdx.x; p < nused; p += gridDim.x) {
@@ -625,7 +1074,8 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         for (int k = 0; k < ES_STAT_SLOTS; ++k) for (int c = 0; c < 6; ++c) { const int v = h[ES_CTR + k * 16 + c]; if (c == 3) sum[3] = v > sum[3] ? v : sum[3]; else sum[c] += v; }
         st.dirty_bricks = h[0]; st.changed_bricks = (int)sum[5]; st.region_bricks = (int)sum[4]; st.brick_relaxations = sum[0]; st.voxel_pushes = sum[1];
         st.rounds = h[7]; st.passes = sum[2]; st.max_passes = (int)sum[3]; st.total_bricks = h[10] < m->M.max_bricks ? h[10] : m->M.max_bricks;
-        if (h[2 + S.rounds % 3] != 0) m->esdf_short = true;                  // the last launched round still had work
+        if (h[2 + S.rounds % 3] != 0 || h[8] != 0) m->esdf_short = true;      // the last launched round still had work (or a raise did not settle)
+        m->esdf_orphans += h[9];
         if (st.incremental && st.rounds > m->esdf_rounds_seen) m->esdf_rounds_seen = st.rounds;
         m->esdf_stats = st;
         m->esdf_tot.updates += 1; m->esdf_tot.incremental += st.incremental; m->esdf_tot.dirty_bricks += st.dirty_bricks; m->esdf_tot.region_bricks += st.region_bricks;
@@ -655,6 +1105,8 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
         if ((rc = dev_alloc(m, (void**)&m->esdf_note, sizeof(uint32_t) * 2 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_nbr, sizeof(int) * 27 * (size_t)nb, 0xff))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_par, (size_t)nb * TSL_BRK3, 13))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_ok, (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 2 * (ES_CTR + ES_STAT_SLOTS * 16), 0))) return rc;
         for (int i = 0; i < TSL_ESDF_SLOTS; ++i) {
             TSL_HIP(hipEventCreateWithFlags(&m->esdf_slot[i].ev, hipEventDisableTiming));
@@ -686,7 +1138,8 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     int* const ctr = m->esdf_ctr + (size_t)m->esdf_ctr_idx * (ES_CTR + ES_STAT_SLOTS * 16);          // this update's counters (zero: allocation / the update before)
     int* const ctr_next = m->esdf_ctr + (size_t)(1 - m->esdf_ctr_idx) * (ES_CTR + ES_STAT_SLOTS * 16);
     m->esdf_ctr_idx = 1 - m->esdf_ctr_idx;
-    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_note, m->esdf_queue, m->esdf_nbr, nb, (unsigned long long*)(ctr + 16), ctr_next, ctr };
+    EsdfDev E = { m->esdf, m->esdf_fl, m->esdf_region, m->esdf_inq, m->esdf_list, m->esdf_note, m->esdf_queue, m->esdf_nbr, m->esdf_par, m->esdf_ok, nb, (unsigned long long*)(ctr + 16), ctr_next, ctr };
+    const bool wavefront = m->esdf_mode != 0;
     EsdfSlot& S = m->esdf_slot[(m->esdf_tail + m->esdf_npend) % TSL_ESDF_SLOTS];
     std::memset(&S.st, 0, sizeof(S.st));
     S.st.incremental = full ? 0 : 1;
@@ -701,11 +1154,19 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     if (q == q0) { hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_gate; }
     else { hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_read; }
     m->esdf_gate_set = true; m->esdf_gate_mask = 0;
+    if (wavefront) {
+        // raise / lower wavefront: the bricks whose ESDF inputs changed start the wave, nothing is dilated or re-initialised
+        if (q != q0) {
+            hipExtLaunchKernelGGL(k_esdf_diff, dim3(1024), dim3(256), 0, q, nullptr, m->esdf_read, 0, m->M, E, s, full ? 1 : 0, gamma, max_dist);
+            TSL_HIP(hipStreamWaitEvent(q0, m->esdf_read, 0));
+        } else hipLaunchKernelGGL(k_esdf_diff, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 1 : 0, gamma, max_dist);
+    } else {
     hipLaunchKernelGGL(k_esdf_dilate, dim3(1024), dim3(256), 0, q, m->M, E, s, full ? 0 : reach, full ? 1 : 0, gamma, max_dist);
     if (q != q0) {
         hipExtLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, nullptr, m->esdf_read, 0, m->M, E, s, gamma, max_dist);
         TSL_HIP(hipStreamWaitEvent(q0, m->esdf_read, 0));
     } else hipLaunchKernelGGL(k_esdf_init, dim3(2048), dim3(256), 0, q, m->M, E, s, gamma, max_dist);
+    }
     // information crosses one brick per round: `reach` rounds carry a value as far as it can matter, bends and late improvements add a
     // few more (8 rounds had work at reach = 4 on the benchmark stream).
     // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards two more than the most any
@@ -713,7 +1174,10 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     int rounds = ((full || m->esdf_rounds_seen == 0) ? 2 * reach + 8 : std::min(2 * reach + 8, std::max(reach + 2, m->esdf_rounds_seen + 2))) + extra_rounds;
     const int grid = 4 * m->ncu;
     if (m->esdf_round_cap > 0 && extra_rounds == 0 && rounds > m->esdf_round_cap) rounds = m->esdf_round_cap;      // test knob: provoke the repair path
-    for (int k = 0; k < rounds; ++k) hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);
+    for (int k = 0; k < rounds; ++k) {
+        if (wavefront) hipLaunchKernelGGL(k_esdf_wave, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);
+        else hipLaunchKernelGGL(k_esdf_round, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);
+    }
     m->prof_group = false; prof_end(m, q);
     TSL_HIP(hipMemcpyAsync(S.host, ctr, sizeof(int) * (ES_CTR + ES_STAT_SLOTS * 16), hipMemcpyDeviceToHost, q));
     TSL_HIP(hipEventRecord(S.ev, q)); m->esdf_last = S.ev;
