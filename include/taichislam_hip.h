@@ -223,8 +223,10 @@ typedef struct {
     int64_t brick_relaxations;   /* LDS relaxations run (a brick is revisited when its surroundings change) */
     int64_t voxel_pushes;        /* voxel values lowered by the sweeps (a voxel may be lowered more than once) */
     int32_t rounds, max_passes;  /* relaxation rounds that had work; most sweep sets (six concurrent directional sweeps) one brick relaxation needed */
-    int32_t reserved_;
+    int32_t raise_sets;          /* esdf_mode 1: sets of raise sweeps (parent links re-derived) over all brick visits */
     int64_t passes;              /* sweep sets over all brick relaxations */
+    int64_t voxels_raised;       /* esdf_mode 1: of voxel_pushes, the values re-derived through their parent link by the raise sweeps (the rest was lowered) */
+    int32_t max_raise_sets, reserved_;
 } tsl_esdf_stats;
 /* sums over the updates of the handle that have completed */
 typedef struct {

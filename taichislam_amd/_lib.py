@@ -39,7 +39,7 @@ class FrameStats(C.Structure):
 
 class EsdfStats(C.Structure):
     _fields_ = [("incremental", C.c_int32), ("dirty_bricks", C.c_int32), ("changed_bricks", C.c_int32), ("region_bricks", C.c_int32), ("total_bricks", C.c_int32),
-                ("brick_relaxations", C.c_int64), ("voxel_pushes", C.c_int64), ("rounds", C.c_int32), ("max_passes", C.c_int32), ("reserved_", C.c_int32), ("passes", C.c_int64)]
+                ("brick_relaxations", C.c_int64), ("voxel_pushes", C.c_int64), ("rounds", C.c_int32), ("max_passes", C.c_int32), ("raise_sets", C.c_int32), ("passes", C.c_int64), ("voxels_raised", C.c_int64), ("max_raise_sets", C.c_int32), ("reserved_", C.c_int32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -39,15 +39,17 @@ namespace tsl {
 #define ES_CTR 256               // ints of counters, followed by
 #define ES_STAT_SLOTS 64         // slots of 16 ints (one cache line each) of statistics, summed by the host: hundreds of workgroups adding to ONE
                                  // line serialise in the L2 (~12 ns each) and hold back the list reservations that share it
-#define ES_STAT(E, k) (&(E).ctr[ES_CTR + (blockIdx.x & (ES_STAT_SLOTS - 1)) * 16 + (k)])      // [0] relaxations [1] lowered [2] sets [3] max sets [4] region [5] changed
+#define ES_STAT(E, k) (&(E).ctr[ES_CTR + (blockIdx.x & (ES_STAT_SLOTS - 1)) * 16 + (k)])      // [0] relaxations [1] lowered [2] sets [3] max sets [4] region [5] changed [6] raise sets [7] voxels re-derived by the raise sweeps [8] most raise sets of one visit
 #define ES_UNOBS 0x7fffffffu
 #define ES_INF 0x7f800000u
 
 #ifdef TSL_TIMING
 // developer timing: thread 0 of every relaxation adds the clock ticks (100 MHz) of its phases to E.ctr64[k]
 #define ESDF_TICK(k) do { if (threadIdx.x == 0) { const long long _n = wall_clock64(); atomicAdd(&E.tm[k], (unsigned long long)(_n - _t)); _t = _n; } } while (0)
+#define ESDF_TICKF(k) do { if (threadIdx.x == 0) { const long long _n = wall_clock64(); atomicAdd(&E.tm[k], (unsigned long long)(_n - _t)); if (first && (k) >= 2) { atomicAdd(&E.tm[72 + (k)], (unsigned long long)(_n - _t)); if ((k) == 4) atomicAdd(&E.tm[73], 1ull); } _t = _n; } } while (0)
 #else
 #define ESDF_TICK(k) do {} while (0)
+#define ESDF_TICKF(k) do {} while (0)
 #endif
 struct EsdfDev {
     float* mag;                // [max_bricks][4096] the signed distance: side << 31 | magnitude bits (a negative float on the negative side), ES_UNOBS (a NaN) where
@@ -60,7 +62,7 @@ struct EsdfDev {
     int* work;                 // [3][max_bricks] work lists of rounds k, k+1, k+2 (mod 3)
     int* nbr;                  // [max_bricks][27] pool indices of the bricks around a region brick (-1: absent), written by k_esdf_init (esdf_mode 0)
     uint8_t* par;              // [max_bricks][4096] esdf_mode 1: direction code of the voxel's PARENT -- the neighbour its value was taken from --
-                               // (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1), 13 = none (band voxel, max_dist, unobserved)          dense_esdf.py:96, :290, :296
+                               // (dx + 1) << 4 | (dy + 1) << 2 | (dz + 1), 0x15 = none (band voxel, max_dist, unobserved)          dense_esdf.py:96, :290, :296
     uint8_t* ok;               // [max_bricks] esdf_mode 1: the brick's mag / fl / par describe the current (submap, gamma, max_dist)
     int cap;                   // max_bricks
     unsigned long long* tm;    // developer timing (TSL_TIMING builds): ticks per phase, summed over relaxations
@@ -70,7 +72,7 @@ struct EsdfDev {
 };
 
 // 1. dirty bricks of submap s (and, when `all`, every brick of it); touch marks are consumed
-__global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s, int all)
+__global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s, int all, int wavefront)
 {
     // the brick count of this update: a snapshot of the pool counter, taken here (every thread reads the same value: the frames before
     // the update have finished, phase A of frames queued AFTER it starts once this kernel has finished, esdf_gate) and left in ctr[10] for
@@ -85,6 +87,17 @@ __global__ void __launch_bounds__(256) k_esdf_collect(MapDev M, EsdfDev E, int s
     if (all && E.ok && p < E.cap) E.ok[p] = 0;               // (esdf_mode 1) a full recompute forgets every brick's state, also of bricks the pool has not handed out yet
     if (p < nused) {
         const bool mine = M.owner[p] / M.nb3 == s;
+        if (mine && wavefront) {                                // (esdf_mode 1) the 27 bricks around this one, for every brick the wave may reach: the pool may have grown since the last update
+            const int b = M.owner[p] - s * M.nb3, bi = b / (M.nbz * M.nbx), bj = (b / M.nbz) % M.nbx, bk = b % M.nbz;
+            int nb27[27];
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int i = bi + t / 9 - 1, j = bj + (t / 3) % 3 - 1, k = bk + t % 3 - 1;
+                nb27[t] = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
+            }
+#pragma unroll
+            for (int t = 0; t < 27; ++t) E.nbr[(size_t)p * 27 + t] = nb27[t] >= nused ? -1 : nb27[t];
+        }
         if (mine) { take = all || M.touch[p] != 0; M.touch[p] = 0; }
         E.region[p] = 0; E.stamp[p] = -1; E.note[p] = 0u; E.note[E.cap + p] = 0u;
     }
@@ -590,12 +603,12 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
 //     (A value that has to rise by more than its descendants' lead -- the surface under it vanished -- can borrow from a stale descendant in
 //     ANOTHER brick and is then corrected round by round; should the rounds launched not suffice, the host repairs with a full recompute,
 //     as for esdf_mode 0.)
-#define EP_NONE 13u
-__device__ __forceinline__ int esdf_code_off(uint32_t code) { const int a = (int)(code / 9u), b = (int)((code / 3u) % 3u), c = (int)(code % 3u); return (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1); }
+#define EP_NONE 0x15u
+__device__ __forceinline__ int esdf_code_off(uint32_t code) { const int a = (int)(code >> 4), b = (int)((code >> 2) & 3u), c = (int)(code & 3u); return (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1); }
 // what the parent link `code` of the voxel at tile index idx (word own) gives it now: side | fl(parent + cost) and the code, or side | max_dist and no parent
 __device__ __forceinline__ void esdf_rederive(const uint32_t* s_t, int idx, uint32_t code, uint32_t own, float c1, float c2, float c3, float max_dist, uint32_t& nw, uint32_t& npar)
 {
-    const int a = (int)(code / 9u), b = (int)((code / 3u) % 3u), c = (int)(code % 3u);
+    const int a = (int)(code >> 4), b = (int)((code >> 2) & 3u), c = (int)(code & 3u);
     const int nz = (a != 1) + (b != 1) + (c != 1);
     const uint32_t pw = ES_LD(&s_t[idx + (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1)]);
     const bool ok = ((pw ^ own) & 0x80000000u) == 0u && (pw & 0x7fffffffu) <= ES_INF;          // the parent is observed and on this voxel's side
@@ -615,7 +628,7 @@ __global__ void __launch_bounds__(256) k_esdf_diff(MapDev M, EsdfDev E, int s, i
         const bool fresh = all || E.ok[pd] == 0;              // nothing valid stored for this brick: everything counts as unobserved before
         const size_t v = (size_t)pd * TSL_BRK3 + (size_t)threadIdx.x * 16;
         const uint4 ob = *reinterpret_cast<const uint4*>(M.obs + v);
-        uint4 fo = make_uint4(0u, 0u, 0u, 0u), po = make_uint4(0x0d0d0d0du, 0x0d0d0d0du, 0x0d0d0d0du, 0x0d0d0d0du);
+        uint4 fo = make_uint4(0u, 0u, 0u, 0u), po = make_uint4(0x15151515u, 0x15151515u, 0x15151515u, 0x15151515u);
         uint4 tw[4], mo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { tw[q] = reinterpret_cast<const uint4*>(M.tw + v)[q]; mo[q] = make_uint4(ES_UNOBS, ES_UNOBS, ES_UNOBS, ES_UNOBS); }
@@ -669,27 +682,44 @@ template <int AXIS, int SIGN>
 __device__ __forceinline__ void esdf_rsweep(uint32_t* s_t, uint8_t* s_par, uint32_t* s_chg, unsigned long long mT, const float c1, const float c2, const float c3, const float max_dist, int& raised)
 {
     const int lane = (int)(threadIdx.x & 63u), q = lane & 3, r = lane >> 2;
+    constexpr uint32_t WANT = SIGN > 0 ? 0u : 2u;                       // the link's component along AXIS: parent one plane back
+    constexpr int SH = AXIS == 0 ? 4 : (AXIS == 1 ? 2 : 0);
 #pragma unroll 1
     for (int i = 0; i < 16; ++i, mT >>= 4) {
         const uint32_t tn = (uint32_t)mT & 15u;
-        if (!__any(tn != 0u)) continue;
         const int sp = SIGN > 0 ? i : 15 - i;
+        // the four voxels of this lane in the plane: interior index l0 + j * LJ, tile index t0 + j * TJ
+        const int x = AXIS == 0 ? sp : r, y0 = AXIS == 0 ? r : (AXIS == 1 ? sp : 4 * q), z0 = AXIS == 2 ? sp : 4 * q;
+        constexpr int LJ = AXIS == 2 ? 16 : 1, TJ = AXIS == 2 ? ES_SY : 1;
+        const int l0 = (x << 8) | (y0 << 4) | z0, t0 = (x + 1) * ES_SX + (y0 + 1) * ES_SY + z0 + 1;
+        uint32_t cw;                                                       // their parent codes
+        if (AXIS != 2) cw = *reinterpret_cast<const volatile uint32_t*>(s_par + l0);
+        else cw = (uint32_t)s_par[l0] | (uint32_t)s_par[l0 + 16] << 8 | (uint32_t)s_par[l0 + 32] << 16 | (uint32_t)s_par[l0 + 48] << 24;
+        uint32_t el = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t code = (cw >> (8 * j)) & 0xffu; el |= ((code != EP_NONE && ((code >> SH) & 3u) == WANT) ? 1u : 0u) << j; }
+        el &= tn;
+        if (!__any(el != 0u)) continue;
         uint32_t cm = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int x = AXIS == 0 ? sp : r, y = AXIS == 0 ? r : (AXIS == 1 ? sp : 4 * q + j), z = AXIS == 2 ? sp : 4 * q + j;
-            const int l = (x << 8) | (y << 4) | z, idx = (x + 1) * ES_SX + (y + 1) * ES_SY + z + 1;
-            const uint32_t code = s_par[l];
-            const uint32_t comp = AXIS == 0 ? code / 9u : (AXIS == 1 ? (code / 3u) % 3u : code % 3u);
-            if (!((tn >> j) & 1u) || code == EP_NONE || comp != (SIGN > 0 ? 0u : 2u)) continue;
+            const uint32_t code = (el >> j) & 1u ? (cw >> (8 * j)) & 0xffu : EP_NONE;          // (a voxel that does not take part reads itself)
+            const int idx = t0 + j * TJ;
             const uint32_t own = ES_LD(&s_t[idx]);
             uint32_t nw, npar;
             esdf_rederive(s_t, idx, code, own, c1, c2, c3, max_dist, nw, npar);
-            if (nw != own) {
+            if (((el >> j) & 1u) && nw != own) {
                 __hip_atomic_store(&s_t[idx], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (npar != code) s_par[l] = (uint8_t)npar;
-                __hip_atomic_fetch_or(&s_chg[l >> 5], 1u << (l & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (npar != code) s_par[l0 + j * LJ] = (uint8_t)npar;
                 cm |= 1u << j;
+            }
+        }
+        if (cm) {                                                          // one OR per lane (the four bits of a lane share a word, or two for the z sweeps), as esdf_sweep does
+            if (AXIS == 0) __hip_atomic_fetch_or(&s_chg[sp * 8 + (r >> 1)], cm << ((r & 1) * 16 + 4 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (AXIS == 1) __hip_atomic_fetch_or(&s_chg[r * 8 + (sp >> 1)], cm << ((sp & 1) * 16 + 4 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else {
+                if (cm & 3u) __hip_atomic_fetch_or(&s_chg[r * 8 + 2 * q], ((cm & 1u) | ((cm & 2u) << 15)) << sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cm & 12u) __hip_atomic_fetch_or(&s_chg[r * 8 + 2 * q + 1], (((cm >> 2) & 1u) | ((cm & 8u) << 13)) << sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         raised += __builtin_popcount(cm);
@@ -705,6 +735,9 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
     __shared__ __attribute__((aligned(4))) uint16_t s_tgt16[256], s_neg16[256];
     __shared__ uint32_t s_chg[TSL_BRK3 / 32];              // interior voxels lowered in this visit (their parents are looked up afterwards)
     __shared__ uint32_t s_chr[TSL_BRK3 / 32];              // interior voxels re-derived by the raise sweeps
+    __shared__ uint32_t s_fr[TSL_BRK3 / 32], s_cur[TSL_BRK3 / 32];      // the lower wave's frontier: voxels lowered whose neighbourhood has not been looked at since
+    __shared__ uint16_t s_list[TSL_BRK3];                  // a compacted voxel list (frontier / the voxels whose parents are looked up)
+    __shared__ int s_cnt;
     __shared__ int s_nb[27];
     __shared__ int s_notify, s_flags, s_layer;
     const uint32_t* const s_tgt = reinterpret_cast<const uint32_t*>(s_tgt16);
@@ -713,7 +746,6 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
     const int n = E.ctr[2 + cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) { E.ctr[2 + clr] = 0; if (n) { E.ctr[7] = round + 1; if (round < 16) E.ctr[240 + round] = n; } }
     if (n == 0) return;
-    const int nused = min(E.ctr[10], M.max_bricks);
     const float c1 = 1.0f * vs, c2 = sqrtf(2.0f) * vs, c3 = sqrtf(3.0f) * vs;                   // dense_esdf.py:286
     const int* list = E.work + (size_t)cur * E.cap;
     int* next = E.work + (size_t)nxt * E.cap;
@@ -737,23 +769,17 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
     }
     for (int w = blockIdx.x; w < n; w += gridDim.x) {
 #ifdef TSL_TIMING
-        long long _t = wall_clock64();
+        long long _t = wall_clock64(); const long long _t0 = _t;
 #endif
         const int p = list[w];
-        if (threadIdx.x < 27) {                                     // the 27 bricks around this one (a brick allocated after the update's snapshot is not part of it)
-            const int t = (int)threadIdx.x, b = M.owner[p] - s * M.nb3;
-            const int i = b / (M.nbz * M.nbx) + t / 9 - 1, j = (b / M.nbz) % M.nbx + (t / 3) % 3 - 1, k = b % M.nbz + t % 3 - 1;
-            int np = (i < 0 || i >= M.nbx || j < 0 || j >= M.nbx || k < 0 || k >= M.nbz) ? -1 : pool_lookup_ro(M, s, (i * M.nbx + j) * M.nbz + k);
-            if (np >= nused) np = -1;
-            s_nb[t] = np;
-        }
+        if (threadIdx.x < 27) s_nb[threadIdx.x] = E.nbr[(size_t)p * 27 + threadIdx.x];          // written by this update's k_esdf_collect
         if (threadIdx.x == 0) { s_notify = 0; s_flags = 0; s_layer = 0; }
         if (threadIdx.x < TSL_BRK3 / 32) { s_chg[threadIdx.x] = 0u; s_chr[threadIdx.x] = 0u; }
         const bool first = E.region[p] == 1;                        // changed by k_esdf_diff and not visited since: every link and every plane is looked at
         uint32_t* const my_note = E.note + (size_t)(round & 1) * E.cap + p;
         const uint32_t note = first ? ~0u : *my_note;
         __syncthreads();
-        ESDF_TICK(0);
+        ESDF_TICKF(0);
         if (threadIdx.x == 0) *my_note = 0u;
         // ---- stage brick + halo, values and parent codes, as ONE batch of independent loads ----
         int flags = 0;
@@ -807,9 +833,9 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
         }
         __syncthreads();
         const bool targets = (s_flags & 1) != 0, work = s_flags == 3;
-        ESDF_TICK(1);
-        int lowered = 0, raised = 0, sets = 0;
-        bool any_raise = false;
+        ESDF_TICKF(1);
+        int lowered = 0, raised = 0, sets = 0, rsets = 0;
+        bool light = false;
         unsigned long long mT = 0ull, mN = 0ull;
         if (targets) {
             switch (wave) {
@@ -823,19 +849,40 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
             // ---- RAISE: links that no longer hold, re-derived parents first.  A flat check of every link decides whether a set of sweeps is needed
             //      (and, behind one, whether it sufficed: the six waves race, and a chain that bends against its sweep takes another set) ----
             for (int rs = 0; ; ++rs) {
+                // a flat pass over every link: broken ones are re-derived on the spot (each voxel by the one thread that owns it).  The first pass
+                // tells whether anything is broken at all; a set of sweeps then carries whole chains; the passes behind it mend what the racing sweeps
+                // left (a child re-derived before its parent) -- shallow, so a few passes do what a second set of sweeps did at ten times the cost
                 bool broken = false;
-                for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
-                    const uint32_t code = s_par[l];
-                    if (code == EP_NONE) continue;
-                    const int idx = ((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1;
-                    const uint32_t own = ES_LD(&s_t[idx]);
-                    uint32_t nw, npar;
-                    esdf_rederive(s_t, idx, code, own, c1, c2, c3, max_dist, nw, npar);
-                    broken = broken || nw != own;
+                for (int g = threadIdx.x; g < TSL_BRK3 / 4; g += 384) {
+                    const uint32_t cw = *reinterpret_cast<const volatile uint32_t*>(s_par + 4 * g);
+                    if (cw == 0x15151515u) continue;
+                    const int l = 4 * g, t0 = ((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1;
+                    uint32_t cm = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t code = (cw >> (8 * j)) & 0xffu;
+                        const uint32_t own = ES_LD(&s_t[t0 + j]);
+                        uint32_t nw, npar;
+                        esdf_rederive(s_t, t0 + j, code, own, c1, c2, c3, max_dist, nw, npar);          // (no parent: the voxel reads itself and fails the test below)
+                        if (code != EP_NONE && nw != own) {
+                            __hip_atomic_store(&s_t[t0 + j], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (npar != code) s_par[l + j] = (uint8_t)npar;
+                            cm |= 1u << j;
+                        }
+                    }
+                    if (cm) { __hip_atomic_fetch_or(&s_chr[l >> 5], cm << (l & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); raised += __builtin_popcount(cm); broken = true; }
                 }
                 if (!__syncthreads_or(broken)) break;
-                if (rs >= 48) { if (threadIdx.x == 0) E.ctr[8] = 1; break; }          // (never seen: the host repairs with a full recompute)
-                any_raise = true;
+                if (rs >= 200) { if (threadIdx.x == 0) E.ctr[8] = 1; break; }          // (never seen: the host repairs with a full recompute)
+                if (rs == 0) {                                              // how much is broken decides: a handful of links (a neighbour moved a few halo values) is mended by flat passes alone
+                    if (threadIdx.x == 0) s_cnt = 0;
+                    __syncthreads();
+                    if (threadIdx.x < TSL_BRK3 / 32) { const uint32_t f = s_chr[threadIdx.x]; if (f) atomicAdd(&s_cnt, __builtin_popcount(f)); }
+                    __syncthreads();
+                    light = s_cnt < 128;
+                }
+                if (light ? (rs % 8 != 4) : (rs % 8 != 0)) continue;        // sweeps behind the first pass (a light visit: behind the fifth), and again should the passes not settle
+                ++rsets;
                 switch (wave) {
                 case 0: esdf_rsweep<0, +1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
                 case 1: esdf_rsweep<0, -1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
@@ -847,11 +894,22 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
                 __syncthreads();
             }
         }
-        ESDF_TICK(5);
-        // ---- LOWER: the pull sweeps (esdf_sweep above).  Everything in the tile is a realisable value now ----
-        if (work) {
+        ESDF_TICKF(5);
+        // ---- LOWER.  Everything in the tile is a realisable value now.  What can still be lowered lies around what changed: the halo entries of the
+        //      notified neighbours (the entering sweeps of esdf_mode 0), the voxels the raise wave re-derived, and whatever gets lowered on the way.
+        //      A visit that changed much (the first one of a brick k_esdf_diff touched, a recompute) sweeps all six directions over all planes once;
+        //      the rest is a push / pull FRONTIER around the voxels that changed: (x -> y) pairs with neither end changed were relaxed before ----
+        // (the staging's "some value can lower a neighbour" flag was taken before the raise wave, which may have brought a value below that mark)
+        if (targets && (work || __syncthreads_or(raised != 0))) {
             const uint32_t entry_mask = wave == 0 ? 0x1ffu : wave == 1 ? 0x1ffu << 18 : wave == 2 ? 0x01c0e07u : wave == 3 ? 0x01c0e07u << 6 : wave == 4 ? 0x1249249u : 0x1249249u << 2;
-            bool full = first || any_raise;
+            if (threadIdx.x == 0) s_cnt = 0;
+            __syncthreads();
+            if (threadIdx.x < TSL_BRK3 / 32) { const uint32_t f = s_chr[threadIdx.x]; if (f) atomicAdd(&s_cnt, __builtin_popcount(f)); }
+            __syncthreads();
+            const int nraised = s_cnt;
+            bool full = first || nraised > 256;
+            const bool local = !full && nraised > 0;             // few voxels re-derived: look around them instead of sweeping everything
+            bool classic = false;
             for (;;) {
                 bool chg = false;
                 if (full || (note & entry_mask)) {
@@ -865,35 +923,126 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
                     }
                 }
                 ++sets;
-                if (!__syncthreads_or(chg)) break;
-                full = true;
+                if (!__syncthreads_or(chg) && !(local && !classic && sets == 1)) break;
+                if (classic) { full = true; continue; }
+                // the frontier: every voxel lowered so far (push to its neighbours) and, first time round, every voxel the raise wave re-derived (pull from
+                // its neighbours -- it may have risen -- and push -- it may have fallen)
+                if (threadIdx.x == 0) s_cnt = 0;
+                __syncthreads();
+                if (threadIdx.x < TSL_BRK3 / 32) {
+                    const uint32_t f = s_chg[threadIdx.x] | (local ? s_chr[threadIdx.x] : 0u);
+                    s_cur[threadIdx.x] = f; s_fr[threadIdx.x] = 0u; if (f) atomicAdd(&s_cnt, __builtin_popcount(f));
+                }
+                __syncthreads();
+                if (s_cnt > 1024) { classic = true; full = true; continue; }          // a recompute from scratch: sets of sweeps to the fixed point, as esdf_mode 0
+                for (int it = 0; ; ++it) {
+                    const int nfr = s_cnt;
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_cnt = 0;
+                    __syncthreads();
+                    if (threadIdx.x < TSL_BRK3 / 32) {
+                        uint32_t f = s_cur[threadIdx.x];
+                        if (f) { int at = atomicAdd(&s_cnt, __builtin_popcount(f)); while (f) { const int b = __builtin_ctz(f); s_list[at++] = (uint16_t)(threadIdx.x * 32 + b); f &= f - 1u; } }
+                    }
+                    __syncthreads();
+                    bool more = false;
+                    for (int k = threadIdx.x; k < nfr; k += 384) {
+                        const int l = s_list[k], x = l >> 8, y = (l >> 4) & 15, z = l & 15;
+                        const int idx = (x + 1) * ES_SX + (y + 1) * ES_SY + z + 1;
+                        uint32_t own = ES_LD(&s_t[idx]);
+                        const bool pull = local && it == 0 && ((s_chr[l >> 5] >> (l & 31)) & 1u) && ((s_tgt16[l >> 4] >> (l & 15)) & 1u);
+                        uint32_t best = own & 0x7fffffffu;                     // pull: the least neighbour value + edge cost on this voxel's side
+#pragma unroll
+                        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                            for (int b = -1; b <= 1; ++b)
+#pragma unroll
+                                for (int c = -1; c <= 1; ++c) {
+                                    if (a == 0 && b == 0 && c == 0) continue;
+                                    const uint32_t w = ES_LD(&s_t[idx + a * ES_SX + b * ES_SY + c]);
+                                    const int nzc = (a != 0) + (b != 0) + (c != 0);
+                                    const float cc = nzc == 1 ? c1 : (nzc == 2 ? c2 : c3);
+                                    const bool same = ((w ^ own) & 0x80000000u) == 0u && (w & 0x7fffffffu) <= ES_INF;
+                                    const float up = __uint_as_float(w & 0x7fffffffu) + cc;
+                                    if (pull && same && __float_as_uint(up) < best) best = __float_as_uint(up);
+                                }
+                        if (best < (own & 0x7fffffffu)) {
+                            __hip_atomic_fetch_min(&s_t[idx], best | (own & 0x80000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(&s_chg[l >> 5], 1u << (l & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            own = best | (own & 0x80000000u); ++lowered;
+                        }
+                        const float om = __uint_as_float(own & 0x7fffffffu);
+#pragma unroll
+                        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                            for (int b = -1; b <= 1; ++b)
+#pragma unroll
+                                for (int c = -1; c <= 1; ++c) {
+                                    if (a == 0 && b == 0 && c == 0) continue;
+                                    const int nx = x + a, ny = y + b, nz_ = z + c;
+                                    const bool in = (unsigned)nx < 16u && (unsigned)ny < 16u && (unsigned)nz_ < 16u;
+                                    const int nl = in ? (nx << 8) | (ny << 4) | nz_ : l;
+                                    const bool tgt = in && ((s_tgt16[nl >> 4] >> (nl & 15)) & 1u);
+                                    const int nidx = idx + (in ? a * ES_SX + b * ES_SY + c : 0);
+                                    const uint32_t w = ES_LD(&s_t[nidx]);
+                                    const int nzc = (a != 0) + (b != 0) + (c != 0);
+                                    const float cand = om + (nzc == 1 ? c1 : (nzc == 2 ? c2 : c3));
+                                    if (tgt && ((w ^ own) & 0x80000000u) == 0u && __float_as_uint(cand) < (w & 0x7fffffffu)) {
+                                        __hip_atomic_fetch_min(&s_t[nidx], __float_as_uint(cand) | (w & 0x80000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_fetch_or(&s_chg[nl >> 5], 1u << (nl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_fetch_or(&s_fr[nl >> 5], 1u << (nl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        ++lowered; more = true;
+                                    }
+                                }
+                    }
+                    if (!__syncthreads_or(more)) break;
+                    if (threadIdx.x == 0) s_cnt = 0;
+                    __syncthreads();
+                    if (threadIdx.x < TSL_BRK3 / 32) { const uint32_t f = s_fr[threadIdx.x]; s_cur[threadIdx.x] = f; s_fr[threadIdx.x] = 0u; if (f) atomicAdd(&s_cnt, __builtin_popcount(f)); }
+                    __syncthreads();
+                }
+                break;
             }
         }
-#ifdef TSL_TIMING
-        if (threadIdx.x == 0) { const long long _n = wall_clock64(); const int pb = sets < 31 ? sets : 31;
-            atomicAdd(&E.tm[8 + pb], (unsigned long long)(_n - _t)); atomicAdd(&E.tm[40 + pb], 1ull); atomicMax(&E.tm[72], (unsigned long long)(_n - _t)); }
-        { const long long pw = wave_sum_ll((long long)(lowered + raised)); if (lane_id() == 0) atomicAdd(&E.tm[80 + (sets < 31 ? sets : 31)], (unsigned long long)pw); }
-#endif
-        ESDF_TICK(2);
+        ESDF_TICKF(2);
         // ---- PARENTS of the voxels the lower wave wrote: the neighbour whose value + edge cost IS the voxel's value.  At the local fixed point the
         //      neighbour a voxel was last lowered from still offers exactly that (it can only have been lowered since, and then the voxel with it) ----
         int orphans = 0;
-        for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
-            if (!((s_chg[l >> 5] >> (l & 31)) & 1u)) continue;
+        if (__syncthreads_or(lowered != 0)) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        if (threadIdx.x < TSL_BRK3 / 32) {
+            uint32_t f = s_chg[threadIdx.x];
+            if (f) { int at = atomicAdd(&s_cnt, __builtin_popcount(f)); while (f) { const int b = __builtin_ctz(f); s_list[at++] = (uint16_t)(threadIdx.x * 32 + b); f &= f - 1u; } }
+        }
+        __syncthreads();
+        const int nlow = s_cnt;
+        for (int k = threadIdx.x; k < nlow; k += 384) {
+            const int l = s_list[k];
             const int idx = ((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1;
             const uint32_t own = ES_LD(&s_t[idx]);
             uint32_t found = EP_NONE;
-#pragma unroll 1
-            for (uint32_t code = 0; code < 27u; ++code) {
-                if (code == EP_NONE) continue;
-                uint32_t nw, npar;
-                esdf_rederive(s_t, idx, code, own, c1, c2, c3, max_dist, nw, npar);
-                if (npar != EP_NONE && nw == own) { found = code; break; }
-            }
+            const uint32_t om = own & 0x7fffffffu;
+            // all 26 candidates as independent LDS reads; the lowest code that supports the value wins (any supporter will do: the choice is only made reproducible)
+#pragma unroll
+            for (int a = 2; a >= 0; --a)
+#pragma unroll
+                for (int b = 2; b >= 0; --b)
+#pragma unroll
+                    for (int c = 2; c >= 0; --c) {
+                        if (a == 1 && b == 1 && c == 1) continue;
+                        const uint32_t pw = ES_LD(&s_t[idx + (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1)]);
+                        const int nz = (a != 1) + (b != 1) + (c != 1);
+                        const float tv = __uint_as_float(pw & 0x7fffffffu) + (nz == 1 ? c1 : (nz == 2 ? c2 : c3));
+                        const bool hit = ((pw ^ own) & 0x80000000u) == 0u && (pw & 0x7fffffffu) <= ES_INF && __float_as_uint(tv) == om && tv < max_dist;
+                        found = hit ? (uint32_t)(a << 4 | b << 2 | c) : found;
+                    }
             if (found == EP_NONE) ++orphans;
             s_par[l] = (uint8_t)found;
         }
+        }
         __syncthreads();
+        ESDF_TICKF(6);
         // ---- write back the rows that changed (values + parent codes), and note which of the 26 outer layers did ----
         if (threadIdx.x < 256) {
             const int row = (int)threadIdx.x, x = row >> 4, y = row & 15;
@@ -922,6 +1071,7 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
                 atomicOr(&s_layer, lay & ~(1 << 13));
             }
         }
+        ESDF_TICKF(7);
         // ---- which neighbours to tell.  Seen from here a voxel z of a neighbour (an entry of this tile's halo, as STAGED) needs a visit of its brick iff
         //      RAISE: its parent is a voxel of this brick and the link no longer holds, or LOWER: a voxel of this brick now offers it less ----
         if (first || __syncthreads_or((lowered | raised) != 0)) {
@@ -967,10 +1117,12 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
             if ((threadIdx.x & 63u) == 0 && told) atomicOr(&s_notify, told);
         }
         __syncthreads();
-        ESDF_TICK(3);
+        ESDF_TICKF(3);
         {
             const long long lw = wave_sum_ll((long long)(lowered + raised));
             if (lane_id() == 0 && lw) __hip_atomic_fetch_add(ES_STAT(E, 1), (int)lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long rw = wave_sum_ll((long long)raised);
+            if (lane_id() == 0 && rw) __hip_atomic_fetch_add(ES_STAT(E, 7), (int)rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const long long ow = wave_sum_ll((long long)orphans);
             if (lane_id() == 0 && ow) __hip_atomic_fetch_add(&E.ctr[9], (int)ow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -981,7 +1133,10 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
                 const bool told = (s_notify >> q) & 1, layer = (s_layer >> q) & 1;
                 // a neighbour visited in THIS round may have staged values this visit has changed since: it looks again (and so does this brick, by the
                 // neighbour's same rule, if the neighbour's layer next to it changed)
-                if (told || (layer && __hip_atomic_load(&E.stamp[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round)) {
+                // (... or is on the next round's list already -- through another neighbour, whose note bit says nothing about THIS side: without the bit
+                //  for this side the entering sweeps from here would not run)
+                const int st = (layer && !told) ? __hip_atomic_load(&E.stamp[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                if (told || st == round || st == round + 1) {
                     const int seen = __hip_atomic_exchange(&E.stamp[np], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_or(E.note + (size_t)((round + 1) & 1) * E.cap + np, 1u << (26 - q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     put = seen != round + 1;
@@ -996,9 +1151,15 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
             __hip_atomic_fetch_add(ES_STAT(E, 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(ES_STAT(E, 2), sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_max(ES_STAT(E, 3), sets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rsets) { __hip_atomic_fetch_add(ES_STAT(E, 6), rsets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_max(ES_STAT(E, 8), rsets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
-        ESDF_TICK(4);
+        ESDF_TICKF(4);
+#ifdef TSL_TIMING      // histogram of whole visits by duration (bins of 4 us)
+        if (threadIdx.x == 0) { const long long d = wall_clock64() - _t0; int pb = (int)(d / 400); pb = pb < 31 ? pb : 31;
+            atomicAdd(&E.tm[8 + pb], (unsigned long long)d); atomicAdd(&E.tm[40 + pb], 1ull); atomicMax(&E.tm[72], (unsigned long long)d); }
+        { const long long pw = wave_sum_ll((long long)(lowered + raised)); if (lane_id() == 0) { const long long d = wall_clock64() - _t0; int pb = (int)(d / 400); pb = pb < 31 ? pb : 31; atomicAdd(&E.tm[80 + pb], (unsigned long long)pw); } }
+#endif
     }
 }
 
@@ -1070,10 +1231,10 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         if (wait_all) (void)hipEventSynchronize(S.ev);
         const int* h = S.host;
         tsl_esdf_stats st = S.st;
-        long long sum[6] = { 0, 0, 0, 0, 0, 0 };
-        for (int k = 0; k < ES_STAT_SLOTS; ++k) for (int c = 0; c < 6; ++c) { const int v = h[ES_CTR + k * 16 + c]; if (c == 3) sum[3] = v > sum[3] ? v : sum[3]; else sum[c] += v; }
+        long long sum[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int k = 0; k < ES_STAT_SLOTS; ++k) for (int c = 0; c < 9; ++c) { const int v = h[ES_CTR + k * 16 + c]; if (c == 3 || c == 8) sum[c] = v > sum[c] ? v : sum[c]; else sum[c] += v; }
         st.dirty_bricks = h[0]; st.changed_bricks = (int)sum[5]; st.region_bricks = (int)sum[4]; st.brick_relaxations = sum[0]; st.voxel_pushes = sum[1];
-        st.rounds = h[7]; st.passes = sum[2]; st.max_passes = (int)sum[3]; st.total_bricks = h[10] < m->M.max_bricks ? h[10] : m->M.max_bricks;
+        st.rounds = h[7]; st.raise_sets = (int)sum[6]; st.voxels_raised = sum[7]; st.max_raise_sets = (int)sum[8]; st.passes = sum[2]; st.max_passes = (int)sum[3]; st.total_bricks = h[10] < m->M.max_bricks ? h[10] : m->M.max_bricks;
         if (h[2 + S.rounds % 3] != 0 || h[8] != 0) m->esdf_short = true;      // the last launched round still had work (or a raise did not settle)
         m->esdf_orphans += h[9];
         if (st.incremental && st.rounds > m->esdf_rounds_seen) m->esdf_rounds_seen = st.rounds;
@@ -1082,8 +1243,10 @@ static void esdf_retire(tsl_tsdf* m, bool wait_all)
         m->esdf_tot.brick_relaxations += st.brick_relaxations; m->esdf_tot.voxel_pushes += st.voxel_pushes; m->esdf_tot.passes += st.passes;
 #ifdef TSL_TIMING
         { const unsigned long long* tm = (const unsigned long long*)&h[16]; const double n = st.brick_relaxations ? st.brick_relaxations : 1;
-          std::fprintf(stderr, "esdf timing: us per relaxation: setup %.2f stage %.2f relax %.2f writeback %.2f notify %.2f (%lld relaxations)\n",
-                       tm[0] / n / 100.0, tm[1] / n / 100.0, tm[2] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, (long long)st.brick_relaxations);
+          std::fprintf(stderr, "esdf timing: us per relaxation: setup %.2f stage %.2f [raise %.2f] relax %.2f [parents %.2f writeback %.2f] notify-test %.2f list %.2f (%lld relaxations)\n",
+                       tm[0] / n / 100.0, tm[1] / n / 100.0, tm[5] / n / 100.0, tm[2] / n / 100.0, tm[6] / n / 100.0, tm[7] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, (long long)st.brick_relaxations);
+          if (tm[73]) { const double f = (double)tm[73]; std::fprintf(stderr, "esdf timing, FIRST visits (%llu): [raise %.2f] relax %.2f [parents %.2f writeback %.2f] notify-test %.2f list %.2f\n", tm[73],
+                       tm[77] / f / 100.0, tm[74] / f / 100.0, tm[78] / f / 100.0, tm[79] / f / 100.0, tm[75] / f / 100.0, tm[76] / f / 100.0); }
           std::fprintf(stderr, "esdf bricks per round:"); for (int k = 0; k < 16 && h[240 + k]; ++k) std::fprintf(stderr, " %d", h[240 + k]); std::fprintf(stderr, "\n");
           std::fprintf(stderr, "esdf relax by passes (count: mean us, mean pushes); max relax %.1f us\n", tm[72] / 100.0);
           for (int k = 0; k < 32; ++k) if (tm[40 + k]) std::fprintf(stderr, "  %2d passes: %5llu relaxations, %7.1f us, %7.0f pushes\n", k, tm[40 + k], tm[8 + k] / (double)tm[40 + k] / 100.0, tm[80 + k] / (double)tm[40 + k]); }
@@ -1105,7 +1268,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
         if ((rc = dev_alloc(m, (void**)&m->esdf_note, sizeof(uint32_t) * 2 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_queue, sizeof(int) * 3 * (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_nbr, sizeof(int) * 27 * (size_t)nb, 0xff))) return rc;
-        if ((rc = dev_alloc(m, (void**)&m->esdf_par, (size_t)nb * TSL_BRK3, 13))) return rc;
+        if ((rc = dev_alloc(m, (void**)&m->esdf_par, (size_t)nb * TSL_BRK3, 0x15))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_ok, (size_t)nb, 0))) return rc;
         if ((rc = dev_alloc(m, (void**)&m->esdf_ctr, sizeof(int) * 2 * (ES_CTR + ES_STAT_SLOTS * 16), 0))) return rc;
         for (int i = 0; i < TSL_ESDF_SLOTS; ++i) {
@@ -1151,8 +1314,8 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     // is the collect kernel's own completion (an event recorded behind it costs a marker packet and ~6 us before the next kernel starts)
     // Beside the next frame (q != q0) ONE event serves both purposes, the completion of the init kernel: phase A has slack there -- the update is
     // the longer chain -- and every event attached to a dispatch costs the update ~5 us before its next kernel starts.
-    if (q == q0) { hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_gate; }
-    else { hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0); m->esdf_gate_ev = m->esdf_read; }
+    if (q == q0) { hipExtLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, nullptr, m->esdf_gate, 0, m->M, E, s, full ? 1 : 0, wavefront ? 1 : 0); m->esdf_gate_ev = m->esdf_gate; }
+    else { hipLaunchKernelGGL(k_esdf_collect, dim3(nbk), dim3(256), 0, q, m->M, E, s, full ? 1 : 0, wavefront ? 1 : 0); m->esdf_gate_ev = m->esdf_read; }
     m->esdf_gate_set = true; m->esdf_gate_mask = 0;
     if (wavefront) {
         // raise / lower wavefront: the bricks whose ESDF inputs changed start the wave, nothing is dilated or re-initialised
