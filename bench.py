@@ -257,6 +257,17 @@ def configs_leg(dev, host, cpu=True):
                 out[key]["cpu_baseline"] = cpu_baseline_config(config, budget_s=1.5)
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
+    # configs[3] once more with the ESDF update as the raise / lower wavefront with parent directions (option esdf_mode = 1; exact as well: tests/test_esdf_gpu.py)
+    try:
+        os.environ["TSL_C4_OPTS"] = (os.environ.get("TSL_C4_OPTS", "") + " esdf_mode=1").strip()
+        line = bench_configs.run(4, 40, 10, dev, host=host)
+        out["c4_esdf_wavefront"] = {"value": line["value"], "unit": line["unit"], "steps": 40, "esdf_ms_per_update": line["config"].get("esdf_ms_per_update"),
+                                    "esdf_voxel_pushes_per_update": line["config"].get("esdf_voxel_pushes_per_update"),
+                                    "esdf_region_bricks_per_update": line["config"].get("esdf_region_bricks_per_update")}
+    except Exception as e:
+        out["c4_esdf_wavefront"] = {"error": repr(e)[:200]}
+    finally:
+        os.environ["TSL_C4_OPTS"] = os.environ.get("TSL_C4_OPTS", "").replace("esdf_mode=1", "").strip()
     return out
 
 
@@ -686,6 +697,7 @@ def main():
                           "value_host_input": {"pageable": _v(host_rates, "pageable"), "pinned": _v(host_rates, "pinned")},
                           "c1_meshes_per_s": _v(cf, "c1_marching_cubes_128", "value"), "c3_octomap_frames_per_s": _v(cf, "c3_octomap_1024", "value"),
                           "c4_tsdf_esdf_mesh_frames_per_s": _v(cf, "c4_tsdf_esdf_mesh", "value"), "c4_esdf_ms_per_update": _v(cf, "c4_tsdf_esdf_mesh", "detail", "esdf_ms_per_update"),
+                          "c4_wavefront": {"frames_per_s": _v(cf, "c4_esdf_wavefront", "value"), "esdf_ms": _v(cf, "c4_esdf_wavefront", "esdf_ms_per_update"), "voxel_writes": _v(cf, "c4_esdf_wavefront", "esdf_voxel_pushes_per_update")},
                           "c5_merge_one_gpu_ms": _v(merge, "ms"), "roofline_frac": _v(roof, "frac"), "cpu_baseline_frames_per_s": _v(out, "cpu_baseline", "value"),
                           "parity_ok": out.get("parity_ok")}
         emit(out)

@@ -303,6 +303,10 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "ugrid" / "pgrid" resident workgroups of the units / parts launch in percent of the slots (defaults 75 / 25)
      "mesh_gather" 1 = marching cubes reads every value through the brick table also at step 1 (default: brick + halo staged in LDS)
      "esdf_full" 1 = every tsl_esdf_update recomputes all bricks (the reference for the incremental update)
+     "esdf_mode" 0 (default) = regional recompute: the bricks whose ESDF inputs changed, dilated by max_dist, are re-initialised and relaxed;
+                 1 = raise / lower wavefront with a parent direction per voxel (dense_esdf.py:96, :255-333): only the voxels whose parent chain passes
+                 through a changed voxel are re-derived, then lowered -- a third of the voxel writes, the same map bit for bit, ~1.45x the time on the
+                 benchmark stream (tsl_esdf.hip has the measurements); read-only "esdf_orphans" = lowered voxels without a supporting neighbour (always 0)
      "esdf_overlap" 1 (default) = an update's kernels run on one of the handle's phase-A streams: the relaxation rounds of update n overlap
                     the integration of frame n + 1 (which waits only until the update has read the TSDF); 0 = on the handle's stream
      "esdf_round_cap" n > 0 = launch at most n relaxation rounds per update (test knob: an update that stops early must be repaired)

@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
 }
 
 // =====================================================================================================================================
-// esdf_mode 1 (default since round 6): the update as a RAISE / LOWER WAVEFRONT with parent directions, dense_esdf.py:255-333.
+// esdf_mode 1 (round 6; opt-in, see the measurements at the end of this comment): the update as a RAISE / LOWER WAVEFRONT with parent directions, dense_esdf.py:255-333.
 //
 // The reference keeps `parent_dir` per voxel (:96): a lowered voxel remembers the neighbour it took its value from (:290, :296); when a
 // voxel's value goes up, the raise queue visits exactly the voxels whose parent chain passes through it (:255-273), and the lower queue then
@@ -603,6 +603,13 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
 //     (A value that has to rise by more than its descendants' lead -- the surface under it vanished -- can borrow from a stale descendant in
 //     ANOTHER brick and is then corrected round by round; should the rounds launched not suffice, the host repairs with a full recompute,
 //     as for esdf_mode 0.)
+// MEASURED (512^3 / 2 cm benchmark stream, max_dist 1 m, MI355X; profiles/r06_esdf_wavefront.txt): exact on every frame of every test stream; 0.96 M voxel writes
+// per update (0.87 M re-derived by the raise wave, 0.10 M lowered) against 3.1 M for esdf_mode 0, 461 bricks reached against 705 -- and 0.51 ms per update
+// against 0.35: the stream's f16 band values drift by an ulp every frame, so the wave passes through almost every voxel within max_dist of the visible
+// surface anyway, and a visit costs a raise phase, a lower phase and a parent lookup where esdf_mode 0 only lowers (a wave's ~10 k instructions per visit at
+// three waves per SIMD ARE the visit's latency, and eight rounds of them the update's).  A scene where a surface vanishes (a ball moving in front of the
+// wall: tools/esdf_sparse_probe.py) makes values rise past their descendants in neighbouring bricks; those updates end in the full-recompute repair.
+// esdf_mode 0 therefore stays the default; every ESDF test runs for both.
 #define EP_NONE 0x15u
 __device__ __forceinline__ int esdf_code_off(uint32_t code) { const int a = (int)(code >> 4), b = (int)((code >> 2) & 3u), c = (int)(code & 3u); return (a - 1) * ES_SX + (b - 1) * ES_SY + (c - 1); }
 // what the parent link `code` of the voxel at tile index idx (word own) gives it now: side | fl(parent + cost) and the code, or side | max_dist and no parent
@@ -835,7 +842,6 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
         const bool targets = (s_flags & 1) != 0, work = s_flags == 3;
         ESDF_TICKF(1);
         int lowered = 0, raised = 0, sets = 0, rsets = 0;
-        bool light = false;
         unsigned long long mT = 0ull, mN = 0ull;
         if (targets) {
             switch (wave) {
@@ -874,14 +880,9 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
                 }
                 if (!__syncthreads_or(broken)) break;
                 if (rs >= 200) { if (threadIdx.x == 0) E.ctr[8] = 1; break; }          // (never seen: the host repairs with a full recompute)
-                if (rs == 0) {                                              // how much is broken decides: a handful of links (a neighbour moved a few halo values) is mended by flat passes alone
-                    if (threadIdx.x == 0) s_cnt = 0;
-                    __syncthreads();
-                    if (threadIdx.x < TSL_BRK3 / 32) { const uint32_t f = s_chr[threadIdx.x]; if (f) atomicAdd(&s_cnt, __builtin_popcount(f)); }
-                    __syncthreads();
-                    light = s_cnt < 128;
-                }
-                if (light ? (rs % 8 != 4) : (rs % 8 != 0)) continue;        // sweeps behind the first pass (a light visit: behind the fifth), and again should the passes not settle
+                if (rs % 8 != 0) continue;                                  // sweeps behind the first pass, and again should the passes not settle.  (Mending a handful of
+                                                                            // broken links by flat passes alone was tried: a moved halo value changes a whole chain, one
+                                                                            // level per pass -- 0.65 ms per update against 0.50)
                 ++rsets;
                 switch (wave) {
                 case 0: esdf_rsweep<0, +1>(s_t, s_par, s_chr, mT, c1, c2, c3, max_dist, raised); break;
@@ -907,7 +908,7 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_wave(MapDev M, EsdfDev E
             if (threadIdx.x < TSL_BRK3 / 32) { const uint32_t f = s_chr[threadIdx.x]; if (f) atomicAdd(&s_cnt, __builtin_popcount(f)); }
             __syncthreads();
             const int nraised = s_cnt;
-            bool full = first || nraised > 256;
+            bool full = first || nraised > 0;          // (a push / pull frontier around a few re-derived voxels instead of the set was tried: level by level it is slower than one sweep)
             const bool local = !full && nraised > 0;             // few voxels re-derived: look around them instead of sweeping everything
             bool classic = false;
             for (;;) {
@@ -1335,7 +1336,7 @@ static int esdf_enqueue(tsl_tsdf* m, float gamma, float max_dist, bool force_ful
     // The batch is launched blind: 2 * reach + 8 rounds to begin with and for full recomputes, afterwards two more than the most any
     // completed update of this handle needed (a round without work costs ~5 us; stopping early costs a full recompute, see esdf_finish).
     int rounds = ((full || m->esdf_rounds_seen == 0) ? 2 * reach + 8 : std::min(2 * reach + 8, std::max(reach + 2, m->esdf_rounds_seen + 2))) + extra_rounds;
-    const int grid = 4 * m->ncu;
+    const int grid = m->esdf_grid > 0 ? m->esdf_grid : 4 * m->ncu;
     if (m->esdf_round_cap > 0 && extra_rounds == 0 && rounds > m->esdf_round_cap) rounds = m->esdf_round_cap;      // test knob: provoke the repair path
     for (int k = 0; k < rounds; ++k) {
         if (wavefront) hipLaunchKernelGGL(k_esdf_wave, dim3(grid), dim3(384), 0, q, m->M, E, s, m->P.vs, max_dist, k);

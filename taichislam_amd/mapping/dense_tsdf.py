@@ -4,6 +4,7 @@ running on hand-written HIP kernels for MI355X through include/taichislam_hip.h.
 Same constructor keywords, methods and attribute names as the reference; numpy in / numpy out.  Depth images
 and point clouds may also be torch CUDA tensors (their device pointer is handed to the *_dev entry points)."""
 import ctypes as C
+import os
 import math
 import time
 
@@ -104,6 +105,8 @@ class DenseTSDF(BaseMap):
         self._call("get_dims", C.byref(n), C.byref(nz), None, None)
         assert (n.value, nz.value) == (self.N, self.Nz), "host/device extent mismatch"
         self.initialize_fields()
+        if os.environ.get("TSL_ESDF_MODE"):          # developer / test aid: the form of the incremental ESDF update for handles made from here on (set_option("esdf_mode", ...))
+            self.set_option("esdf_mode", int(os.environ["TSL_ESDF_MODE"]))
         print(f"TSDF map initialized blocks {self.block_num_xy}x{self.block_num_xy}x{self.block_num_z}")
 
     # ---- fields (dense_tsdf.py:52-106) -------------------------------------------------------------------
