@@ -363,6 +363,9 @@ int  tsl_octo_get_active_submap(const tsl_octo* m, int32_t* sid);
 int  tsl_octo_set_active_submap(tsl_octo* m, int32_t sid);
 int  tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
                               const uint8_t* tex, int th, int tw);                   /* :130-132,147-169; tex u8[th][tw][3] BGR (:120-124) or NULL */
+/* device-resident depth (and texture).  Untextured frames are only QUEUED: up to eight are inserted by ONE launch (the insert is an order-free count), issued when
+ * eight are queued or as soon as any other call on the handle needs the map or its stream -- invisible except in timing.  The buffers must stay unchanged until
+ * tsl_octo_sync (or any call that returns map contents). */
 int  tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[3], const void* depth_dev, int h, int w,
                                   const void* tex_dev, int th, int tw);
 int  tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3], const float* xyz, const uint8_t* rgb, int64_t n);   /* :126-128,134-145 */

@@ -191,6 +191,19 @@ def device_count():
 _HOST_FN = None
 
 
+_OCTO_DEV_FN = None
+
+
+def octo_integrate_depth_dev_fn():
+    """tsl_octo_integrate_depth_dev with integer pointer arguments (no ctypes pointer objects per call): the per-frame path of a device-resident stream into the
+    Octomap, which the library only queues -- the host side of a call is what a frame costs."""
+    global _OCTO_DEV_FN
+    if _OCTO_DEV_FN is None:
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int)
+        _OCTO_DEV_FN = proto(("tsl_octo_integrate_depth_dev", lib()))
+    return _OCTO_DEV_FN
+
+
 def integrate_depth_host_fn():
     """tsl_tsdf_integrate_depth bound a second time with integer pointer arguments (no ctypes pointer objects per call): the per-frame path of
     a host-image stream, see DenseTSDF.recast_depth_to_map."""

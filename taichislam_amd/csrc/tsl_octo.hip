@@ -110,6 +110,60 @@ __global__ void __launch_bounds__(256) k_octo_depth(OctoDev M, OctoParams P, int
     block_count_add(&st->p_valid, ok);
     block_count_add(&st->p_oob, gate && !ok);
 }
+// The same insert for up to OCTO_NB queued frames in ONE launch (round 6; blockIdx.y = frame).  The insert is a count: leaf += 1.0f, integers below 2^24 in
+// f32, exact in any order, and a brick is claimed once whoever comes first -- so frames may share a launch like pixels do.  A frame is ~10 us of kernel
+// behind ~6 us of launch; eight per launch take the launch out of the per-frame cost (65 k -> 200 k+ frames/s at 640 x 480 / recast_step 2).
+#define OCTO_NB 8
+struct OctoBatchArgs { OctoParams P[OCTO_NB]; const uint16_t* depth[OCTO_NB]; tsl_frame_stats* st[OCTO_NB]; int s[OCTO_NB]; int n; };
+__global__ void __launch_bounds__(256) k_octo_depth_batch(OctoDev M, OctoBatchArgs B)
+{
+    const int f = blockIdx.y;
+    const OctoParams& P = B.P[f];
+    // a workgroup per 16 x 16 tile of sampled pixels, a wave per 4 rows x 16 columns of it: at 5 cm and 3 m some ten neighbouring pixels fall into one leaf, and
+    // 76 800 same-address f32 atomics per frame on ~8 000 leaves were what the one-pixel-one-atomic kernel took its 10 us for.  The lanes of a wave are grouped by
+    // leaf (lane arithmetic, one iteration per distinct leaf) and the first lane of a group adds the group's size: an integer below 2^24, exact.
+    const int tiles_x = (P.ww + 15) >> 4, tiles_y = (P.hh + 15) >> 4;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;              // (uniform: the grid is sized for the largest frame of the batch)
+    const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+    const int ii = tx * 16 + (int)(threadIdx.x & 15u), jj = ty * 16 + (int)(threadIdx.x >> 4);
+    bool gate = false, in = false;
+    int ci = 0, cj = 0, ck = 0;
+    if (ii < P.ww && jj < P.hh) {
+        const int j = jj * P.step, i = ii * P.step;
+        const uint16_t d = B.depth[f][(size_t)j * P.W + i];
+        const float df = (float)d;
+        if (d != 0 && !(df > P.thr_max) && !(df < P.thr_min)) {                               // :155
+            gate = true;
+            const float dep = df / 1000.0f;                                                   // :157
+            const float px = ((float)i - P.cx) * dep / P.fx, py = ((float)j - P.cy) * dep / P.fy, pz = dep;
+            const float mx = ((P.R[0] * px + P.R[1] * py) + P.R[2] * pz) + P.T[0];            // :159
+            const float my = ((P.R[3] * px + P.R[4] * py) + P.R[5] * pz) + P.T[1];
+            const float mz = ((P.R[6] * px + P.R[7] * py) + P.R[8] * pz) + P.T[2];
+            ci = rnd_i(mx / P.vs); cj = rnd_i(my / P.vs); ck = rnd_i(mz / P.vs);               // process_point :116-119, mapping_common.py:252-266
+            in = octo_in_tree(M, ci, cj, ck);
+        }
+    }
+    const int lane = lane_id();
+    int leader = lane, gsize = 1;
+    for (unsigned long long todo = __ballot(in); todo; ) {
+        const int l0 = (int)__builtin_ctzll(todo);                                            // (uniform)
+        const int i0 = __builtin_amdgcn_readlane(ci, l0), j0 = __builtin_amdgcn_readlane(cj, l0), k0 = __builtin_amdgcn_readlane(ck, l0);
+        const bool mine = in && ci == i0 && cj == j0 && ck == k0;
+        const unsigned long long grp = __ballot(mine);
+        if (mine) { leader = l0; gsize = popc64(grp); }
+        todo &= ~grp;
+    }
+    int got = 0;
+    if (in && lane == leader) {
+        int l; const int b = octo_brick_of(M, ci, cj, ck, &l);
+        const int p = octo_claim(M, B.s[f], b);
+        if (p >= 0) { atomicAdd(M.cnt + (long long)p * TSL_BRK3 + l, (float)gsize); got = 1; }      // :119, gsize times
+    }
+    got = __shfl(got, leader);
+    const bool ok = in && got != 0;
+    block_count_add(&B.st[f]->p_valid, ok);
+    block_count_add(&B.st[f]->p_oob, gate && !ok);
+}
 // recast_pcl_to_map_kernel  taichi_octomap.py:134-145 (no range gate)
 __global__ void __launch_bounds__(256) k_octo_points(OctoDev M, OctoParams P, int s, const float* __restrict__ xyz, int n, tsl_frame_stats* st, long long* leaf_of)
 {
@@ -215,7 +269,7 @@ void convert_pose(const double* Rb, const double* Tb, const double* R, const dou
 }  // namespace tsl
 
 struct tsl_octo {
-    tsl_octo_cfg cfg; int device; hipStream_t stream;
+    tsl_octo_cfg cfg; int device; hipStream_t stream_;      // (use os(m): it issues the queued depth frames first)
     int Rxy, Rz, N, Nz, K, nsub;
     double voxel_scale_recomputed;
     tsl::OctoDev M; tsl::OctoParams P;
@@ -228,9 +282,20 @@ struct tsl_octo {
     float* pose_dev;
     void* stage; size_t stage_bytes; void* xbuf; size_t xbuf_bytes;
     void* stage_tex; size_t stage_tex_bytes; long long* leaf_of; size_t leaf_of_n;      // texture staging, leaf of every pixel / point of the frame
+    tsl::OctoBatchArgs* q; int qmax;          // untextured device-resident depth frames queued for one launch (q->n of them; OCTO_NB at most)
 };
 
 using namespace tsl;
+
+// issue the queued depth frames: one launch for all of them
+static void octo_flush(tsl_octo* m)
+{
+    if (!m->q || m->q->n == 0) return;
+    hipLaunchKernelGGL(k_octo_depth_batch, dim3((unsigned)m->qmax, (unsigned)m->q->n), dim3(256), 0, m->stream_, m->M, *m->q);
+    m->q->n = 0; m->qmax = 0;
+}
+// the handle's stream behind everything queued on it: every entry point that reads or writes the map comes through here
+static hipStream_t os(tsl_octo* m) { octo_flush(m); return m->stream_; }
 
 static int octo_ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
 static int octo_ensure_table(tsl_octo* m, int s)
@@ -238,16 +303,16 @@ static int octo_ensure_table(tsl_octo* m, int s)
     if (m->tables[(size_t)s]) return TSL_OK;
     int* t = nullptr;
     TSL_HIP(hipMalloc((void**)&t, sizeof(int) * (size_t)m->M.nb3));
-    TSL_HIP(hipMemsetAsync(t, 0xff, sizeof(int) * (size_t)m->M.nb3, m->stream));
+    TSL_HIP(hipMemsetAsync(t, 0xff, sizeof(int) * (size_t)m->M.nb3, os(m)));
     m->tables[(size_t)s] = t;
-    TSL_HIP(hipMemcpyAsync(m->M.tables + s, &m->tables[(size_t)s], sizeof(int*), hipMemcpyHostToDevice, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->M.tables + s, &m->tables[(size_t)s], sizeof(int*), hipMemcpyHostToDevice, os(m)));
+    TSL_HIP(hipStreamSynchronize(os(m)));
     return TSL_OK;
 }
 static int octo_read_int(tsl_octo* m, const int* dev, int* out)
 {
-    TSL_HIP(hipMemcpyAsync(m->h_stats, dev, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->h_stats, dev, sizeof(int), hipMemcpyDeviceToHost, os(m)));
+    TSL_HIP(hipStreamSynchronize(os(m)));
     *out = *reinterpret_cast<int*>(m->h_stats);
     return TSL_OK;
 }
@@ -256,14 +321,14 @@ static int octo_used(tsl_octo* m, int* n)
 static int octo_check_err(tsl_octo* m)
 {
     int e = 0; int rc = octo_read_int(m, m->M.err, &e); if (rc) return rc;
-    if (e) { (void)hipMemsetAsync(m->M.err, 0, sizeof(int), m->stream); set_error("octomap brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
+    if (e) { (void)hipMemsetAsync(m->M.err, 0, sizeof(int), os(m)); set_error("octomap brick pool exhausted (max_bricks)"); return TSL_ERR_CAPACITY; }
     return TSL_OK;
 }
 
 static int octo_stage_tex(tsl_octo* m, const uint8_t* tex, size_t bytes)
 {
     if (m->stage_tex_bytes < bytes) { if (m->stage_tex) (void)hipFree(m->stage_tex); m->stage_tex = nullptr; TSL_HIP(hipMalloc(&m->stage_tex, bytes + 4096)); m->stage_tex_bytes = bytes + 4096; }
-    TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, bytes, hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipMemcpyAsync(m->stage_tex, tex, bytes, hipMemcpyHostToDevice, os(m)));
     return TSL_OK;
 }
 static int octo_leaf_scratch(tsl_octo* m, size_t n)
@@ -285,7 +350,8 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     TSL_HIP(hipSetDevice(device));
     tsl_octo* m = new tsl_octo();
     m->cfg = *cfg; m->device = device;
-    TSL_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    TSL_HIP(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking));
+    m->q = new OctoBatchArgs(); m->q->n = 0; m->qmax = 0;
     m->K = cfg->K;
     m->Rxy = (int)std::ceil(std::log2(cfg->map_size_xy / cfg->voxel_scale) / std::log2((double)cfg->K));     // taichi_octomap.py:19
     m->Rz = (int)std::ceil(std::log2(cfg->map_size_z / cfg->voxel_scale) / std::log2((double)cfg->K));      // :20
@@ -303,22 +369,22 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     m->nsub = cfg->max_submap_num > 0 ? cfg->max_submap_num : 1;
     M.max_bricks = cfg->max_bricks > 0 ? cfg->max_bricks : 65536;
     TSL_HIP(hipMalloc((void**)&M.tables, sizeof(int*) * (size_t)m->nsub));
-    TSL_HIP(hipMemsetAsync(M.tables, 0, sizeof(int*) * (size_t)m->nsub, m->stream));
+    TSL_HIP(hipMemsetAsync(M.tables, 0, sizeof(int*) * (size_t)m->nsub, os(m)));
     m->tables.assign((size_t)m->nsub, nullptr);
     TSL_HIP(hipMalloc((void**)&M.cnt, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3));
-    TSL_HIP(hipMemsetAsync(M.cnt, 0, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+    TSL_HIP(hipMemsetAsync(M.cnt, 0, sizeof(float) * (size_t)M.max_bricks * TSL_BRK3, os(m)));
     M.col = nullptr; M.win = nullptr;
     if (cfg->texture_enabled) {
         TSL_REQUIRE(M.ext_xy <= (1 << 18) && m->nsub <= 1024, "tsl_octo_create: textured maps are limited to 2^18 cells per axis and 1024 submaps");
         TSL_HIP(hipMalloc((void**)&M.col, sizeof(float) * 3 * (size_t)M.max_bricks * TSL_BRK3));
-        TSL_HIP(hipMemsetAsync(M.col, 0, sizeof(float) * 3 * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+        TSL_HIP(hipMemsetAsync(M.col, 0, sizeof(float) * 3 * (size_t)M.max_bricks * TSL_BRK3, os(m)));
         TSL_HIP(hipMalloc((void**)&M.win, sizeof(unsigned long long) * (size_t)M.max_bricks * TSL_BRK3));
-        TSL_HIP(hipMemsetAsync(M.win, 0, sizeof(unsigned long long) * (size_t)M.max_bricks * TSL_BRK3, m->stream));
+        TSL_HIP(hipMemsetAsync(M.win, 0, sizeof(unsigned long long) * (size_t)M.max_bricks * TSL_BRK3, os(m)));
     }
     TSL_HIP(hipMalloc((void**)&M.owner_s, sizeof(int) * (size_t)M.max_bricks));
     TSL_HIP(hipMalloc((void**)&M.owner_b, sizeof(int) * (size_t)M.max_bricks));
     TSL_HIP(hipMalloc((void**)&M.pool_top, sizeof(int) * 4));
-    TSL_HIP(hipMemsetAsync(M.pool_top, 0, sizeof(int) * 4, m->stream));
+    TSL_HIP(hipMemsetAsync(M.pool_top, 0, sizeof(int) * 4, os(m)));
     M.err = M.pool_top + 1;
     OctoParams& P = m->P; std::memset(&P, 0, sizeof(P));
     for (int i = 0; i < 3; ++i) P.R[i * 4] = 1.0f;
@@ -331,19 +397,19 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
     for (int s = 0; s < m->nsub; ++s) for (int i = 0; i < 3; ++i) { m->baseR[(size_t)s * 9 + i * 4] = 1.0; m->baseRf[(size_t)s * 9 + i * 4] = 1.0f; }   // identity default
     m->active = 0; m->p_used = 0;
     TSL_HIP(hipMalloc((void**)&m->stats_ring, sizeof(tsl_frame_stats) * OCTO_STAT_RING));
-    TSL_HIP(hipMemsetAsync(m->stats_ring, 0, sizeof(tsl_frame_stats) * OCTO_STAT_RING, m->stream));
+    TSL_HIP(hipMemsetAsync(m->stats_ring, 0, sizeof(tsl_frame_stats) * OCTO_STAT_RING, os(m)));
     m->stats = m->stats_ring; m->stat_idx = 0;
     TSL_HIP(hipHostMalloc((void**)&m->h_stats, sizeof(tsl_frame_stats), hipHostMallocDefault));
     m->max_disp = cfg->max_disp_particles > 0 ? cfg->max_disp_particles : 1000000;
     TSL_HIP(hipMalloc((void**)&m->exp_xyz, sizeof(float) * 3 * (size_t)m->max_disp));
     TSL_HIP(hipMalloc((void**)&m->exp_rgb, sizeof(float) * 3 * (size_t)m->max_disp));
     TSL_HIP(hipMalloc((void**)&m->num_particles, sizeof(int) * 4));
-    TSL_HIP(hipMemsetAsync(m->num_particles, 0, sizeof(int) * 4, m->stream));
+    TSL_HIP(hipMemsetAsync(m->num_particles, 0, sizeof(int) * 4, os(m)));
     TSL_HIP(hipMalloc((void**)&m->pose_dev, sizeof(float) * 12 * (size_t)m->nsub));
     m->stage = nullptr; m->stage_bytes = 0; m->xbuf = nullptr; m->xbuf_bytes = 0;
     m->stage_tex = nullptr; m->stage_tex_bytes = 0; m->leaf_of = nullptr; m->leaf_of_n = 0;
     int rc = octo_ensure_table(m, 0); if (rc) return rc;
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(os(m)));
     *out = m;
     return TSL_OK;
 }
@@ -351,25 +417,25 @@ int tsl_octo_create(const tsl_octo_cfg* cfg, int device, tsl_octo** out)
 void tsl_octo_destroy(tsl_octo* m)
 {
     if (!m) return;
-    (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream);
+    (void)hipSetDevice(m->device); (void)hipStreamSynchronize(os(m));
     for (int* t : m->tables) if (t) (void)hipFree(t);
     void* ptrs[] = { m->M.col, m->M.win, m->stage_tex, m->leaf_of, m->M.tables, m->M.cnt, m->M.owner_s, m->M.owner_b, m->M.pool_top, m->stats_ring, m->exp_xyz, m->exp_rgb, m->num_particles, m->pose_dev, m->stage, m->xbuf };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
-    (void)hipStreamDestroy(m->stream);
+    (void)hipStreamDestroy(m->stream_); delete m->q; m->q = nullptr;
     delete m;
 }
 
 int tsl_octo_get_dims(const tsl_octo* m, int32_t* N, int32_t* Nz, int32_t* Rxy, int32_t* Rz, double* vs)
 { TSL_REQUIRE(m, "null handle"); if (N) *N = m->N; if (Nz) *Nz = m->Nz; if (Rxy) *Rxy = m->Rxy; if (Rz) *Rz = m->Rz; if (vs) *vs = m->voxel_scale_recomputed; return TSL_OK; }
-int tsl_octo_sync(tsl_octo* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(m->stream)); return TSL_OK; }
+int tsl_octo_sync(tsl_octo* m) { TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device)); TSL_HIP(hipStreamSynchronize(os(m))); return TSL_OK; }
 
 int tsl_octo_reset(tsl_octo* m)                                                              // taichi_octomap.py:210-211
 {
     TSL_REQUIRE(m, "null handle"); TSL_HIP(hipSetDevice(m->device));
     int used = 0; int rc = octo_used(m, &used); if (rc) return rc;
-    if (used > 0) hipLaunchKernelGGL(k_octo_reset, dim3(used < 4096 ? used : 4096), dim3(256), 0, m->stream, m->M, used);
-    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, m->stream));
+    if (used > 0) hipLaunchKernelGGL(k_octo_reset, dim3(used < 4096 ? used : 4096), dim3(256), 0, os(m), m->M, used);
+    TSL_HIP(hipMemsetAsync(m->M.pool_top, 0, sizeof(int) * 2, os(m)));
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -403,7 +469,7 @@ static int octo_next_stats(tsl_octo* m)
 {
     m->stat_idx = (m->stat_idx + 1) % OCTO_STAT_RING;
     const int half = OCTO_STAT_RING / 2;
-    if (m->stat_idx % half == 0) TSL_HIP(hipMemsetAsync(m->stats_ring + m->stat_idx, 0, sizeof(tsl_frame_stats) * half, m->stream));
+    if (m->stat_idx % half == 0) TSL_HIP(hipMemsetAsync(m->stats_ring + m->stat_idx, 0, sizeof(tsl_frame_stats) * half, os(m)));
     m->stats = m->stats_ring + m->stat_idx;
     return TSL_OK;
 }
@@ -425,10 +491,24 @@ int tsl_octo_integrate_depth_dev(tsl_octo* m, const double R[9], const double T[
         P.th = th; P.tw = tw;
         int rc = octo_leaf_scratch(m, (size_t)total); if (rc) return rc;
     }
+    if (!tex && m->q) {
+        // only QUEUED: up to OCTO_NB frames are inserted by one launch, issued when the queue is full or as soon as anything else wants the map or the stream
+        // (the slot's statistics words are cleared by a memset ordered in front of that launch: the ring's half is entered here, the launch comes later)
+        m->stat_idx = (m->stat_idx + 1) % OCTO_STAT_RING;
+        if (m->stat_idx % (OCTO_STAT_RING / 2) == 0) { octo_flush(m); TSL_HIP(hipMemsetAsync(m->stats_ring + m->stat_idx, 0, sizeof(tsl_frame_stats) * (OCTO_STAT_RING / 2), m->stream_)); }
+        m->stats = m->stats_ring + m->stat_idx;
+        if (total > 0) {
+            OctoBatchArgs& Q = *m->q;
+            Q.P[Q.n] = P; Q.depth[Q.n] = (const uint16_t*)depth_dev; Q.st[Q.n] = m->stats; Q.s[Q.n] = m->active; ++Q.n;
+            { const int tiles = ((P.ww + 15) >> 4) * ((P.hh + 15) >> 4); if (tiles > m->qmax) m->qmax = tiles; }          // workgroups of the largest frame
+            if (Q.n == OCTO_NB) octo_flush(m);
+        }
+        return TSL_OK;
+    }
     { const int rc = octo_next_stats(m); if (rc) return rc; }
     if (total > 0) {
-        hipLaunchKernelGGL(k_octo_depth, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, m->active, (const uint16_t*)depth_dev, m->stats, tex ? m->leaf_of : nullptr);
-        if (tex) hipLaunchKernelGGL(k_octo_colour, dim3((total + 255) / 256), dim3(256), 0, m->stream, m->M, P, (const uint8_t*)tex_dev, (const long long*)m->leaf_of, total, 0);
+        hipLaunchKernelGGL(k_octo_depth, dim3((total + 255) / 256), dim3(256), 0, os(m), m->M, P, m->active, (const uint16_t*)depth_dev, m->stats, tex ? m->leaf_of : nullptr);
+        if (tex) hipLaunchKernelGGL(k_octo_colour, dim3((total + 255) / 256), dim3(256), 0, os(m), m->M, P, (const uint8_t*)tex_dev, (const long long*)m->leaf_of, total, 0);
     }
     TSL_HIP(hipGetLastError());
     return TSL_OK;
@@ -439,11 +519,13 @@ int tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], 
     TSL_HIP(hipSetDevice(m->device));
     const size_t nb = (size_t)h * w * 2;
     if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
-    TSL_HIP(hipMemcpyAsync(m->stage, depth, nb, hipMemcpyHostToDevice, m->stream));
+    TSL_HIP(hipMemcpyAsync(m->stage, depth, nb, hipMemcpyHostToDevice, os(m)));
     const bool use_tex = m->M.col && tex && th > 0 && tw > 0;
     if (use_tex) { int rc = octo_stage_tex(m, tex, (size_t)th * tw * 3); if (rc) return rc; }
-    TSL_HIP(hipStreamSynchronize(m->stream));
-    return tsl_octo_integrate_depth_dev(m, R, T, m->stage, h, w, use_tex ? m->stage_tex : nullptr, th, tw);
+    TSL_HIP(hipStreamSynchronize(os(m)));
+    const int rc = tsl_octo_integrate_depth_dev(m, R, T, m->stage, h, w, use_tex ? m->stage_tex : nullptr, th, tw);
+    octo_flush(m);                                          // (the staging buffer is written again by the next call)
+    return rc;
 }
 /* recast_pcl_to_map with DEVICE buffers: xyz f32 [n][3], rgb u8 [n][3] or NULL (taichi_octomap.py:126-128,134-145).  Enqueued on the
  * handle's stream; the buffers must be complete (the caller's producing stream synchronised) and stay unchanged until tsl_octo_sync. */
@@ -457,8 +539,8 @@ int tsl_octo_integrate_points_dev(tsl_octo* m, const double R[9], const double T
     { const int rc = octo_next_stats(m); if (rc) return rc; }
     if (n == 0) return TSL_OK;
     if (use_tex) { int rc = octo_leaf_scratch(m, (size_t)n); if (rc) return rc; }
-    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, m->active, (const float*)xyz_dev, (int)n, m->stats, use_tex ? m->leaf_of : nullptr);
-    if (use_tex) hipLaunchKernelGGL(k_octo_colour, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->M, m->P, (const uint8_t*)rgb_dev, (const long long*)m->leaf_of, (int)n, 1);
+    hipLaunchKernelGGL(k_octo_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, os(m), m->M, m->P, m->active, (const float*)xyz_dev, (int)n, m->stats, use_tex ? m->leaf_of : nullptr);
+    if (use_tex) hipLaunchKernelGGL(k_octo_colour, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, os(m), m->M, m->P, (const uint8_t*)rgb_dev, (const long long*)m->leaf_of, (int)n, 1);
     TSL_HIP(hipGetLastError());
     return TSL_OK;
 }
@@ -470,17 +552,17 @@ int tsl_octo_integrate_points(tsl_octo* m, const double R[9], const double T[3],
     if (n > 0) {
         const size_t nb = (size_t)n * 12;
         if (m->stage_bytes < nb) { if (m->stage) (void)hipFree(m->stage); m->stage = nullptr; TSL_HIP(hipMalloc(&m->stage, nb + 4096)); m->stage_bytes = nb + 4096; }
-        TSL_HIP(hipMemcpyAsync(m->stage, xyz, nb, hipMemcpyHostToDevice, m->stream));
+        TSL_HIP(hipMemcpyAsync(m->stage, xyz, nb, hipMemcpyHostToDevice, os(m)));
         if (use_tex) { int rc = octo_stage_tex(m, rgb, (size_t)n * 3); if (rc) return rc; }
-        TSL_HIP(hipStreamSynchronize(m->stream));
+        TSL_HIP(hipStreamSynchronize(os(m)));
     }
     return tsl_octo_integrate_points_dev(m, R, T, m->stage, use_tex ? m->stage_tex : nullptr, n);
 }
 int tsl_octo_last_frame_stats(tsl_octo* m, tsl_frame_stats* out)
 {
     TSL_REQUIRE(m && out, "null"); TSL_HIP(hipSetDevice(m->device));
-    TSL_HIP(hipMemcpyAsync(m->h_stats, m->stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipMemcpyAsync(m->h_stats, m->stats, sizeof(tsl_frame_stats), hipMemcpyDeviceToHost, os(m)));
+    TSL_HIP(hipStreamSynchronize(os(m)));
     *out = *m->h_stats; out->p_used = m->p_used;
     return octo_check_err(m);
 }
@@ -500,13 +582,13 @@ static int octo_export(tsl_octo* m, tsl_octo* dst, int mode, int level, int keep
         if (m->xbuf_bytes < need) { if (m->xbuf) (void)hipFree(m->xbuf); m->xbuf = nullptr; TSL_HIP(hipMalloc(&m->xbuf, need + 4096)); m->xbuf_bytes = need + 4096; }
         didx = (int32_t*)m->xbuf; dcnt = (float*)((char*)m->xbuf + (size_t)cap * 12); drgb = (float*)((char*)m->xbuf + (size_t)cap * 16);
         counter = m->num_particles + 2; dcap = cap;
-        TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));
+        TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), os(m)));
     } else {
         if (!dst) dst = m;
         counter = dst->num_particles; dxyz = dst->exp_xyz; drgb = dst->exp_rgb; dcap = dst->max_disp;
-        if (!keep) TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), m->stream));                // :93
+        if (!keep) TSL_HIP(hipMemsetAsync(counter, 0, sizeof(int), os(m)));                // :93
     }
-    if (used > 0) hipLaunchKernelGGL(k_octo_export, dim3(used < 8192 ? used : 8192), dim3(256), 0, m->stream, m->M, m->active, used, mode, m->occ_thres, gxy, gz, B, m->P.vs,
+    if (used > 0) hipLaunchKernelGGL(k_octo_export, dim3(used < 8192 ? used : 8192), dim3(256), 0, os(m), m->M, m->active, used, mode, m->occ_thres, gxy, gz, B, m->P.vs,
                                      didx, dcnt, dxyz, drgb, dcap, counter);
     int c = 0; rc = octo_read_int(m, counter, &c); if (rc) return rc;
     *n = c;
@@ -530,7 +612,7 @@ int tsl_octo_occupied_voxels(tsl_octo* m, tsl_octo* dst, int level, int add_to_c
 int tsl_octo_read_exports(tsl_octo* m, float* xyz, float* rgb, int64_t n)
 {
     TSL_REQUIRE(m, "null handle"); TSL_REQUIRE(n >= 0 && n <= m->max_disp, "read_exports: n out of range"); TSL_HIP(hipSetDevice(m->device));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    TSL_HIP(hipStreamSynchronize(os(m)));
     if (n && xyz) TSL_HIP(hipMemcpy(xyz, m->exp_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
     if (n && rgb) TSL_HIP(hipMemcpy(rgb, m->exp_rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
     return TSL_OK;
@@ -562,9 +644,9 @@ int tsl_octo_pack_pointcloud2(tsl_octo* m, int has_rgb, int64_t n, void* out_hos
     const int stride = has_rgb ? 6 : 3;
     const size_t need = sizeof(float) * (size_t)stride * (size_t)n;
     if (m->xbuf_bytes < need) { if (m->xbuf) (void)hipFree(m->xbuf); m->xbuf = nullptr; TSL_HIP(hipMalloc(&m->xbuf, need + 4096)); m->xbuf_bytes = need + 4096; }
-    hipLaunchKernelGGL(k_octo_pack_pointcloud2, dim3((unsigned)(((long long)n * stride + 255) / 256)), dim3(256), 0, m->stream, m->exp_xyz, m->exp_rgb, (float*)m->xbuf, (long long)n, stride);
-    TSL_HIP(hipMemcpyAsync(out_host, m->xbuf, need, hipMemcpyDeviceToHost, m->stream));
-    TSL_HIP(hipStreamSynchronize(m->stream));
+    hipLaunchKernelGGL(k_octo_pack_pointcloud2, dim3((unsigned)(((long long)n * stride + 255) / 256)), dim3(256), 0, os(m), m->exp_xyz, m->exp_rgb, (float*)m->xbuf, (long long)n, stride);
+    TSL_HIP(hipMemcpyAsync(out_host, m->xbuf, need, hipMemcpyDeviceToHost, os(m)));
+    TSL_HIP(hipStreamSynchronize(os(m)));
     return TSL_OK;
 }
 int tsl_octo_num_particles(tsl_octo* m, int32_t* n) { TSL_REQUIRE(m && n, "null"); TSL_HIP(hipSetDevice(m->device)); int v = 0; int rc = octo_read_int(m, m->num_particles, &v); *n = v; return rc; }
@@ -582,15 +664,15 @@ int tsl_octo_fuse_submaps(tsl_octo* g, tsl_octo* sub)
     }
     std::vector<float> tab((size_t)g->nsub * 12);
     for (int s = 0; s < g->nsub; ++s) { for (int a = 0; a < 9; ++a) tab[(size_t)s * 12 + a] = g->baseRf[(size_t)s * 9 + a]; for (int a = 0; a < 3; ++a) tab[(size_t)s * 12 + 9 + a] = g->baseTf[(size_t)s * 3 + a]; }
-    TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, g->stream));
-    TSL_HIP(hipStreamSynchronize(g->stream));
+    TSL_HIP(hipMemcpyAsync(g->pose_dev, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, os(g)));
+    TSL_HIP(hipStreamSynchronize(os(g)));
     int nsrc = 0; if ((rc = octo_used(sub, &nsrc))) return rc;
     if (nsrc > 0) {
-        hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres, 0);
-        if (sub->M.col && g->M.col) hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, g->stream, sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres, 1);
+        hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, os(g), sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres, 0);
+        if (sub->M.col && g->M.col) hipLaunchKernelGGL(k_octo_fuse, dim3(nsrc < 8192 ? nsrc : 8192), dim3(256), 0, os(g), sub->M, g->M, nsrc, g->pose_dev, g->nsub, g->P.vs, g->occ_thres, 1);
     }
     TSL_HIP(hipGetLastError());
-    TSL_HIP(hipStreamSynchronize(g->stream));
+    TSL_HIP(hipStreamSynchronize(os(g)));
     return octo_check_err(g);
 }
 

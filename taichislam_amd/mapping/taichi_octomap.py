@@ -47,6 +47,8 @@ class Octomap(BaseMap):
         h = C.c_void_p()
         _lib.check(self.L.tsl_octo_create(C.byref(cfg), int(device), C.byref(h)))
         self.h = h
+        self._queued = []
+        self._integrate_depth_dev = _lib.octo_integrate_depth_dev_fn()
         self.num_export_particles = ScalarField(self._get_num, None, "num_export_particles")
         self.device = device
         self.export_x = DeviceArrayField(self, lambda n: self._read(n)[0], max_disp_particles, 3, "export_x", dev=lambda: self._exports_dev(0))
@@ -108,13 +110,28 @@ class Octomap(BaseMap):
         self._call("integrate_points", _dptr(R, 9)[1], _dptr(T, 3)[1], _vp(xyz), _vp(rgb) if rgb is not None else None, int(xyz.shape[0]))
 
     def recast_depth_to_map(self, R, T, depthmap, texture=None):
-        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
         use_tex = self.enable_texture and texture is not None and np.ndim(texture) == 3
+        if not use_tex and hasattr(depthmap, "data_ptr") and depthmap.is_cuda:
+            # the per-frame path of a device-resident stream: the library only QUEUES the frame (up to eight per launch), so the host side of this call is
+            # the frame's cost -- pointers as plain integers, no numpy / ctypes temporaries for poses that already are float64 arrays
+            Ra = R if (type(R) is np.ndarray and R.dtype == np.float64 and R.size == 9 and R.flags.c_contiguous) else _dptr(R, 9)[0]
+            Ta = T if (type(T) is np.ndarray and T.dtype == np.float64 and T.size == 3 and T.flags.c_contiguous) else _dptr(T, 3)[0]
+            q = self._queued
+            q.append(depthmap)                                  # the tensor has to outlive the queue
+            if len(q) > 16:
+                del q[:8]
+            shape = depthmap.shape
+            rc = self._integrate_depth_dev(self.h, Ra.ctypes.data, Ta.ctypes.data, depthmap.data_ptr(), shape[0], shape[1], None, 0, 0)
+            if rc:
+                _lib.check(rc)
+            return
+        r, t = _dptr(R, 9)[1], _dptr(T, 3)[1]
         if hasattr(depthmap, "data_ptr") and getattr(depthmap, "is_cuda", False):
-            if use_tex and hasattr(texture, "data_ptr") and getattr(texture, "is_cuda", False):
+            if hasattr(texture, "data_ptr") and getattr(texture, "is_cuda", False):
                 self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]), int(depthmap.shape[1]),
                            C.c_void_p(texture.data_ptr()), int(texture.shape[0]), int(texture.shape[1]))
             else:
+                self._queued.append(depthmap)
                 self._call("integrate_depth_dev", r, t, C.c_void_p(depthmap.data_ptr()), int(depthmap.shape[0]), int(depthmap.shape[1]), None, 0, 0)
             return
         depth = np.ascontiguousarray(np.asarray(depthmap, dtype=np.uint16))

@@ -137,3 +137,37 @@ def test_octomap_coloured_fusion(hip_lib):
     gs.active_submap_id[None] = 2; os_.set_active_submap(2)
     gg.fuse_submaps(gs); og.fuse_submaps(os_)
     _coloured_leaves_equal(gg, og, "fused colours")
+
+
+def test_octomap_device_frames_queued_eight_per_launch(hip_lib):
+    """Round 6: device-resident depth frames are only queued by recast_depth_to_map and inserted up to eight per launch (taichi_octomap.py:147-169: the insert is a count,
+    exact in any order).  21 frames at the C3 geometry handed over back to back -- two and a half batches, frames of two sizes in one batch, a switch of the active
+    submap and a point cloud in between -- must leave exactly the oracle's leaves; the last frame's statistics are that frame's."""
+    import torch
+    from oracle import OracleOctomap
+    from taichislam_amd.mapping import Octomap
+    cfg = dict(map_scale=[51.2, 51.2], voxel_scale=0.05, K=2, max_ray_length=5.0, max_submap_num=4)
+    g, o = Octomap(**cfg), OracleOctomap(**cfg)
+    g.set_dep_camera_intrinsic(syn.K_DEPTH); o.set_intrinsics(syn.K_DEPTH)
+    frames = list(syn.sphere_room_stream(21))
+    dev = [torch.from_numpy(d.view(np.int16)).cuda() for _, _, d in frames]
+    half = [torch.from_numpy(np.ascontiguousarray(d[:240]).view(np.int16)).cuda() for _, _, d in frames]
+    so = None
+    for f, (R, T, d) in enumerate(frames):
+        if f == 13:                              # something else on the handle in the middle of a batch: the queue is issued first
+            pts = np.random.default_rng(5).uniform(-4, 4, size=(3000, 3)).astype(np.float32)
+            g.recast_pcl_to_map(R, T, pts, None, 3000); o.integrate_points(R, T, pts)
+        if f % 5 == 3:                           # a frame of another size inside the batch
+            g.recast_depth_to_map(R, T, half[f], None); so = o.integrate_depth(R, T, np.ascontiguousarray(d[:240]))
+        else:
+            g.recast_depth_to_map(R, T, dev[f], None); so = o.integrate_depth(R, T, d)
+    sg = g.last_frame_stats()
+    assert (sg["p_used"], sg["p_valid"], sg["p_oob"]) == (so["p_used"], so["p_valid"], so["p_oob"])
+    _leaves_equal(g, o)
+    # host images go through the same insert, one at a time (their staging buffer is reused by the next call)
+    g2 = Octomap(**cfg); g2.set_dep_camera_intrinsic(syn.K_DEPTH)
+    for f, (R, T, d) in enumerate(frames):
+        if f == 13:
+            g2.recast_pcl_to_map(R, T, pts, None, 3000)
+        g2.recast_depth_to_map(R, T, np.ascontiguousarray(d[:240]) if f % 5 == 3 else d, None)
+    _leaves_equal(g2, o)
