@@ -428,7 +428,8 @@ def main():
     m.set_base_pose_submap(rank, poses[0][0], poses[0][1])
     for kv in args.opt:
         k, v = kv.split("=")
-        m.set_option(k, int(v))
+        if not k.startswith("fuse_"):
+            m.set_option(k, int(v))
 
     frames_dev = [depth_dev[f] for f in range(ngen)]        # one [480, 640] view per frame, made before the timed region
 
@@ -546,6 +547,9 @@ def main():
             g = comm = None
             try:
                 g = DenseTSDF(**C2, device=dev, is_global_map=True, max_submap_num=nsub, max_bricks=65536)
+                for kv in args.opt:                                      # (A/B options of the global map's side: --opt fuse_direct=1)
+                    if kv.startswith("fuse_"):
+                        g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
                 for r in range(world):
                     Rb, Tb = syn.camera_pose(0, start_deg=D.stream_start_deg(r))
                     g.set_base_pose_submap(r, Rb, Tb)

@@ -1027,7 +1027,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0; m->mesh_flags = nullptr;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_par = nullptr; m->esdf_ok = nullptr; m->esdf_mode = 0; m->esdf_grid = 0; m->esdf_orphans = 0; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_gate_mask = 0; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_par = nullptr; m->esdf_ok = nullptr; m->esdf_mode = 0; m->esdf_grid = 0; m->fuse_direct = false; m->esdf_orphans = 0; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_gate_mask = 0; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
@@ -1681,6 +1681,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_mode")) { TSL_REQUIRE(value == 0 || value == 1, "esdf_mode: 0 = regional recompute (default), 1 = raise / lower wavefront with parent directions"); int rc = esdf_finish(m); if (rc) return rc; m->esdf_mode = value; m->esdf_valid = false; return TSL_OK; }
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
+    if (!std::strcmp(name, "fuse_direct")) { m->fuse_direct = value != 0; return TSL_OK; }      // 1 = round 5's splat (global atomics per corner) on the global map, for A/B
     if (!std::strcmp(name, "esdf_grid")) { TSL_REQUIRE(value >= 0, "esdf_grid: workgroups of a relaxation round (0 = four per CU)"); m->esdf_grid = value; return TSL_OK; }
     if (!std::strcmp(name, "esdf_overlap")) { int rc = esdf_finish(m); if (rc) return rc; m->esdf_overlap = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "unit")) { TSL_REQUIRE(value >= 0 && value <= (1 << 20), "unit must be 0..2^20 segments"); int rc = tsl_tsdf_sync(m); if (rc) return rc; m->unit_max = value; return TSL_OK; }

@@ -262,7 +262,7 @@ struct tsl_tsdf {
     uint8_t* mrg_mask; int *mrg_list, *mrg_count; int mrg_nunion;      // multi-GPU merge: touched-brick mask, union list (tsl_merge.hip)
     void *mrg_pacc, *mrg_pcnt; size_t mrg_pacc_bytes, mrg_pcnt_bytes;  // packed union bricks of the one-call form
     // esdf
-    float* esdf; uint8_t *esdf_fl, *esdf_region, *esdf_par, *esdf_ok; int esdf_mode, esdf_grid; long long esdf_orphans; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq, *esdf_nbr; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
+    float* esdf; uint8_t *esdf_fl, *esdf_region, *esdf_par, *esdf_ok; int esdf_mode, esdf_grid; bool fuse_direct; long long esdf_orphans; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq, *esdf_nbr; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
     float *esdf_exp_xyz, *esdf_exp_val; int* esdf_exp_count; int esdf_exp_n;      // export_ESDF_xyz / export_ESDF / num_export_ESDF_particles (dense_esdf.py:498-509), allocated by the first slice
     bool esdf_valid, esdf_force_full; int esdf_submap; float esdf_gamma, esdf_maxd; tsl_esdf_stats esdf_stats;
     hipEvent_t esdf_gate, esdf_gate_ev; bool esdf_gate_set; unsigned esdf_gate_mask;      // recorded behind the collect kernel of the latest ESDF update: phase A of later frames waits for it
