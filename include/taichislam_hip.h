@@ -186,6 +186,15 @@ int   tsl_tsdf_merge_begin(tsl_tsdf* global, tsl_tsdf* submaps, void* mask_dev, 
 int   tsl_tsdf_merge_union(tsl_tsdf* global, const void* mask_dev, int32_t* nunion);
 int   tsl_tsdf_merge_pack(tsl_tsdf* global, void* acc_dev, void* cnt_dev);
 int   tsl_tsdf_merge_finish(tsl_tsdf* global, const void* acc_dev, const void* cnt_dev);
+/* The second form of the exchange: REDUCE-SCATTER the packed planes (pad them to whole bricks per rank with zeros), every rank turns the
+ * `nbricks` bricks of sums it received into finalised records -- per brick tsl_tsdf_merge_record_bytes = 20 992 bytes: f16 {TSDF, W} words, occupancy bytes, a
+ * "written" bit per voxel (dense_tsdf.py:272-280 applied once per voxel) -- and with the records of all union bricks ALL-GATHERED (union order) the map is written:
+ *   merge_begin -> all-reduce(MAX) -> merge_union -> merge_pack -> reduce-scatter(SUM) x2 -> merge_finalize_slice -> all-gather -> merge_finish_records.
+ * 5.1 bytes per union voxel travel in the second half instead of the 20 an all-reduce sends round again.  tsl_tsdf_allreduce_merge takes this form with
+ * option "merge_exchange" = 1 on the global map (ncclReduceScatter / ncclAllGather). */
+int   tsl_tsdf_merge_record_bytes(int64_t* n);
+int   tsl_tsdf_merge_finalize_slice(tsl_tsdf* global, const void* acc_dev, const void* cnt_dev, int32_t nbricks, void* rec_dev);
+int   tsl_tsdf_merge_finish_records(tsl_tsdf* global, const void* rec_dev);
 
 /* ---- marching cubes  (marching_cube_mesher.py:127-193) ------------------------------------------- */
 /* generate_mesh(step): result stays on the device in the map's mesh buffers (3*max_tri rows each);

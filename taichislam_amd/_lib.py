@@ -113,6 +113,9 @@ SIGNATURES = {
     "tsl_tsdf_merge_union": (C.c_int, [vp, vp, pi32]),
     "tsl_tsdf_merge_pack": (C.c_int, [vp, vp, vp]),
     "tsl_tsdf_merge_finish": (C.c_int, [vp, vp, vp]),
+    "tsl_tsdf_merge_record_bytes": (C.c_int, [pi64]),
+    "tsl_tsdf_merge_finalize_slice": (C.c_int, [vp, vp, vp, i32, vp]),
+    "tsl_tsdf_merge_finish_records": (C.c_int, [vp, vp]),
     "tsl_mesh_generate": (C.c_int, [vp, C.c_int, f32, i64, pi32]),
     "tsl_mesh_read": (C.c_int, [vp, vp, vp, vp, i64]),
     "tsl_mesh_buffers_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), pi32]),

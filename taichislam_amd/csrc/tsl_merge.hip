@@ -86,6 +86,51 @@ __global__ void __launch_bounds__(256) k_merge_finish(MapDev G, const int* list,
     }
 }
 
+// ---- the second form of the exchange (round 6): REDUCE-SCATTER the packed sums, every rank finalises the slice of union bricks it
+// received, ALL-GATHER the finalised voxels.  A finalised voxel is its f16 {TSDF, W} word, its occupancy byte and one "written" bit: 5.125 bytes instead of the
+// 20 bytes of sums an all-reduce sends round the ring a second time.  A brick's record: 4096 x u32 | 4096 x i8 | 4096 bits.
+#define MRG_REC_BYTES (TSL_BRK3 * 4 + TSL_BRK3 + TSL_BRK3 / 8)
+__global__ void __launch_bounds__(256) k_merge_final_slice(const ulonglong2* __restrict__ pacc, const int* __restrict__ pcnt, int nbricks, uint8_t* __restrict__ rec)
+{
+    for (int u = blockIdx.x; u < nbricks; u += gridDim.x) {
+        uint8_t* const r = rec + (size_t)u * MRG_REC_BYTES;
+        uint32_t* const tw = reinterpret_cast<uint32_t*>(r);
+        int8_t* const oc = reinterpret_cast<int8_t*>(r + TSL_BRK3 * 4);
+        unsigned long long* const bits = reinterpret_cast<unsigned long long*>(r + TSL_BRK3 * 5);
+        for (int l = threadIdx.x; l < TSL_BRK3; l += 256) {
+            const size_t o = (size_t)u * TSL_BRK3 + l;
+            const int c = pcnt[o];
+            uint32_t w = 0u; int8_t occ = 0;
+            if (c != 0) {                                              // fuse_write_voxel (tsl_common.hpp), into the record instead of the map
+                const float num = from_fix((long long)pacc[o].x), den = from_fix((long long)pacc[o].y);
+                w = (uint32_t)f2h(num / den) | ((uint32_t)f2h(den) << 16);
+                occ = (int8_t)(int)(int16_t)(c & 0xffff);
+            }
+            tw[l] = w; oc[l] = occ;
+            const unsigned long long m = __ballot(c != 0);
+            if (lane_id() == 0) bits[l >> 6] = m;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_merge_finish_rec(MapDev G, const int* list, int nunion, const uint8_t* __restrict__ rec)
+{
+    __shared__ int s_p;
+    for (int u = blockIdx.x; u < nunion; u += gridDim.x) {
+        if (threadIdx.x == 0) s_p = pool_claim<false>(G, 0, list[u]);
+        __syncthreads();
+        const int p = s_p;
+        if (p >= 0) {
+            const uint8_t* const r = rec + (size_t)u * MRG_REC_BYTES;
+            const uint32_t* const tw = reinterpret_cast<const uint32_t*>(r);
+            const int8_t* const oc = reinterpret_cast<const int8_t*>(r + TSL_BRK3 * 4);
+            const unsigned long long* const bits = reinterpret_cast<const unsigned long long*>(r + TSL_BRK3 * 5);
+            for (int l = threadIdx.x; l < TSL_BRK3; l += 256)
+                if ((bits[l >> 6] >> (l & 63)) & 1ull) { const size_t v = (size_t)p * TSL_BRK3 + l; G.tw[v] = tw[l]; G.obs[v] = 1; G.occ[v] = oc[l]; }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- RCCL, bound at run time ---------------------------------------------------------------------------------------------------------
 struct Rccl {
     void* h = nullptr;
@@ -93,6 +138,10 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static Rccl g_rccl;
@@ -111,7 +160,11 @@ static int rccl_load()
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) { set_error("RCCL: missing symbols"); return TSL_ERR_HIP; }
+    r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(h, "ncclReduceScatter");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(h, "ncclCommUserRank");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString || !r.ReduceScatter || !r.AllGather || !r.CommCount || !r.CommUserRank) { set_error("RCCL: missing symbols"); return TSL_ERR_HIP; }
     g_rccl = r;
     return TSL_OK;
 }
@@ -193,6 +246,30 @@ int tsl_tsdf_merge_finish(tsl_tsdf* g, const void* acc_dev, const void* cnt_dev)
     return tsl_tsdf_sync(g);                        // reports an exhausted brick pool of the global map
 }
 
+// the reduce-scatter + all-gather form: a rank finalises the `nbricks` union bricks whose reduced sums it holds (any slice of the packed planes) into records of
+// tsl_tsdf_merge_record_bytes each, and -- with all records gathered, union order -- writes the global map from them
+int tsl_tsdf_merge_record_bytes(int64_t* n) { TSL_REQUIRE(n, "null"); *n = MRG_REC_BYTES; return TSL_OK; }
+int tsl_tsdf_merge_finalize_slice(tsl_tsdf* g, const void* acc_dev, const void* cnt_dev, int32_t nbricks, void* rec_dev)
+{
+    TSL_REQUIRE(g && nbricks >= 0 && (nbricks == 0 || (acc_dev && cnt_dev && rec_dev)), "merge_finalize_slice: bad argument");
+    TSL_HIP(hipSetDevice(g->device));
+    if (nbricks > 0) hipLaunchKernelGGL(k_merge_final_slice, dim3(nbricks < 4096 ? nbricks : 4096), dim3(256), 0, ms(g), (const ulonglong2*)acc_dev, (const int*)cnt_dev, (int)nbricks, (uint8_t*)rec_dev);
+    TSL_HIP(hipGetLastError());
+    TSL_HIP(hipStreamSynchronize(ms(g)));
+    return TSL_OK;
+}
+int tsl_tsdf_merge_finish_records(tsl_tsdf* g, const void* rec_dev)
+{
+    TSL_REQUIRE(g && g->mrg_nunion >= 0, "merge_finish_records: call merge_union / merge_pack first");
+    TSL_REQUIRE(g->mrg_nunion == 0 || rec_dev, "merge_finish_records: null records");
+    TSL_HIP(hipSetDevice(g->device));
+    const int n = g->mrg_nunion;
+    if (n > 0) hipLaunchKernelGGL(k_merge_finish_rec, dim3(n < 4096 ? n : 4096), dim3(256), 0, ms(g), g->M, g->mrg_list, n, (const uint8_t*)rec_dev);
+    TSL_HIP(hipGetLastError());
+    g->mrg_nunion = -1;
+    return tsl_tsdf_sync(g);
+}
+
 // ---- communicator + one-call form ---------------------------------------------------------------------------------------------------------
 int tsl_comm_unique_id(char id[128])
 {
@@ -246,8 +323,18 @@ int tsl_tsdf_allreduce_merge(tsl_tsdf* g, tsl_tsdf* sub, void* rccl_comm, int64_
     int32_t n = 0;
     local = tsl_tsdf_merge_union(g, g->mrg_mask, &n);
     const size_t nv = (size_t)(local ? 0 : n) * TSL_BRK3;
-    if (!local) local = grow(&g->mrg_pacc, &g->mrg_pacc_bytes, nv * 16 + 16);
-    if (!local) local = grow(&g->mrg_pcnt, &g->mrg_pcnt_bytes, nv * 4 + 16);
+    size_t nvpad = nv;                                              // merge_exchange 1: whole bricks per rank, the last slice padded with zero bricks
+    if (!local && g->merge_exchange == 1 && n > 0) {
+        int nranks = 1;
+        if (comm && g_rccl.CommCount(comm, &nranks) != ncclSuccess) nranks = 1;
+        nvpad = (size_t)((n + nranks - 1) / nranks) * nranks * TSL_BRK3;
+    }
+    if (!local) local = grow(&g->mrg_pacc, &g->mrg_pacc_bytes, nvpad * 16 + 16);
+    if (!local) local = grow(&g->mrg_pcnt, &g->mrg_pcnt_bytes, nvpad * 4 + 16);
+    if (!local && nvpad > nv) {
+        (void)hipMemsetAsync((char*)g->mrg_pacc + nv * 16, 0, (nvpad - nv) * 16, st);
+        (void)hipMemsetAsync((char*)g->mrg_pcnt + nv * 4, 0, (nvpad - nv) * 4, st);
+    }
     if (!local) local = tsl_tsdf_merge_pack(g, g->mrg_pacc, g->mrg_pcnt);
     if (local) first_err = tsl_last_error();
     if (comm) {                                     // second status exchange: one word
@@ -260,6 +347,33 @@ int tsl_tsdf_allreduce_merge(tsl_tsdf* g, tsl_tsdf* sub, void* rccl_comm, int64_
         if (hs && !local) { set_error("allreduce_merge: another rank failed while packing; nothing was merged"); g->mrg_nunion = -1; return TSL_ERR_HIP; }
     }
     if (local) { set_error("allreduce_merge: " + first_err); g->mrg_nunion = -1; return local; }
+    if (g->merge_exchange == 1 && n > 0) {
+        // reduce-scatter + all-gather (option "merge_exchange" = 1): the packed planes are padded to nranks equal slices of whole bricks (the pad is zeros:
+        // the buffers were grown for it and cleared above), rank r receives the sums of slice r, finalises it and every rank gathers the records
+        int nranks = 1, me = 0;
+        if (comm) { TSL_NCCL(g_rccl.CommCount(comm, &nranks)); TSL_NCCL(g_rccl.CommUserRank(comm, &me)); }
+        const int nper = (n + nranks - 1) / nranks;
+        const size_t sv = (size_t)nper * TSL_BRK3;                  // voxels of a slice
+        int lrc = grow(&g->mrg_racc, &g->mrg_racc_bytes, sv * 16 + 16);
+        if (!lrc) lrc = grow(&g->mrg_rcnt, &g->mrg_rcnt_bytes, sv * 4 + 16);
+        if (!lrc) lrc = grow(&g->mrg_rec, &g->mrg_rec_bytes, (size_t)nper * nranks * MRG_REC_BYTES + 16);
+        if (lrc) return lrc;                                        // (an allocation failure HERE leaves the peers in the collective: the buffers are small next to the packed planes just grown)
+        if (comm) {
+            TSL_NCCL(g_rccl.ReduceScatter(g->mrg_pacc, g->mrg_racc, sv * 2, ncclInt64, ncclSum, comm, st));
+            TSL_NCCL(g_rccl.ReduceScatter(g->mrg_pcnt, g->mrg_rcnt, sv, ncclInt32, ncclSum, comm, st));
+        } else {
+            TSL_HIP(hipMemcpyAsync(g->mrg_racc, g->mrg_pacc, sv * 16, hipMemcpyDeviceToDevice, st));
+            TSL_HIP(hipMemcpyAsync(g->mrg_rcnt, g->mrg_pcnt, sv * 4, hipMemcpyDeviceToDevice, st));
+        }
+        uint8_t* const mine = (uint8_t*)g->mrg_rec + (size_t)me * nper * MRG_REC_BYTES;
+        hipLaunchKernelGGL(k_merge_final_slice, dim3(nper < 4096 ? nper : 4096), dim3(256), 0, st, (const ulonglong2*)g->mrg_racc, (const int*)g->mrg_rcnt, nper, mine);
+        if (comm) TSL_NCCL(g_rccl.AllGather(mine, g->mrg_rec, (size_t)nper * MRG_REC_BYTES, ncclUint8, comm, st));
+        // what a rank sends in a ring: (N - 1) / N of the scattered planes, then (N - 1) / N of the gathered records
+        if (comm) bytes += (int64_t)((double)(nranks - 1) / nranks * ((double)nper * nranks * TSL_BRK3 * 20 + (double)nper * nranks * MRG_REC_BYTES));
+        if (bytes_per_rank) *bytes_per_rank = bytes;
+        TSL_HIP(hipGetLastError());
+        return tsl_tsdf_merge_finish_records(g, g->mrg_rec);
+    }
     if (comm && n > 0) {
         TSL_NCCL(g_rccl.AllReduce(g->mrg_pacc, g->mrg_pacc, nv * 2, ncclInt64, ncclSum, comm, st));
         TSL_NCCL(g_rccl.AllReduce(g->mrg_pcnt, g->mrg_pcnt, nv, ncclInt32, ncclSum, comm, st));

@@ -1027,7 +1027,7 @@ static int init_handle(tsl_tsdf* m, const tsl_tsdf_cfg* cfg, int device)
     m->sort_temp = nullptr; m->sort_temp_bytes = 0;
     m->xbuf = nullptr; m->xbuf_bytes = 0; m->mesh_v = m->mesh_n = m->mesh_c = nullptr; m->mesh_count = nullptr; m->mesh_cap = 0; m->mesh_flags = nullptr;
     m->fuse_acc = nullptr; m->fuse_cnt = nullptr; m->fuse_cacc = nullptr; m->fuse_dirty = false; m->mrg_nunion = -1;
-    m->esdf = nullptr; m->esdf_par = nullptr; m->esdf_ok = nullptr; m->esdf_mode = 0; m->esdf_grid = 0; m->fuse_direct = false; m->esdf_orphans = 0; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_gate_mask = 0; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
+    m->esdf = nullptr; m->esdf_par = nullptr; m->esdf_ok = nullptr; m->esdf_mode = 0; m->esdf_grid = 0; m->fuse_direct = false; m->merge_exchange = 0; m->mrg_racc = m->mrg_rcnt = m->mrg_rec = nullptr; m->mrg_racc_bytes = m->mrg_rcnt_bytes = m->mrg_rec_bytes = 0; m->esdf_orphans = 0; m->esdf_last = nullptr; m->esdf_in = nullptr; m->esdf_read = nullptr; m->esdf_overlap = true; m->esdf_ctr_idx = 0; for (int k = 0; k < 2; ++k) { m->fseq_keys[k] = m->fseq_vals[k] = nullptr; m->fseq_bytes[k] = m->fseq_vbytes[k] = 0; } m->fseq_temp = nullptr; m->fseq_tbytes = 0; m->fseq_ctr = nullptr; m->esdf_gate = nullptr; m->esdf_gate_ev = nullptr; m->esdf_gate_set = false; m->esdf_gate_mask = 0; m->esdf_valid = false; m->esdf_force_full = false; m->pose_dev = nullptr;
 
     // ---- map storage ----
     MapDev& M = m->M; std::memset(&M, 0, sizeof(M));
@@ -1149,7 +1149,7 @@ void tsl_tsdf_destroy(tsl_tsdf* m)
     void* ptrs[] = { m->M.table, m->M.tw, m->M.obs, m->M.occ, m->M.col, m->M.owner, m->M.pool_top, m->F.slot_tab, m->F.touched, m->F.touched_b, m->F.acc, m->F.accw, m->F.dbg,
                      m->exp_xyz, m->exp_rgb, m->exp_val, m->num_particles, m->colormap, m->pose_dev, m->xbuf,
                      m->mesh_v, m->mesh_n, m->mesh_c, m->mesh_count, m->mesh_flags, m->esdf, m->esdf_fl, m->esdf_region, m->esdf_list, m->esdf_queue, m->esdf_ctr, m->esdf_inq, m->esdf_nbr, m->esdf_par, m->esdf_ok, m->esdf_note, m->fseq_keys[0], m->fseq_keys[1], m->fseq_vals[0], m->fseq_vals[1], m->fseq_temp, m->fseq_ctr, m->esdf_exp_xyz, m->esdf_exp_val, m->esdf_exp_count, m->M.touch, m->fuse_acc, m->fuse_cnt, m->fuse_cacc, m->seq_keys[0], m->seq_keys[1], m->seq_vals[0], m->seq_vals[1], m->seq_ctr, m->seq_temp,
-                     m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt };
+                     m->mrg_mask, m->mrg_list, m->mrg_pacc, m->mrg_pcnt, m->mrg_racc, m->mrg_rcnt, m->mrg_rec };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->h_stats) (void)hipHostFree(m->h_stats);
     if (m->h_ints) (void)hipHostFree(m->h_ints);
@@ -1681,6 +1681,7 @@ int tsl_tsdf_set_option(tsl_tsdf* m, const char* name, int value)
     if (!std::strcmp(name, "esdf_full")) { m->esdf_force_full = value != 0; return TSL_OK; }
     if (!std::strcmp(name, "esdf_mode")) { TSL_REQUIRE(value == 0 || value == 1, "esdf_mode: 0 = regional recompute (default), 1 = raise / lower wavefront with parent directions"); int rc = esdf_finish(m); if (rc) return rc; m->esdf_mode = value; m->esdf_valid = false; return TSL_OK; }
     if (!std::strcmp(name, "esdf_round_cap")) { m->esdf_round_cap = value; return TSL_OK; }
+    if (!std::strcmp(name, "merge_exchange")) { TSL_REQUIRE(value == 0 || value == 1, "merge_exchange: 0 = all-reduce of the packed sums, 1 = reduce-scatter + all-gather of finalised voxels"); m->merge_exchange = value; return TSL_OK; }
     if (!std::strcmp(name, "fuse_direct")) { m->fuse_direct = value != 0; return TSL_OK; }      // 1 = round 5's splat (global atomics per corner) on the global map, for A/B
     if (!std::strcmp(name, "esdf_grid")) { TSL_REQUIRE(value >= 0, "esdf_grid: workgroups of a relaxation round (0 = four per CU)"); m->esdf_grid = value; return TSL_OK; }
     if (!std::strcmp(name, "esdf_overlap")) { int rc = esdf_finish(m); if (rc) return rc; m->esdf_overlap = value != 0; return TSL_OK; }

@@ -261,6 +261,7 @@ struct tsl_tsdf {
     void *fuse_acc, *fuse_cnt, *fuse_cacc; bool fuse_dirty;      // global-map fusion scratch ({num,den} int64 pairs, count|occupancy, colour sums); dirty: a splat was not followed by its finalise / pack
     uint8_t* mrg_mask; int *mrg_list, *mrg_count; int mrg_nunion;      // multi-GPU merge: touched-brick mask, union list (tsl_merge.hip)
     void *mrg_pacc, *mrg_pcnt; size_t mrg_pacc_bytes, mrg_pcnt_bytes;  // packed union bricks of the one-call form
+    void *mrg_racc, *mrg_rcnt, *mrg_rec; size_t mrg_racc_bytes, mrg_rcnt_bytes, mrg_rec_bytes; int merge_exchange;      // option "merge_exchange" 1: this rank's reduced slice, the gathered records
     // esdf
     float* esdf; uint8_t *esdf_fl, *esdf_region, *esdf_par, *esdf_ok; int esdf_mode, esdf_grid; bool fuse_direct; long long esdf_orphans; int *esdf_list, *esdf_queue, *esdf_ctr, *esdf_inq, *esdf_nbr; uint32_t* esdf_note; int esdf_qcap;      // tsl_esdf.hip
     float *esdf_exp_xyz, *esdf_exp_val; int* esdf_exp_count; int esdf_exp_n;      // export_ESDF_xyz / export_ESDF / num_export_ESDF_particles (dense_esdf.py:498-509), allocated by the first slice

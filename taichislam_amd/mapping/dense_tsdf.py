@@ -372,6 +372,24 @@ class DenseTSDF(BaseMap):
         """Step 3 (after the SUM all-reduce of both): write the global map."""
         self._call("merge_finish", C.c_void_p(acc.data_ptr()) if len(acc) else None, C.c_void_p(cnt.data_ptr()) if len(cnt) else None)
 
+    MERGE_RECORD_BYTES = 4096 * 4 + 4096 + 4096 // 8          # tsl_tsdf_merge_record_bytes
+
+    def merge_finalize_slice(self, acc, cnt):
+        """Reduce-scatter form, step 3: the union bricks whose reduced sums this rank holds (int64 [k,4096,2], int32 [k,4096]) as finalised records, uint8 [k, 20992]."""
+        import torch
+        k = int(acc.shape[0])
+        rec = torch.empty((k, self.MERGE_RECORD_BYTES), dtype=torch.uint8, device=acc.device)
+        torch.cuda.current_stream(acc.device).synchronize()
+        _lib.check(self.L.tsl_tsdf_merge_finalize_slice(self.h, C.c_void_p(acc.data_ptr()) if k else None, C.c_void_p(cnt.data_ptr()) if k else None, k,
+                                                        C.c_void_p(rec.data_ptr()) if k else None))
+        return rec
+
+    def merge_finish_records(self, rec):
+        """Reduce-scatter form, step 4 (after the all-gather): write the global map from the records of all union bricks (those behind the union are padding)."""
+        import torch
+        torch.cuda.current_stream(rec.device).synchronize()
+        _lib.check(self.L.tsl_tsdf_merge_finish_records(self.h, C.c_void_p(rec.data_ptr()) if len(rec) else None))
+
     # ---- visualisation exports (dense_tsdf.py:320-404) --------------------------------------------------------------
     def cvt_occupy_to_voxels(self):
         self.cvt_TSDF_surface_to_voxels()

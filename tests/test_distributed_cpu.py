@@ -72,6 +72,36 @@ class _OracleGlobal:
         self._bricks(Cn)[bi, :, bj, :, bk] = cnt.reshape(len(bi), 16, 16, 16)
         self.o.fuse_finalize(A, Cn)
 
+    # the reduce-scatter + all-gather form (tsl_tsdf_merge_finalize_slice / _finish_records): a brick's record is 4096 u32 {f16 TSDF | f16 W << 16},
+    # 4096 occupancy bytes, 4096 "written" bits
+    def merge_finalize_slice(self, acc, cnt):
+        k = len(acc)
+        rec = np.zeros((k, 4096 * 4 + 4096 + 512), np.uint8)
+        with np.errstate(all="ignore"):
+            num = (acc[..., 0].astype(np.float64) * 2.0 ** -24).astype(np.float32)
+            den = (acc[..., 1].astype(np.float64) * 2.0 ** -24).astype(np.float32)
+            t = (num / den).astype(np.float16).view(np.uint16).astype(np.uint32)
+            w = den.astype(np.float16).view(np.uint16).astype(np.uint32)
+        on = cnt != 0
+        tw = np.where(on, t | (w << 16), 0).astype(np.uint32)
+        occ = np.where(on, (cnt & 0xffff).astype(np.uint16).view(np.int16).astype(np.int8), 0).astype(np.int8)
+        rec[:, :4096 * 4] = tw.view(np.uint8).reshape(k, -1)
+        rec[:, 4096 * 4:4096 * 5] = occ.view(np.uint8)
+        rec[:, 4096 * 5:] = np.packbits(on, axis=1, bitorder="little")
+        return rec
+
+    def merge_finish_records(self, rec):
+        bi, bj, bk = self.union
+        n = len(bi)
+        rec = np.asarray(rec)[:n]
+        tw = np.ascontiguousarray(rec[:, :4096 * 4]).view(np.uint32).reshape(n, 4096)
+        occ = np.ascontiguousarray(rec[:, 4096 * 4:4096 * 5]).view(np.int8).reshape(n, 4096)
+        on = np.unpackbits(np.ascontiguousarray(rec[:, 4096 * 5:]), axis=1, bitorder="little").astype(bool)
+        u, l = np.nonzero(on)
+        idx = np.stack([bi[u] * 16 + (l >> 8) - self.N // 2, bj[u] * 16 + ((l >> 4) & 15) - self.N // 2, bk[u] * 16 + (l & 15) - self.Nz // 2], 1).astype(np.int16)
+        v = tw[u, l]
+        self.o.import_sparse(0, idx, (v & 0xffff).astype(np.uint16).view(np.float16), (v >> 16).astype(np.uint16).view(np.float16), occ[u, l])
+
     def export_sparse(self):
         return self.o.export_sparse()
 
@@ -130,7 +160,7 @@ def test_a_failing_rank_does_not_hang_the_others(tmp_path, fail_in):
     assert "another rank failed" in m0 and "this rank failed" in m1, (m0, m1)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, exchange="allreduce"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -140,7 +170,7 @@ def _worker(rank, world, port, out):
     sub, _ = _build_submap(rank)
     bases = [syn.camera_pose(0, start_deg=D.stream_start_deg(r)) for r in range(world)]
     g = _global(bases)
-    nbytes = D.allreduce_merge(g, sub)                       # brick-sparse exchange over gloo
+    nbytes = D.allreduce_merge(g, sub, exchange=exchange)     # brick-sparse exchange over gloo
     e = g.export_sparse()
     np.savez(os.path.join(out, f"rank{rank}.npz"), idx=e["indices"], t=e["TSDF"].view(np.uint16), w=e["W_TSDF"].view(np.uint16), occ=e["occupy"],
              nbytes=nbytes)
@@ -148,12 +178,15 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_merge_equals_single_process(tmp_path):
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+def test_two_rank_merge_equals_single_process(tmp_path, exchange):
+    """Both forms of the exchange (all-reduce of the packed sums; reduce-scatter, finalise the slice, all-gather of the finalised voxels) over a 2-rank gloo
+    group: both ranks end with the map ONE process gets from fusing both submaps."""
     from oracle import BATCHED, OracleTSDF
     from taichislam_amd import distributed as D
     from taichislam_amd.utils import synthetic as syn
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), exchange), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in ("idx", "t", "w", "occ"):
         assert np.array_equal(r0[k], r1[k]), f"ranks disagree on {k}"

@@ -89,6 +89,14 @@ def test_one_rank_merge_equals_fuse_submaps(hip_lib):
     _assert_same(sort_export(g2.export_submap()), ref, "steps, one rank")
     g2.allreduce_merge(sub, None)                                   # merging again rebuilds the same map (accumulators were left at zero)
     _assert_same(sort_export(g2.export_submap()), ref, "second merge")
+    # the reduce-scatter + all-gather form of the exchange: one rank finalises every union brick into records and writes the map from them
+    g3 = _global(1)
+    g3.set_option("merge_exchange", 1)
+    assert g3.allreduce_merge(sub, None) == 0
+    _assert_same(sort_export(g3.export_submap()), ref, "native, one rank, records")
+    g4 = _global(1)
+    assert D.allreduce_merge(g4, sub, exchange="scatter_gather") == 0
+    _assert_same(sort_export(g4.export_submap()), ref, "steps, one rank, records")
 
 
 def test_two_ranks_simulated_in_one_process(hip_lib):
@@ -104,9 +112,16 @@ def test_two_ranks_simulated_in_one_process(hip_lib):
     assert packs[0][0].shape == packs[1][0].shape and packs[0][0].shape[0] == int(m.sum())
     acc, cnt = packs[0][0] + packs[1][0], packs[0][1] + packs[1][1]
     torch.cuda.synchronize()
-    for g in gs:
-        g.merge_finish(acc, cnt)
-        _assert_same(sort_export(g.export_submap()), ref, "two simulated ranks")
+    # second form: rank r gets the reduced sums of ITS half of the (padded) union, finalises it, the records are gathered
+    n = acc.shape[0]; nper = (n + 1) // 2
+    pa = torch.cat([acc, torch.zeros((2 * nper - n, 4096, 2), dtype=acc.dtype, device=acc.device)])
+    pc = torch.cat([cnt, torch.zeros((2 * nper - n, 4096), dtype=cnt.dtype, device=cnt.device)])
+    recs = torch.cat([gs[r].merge_finalize_slice(pa[r * nper:(r + 1) * nper].contiguous(), pc[r * nper:(r + 1) * nper].contiguous()) for r in range(2)])
+    assert recs.shape == (2 * nper, 4096 * 4 + 4096 + 512)
+    gs[1].merge_finish_records(recs)
+    _assert_same(sort_export(gs[1].export_submap()), ref, "two simulated ranks, reduce-scatter + all-gather")
+    gs[0].merge_finish(acc, cnt)
+    _assert_same(sort_export(gs[0].export_submap()), ref, "two simulated ranks")
 
 
 def test_native_rccl_communicator_world_1(hip_lib):
@@ -118,10 +133,13 @@ def test_native_rccl_communicator_world_1(hip_lib):
     nbytes = D.allreduce_merge(g, sub, comm=comm)
     assert nbytes > 32 * 32 * 32 // 64 and nbytes % 20 in (0, ((g.N // 16) ** 2 * (g.Nz // 16) + 1) % 20)      # brick mask + status byte, 20 bytes per union voxel
     _assert_same(sort_export(g.export_submap()), ref, "RCCL world 1")
+    g2 = _global(1)
+    D.allreduce_merge(g2, sub, comm=comm, exchange="scatter_gather")      # ncclReduceScatter / ncclAllGather on the one-rank communicator
+    _assert_same(sort_export(g2.export_submap()), ref, "RCCL world 1, reduce-scatter + all-gather")
     comm.close()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, exchange="allreduce"):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
@@ -129,18 +147,19 @@ def _worker(rank, world, port, out):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     sub, g = _rank_submaps(rank), _global(world)
-    nbytes = D.allreduce_merge(g, sub)                              # CUDA tensors through gloo: real HIP handles, real 2-rank reductions
+    nbytes = D.allreduce_merge(g, sub, exchange=exchange)           # CUDA tensors through gloo: real HIP handles, real 2-rank reductions
     e = sort_export(g.export_submap())
     np.savez(os.path.join(out, f"rank{rank}.npz"), indices=e["indices"], TSDF=e["TSDF"], W_TSDF=e["W_TSDF"], occupy=e["occupy"], nbytes=nbytes)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_processes_on_one_gpu_over_gloo(hip_lib, tmp_path):
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+def test_two_processes_on_one_gpu_over_gloo(hip_lib, tmp_path, exchange):
     import torch.multiprocessing as mp
     ref = _single_process_reference(2)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), exchange), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     _assert_same(dict(r0), ref, "rank 0 vs single process")
     _assert_same(dict(r1), ref, "rank 1 vs single process")
@@ -207,6 +226,24 @@ def test_config5_eight_submaps_at_512_cubed_against_the_oracle(hip_lib):
     nbytes = union.numel() + 1 + n_union * 4096 * 20       # what tsl_tsdf_allreduce_merge / distributed.allreduce_merge put through the all-reduces per rank
     print(f"config 5: union {n_union} bricks, {nbytes / 1e6:.0f} MB all-reduced per rank, {want['indices'].shape[0]} global voxels")
     assert 150e6 < nbytes < 350e6, nbytes                  # ~2 700 bricks x 4096 voxels x 20 B = ~220 MB
+    # the second form of the exchange: reduce-scatter of the same planes, rank r finalises its eighth of the union bricks, all-gather of
+    # the records -- emulated like the sums above -- and what a rank then puts on its links
+    nper = (n_union + world - 1) // world
+    pa = torch.cat([acc, torch.zeros((nper * world - n_union, 4096, 2), dtype=acc.dtype, device=acc.device)])
+    pc = torch.cat([cnt, torch.zeros((nper * world - n_union, 4096), dtype=cnt.dtype, device=cnt.device)])
+    recs = torch.cat([globs[r].merge_finalize_slice(pa[r * nper:(r + 1) * nper].contiguous(), pc[r * nper:(r + 1) * nper].contiguous()) for r in range(world)])
+    del pa, pc
+    ring_allreduce = 2 * (world - 1) / world * n_union * 4096 * 20
+    ring_scatter_gather = (world - 1) / world * (nper * world * 4096 * 20 + recs.numel())
+    print(f"config 5: a rank sends {ring_allreduce / 1e6:.0f} MB round a ring with the all-reduce, {ring_scatter_gather / 1e6:.0f} MB with reduce-scatter + all-gather")
+    assert ring_scatter_gather < 0.65 * ring_allreduce and ring_scatter_gather / 2 < 140e6      # (VERDICT r5's mark, in its units: half the ring traffic <= 140 MB)
+    for r in (2, 7):
+        globs[r].merge_finish_records(recs)
+        got = sort_export(globs[r].export_submap())
+        assert got["indices"].shape == want["indices"].shape and np.array_equal(got["indices"], want["indices"]), f"rank {r} (records): voxel sets differ"
+        ok = ~np.isnan(want["TSDF"].view(np.float16))
+        assert np.array_equal(got["TSDF"][ok], want["TSDF"][ok]) and np.array_equal(got["W_TSDF"], want["W_TSDF"]) and np.array_equal(got["occupy"], want["occupy"]), f"rank {r} (records)"
+    del recs
     for r in (0, 5):                                       # every rank ends with the same map (tested for all ranks at small size above): two of them here
         globs[r].merge_finish(acc, cnt)
         got = sort_export(globs[r].export_submap())
