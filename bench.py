@@ -50,7 +50,7 @@ def cpu_baselines(frames, budget_s=10.0):
     one = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"first {n} frames of the same 640x480 stream into the same 512^3/2cm map, {dt:.1f} s, 1 thread, oracle FAITHFUL mode "
                      f"(sequential f16 replay of dense_tsdf.py:188-270; Taichi itself unavailable)"}
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)      # (bench.py binds itself to one NUMA node)
     p = OracleTSDF(**C2)
     p.set_intrinsics(syn.K_DEPTH)
     p.integrate_depth_mt(*frames[0], ncpu)                 # first touch of the thread pool and the bricks
@@ -73,9 +73,7 @@ def cpu_baselines(frames, budget_s=10.0):
     dt2 = time.perf_counter() - t0
     allc = {"value": m / max(dt2, 1e-9), "unit": "frames/s", "cores": cores, "kind": "port", "host_threads": ncpu,
             "frames_per_s_by_threads": {str(k): v for k, v in trial.items()},
-            "sample": f"{m} frames of the same stream, {dt2:.1f} s, {cores} of {ncpu} OpenMP threads (best of the sweep): BATCHED sums, rays cut into "
-                      f"per-brick segments and bricks integrated in parallel like the GPU path (ray-parallel atomics scale negatively); "
-                      f"bit-identical to the one-thread BATCHED map"}
+            "sample": f"{m} frames of the same stream, {dt2:.1f} s, {cores} of {ncpu} OpenMP threads (best of the sweep): brick-binned BATCHED sums, bit-identical to the one-thread BATCHED map"}
     return one, allc, o, n
 
 
@@ -292,7 +290,7 @@ def reference_source_leg(dev):
         voxels += int(want["indices"].shape[0])
     return {"vectors": names, "voxels": voxels, "oracle_FAITHFUL_bit_exact": all(ora_ok.values()), "hip_semantics_1_bit_exact": all(hip_ok.values()),
             "per_vector": {n: {"oracle_FAITHFUL": ora_ok[n], "hip_semantics_1": hip_ok[n]} for n in names}, "differences": detail or None,
-            "note": "golden maps made by the reference's dense_tsdf.py + mapping_common.py, imported unmodified and run on tools/ti_seq (not by Taichi itself)"}
+            "note": "golden maps made by the reference's own source on tools/ti_seq (not by Taichi itself)"}
 
 
 def first_difference(got, want, keys, sensor_xyz=None, voxel_scale=None):
@@ -328,6 +326,37 @@ def stored_counters():
         return tj, None
     except Exception as e:
         return None, repr(e)[:200]
+
+
+def bind_to_gpu_numa_node():
+    """Bind this process to the CPUs of the NUMA node its pinned host allocations land on (the driver prefers one node per GPU): the host side of the
+    host-input legs -- a strided copy out of the caller's image -- runs at local- or remote-memory speed depending on where the scheduler happens to have put
+    the thread, 1.7x apart on the two-socket box (profiles/r06_pinned_probe.txt).  Returns what was done, for the line."""
+    try:
+        import re
+        import torch
+        t = torch.empty(1 << 20, dtype=torch.uint8).pin_memory()
+        t.fill_(1)
+        addr, best = t.data_ptr(), None
+        for ln in open("/proc/self/numa_maps"):
+            a = int(ln.split()[0], 16)
+            if a <= addr and (best is None or a > best[0]):
+                best = (a, ln)
+        nodes = re.findall(r"N(\d+)=(\d+)", best[1]) if best else []
+        if not nodes:
+            return {"bound": False, "why": "no node in numa_maps"}
+        node = max(nodes, key=lambda x: int(x[1]))[0]
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"bound": False, "why": "no allowed cpu on that node"}
+        os.sched_setaffinity(0, cpus)
+        return {"bound": True, "node": int(node), "cpus": len(cpus)}
+    except Exception as e:
+        return {"bound": False, "why": repr(e)[:120]}
 
 
 def relaunch(args):
@@ -386,6 +415,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if distributed else 0
     torch.cuda.set_device(dev)
+    host_numa = bind_to_gpu_numa_node()            # before any data is made: images, poses and the library's staging buffers are first touched from that node
     if args.config != 2:
         if distributed:
             raise SystemExit("--config 1/3/4 are single-GPU measurements")
@@ -509,8 +539,7 @@ def main():
             m.sync()
             host_rates[label] = nh / (time.perf_counter() - th)
             gc.enable()
-        host_rates["note"] = (f"{nh} calls over {nsrc} images, 614 kB uint16 numpy image per call through tsl_tsdf_integrate_depth (the reference API's form, taichislam_node.py:381-382): "
-                              "the host copies the visited rows into a pinned, device-mapped buffer of the frame's working set and phase A reads them in place (no copy call, no stream synchronisation per call); rank 0 only")
+        host_rates["note"] = f"{nh} calls over {nsrc} images: a 614 kB uint16 numpy image per call through tsl_tsdf_integrate_depth (taichislam_node.py:381-382), rank 0 only"
 
     # ---- steady state, driver-visible: >= 300 frames behind the contract region, same map, same clock (the contract's K may be a 20-frame
     #      burst, which is dominated by filling and draining the batch pipeline) ----
@@ -646,6 +675,7 @@ def main():
                            "note": "each: W warm-up steps done once, then EXACTLY K steps, barrier + sync on both sides; [0] is the first region behind the warm-up"},
             "value_steady": steady,
             "value_host_input": host_rates,
+            "host_numa": host_numa,
         }
         if dry:
             out["dry_run"] = {"as_rank": rank, "of": world, "note": "single-process dry run of the multi-rank branch: this rank's stream offset, submap id and pose table, "
