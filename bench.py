@@ -311,18 +311,18 @@ def first_difference(got, want, keys, sensor_xyz=None, voxel_scale=None):
 
 
 def stored_counters():
-    """profiles/r05_traffic.json -- PMC counters of separate rocprofv3 passes over the driver's command (tools/gpu_profiles_r05.sh) -- or None when
+    """profiles/r06_traffic.json -- PMC counters of separate rocprofv3 passes over the driver's command (tools/gpu_profiles_r05.sh) -- or None when
     the file was collected on OTHER kernels: it carries the hash of the kernel sources it was measured on (taichislam_amd.build.source_hash), and
     a line never replays counters of kernels that have changed since."""
-    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r06_traffic.json")
     if not os.path.exists(path):
-        return None, "profiles/r05_traffic.json is missing"
+        return None, "profiles/r06_traffic.json is missing"
     try:
         tj = json.load(open(path))
         from taichislam_amd import build
         have = build.source_hash()
         if tj.get("lib_source_hash") != have:
-            return None, f"profiles/r05_traffic.json was collected on kernel sources {tj.get('lib_source_hash')}, these are {have}: counters not replayed"
+            return None, f"profiles/r06_traffic.json was collected on kernel sources {tj.get('lib_source_hash')}, these are {have}: counters not replayed"
         return tj, None
     except Exception as e:
         return None, repr(e)[:200]
@@ -430,7 +430,7 @@ def main():
             try:
                 tj = tall.get(f"config{args.config}")
                 if tj:
-                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"] / tj.get("frames_per_launch", 1.0)      # (config 3: eight queued frames per launch, the line's unit is a frame)
                     line["roofline"]["traffic_source"] = tj.get("command")
             except Exception:
                 pass

@@ -316,6 +316,11 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
                  1 = raise / lower wavefront with a parent direction per voxel (dense_esdf.py:96, :255-333): only the voxels whose parent chain passes
                  through a changed voxel are re-derived, then lowered -- a third of the voxel writes, the same map bit for bit, ~1.45x the time on the
                  benchmark stream (tsl_esdf.hip has the measurements); read-only "esdf_orphans" = lowered voxels without a supporting neighbour (always 0)
+     "esdf_grid" n > 0 = workgroups of a relaxation round (default 0 = four per CU; developer A/B)
+     "merge_exchange" (on the GLOBAL map) 0 (default) = tsl_tsdf_allreduce_merge all-reduces the packed sums of the union bricks; 1 = reduce-scatter of the
+                 sums, every rank finalises its slice, all-gather of the finalised 5.1-byte voxels (the step form: tsl_tsdf_merge_finalize_slice / _finish_records)
+     "fuse_direct" (on the GLOBAL map) 1 = the fusion splat of round 5, one set of global atomics per corner (A/B); 0 (default) = sums gathered per 8^3 source
+                 block in a 15^3 LDS window first.  Textured maps always take the direct form
      "esdf_overlap" 1 (default) = an update's kernels run on one of the handle's phase-A streams: the relaxation rounds of update n overlap
                     the integration of frame n + 1 (which waits only until the update has read the TSDF); 0 = on the handle's stream
      "esdf_round_cap" n > 0 = launch at most n relaxation rounds per update (test knob: an update that stops early must be repaired)
