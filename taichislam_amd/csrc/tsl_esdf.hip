@@ -491,11 +491,17 @@ __global__ void __launch_bounds__(384, ESDF_WPE) k_esdf_round(MapDev M, EsdfDev 
 #endif
         ESDF_TICK(2);
         // ---- write back the voxels that were lowered ----
-        {
-            float* gm = E.mag + (size_t)p * TSL_BRK3;
-            for (int l = threadIdx.x; l < TSL_BRK3; l += 384) {
-                if (!((s_chg[l >> 5] >> (l & 31)) & 1u)) continue;
-                gm[l] = __uint_as_float(s_t[((l >> 8) + 1) * ES_SX + (((l >> 4) & 15) + 1) * ES_SY + (l & 15) + 1]);
+        if (threadIdx.x < 256) {      // a thread per interior row: the row goes back whole (four 16-byte stores) when any of its voxels was lowered (round 6: a
+                                      // store per lowered voxel, eleven bit tests per thread, took 4.3 us of a visit; this takes 1.2)
+            const int row = (int)threadIdx.x;
+            if ((s_chg[row >> 1] >> ((row & 1) * 16)) & 0xffffu) {
+                const int t0 = ((row >> 4) + 1) * ES_SX + ((row & 15) + 1) * ES_SY + 1;
+                uint32_t wv[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z) wv[z] = s_t[t0 + z];
+                uint4* gm = reinterpret_cast<uint4*>(E.mag + (size_t)p * TSL_BRK3 + (size_t)row * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gm[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
             }
         }
         // ---- which neighbours to tell: a neighbour is listed for the next round iff one of its voxels in this tile's halo could be lowered
