@@ -428,7 +428,8 @@ def main():
             line["roofline"]["traffic_source"] = why
         if tall is not None and line.get("roofline"):
             try:
-                tj = tall.get(f"config{args.config}")
+                wave = args.config == 4 and "esdf_mode=1" in os.environ.get("TSL_C4_OPTS", "")
+                tj = tall.get(f"config{args.config}" + ("_wavefront" if wave else ""))
                 if tj:
                     line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"] / tj.get("frames_per_launch", 1.0)      # (config 3: eight queued frames per launch, the line's unit is a frame)
                     line["roofline"]["traffic_source"] = tj.get("command")

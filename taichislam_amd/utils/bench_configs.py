@@ -121,6 +121,6 @@ def run(config, steps, warmup, dev, host=None):
                      {"esdf_ms_per_update": ems / max(1, en), "esdf_brick_relaxations_per_update": relax / max(1, steps),
                       "esdf_voxel_pushes_per_update": pushes / max(1, steps), "esdf_region_bricks_per_update": region / max(1, steps),
                       "mesh_ms_per_call": mms / max(1, mn), "mesh_triangles": tri, "observed_voxels": a, "bricks": m.bricks_in_use(), "esdf_max_dist_m": md},
-                     _roof("tsl::k_esdf_round (all launches of one update)", 8 * cells, 1000.0 * ems / max(1, en),
-                           "(4 + 4) B per cell of the re-relaxed region; the update is a chain of dependent rounds (latency-bound), not a stream"))
+                     _roof(("tsl::k_esdf_wave" if m.get_option("esdf_mode") == 1 else "tsl::k_esdf_round") + " (all launches of one update)", 8 * cells, 1000.0 * ems / max(1, en),
+                           "(4 + 4) B per cell of the bricks the update reaches; the update is a chain of dependent rounds (latency-bound), not a stream"))
     raise ValueError(config)
