@@ -319,6 +319,8 @@ int  tsl_esdf_slice_dev(tsl_tsdf* m, void** xyz_dev, void** val_dev, int32_t* n)
      "esdf_grid" n > 0 = workgroups of a relaxation round (default 0 = four per CU; developer A/B)
      "merge_exchange" (on the GLOBAL map) 0 (default) = tsl_tsdf_allreduce_merge all-reduces the packed sums of the union bricks; 1 = reduce-scatter of the
                  sums, every rank finalises its slice, all-gather of the finalised 5.1-byte voxels (the step form: tsl_tsdf_merge_finalize_slice / _finish_records)
+     "fuse_window_misses" (read-only, on the GLOBAL map) corner splats of the LDS-window fusion that fell outside their 15^3 window and went straight to memory
+                 (0 for every pose tested: the window is sized for the worst rotation; a miss costs time, not correctness)
      "fuse_direct" (on the GLOBAL map) 1 = the fusion splat of round 5, one set of global atomics per corner (A/B); 0 (default) = sums gathered per 8^3 source
                  block in a 15^3 LDS window first.  Textured maps always take the direct form
      "esdf_overlap" 1 (default) = an update's kernels run on one of the handle's phase-A streams: the relaxation rounds of update n overlap

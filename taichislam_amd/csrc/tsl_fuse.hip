@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(256) k_fuse_splat_lds(MapDev S, MapDev G, Pose
                     __hip_atomic_fetch_add(&s_den[e], qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                     // :274
                     __hip_atomic_fetch_add(&s_cnt[e], (1 << 16) + occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        // :279-280
                 } else {
+                    atomicAdd(G.pool_top + 2, 1);                      // (counted: option "fuse_window_misses" -- the tests require 0)
                     int gl; const int gb = brick_of(G, ci, cj, ck, &gl);
                     const int gp = pool_claim<false>(G, 0, gb);
                     if (gp < 0) continue;

@@ -1219,6 +1219,7 @@ int tsl_tsdf_get_option(tsl_tsdf* m, const char* name, int* value)
     TSL_REQUIRE(m && name && value, "null");
     if (!std::strcmp(name, "group")) { *value = m->P.group; return TSL_OK; }
     if (!std::strcmp(name, "esdf_mode")) { *value = m->esdf_mode; return TSL_OK; }
+    if (!std::strcmp(name, "fuse_window_misses")) { return read_int(m, m->M.pool_top + 2, value); }      // corner splats of k_fuse_splat_lds that fell outside the 15^3 window since the map was created
     if (!std::strcmp(name, "esdf_orphans")) { int rc = esdf_finish(m); if (rc) return rc; *value = (int)m->esdf_orphans; return TSL_OK; }      // lowered voxels whose supporting neighbour was not found (0, or the wavefront has a hole)
     if (!std::strcmp(name, "semantics")) { *value = m->semantics; return TSL_OK; }
     if (!std::strcmp(name, "seq_impl")) { *value = m->seq_impl; return TSL_OK; }

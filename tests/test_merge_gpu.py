@@ -67,6 +67,7 @@ def _single_process_reference(world):
     both.active_submap_id[None] = world
     g = _global(world)
     g.fuse_submaps(both)
+    assert g.get_option("fuse_window_misses") == 0
     return sort_export(g.export_submap())
 
 
@@ -244,6 +245,7 @@ def test_config5_eight_submaps_at_512_cubed_against_the_oracle(hip_lib):
         ok = ~np.isnan(want["TSDF"].view(np.float16))
         assert np.array_equal(got["TSDF"][ok], want["TSDF"][ok]) and np.array_equal(got["W_TSDF"], want["W_TSDF"]) and np.array_equal(got["occupy"], want["occupy"]), f"rank {r} (records)"
     del recs
+    assert all(g.get_option("fuse_window_misses") == 0 for g in globs)      # eight poses 45 degrees apart: every corner splat landed inside its block's 15^3 LDS window
     for r in (0, 5):                                       # every rank ends with the same map (tested for all ranks at small size above): two of them here
         globs[r].merge_finish(acc, cnt)
         got = sort_export(globs[r].export_submap())
