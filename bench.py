@@ -730,7 +730,7 @@ def main():
                           "value_sequential": {"value": _v(out, "value_sequential", "value"), "value_steady": _v(out, "value_sequential", "value_steady"),
                                                "bit_exact": _v(out, "value_sequential", "bit_exact_with_oracle_FAITHFUL")},
                           "value_host_input": {"pageable": _v(host_rates, "pageable"), "pinned": _v(host_rates, "pinned")},
-                          "c1_meshes_per_s": _v(cf, "c1_marching_cubes_128", "value"), "c3_octomap_frames_per_s": _v(cf, "c3_octomap_1024", "value"),
+                          "c1_meshes_per_s": _v(cf, "c1_marching_cubes_128", "value"), "c3_octomap_frames_per_s": _v(cf, "c3_octomap_1024", "value"), "c3_host_images_frames_per_s": _v(cf, "c3_octomap_1024", "detail", "host_input_frames_per_s"),
                           "c4_tsdf_esdf_mesh_frames_per_s": _v(cf, "c4_tsdf_esdf_mesh", "value"), "c4_esdf_ms_per_update": _v(cf, "c4_tsdf_esdf_mesh", "detail", "esdf_ms_per_update"),
                           "c4_wavefront": {"frames_per_s": _v(cf, "c4_esdf_wavefront", "value"), "esdf_ms": _v(cf, "c4_esdf_wavefront", "esdf_ms_per_update"), "voxel_writes": _v(cf, "c4_esdf_wavefront", "esdf_voxel_pushes_per_update")},
                           "c5_merge_one_gpu_ms": _v(merge, "ms"), "roofline_frac": _v(roof, "frac"), "cpu_baseline_frames_per_s": _v(out, "cpu_baseline", "value"),

@@ -377,6 +377,8 @@ int  tsl_octo_set_intrinsics(tsl_octo* m, const double Kdep[9], const double Kco
 int  tsl_octo_set_base_pose_submap(tsl_octo* m, int sid, const double R[9], const double T[3]);
 int  tsl_octo_get_active_submap(const tsl_octo* m, int32_t* sid);
 int  tsl_octo_set_active_submap(tsl_octo* m, int32_t sid);
+/* host image.  Untextured: the visited pixels are copied into a pinned, device-mapped slot of a ring at once (the image may be reused on return) and the frame is
+ * queued like a device-resident one: no copy call, no synchronisation per frame (30 k frames/s from numpy images).  Textured: staged and inserted at once. */
 int  tsl_octo_integrate_depth(tsl_octo* m, const double R[9], const double T[3], const uint16_t* depth, int h, int w,
                               const uint8_t* tex, int th, int tw);                   /* :130-132,147-169; tex u8[th][tw][3] BGR (:120-124) or NULL */
 /* device-resident depth (and texture).  Untextured frames are only QUEUED: up to eight are inserted by ONE launch (the insert is an order-free count), issued when
