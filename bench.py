@@ -233,7 +233,7 @@ def default_exact_leg(dev, frames):
         if not res[kind]:
             where[kind] = first_difference(got, want, ("TSDF", "W_TSDF", "occupy"), sensor_xyz=frames[-1][1], voxel_scale=C2["voxel_scale"])
     return {"frames": len(frames), "voxels": int(want["indices"].shape[0]), "bit_exact_with_oracle_BATCHED": all(res.values()), "per_input": res, "differences": where or None,
-            "note": "semantics = 0 (the path `value` measures) == oracle BATCHED on every voxel index, TSDF / W bit and occupancy byte; frames queued back to back"}
+            "note": "semantics = 0 (the path `value` measures) == oracle BATCHED on every index, TSDF / W bit and occupancy byte; frames queued back to back"}
 
 
 def configs_leg(dev, host, cpu=True):
@@ -645,7 +645,7 @@ def main():
                 try:
                     # the counters are averages per launch of the PMC command (its launches cover other frame counts than this run's): per frame, x this run's frames per launch
                     traffic = tj["integrate"]["hbm_bytes_per_launch"] / tj["integrate"]["frames_per_launch"] * fpl
-                    traffic_src = tj.get("command") + f" (hbm_bytes_per_launch / {tj['integrate']['frames_per_launch']:.2f} frames per launch there x {fpl:g} here; kernel sources {tj.get('lib_source_hash')})"
+                    traffic_src = tj.get("command") + f" (per frame there x {fpl:g} frames per launch here; kernel sources {tj.get('lib_source_hash')})"
                     # what actually bounds the kernel: its VALU issue rate.  SQ_INSTS_VALU (wave instructions per launch, PMC pass of the same
                     # command) x 4 cycles per wave64 instruction / (SIMDs x cycles of THIS run's average launch)
                     vi, fpl_p = tj["integrate"].get("valu_wave_insts_per_launch"), tj["integrate"].get("frames_per_launch")
@@ -661,15 +661,13 @@ def main():
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": us,
                     "frame_bytes": bytes_a + bytes_b, "frame_gbs": (bytes_a + bytes_b) * fps / world / 1e9,
                     "frame_frac": (bytes_a + bytes_b) * fps / world / 1e9 / HBM_PEAK_GBS,
-                    "note": "one 640x480 frame touches ~12 MB: the launch is bounded by the exact per-step arithmetic (walk VALU-bound), load "
-                            "imbalance of the bricks next to the sensor and the merge of split bricks, not by bytes (DESIGN.md section 4)"}
+                    "note": "one 640x480 frame touches ~12 MB: the launch is bound by the exact per-step arithmetic and load imbalance, not by bytes (DESIGN.md section 4)"}
         out = {
             "metric": "depth-frames/s integrated (640x480->512^3 TSDF)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 + int64 fixed-point arithmetic",
             "data": "synthetic",
             "config": {"workload": WORKLOAD, "frame_stats": stats, "kernels_us": kern,
-                       "kernels_us_note": "every kernel is launched once per batch of up to 8 queued frames",
                        "updates_per_s": stats["steps"] * fps, "per_rank_frames_per_s": per_rank, "merge": merge},
             "roofline": roof,
             "burst_runs": {"frames_per_s": [(1 if dry else world) * args.steps / b[0] for b in bursts], "value_is": "median",
@@ -680,7 +678,7 @@ def main():
         }
         if dry:
             out["dry_run"] = {"as_rank": rank, "of": world, "note": "single-process dry run of the multi-rank branch: this rank's stream offset, submap id and pose table, "
-                              "merge leg without a communicator; `value` is this rank's rate alone, n_gpus is the simulated world size"}
+                              "merge leg without a communicator; `value` is this rank's rate alone"}
         if not args.no_cpu_baseline and world == 1:              # the CPU legs: rank 0 at N = 1 only (the other ranks of a multi-GPU run would wait at the barrier)
             sample = [(R, T, d) for R, T, d in host[: max(8, min(len(host), 200))]]
             one, allc, omap, n_done = cpu_baselines(sample)

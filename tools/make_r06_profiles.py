@@ -81,7 +81,7 @@ for c, short in ((1, "k_marching_cubes_lds"), (3, "k_octo_depth"), (4, "k_esdf_r
                            "SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE": l4["SQ_LDS_BANK_CONFLICT"][0] / l4["SQ_LDS_IDX_ACTIVE"][0],
                            "SQ_LDS_IDX_ACTIVE/SQ_BUSY_CYCLES": l4["SQ_LDS_IDX_ACTIVE"][0] / q4["SQ_BUSY_CYCLES"][0]}
         if c == 3:      # eight queued frames per launch (round 6): the bench line's unit is a frame
-            e["frames_per_launch"] = 25.0 / e["launches"]; e["note"] = "k_octo_depth_batch: per launch of up to eight queued frames (the PMC command integrates 25)"
+            e["frames_per_launch"] = 45.0 / e["launches"]; e["note"] = "k_octo_depth_batch: per launch of up to eight queued frames (the PMC command integrates 25 device-resident frames and 20 host images)"
         out[f"config{c}"] = e
 if "fetch_c4w" in sec:      # configs[3] with esdf_mode 1: one update = k_esdf_diff + all k_esdf_wave launches
     k = [x for x in sec["fetch_c4w"]["k"] if "k_esdf_wave" in x]
