@@ -125,6 +125,37 @@ def test_two_ranks_simulated_in_one_process(hip_lib):
     _assert_same(sort_export(gs[0].export_submap()), ref, "two simulated ranks")
 
 
+def test_three_simulated_ranks_with_a_padded_last_slice(hip_lib):
+    """The reduce-scatter form cuts the union into nranks slices of WHOLE bricks: with three ranks the union (not a multiple of three here, or made so by dropping
+    nothing: the pad is asserted) ends in zero bricks that every rank finalises into empty records and nobody writes.  Also: records finalised by DIFFERENT handles
+    are interchangeable (finalising is a pure function of the sums)."""
+    import torch
+    world = 3
+    ref = _single_process_reference(world)
+    subs = [_rank_submaps(r) for r in range(world)]
+    gs = [_global(world) for _ in range(world)]
+    masks = [g.merge_begin(s) for g, s in zip(gs, subs)]
+    m = masks[0]
+    for x in masks[1:]:
+        m = torch.maximum(m, x)
+    packs = [g.merge_pack(m) for g in gs]
+    acc, cnt = sum(p[0] for p in packs), sum(p[1] for p in packs)
+    n = acc.shape[0]
+    if n % world == 0:                                             # force a pad: pretend the communicator had one rank more than divides the union
+        world_x = next(w for w in (4, 5, 7) if n % w)
+    else:
+        world_x = world
+    nper = (n + world_x - 1) // world_x
+    assert nper * world_x > n
+    pa = torch.cat([acc, torch.zeros((nper * world_x - n, 4096, 2), dtype=acc.dtype, device=acc.device)])
+    pc = torch.cat([cnt, torch.zeros((nper * world_x - n, 4096), dtype=cnt.dtype, device=cnt.device)])
+    recs = torch.cat([gs[r % world].merge_finalize_slice(pa[r * nper:(r + 1) * nper].contiguous(), pc[r * nper:(r + 1) * nper].contiguous()) for r in range(world_x)])
+    assert recs.shape[0] == nper * world_x and not recs[n:].any()          # the pad's records are empty
+    for g in gs:
+        g.merge_finish_records(recs)
+        _assert_same(sort_export(g.export_submap()), ref, "three simulated ranks, padded reduce-scatter + all-gather")
+
+
 def test_native_rccl_communicator_world_1(hip_lib):
     """tsl_comm_* + tsl_tsdf_allreduce_merge on a one-rank RCCL communicator created by the library itself."""
     from taichislam_amd import distributed as D

@@ -171,3 +171,22 @@ def test_octomap_device_frames_queued_eight_per_launch(hip_lib):
             g2.recast_pcl_to_map(R, T, pts, None, 3000)
         g2.recast_depth_to_map(R, T, np.ascontiguousarray(d[:240]) if f % 5 == 3 else d, None)
     _leaves_equal(g2, o)
+
+
+def test_octomap_reset_and_submap_switch_with_frames_still_queued(hip_lib):
+    """Frames queued but not yet launched when reset() / a switch of the active submap / an export comes: the queue is issued first, in order."""
+    import torch
+    from oracle import OracleOctomap
+    from taichislam_amd.mapping import Octomap
+    cfg = dict(CFG)
+    g, o = Octomap(**cfg), OracleOctomap(**{k: v for k, v in cfg.items() if k != "max_disp_particles"})
+    K, frames = small_stream(7)
+    g.set_dep_camera_intrinsic(K); o.set_intrinsics(K)
+    dev = [torch.from_numpy(d.view(np.int16)).cuda() for _, _, d in frames]
+    for f in range(3):                                  # three frames in the queue, then everything is thrown away
+        g.recast_depth_to_map(frames[f][0], frames[f][1], dev[f], None)
+    g.reset()
+    for f in range(3, 7):                               # four more (still fewer than a batch), read back at once
+        g.recast_depth_to_map(frames[f][0], frames[f][1], dev[f] if f % 2 else frames[f][2], None)
+        o.integrate_depth(*frames[f])
+    _leaves_equal(g, o)
