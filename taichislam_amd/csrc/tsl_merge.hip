@@ -324,13 +324,19 @@ int tsl_tsdf_allreduce_merge(tsl_tsdf* g, tsl_tsdf* sub, void* rccl_comm, int64_
     local = tsl_tsdf_merge_union(g, g->mrg_mask, &n);
     const size_t nv = (size_t)(local ? 0 : n) * TSL_BRK3;
     size_t nvpad = nv;                                              // merge_exchange 1: whole bricks per rank, the last slice padded with zero bricks
+    int xranks = 1, xme = 0, xper = 0;                              // ... its communicator's size, this rank, union bricks per rank
     if (!local && g->merge_exchange == 1 && n > 0) {
-        int nranks = 1;
-        if (comm && g_rccl.CommCount(comm, &nranks) != ncclSuccess) nranks = 1;
-        nvpad = (size_t)((n + nranks - 1) / nranks) * nranks * TSL_BRK3;
+        if (comm && (g_rccl.CommCount(comm, &xranks) != ncclSuccess || g_rccl.CommUserRank(comm, &xme) != ncclSuccess)) { xranks = 1; xme = 0; }
+        xper = (n + xranks - 1) / xranks;
+        nvpad = (size_t)xper * xranks * TSL_BRK3;
     }
     if (!local) local = grow(&g->mrg_pacc, &g->mrg_pacc_bytes, nvpad * 16 + 16);
     if (!local) local = grow(&g->mrg_pcnt, &g->mrg_pcnt_bytes, nvpad * 4 + 16);
+    if (!local && xper > 0) {                                       // the second form's buffers are allocated HERE too: a failure travels with the status word below
+        local = grow(&g->mrg_racc, &g->mrg_racc_bytes, (size_t)xper * TSL_BRK3 * 16 + 16);
+        if (!local) local = grow(&g->mrg_rcnt, &g->mrg_rcnt_bytes, (size_t)xper * TSL_BRK3 * 4 + 16);
+        if (!local) local = grow(&g->mrg_rec, &g->mrg_rec_bytes, (size_t)xper * xranks * MRG_REC_BYTES + 16);
+    }
     if (!local && nvpad > nv) {
         (void)hipMemsetAsync((char*)g->mrg_pacc + nv * 16, 0, (nvpad - nv) * 16, st);
         (void)hipMemsetAsync((char*)g->mrg_pcnt + nv * 4, 0, (nvpad - nv) * 4, st);
@@ -350,14 +356,8 @@ int tsl_tsdf_allreduce_merge(tsl_tsdf* g, tsl_tsdf* sub, void* rccl_comm, int64_
     if (g->merge_exchange == 1 && n > 0) {
         // reduce-scatter + all-gather (option "merge_exchange" = 1): the packed planes are padded to nranks equal slices of whole bricks (the pad is zeros:
         // the buffers were grown for it and cleared above), rank r receives the sums of slice r, finalises it and every rank gathers the records
-        int nranks = 1, me = 0;
-        if (comm) { TSL_NCCL(g_rccl.CommCount(comm, &nranks)); TSL_NCCL(g_rccl.CommUserRank(comm, &me)); }
-        const int nper = (n + nranks - 1) / nranks;
+        const int nranks = xranks, me = xme, nper = xper;           // (the slice and record buffers were allocated with the packed planes, in front of the status exchange)
         const size_t sv = (size_t)nper * TSL_BRK3;                  // voxels of a slice
-        int lrc = grow(&g->mrg_racc, &g->mrg_racc_bytes, sv * 16 + 16);
-        if (!lrc) lrc = grow(&g->mrg_rcnt, &g->mrg_rcnt_bytes, sv * 4 + 16);
-        if (!lrc) lrc = grow(&g->mrg_rec, &g->mrg_rec_bytes, (size_t)nper * nranks * MRG_REC_BYTES + 16);
-        if (lrc) return lrc;                                        // (an allocation failure HERE leaves the peers in the collective: the buffers are small next to the packed planes just grown)
         if (comm) {
             TSL_NCCL(g_rccl.ReduceScatter(g->mrg_pacc, g->mrg_racc, sv * 2, ncclInt64, ncclSum, comm, st));
             TSL_NCCL(g_rccl.ReduceScatter(g->mrg_pcnt, g->mrg_rcnt, sv, ncclInt32, ncclSum, comm, st));
